@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py - frames/s of the milliEye detection(+fusion) hot path on N MI355X (one process per GPU).
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+A *step* = one pass of the hot path over one batch of synthetic frames already resident in HBM.
+Weak scaling: every rank processes its own ``--batch`` frames (frames are independent units,
+SURVEY.md section 8e) - no data-path collective; the barrier / max-over-ranks timing is the only
+communication.
+
+Workloads (``--workload``):
+  detector  yolov3.cfg (Darknet-53) 416x416 fp32 forward -> (featuremap, yolo_outputs)   [BASELINE configs[1]]
+  full      detector + NMS + R-CNN/radar-fusion heads (Network.forward, mode 0)          [metric's "+fusion"]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--cfg", default="yolov3")
+    ap.add_argument("--workload", default="detector", choices=["detector", "full"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    return world, rank, local
+
+
+def conv_roofline(model, x, steps):
+    """Per-launch HIP-event timing of every conv_igemm/stem launch of the plan, on the stream the
+    kernels run on.  Returns (achieved TFLOP/s of the MFMA conv kernel, avg launch us, launches,
+    algorithmic flops per launch)."""
+    from millieye_amd import hip
+
+    engine = model.engine
+    plan = engine.plan_for(x)
+    stream = hip.stream_ptr()
+    engine.run(x)  # patches the input / output pointers of the plan
+    torch.cuda.synchronize()
+    lib = hip.lib()
+    descs = {m: d for m, d in plan.conv_descs}
+    timed = {}  # module -> list of (start, end) events; launches stay IN SEQUENCE (real cache state)
+    for _ in range(steps):
+        for fn, args, _k, name in plan.launches:
+            mfma_conv = fn is lib.me_conv2d_f32 and descs[int(name[4:])].cin > 4
+            if mfma_conv:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn(*args, stream)
+                b.record()
+                timed.setdefault(int(name[4:]), []).append((a, b))
+            else:
+                fn(*args, stream)
+    torch.cuda.synchronize()
+    total_ms, total_flops, launches = 0.0, 0, 0
+    per_layer = []
+    for mod, evs in timed.items():
+        ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        flops = lib.me_conv2d_flops(descs[mod])
+        per_layer.append((mod, flops, ms))
+        total_ms += ms
+        total_flops += flops
+        launches += 1
+    achieved = total_flops / (total_ms * 1e-3) / 1e12
+    return achieved, total_ms * 1e3 / launches, launches, total_flops / launches, per_layer
+
+
+def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s):
+    """The oracle (stock torch CPU ops = the reference's CPU path, pinned by tests/golden) timed on the
+    host cores: a bounded sample of the same workload (batch-1 passes of the same cfg / size)."""
+    from oracle import darknet_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x1 = frames_cpu[:1]
+    t0 = time.perf_counter()
+    darknet_ref.darknet_forward(cfg_text, state_dict, x1, tap_module=tap)  # warm-up (also bounds one pass)
+    one = time.perf_counter() - t0
+    reps = max(1, min(10, int(budget_s / max(one, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        darknet_ref.darknet_forward(cfg_text, state_dict, x1, tap_module=tap)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(1.0 / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} batch-1 passes of {args.cfg} {args.size}x{args.size} fp32 detector forward "
+                      f"(oracle/darknet_ref.py, torch {torch.__version__} CPU, {cores} threads)"}
+
+
+def main():
+    args = parse()
+    world, rank, local = init_dist(args)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+    from millieye_amd import cfgs, synth  # noqa: E402
+    from millieye_amd.yolov3.models import Darknet
+
+    batch = args.batch or (8 if args.workload == "detector" else 32)
+    cfg_path = cfgs.write_cfg(args.cfg, os.path.join("/tmp", f"millieye_bench_cfg_{os.getuid()}_{rank}"))
+    model = Darknet(cfg_path).eval()
+    synth.fill_state_dict(model, "bench/" + args.cfg)
+    synth.trained_like_(model, "bench/" + args.cfg + "/trained")
+    state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    frames_cpu = torch.from_numpy(synth.uniform(f"bench/frames/{rank}", (batch, 3, args.size, args.size)))
+    x = frames_cpu.to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = batch * world * args.steps
+        plan = model.engine.plan_for(x)
+        ach, avg_us, launches, flops_per_launch, per_layer = conv_roofline(model, x, max(3, min(args.steps, 10)))
+        out = {
+            "metric": "frames/sec YOLOv3-416+fusion @batch32, 1/2/4/8 MI355X; mAP@0.5 vs ref",
+            "value": round(frames / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.cfg}.cfg Darknet-53 {args.size}x{args.size} fp32 inference, batch={batch} per GPU "
+                            f"({args.workload}: Darknet.forward -> featuremap + yolo_outputs), synthetic frames U[0,1), "
+                            f"deterministic trained-like weights",
+                "batch_per_gpu": batch,
+                "global_batch": batch * world,
+                "img_size": args.size,
+                "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                "conv_gflop_per_frame": round(plan.conv_flops / batch / 1e9, 3),
+                "arena_mb": round(plan.arena_floats * 4 / 2 ** 20, 1),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit-GEMM conv, all 3x3 / 1x1 layers)",
+                "achieved": round(ach, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches_per_step": launches,
+                "avg_launch_us": round(avg_us, 2),
+                "gflop_per_launch": round(flops_per_launch / 1e9, 3),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from millieye_amd.engine import pick_tap_module
+            out["cpu_baseline"] = cpu_baseline(args, frames_cpu, state_cpu, cfgs.KNOWN[args.cfg](),
+                                               pick_tap_module(model.module_defs), args.cpu_seconds)
+        if os.environ.get("BENCH_LAYERS"):
+            for mod, flops, ms in per_layer:
+                print(f"[layer] conv{mod}: {flops / 1e9:.3f} GF {ms * 1e3:.1f} us {flops / ms / 1e9:.1f} TF/s",
+                      file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

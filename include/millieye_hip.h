@@ -1,0 +1,250 @@
+/*
+ * millieye_hip.h - C ABI of libmillieye_hip.so (gfx950 / MI355X).
+ *
+ * The reference (sxontheway/milliEye) is pure Python and owns no native layer: every
+ * FLOP of its hot path is a call into PyTorch / torchvision.
+ * This header is therefore the FFI a maintainer binds with ctypes (see INTEGRATION.md
+ * and millieye_amd/hip.py): each entry point replaces the library call(s) made at
+ * the reference call site quoted above it.  All paths are relative to /root/reference.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *   - every function returns 0 on success, a positive hipError_t value if a HIP call
+ *     failed, or a negative ME_E_* code for argument errors; me_last_error() gives text.
+ *   - activations are fp32 channels-last ("NHWC"): element (n,y,x,c) of a tensor lives at
+ *     ptr[((n*H + y)*W + x)*pitch + c], pitch >= C (pitch > C addresses a channel slice
+ *     of a wider concat buffer - that is how darknet [route] concatenation costs nothing).
+ *   - launches are asynchronous on `stream`; nothing here allocates or synchronises.
+ */
+#ifndef MILLIEYE_HIP_H
+#define MILLIEYE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ME_ABI_VERSION 1
+
+#define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
+#define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
+#define ME_E_ALIGN (-3)    /* pointer or pitch not aligned as the kernel needs  */
+#define ME_E_TOOBIG (-4)   /* size exceeds a kernel capacity (stated per call)  */
+
+/* activation codes (conv epilogue) */
+#define ME_ACT_LINEAR 0
+#define ME_ACT_LEAKY 1   /* LeakyReLU(0.1): v > 0 ? v : 0.1f * v */
+#define ME_ACT_SIGMOID 2 /* 1 / (1 + expf(-v))                    */
+
+int me_abi_version(void);
+const char* me_last_error(void);
+/* number of CUs / max clock (kHz) / LDS bytes per workgroup of the current device */
+int me_device_query(int32_t* cu_count, int32_t* clock_khz, int32_t* lds_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * me_conv2d_f32 - fused  y = act(conv(x, w) * scale + shift) [+ residual]  [nearest x2]
+ *
+ * replaces: nn.Conv2d + nn.BatchNorm2d(eval) + nn.LeakyReLU(0.1) blocks built at
+ *   module3_our_dataset/yolov3/models.py:22-41 and run at :252-253; the [shortcut] add
+ *   at :258-260 (residual); the Upsample at :82-92 when it directly follows the conv;
+ *   cnn_layers_1 (module3_our_dataset/my_models.py:62-77), cnn_layers_3 (:132-157).
+ * BatchNorm (eval) and/or the conv bias are folded by the caller into per-output-channel
+ *   (scale, shift):  scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+ *   (+ bias * scale); plain bias conv: scale = 1, shift = bias.
+ * weights: fp32, packed [cout][ky][kx][cin] (i.e. OIHW -> OHWI), row length ksize*ksize*cin.
+ * x: NHWC (pitch x_pitch), or NCHW when x_nchw != 0 (the network input, models.py:247).
+ * residual (optional, NHWC [n,ho,wo,cout]) is added AFTER the activation (models.py:260).
+ * upsample == 2 writes every output pixel to the 2x2 block (2y..2y+1, 2x..2x+1) of a
+ *   [n,2*ho,2*wo] tensor (F.interpolate(scale_factor=2, mode="nearest")).
+ * constraints: cin % 4 == 0 unless cin <= 4 (direct small-cin kernel, ksize 3, stride 1);
+ *   x / wgt / y 16-byte aligned, pitches % 4 == 0 (NHWC).
+ */
+typedef struct me_conv_desc {
+  const float* x;
+  const float* wgt;
+  const float* scale;
+  const float* shift;
+  const float* res; /* may be NULL */
+  float* y;
+  int64_t x_pitch;   /* elements between consecutive pixels of x (NHWC); ignored for NCHW */
+  int64_t res_pitch;
+  int64_t y_pitch;
+  int32_t n, h, w, cin;
+  int32_t cout, ksize, stride, pad;
+  int32_t ho, wo;
+  int32_t act;
+  int32_t upsample; /* 1 or 2 */
+  int32_t x_nchw;   /* 0 / 1 */
+  int32_t tile;     /* 0 = auto; else force a tile config id (testing / tuning) */
+} me_conv_desc;
+int me_conv2d_f32(const me_conv_desc* d, void* stream);
+/* algorithmic FLOPs (2*MAC) of the descriptor - used by bench.py for the roofline */
+int64_t me_conv2d_flops(const me_conv_desc* d);
+
+/* ------------------------------------------------------------------------------------
+ * me_maxpool_f32 - NHWC max pooling.
+ * replaces: nn.MaxPool2d(size, stride, padding=(size-1)//2) and, for size 2 / stride 1, the
+ *   preceding nn.ZeroPad2d((0,1,0,1)) (models.py:43-49): zero_ext != 0 extends the input by
+ *   one row/column of ZEROS (value 0.0 takes part in the max - quirk q16), while `pad`
+ *   behaves like torch's implicit -inf padding.
+ */
+typedef struct me_pool_desc {
+  const float* x;
+  float* y;
+  int64_t x_pitch, y_pitch;
+  int32_t n, h, w, c;
+  int32_t size, stride, pad, zero_ext;
+  int32_t ho, wo;
+} me_pool_desc;
+int me_maxpool_f32(const me_pool_desc* d, void* stream);
+
+/* nearest-neighbour x`factor` upsample, NHWC (models.py:82-92) - stand-alone fallback */
+int me_upsample_f32(const float* x, int64_t x_pitch, float* y, int64_t y_pitch, int32_t n, int32_t h,
+                    int32_t w, int32_t c, int32_t factor, void* stream);
+/* y = a + b over [pixels, c] with independent pitches ([shortcut] fallback, models.py:258-260) */
+int me_add_f32(const float* a, int64_t a_pitch, const float* b, int64_t b_pitch, float* y, int64_t y_pitch,
+               int64_t pixels, int32_t c, void* stream);
+/* copy a channel slice ([route] fallback, torch.cat at models.py:257) */
+int me_copy_f32(const float* x, int64_t x_pitch, float* y, int64_t y_pitch, int64_t pixels, int32_t c,
+                void* stream);
+/* NHWC (pitch) -> dense NCHW and back: API-boundary layout conversion only */
+int me_nhwc_to_nchw_f32(const float* x, int64_t x_pitch, float* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * me_yolo_decode_f32 - YOLO head decode for one scale.
+ * replaces: YOLOLayer.forward inference branch, models.py:132-179 (+ compute_grid_offsets
+ *   :119-129): x = raw detection conv output NHWC [n,g,g,A*(5+C)], channel a*(5+C)+k.
+ *   out row r = row_offset + a*g*g + gy*g + gx of out[n, rows_total, 5+C]:
+ *     k=0: (sigmoid(v) + gx) * stride      k=1: (sigmoid(v) + gy) * stride
+ *     k=2: exp(v) * (anchor_w/stride) * stride   k=3: same with anchor_h
+ *     k>=4: sigmoid(v)
+ *   anchors: A pairs (w/stride, h/stride) - the reference's `scaled_anchors`, divided on the
+ *   host in double precision and rounded to fp32 exactly like models.py:126 does (A <= 8).
+ */
+typedef struct me_yolo_desc {
+  const float* x;
+  float* out;
+  int64_t x_pitch;
+  int32_t n, g, num_anchors, num_classes;
+  int32_t rows_total, row_offset;
+  float stride;
+  float anchors[16];
+} me_yolo_desc;
+int me_yolo_decode_f32(const me_yolo_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * me_nms_batched_f32 - confidence filter + class-aware greedy NMS, per image.
+ * replaces: non_max_suppression_cpp (module3_our_dataset/utils/utils.py:337-378) including
+ *   xywh2xyxy (:68-74) and torchvision.ops.boxes.batched_nms / nms (utils.py:372; semantics
+ *   restated in SURVEY.md Appendix C: offset trick boxes + label*(max+1), IoU without +1,
+ *   suppress when IoU > iou_thresh, rank by objectness, ties -> lower row first).
+ * pred: [n, rows, 5+C] (cx,cy,w,h,obj,cls...).  If writeback_xyxy != 0 the first four
+ *   columns of every row are overwritten with (x1,y1,x2,y2) like the reference does in place.
+ * det:  [n, max_det, 7+C] rows (x1,y1,x2,y2,obj,cls_conf,cls_pred,C scores); count[n] valid rows
+ *   each (rows beyond count are left untouched).
+ * workspace: me_nms_workspace_bytes(n, rows) bytes, 256-byte aligned, contents irrelevant.
+ * capacity: rows <= 32768.
+ */
+typedef struct me_nms_desc {
+  float* pred;
+  float* det;
+  int32_t* count;
+  void* workspace;
+  int32_t n, rows, num_classes, max_det;
+  float conf_thresh, iou_thresh;
+  int32_t writeback_xyxy;
+} me_nms_desc;
+int64_t me_nms_workspace_bytes(int32_t n, int32_t rows);
+int me_nms_batched_f32(const me_nms_desc* d, void* stream);
+
+/* plain torchvision-style nms / batched_nms on explicit boxes (box_ops.* re-export used by
+ *   run_sp.py:214 / run_mp.py:320).  boxes [m,4] xyxy, scores [m], labels [m] (float class ids,
+ *   may be NULL -> plain nms).  keep[m] receives kept indices in descending-score order,
+ *   *keep_count (device int32) their number.  workspace: me_nms_workspace_bytes(1, m). m <= 32768. */
+int me_nms_boxes_f32(const float* boxes, const float* scores, const float* labels, int32_t m, float iou_thresh,
+                     int64_t* keep, int32_t* keep_count, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * me_gather_class_boxes_f32 - proposal assembly.
+ * replaces: the per-image python loop of Network.forward, my_models.py:459-473: keep detections
+ *   with cls_pred == class_idx, emit rows (image_i, x1,y1,x2,y2, obj, cls_conf, cls_pred,
+ *   score[0:class_num]) image-major / NMS order.  boxes: [n*max_det, 8+class_num]; *total (device).
+ */
+int me_gather_class_boxes_f32(const float* det, const int32_t* count, int32_t n, int32_t max_det,
+                              int32_t num_classes, int32_t class_idx, int32_t class_num, float* boxes,
+                              int32_t* total, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * me_roi_heads_f32 - RoI pooling + refinement head + ensemble head + output rows (inference).
+ * replaces: torchvision.ops.ps_roi_align / roi_align calls at my_models.py:495-496 (semantics:
+ *   SURVEY.md Appendix C), refinement_head.forward (:260-284), ensemble_head.forward (:202-210),
+ *   mask/threshold/box_regress/output assembly (:502-535, box_regress :378-391).
+ *
+ * RoIs = the first *n_img rows of img_boxes (from me_gather_class_boxes_f32) followed by n_radar
+ *   rows of radar_boxes [n_radar,5] (image_i, x1,y1,x2,y2 in pixels).
+ * img_map:   NHWC [n, fh, fw, 490] (pitch img_pitch)  - cnn_layers_1 output
+ * radar_map: NHWC [n, fh, fw, 10]  (pitch radar_pitch) - cnn_layers_3 output
+ * per-RoI results (arrays sized cap = n_img_cap + n_radar, row k = RoI k):
+ *   regress [cap,4], refine [cap,2], mask1 [cap] (p foreground), out_rows [cap,8]
+ *   (image_i, x1,y1,x2,y2, p, cls_score, cls_pred), keep [cap] uint8 (p > threshold),
+ *   sort_key [cap] (p for image proposals, p/5 for radar proposals - quirk q4).
+ * weights (fp32, device): see me_heads_weights.
+ */
+typedef struct me_heads_weights {
+  const float* w0t;   /* refinement_head.net0.0.weight transposed: [490][256] */
+  const float* b0;    /* [256] */
+  const float* w1;    /* net1.0.weight [4][256]  */
+  const float* b1;    /* [4] */
+  const float* w2;    /* net2.0.weight [13][256] (only rows 0,1 are used - quirk q2) */
+  const float* b2;    /* [13] */
+  const float* rw;    /* radar_net.0.weight [10][490] (10x10x7x7 flattened) */
+  const float* rscale; /* [10] folded BN(eval) + conv bias: v*rscale + rshift */
+  const float* rshift; /* [10] */
+  const float* rw2;   /* radar_net.3.weight [10] */
+  const float* rb2;   /* [1] */
+  const float* e1w;   /* ensemble_head.fc1.0.weight [32][2] */
+  const float* e1b;   /* [32] */
+  const float* e2w;   /* ensemble_head.fc2.0.weight [2][64] */
+  const float* e2b;   /* [2] */
+} me_heads_weights;
+
+typedef struct me_heads_desc {
+  const float* img_map;
+  const float* radar_map;
+  int64_t img_pitch, radar_pitch;
+  int32_t n, fh, fw;
+  float spatial_scale;         /* 1/16 */
+  const float* img_boxes;      /* [n_img_cap, box_cols] */
+  const int32_t* n_img;        /* device scalar */
+  int32_t n_img_cap, box_cols; /* box_cols = 8 + class_num (9) */
+  const float* radar_boxes;    /* [n_radar,5] or NULL */
+  int32_t n_radar;
+  float thr_img, thr_radar;
+  int32_t regress;             /* 1: box_regress the kept boxes (modes 0,3); 0: mode 2 */
+  me_heads_weights wts;
+  float* regress_out;
+  float* refine_out;
+  float* mask1_out;
+  float* out_rows;
+  uint8_t* keep;
+  float* sort_key;
+} me_heads_desc;
+int me_roi_heads_f32(const me_heads_desc* d, void* stream);
+
+/* stand-alone RoI ops (tests, training path): out [k, c_out, 7, 7] dense */
+int me_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                     const float* rois, int32_t k, int32_t pooled, float spatial_scale, float* out,
+                     void* stream);
+int me_ps_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                        const float* rois, int32_t k, int32_t pooled, float spatial_scale, float* out,
+                        void* stream);
+
+/* sizes of the descriptor structs, so a binding can assert its mirror layout */
+int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MILLIEYE_HIP_H */

@@ -1,0 +1,443 @@
+// conv.hip - fused convolution kernels for gfx950 (MI355X / CDNA4), fp32.
+//
+//   conv_igemm_f32  : im2col-free implicit GEMM on the f32 matrix cores
+//                     (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains, 157 TFLOP/s peak).
+//                     M = n*ho*wo output pixels, N = cout, K = ksize^2 * cin.
+//                     The K loop walks (tap, cin-chunk); for one tap the A tile is a set of
+//                     BM pixel rows x BK contiguous channels of the NHWC input (coalesced 16 B
+//                     loads, zero for padding taps), the B tile BN weight rows x BK.  Tiles are
+//                     register-prefetched one stage ahead and double buffered in LDS.
+//                     Epilogue (fused): per-channel affine (folded BN / bias), LeakyReLU /
+//                     sigmoid, residual add ([shortcut]), nearest x2 replication ([upsample]),
+//                     pitched store into a channel slice of a concat buffer ([route]).
+//   conv_smallcin_f32: direct 3x3 convolution for cin <= 4 (network stem / radar stem): HBM
+//                     bound (arithmetic intensity ~12 flop/B), no MFMA benefit; reads NCHW or
+//                     NHWC, writes NHWC.
+//
+// Replaces the nn.Conv2d + BatchNorm2d + LeakyReLU blocks of
+// module3_our_dataset/yolov3/models.py:22-41 (see include/millieye_hip.h).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvP {
+  const float* x;
+  const float* wgt;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  long long x_pitch, res_pitch, y_pitch;
+  int n, h, w, cin, cout, ks, stride, pad, ho, wo, act, ups, x_nchw;
+  int M;       // n*ho*wo
+  int ktot;    // ks*ks*cin
+  int cs;      // channel chunks per tap = ceil(cin / BK)
+  int stages;  // ks*ks*cs
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ME_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+  if (act == ME_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM MFMA kernel
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WR, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WR, TN = BN / WC;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  static_assert(MT >= 1 && NT >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+  constexpr int LP = BK + 4;  // LDS row pitch (floats): (LP/4) odd -> conflict-free ds_read_b128
+  constexpr int CH = BK / 4;  // 16-byte chunks per row
+  constexpr int A_IT = (BM * CH + 255) / 256;
+  constexpr int B_IT = (BN * CH + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM*LP]
+  float* Bs = smem + 2 * BM * LP;   // [2][BN*LP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int r32 = lane & 31, hh = lane >> 5;
+
+  // XCD-aware bijective remap: consecutive tile ids stay on one XCD (private L2).
+  int tile_m, tile_n;
+  {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_n = wg % p.tiles_n;
+    tile_m = wg / p.tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // per-thread A-row bookkeeping (constant over the K loop)
+  int a_iy0[A_IT], a_ix0[A_IT], a_pix0[A_IT], a_lds[A_IT], a_q[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id / CH, q = id % CH;
+    a_lds[i] = row * LP + 4 * q;
+    a_q[i] = 4 * q;
+    const int m = m0 + row;
+    if (id < BM * CH && m < p.M) {
+      const int hw = p.ho * p.wo;
+      const int nimg = m / hw;
+      const int rem = m - nimg * hw;
+      const int oy = rem / p.wo, ox = rem - oy * p.wo;
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      a_pix0[i] = nimg * p.h * p.w;
+    } else {
+      a_iy0[i] = -(1 << 28);  // every tap out of bounds -> zeros
+      a_ix0[i] = 0;
+      a_pix0[i] = 0;
+    }
+  }
+  long long b_off[B_IT];
+  int b_lds[B_IT], b_q[B_IT];
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id / CH, q = id % CH;
+    b_lds[i] = row * LP + 4 * q;
+    b_q[i] = 4 * q;
+    const int co = n0 + row;
+    b_ok[i] = (id < BN * CH) && (co < p.cout);
+    b_off[i] = (long long)co * p.ktot + 4 * q;
+  }
+
+  float4 a_reg[A_IT], b_reg[B_IT];
+  int tap = 0, cc = 0;  // stage -> (tap, channel chunk)
+
+  auto load_stage = [&]() {
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    const int c0 = cc * BK;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = ((unsigned)iy < (unsigned)p.h) && ((unsigned)ix < (unsigned)p.w) && (c0 + a_q[i] < p.cin);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float* src = p.x + (long long)(a_pix0[i] + iy * p.w + ix) * p.x_pitch + (c0 + a_q[i]);
+        v = *reinterpret_cast<const float4*>(src);
+      }
+      a_reg[i] = v;
+    }
+    const int koff = tap * p.cin + c0;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_ok[i] && (c0 + b_q[i] < p.cin)) v = *reinterpret_cast<const float4*>(p.wgt + b_off[i] + koff);
+      b_reg[i] = v;
+    }
+    if (++cc == p.cs) {
+      cc = 0;
+      ++tap;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* Ad = As + buf * BM * LP;
+    float* Bd = Bs + buf * BN * LP;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      if (A_IT * 256 == BM * CH || tid + 256 * i < BM * CH) *reinterpret_cast<float4*>(Ad + a_lds[i]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      if (B_IT * 256 == BN * CH || tid + 256 * i < BN * CH) *reinterpret_cast<float4*>(Bd + b_lds[i]) = b_reg[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_stage();
+  store_stage(0);
+  __syncthreads();
+
+  const int a_frag = (wr * TM + r32) * LP + 4 * hh;
+  const int b_frag = (wc * TN + r32) * LP + 4 * hh;
+
+  for (int s = 0; s < p.stages; ++s) {
+    const int buf = s & 1;
+    const bool more = (s + 1 < p.stages);
+    if (more) load_stage();  // global loads in flight while the matrix cores work on `buf`
+    const float* Ab = As + buf * BM * LP + a_frag;
+    const float* Bb = Bs + buf * BN * LP + b_frag;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      float4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LP + kk);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LP + kk);
+      // lanes 0-31 hold k = kk..kk+3, lanes 32-63 hold k = kk+4..kk+7 (same split for A and B):
+      // each of the four MFMAs consumes one k from each half -> all 8 k's, each exactly once.
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- fused epilogue -------------------------------------------------------------------
+  // 32x32 C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+  const int hw = p.ho * p.wo;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + wc * TN + j * 32 + r32;
+    const bool co_ok = co < p.cout;
+    const float sc = co_ok ? p.scale[co] : 0.f;
+    const float sh = co_ok ? p.shift[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int m = m0 + wr * TM + i * 32 + row;
+        if (!co_ok || m >= p.M) continue;
+        float v = apply_act(acc[i][j][e] * sc + sh, p.act);
+        if (p.res) v += p.res[(long long)m * p.res_pitch + co];
+        if (p.ups == 1) {
+          p.y[(long long)m * p.y_pitch + co] = v;
+        } else {
+          const int nimg = m / hw;
+          const int rem = m - nimg * hw;
+          const int oy = rem / p.wo, ox = rem - oy * p.wo;
+          const int W2 = p.wo * 2;
+          const long long base = ((long long)nimg * (p.ho * 2) + 2 * oy) * W2 + 2 * ox;
+          p.y[(base)*p.y_pitch + co] = v;
+          p.y[(base + 1) * p.y_pitch + co] = v;
+          p.y[(base + W2) * p.y_pitch + co] = v;
+          p.y[(base + W2 + 1) * p.y_pitch + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct 3x3 convolution, cin <= 4 (stem).  One thread = one output pixel x 8 output channels
+// (cout/8 adjacent lanes share a pixel, so a wave stores one contiguous NHWC span); weights are
+// broadcast from LDS.  CIN is the padded channel count (3 or 4); channels >= p.cin are zero.
+// ---------------------------------------------------------------------------------------------
+constexpr int SC_MAXCOUT = 128;
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_smallcin_f32(ConvP p) {
+  constexpr int K = 9 * CIN;
+  __shared__ __attribute__((aligned(16))) float w_lds[K * SC_MAXCOUT];  // [k][cout_pad]
+  const int cout_pad = (p.cout + 7) & ~7;
+  for (int idx = threadIdx.x; idx < K * cout_pad; idx += 256) {
+    const int k = idx / cout_pad, co = idx - k * cout_pad;
+    const int t = k / CIN, c = k - t * CIN;
+    w_lds[idx] = (co < p.cout && c < p.cin) ? p.wgt[(long long)co * (9 * p.cin) + t * p.cin + c] : 0.f;
+  }
+  __syncthreads();
+
+  const int tpp = cout_pad >> 3;  // threads per pixel
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int m = (int)(gid / tpp);
+  const int co0 = (int)(gid - (long long)m * tpp) * 8;
+  if (m >= p.M) return;
+  const int hw = p.ho * p.wo;
+  const int nimg = m / hw;
+  const int rem = m - nimg * hw;
+  const int oy = rem / p.wo, ox = rem - oy * p.wo;
+
+  float xin[K];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+      const bool ok = ((unsigned)iy < (unsigned)p.h) && ((unsigned)ix < (unsigned)p.w);
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        float v = 0.f;
+        if (ok && c < p.cin) {
+          if (p.x_nchw)
+            v = p.x[(((long long)nimg * p.cin + c) * p.h + iy) * p.w + ix];
+          else
+            v = p.x[((long long)(nimg * p.h + iy) * p.w + ix) * p.x_pitch + c];
+        }
+        xin[(ky * 3 + kx) * CIN + c] = v;
+      }
+    }
+
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const float* wbase = w_lds + co0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float4 w0 = *reinterpret_cast<const float4*>(wbase + k * cout_pad);
+    const float4 w1 = *reinterpret_cast<const float4*>(wbase + k * cout_pad + 4);
+    const float xv = xin[k];
+    acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]);
+    acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
+    acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]);
+    acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
+  }
+  float* yrow = p.y + (long long)m * p.y_pitch + co0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int co = co0 + j;
+    if (co < p.cout) acc[j] = apply_act(acc[j] * p.scale[co] + p.shift[co], p.act);
+  }
+  if (co0 + 8 <= p.cout && (p.y_pitch & 3) == 0) {
+    *reinterpret_cast<float4*>(yrow) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(yrow + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (co0 + j < p.cout) yrow[j] = acc[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tile selection + launch
+// ---------------------------------------------------------------------------------------------
+struct TileCfg {
+  int id, bm, bn;
+  float eff;
+};
+// id 1..4; BK = 16 for all (LDS 2*(BM+BN)*20*4 B: 40 KiB for 128x128 -> 3-4 workgroups per CU)
+const TileCfg kTiles[] = {
+    {1, 128, 128, 1.00f},
+    {2, 128, 64, 0.92f},
+    {3, 64, 64, 0.80f},
+    {4, 128, 32, 0.72f},
+};
+
+template <int BM, int BN, int BK, int WR, int WC>
+int launch_igemm(ConvP& p, hipStream_t stream) {
+  p.cs = (p.cin + BK - 1) / BK;
+  p.stages = p.ks * p.ks * p.cs;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+  auto kern = conv_igemm_f32<BM, BN, BK, WR, WC>;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      attr_set = true;
+    }
+  }
+  const long long blocks = (long long)p.tiles_m * p.tiles_n;
+  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  return me::check_launch("conv_igemm_f32");
+}
+
+int pick_tile(const ConvP& p) {
+  // one "round" = every CU holding 2 workgroups; estimate rounds * tile work / efficiency
+  int best = 1;
+  double best_cost = 1e300;
+  for (const TileCfg& t : kTiles) {
+    const long long tm = (p.M + t.bm - 1) / t.bm, tn = (p.cout + t.bn - 1) / t.bn;
+    const long long blocks = tm * tn;
+    const double rounds = (double)((blocks + 511) / 512);
+    // below one full round the chip is not filled: cost is still one tile latency
+    const double cost = rounds * (double)t.bm * t.bn / t.eff;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = t.id;
+    }
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t me_conv2d_flops(const me_conv_desc* d) {
+  if (!d) return 0;
+  return 2ll * d->n * d->ho * d->wo * (int64_t)d->cout * d->ksize * d->ksize * d->cin;
+}
+
+int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_f32: null descriptor");
+  ME_REQUIRE(d->x && d->wgt && d->scale && d->shift && d->y, ME_E_NULLPTR, "me_conv2d_f32: null tensor pointer");
+  ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
+             "me_conv2d_f32: non-positive dimension");
+  ME_REQUIRE(d->ksize >= 1 && d->stride >= 1 && d->pad >= 0, ME_E_BADARG, "me_conv2d_f32: bad ksize/stride/pad");
+  const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1;
+  const int wo = (d->w + 2 * d->pad - d->ksize) / d->stride + 1;
+  ME_REQUIRE(ho == d->ho && wo == d->wo, ME_E_BADARG, "me_conv2d_f32: ho/wo (%d,%d) != derived (%d,%d)", d->ho,
+             d->wo, ho, wo);
+  ME_REQUIRE(d->upsample == 1 || d->upsample == 2, ME_E_BADARG, "me_conv2d_f32: upsample must be 1 or 2");
+  ME_REQUIRE(d->act >= 0 && d->act <= 2, ME_E_BADARG, "me_conv2d_f32: unknown activation %d", d->act);
+  ME_REQUIRE((long long)d->n * d->ho * d->wo < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: too many output pixels");
+  ME_REQUIRE(d->y_pitch >= d->cout, ME_E_BADARG, "me_conv2d_f32: y_pitch < cout");
+
+  ConvP p;
+  p.x = d->x; p.wgt = d->wgt; p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
+  p.x_pitch = d->x_pitch; p.res_pitch = d->res_pitch; p.y_pitch = d->y_pitch;
+  p.n = d->n; p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout; p.ks = d->ksize;
+  p.stride = d->stride; p.pad = d->pad; p.ho = d->ho; p.wo = d->wo; p.act = d->act; p.ups = d->upsample;
+  p.x_nchw = d->x_nchw;
+  p.M = d->n * d->ho * d->wo;
+  p.ktot = d->ksize * d->ksize * d->cin;
+  p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
+
+  if (d->cin <= 4) {
+    ME_REQUIRE(d->ksize == 3, ME_E_BADARG, "me_conv2d_f32: cin <= 4 needs ksize 3 (direct stem kernel)");
+    ME_REQUIRE(d->cout <= SC_MAXCOUT, ME_E_TOOBIG, "me_conv2d_f32: small-cin kernel supports cout <= %d", SC_MAXCOUT);
+    ME_REQUIRE(d->res == nullptr && d->upsample == 1, ME_E_BADARG,
+               "me_conv2d_f32: small-cin kernel has no residual/upsample epilogue");
+    ME_REQUIRE(d->x_nchw || d->x_pitch >= d->cin, ME_E_BADARG, "me_conv2d_f32: x_pitch < cin");
+    ME_REQUIRE(me::aligned16(d->y), ME_E_ALIGN, "me_conv2d_f32: y not 16-byte aligned");
+    const long long threads = (long long)p.M * (((p.cout + 7) & ~7) >> 3);
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (d->cin == 3)
+      hipLaunchKernelGGL(conv_smallcin_f32<3>, dim3(blocks), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL(conv_smallcin_f32<4>, dim3(blocks), dim3(256), 0, stream, p);
+    return me::check_launch("conv_smallcin_f32");
+  }
+
+  ME_REQUIRE(!d->x_nchw, ME_E_BADARG, "me_conv2d_f32: NCHW input only supported for cin <= 4");
+  ME_REQUIRE(d->cin % 4 == 0, ME_E_BADARG, "me_conv2d_f32: cin %% 4 != 0 (cin=%d)", d->cin);
+  ME_REQUIRE(d->x_pitch >= d->cin && d->x_pitch % 4 == 0, ME_E_ALIGN, "me_conv2d_f32: x_pitch must be >= cin, %% 4");
+  ME_REQUIRE(me::aligned16(d->x) && me::aligned16(d->wgt), ME_E_ALIGN, "me_conv2d_f32: x / wgt not 16-byte aligned");
+  ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_f32: res_pitch < cout");
+
+  int tile = d->tile ? d->tile : pick_tile(p);
+  switch (tile) {
+    case 1: return launch_igemm<128, 128, 16, 2, 2>(p, stream);
+    case 2: return launch_igemm<128, 64, 16, 2, 2>(p, stream);
+    case 3: return launch_igemm<64, 64, 16, 2, 2>(p, stream);
+    case 4: return launch_igemm<128, 32, 16, 4, 1>(p, stream);
+    default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_f32: unknown tile id %d", tile);
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,381 @@
+// heads.hip - proposal assembly, RoI pooling and the fused refinement / ensemble heads (gfx950).
+//
+// Replaces, for inference, the tail of Network.forward (module3_our_dataset/my_models.py):
+//   :459-473  per-image python loop building img_boxes            -> gather_class_boxes_kernel
+//   :495-496  torchvision ps_roi_align / roi_align                -> ps_sample / roi_sample below
+//   :260-284  refinement_head.forward, :202-210 ensemble_head     -> roi_heads_kernel (one launch)
+//   :502-539  masks, thresholds, box_regress (:378-391), sort key -> same launch
+// RoI pooling semantics follow torchvision 0.6 exactly as restated in oracle/tv_ops.c (loop and
+// summation order included; FP contraction is off in the sampling code so pooled values are
+// bit-identical with that oracle).  Samples that the border rule maps to 0 are skipped by
+// bounding the sample loops to the feature map (adding +0.0f is exact), which also bounds the
+// work for degenerate huge boxes.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int P = 7;            // pooled size (my_models.py:495-496)
+constexpr int PP = P * P;       // 49
+constexpr int C_OUT = 10;       // score-map groups
+constexpr int FEAT = C_OUT * PP;  // 490
+constexpr int HID = 256;
+constexpr int RPB = 8;          // RoIs per workgroup
+
+__device__ __forceinline__ float bilinear_nhwc(const float* map, long long pitch, int height, int width, int c,
+                                               float y, float x) {
+#pragma clang fp contract(off)
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return 0.0f;
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - y_low, lx = x - x_low;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float v1 = map[((long long)y_low * width + x_low) * pitch + c];
+  const float v2 = map[((long long)y_low * width + x_high) * pitch + c];
+  const float v3 = map[((long long)y_high * width + x_low) * pitch + c];
+  const float v4 = map[((long long)y_high * width + x_high) * pitch + c];
+  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  return (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+}
+
+// index range [lo, hi] of samples start + ((i + .5f) * bin) / g that can fall inside [-1, limit];
+// conservative (2 extra on each side) - the exact test stays in bilinear_nhwc.
+__device__ __forceinline__ void sample_range(float start, float bin, int g, float limit, int* lo, int* hi) {
+  *lo = 0;
+  *hi = g - 1;
+  if (g <= 0) return;
+  const float step = bin / (float)g;
+  if (!(step > 0.f) || !isfinite(start) || !isfinite(step)) {
+    // non-finite geometry (inf / NaN boxes): the reference's behaviour is undefined there
+    // ((int)NaN, 2^31-iteration loops); take no samples so the launch stays bounded.
+    *hi = -1;
+    return;
+  }
+  const float a = (-1.0f - start) / step - 0.5f;
+  const float b = (limit - start) / step - 0.5f;
+  if (a > 2.f) *lo = (a - 2.f >= (float)g) ? g : (int)(a - 2.f);
+  if (b + 2.f < (float)(g - 1)) *hi = (b + 2.f < 0.f) ? -1 : (int)(b + 2.f);
+}
+
+__device__ __forceinline__ int grid_of(float extent) {
+  // (int)ceil(roi / pooled) like the reference; saturate instead of overflowing for absurd boxes
+  const float g = ceilf(extent / (float)P);
+  if (!(g < 1.0e9f)) return (g != g) ? 0 : 1000000000;
+  if (g < -1.0e9f) return -1000000000;
+  return (int)g;
+}
+
+// one output of torchvision.ops.roi_align(aligned=False, sampling_ratio=-1), map NHWC [n,h,w,c]
+__device__ float roi_sample(const float* map, long long pitch, int height, int width, const float* roi,
+                            float scale, int c, int ph, int pw) {
+#pragma clang fp contract(off)
+  const int b = (int)roi[0];
+  const float sw = roi[1] * scale - 0.0f, sh = roi[2] * scale - 0.0f;
+  const float ew = roi[3] * scale - 0.0f, eh = roi[4] * scale - 0.0f;
+  float roi_w = ew - sw, roi_h = eh - sh;
+  roi_w = roi_w > 1.f ? roi_w : 1.f;
+  roi_h = roi_h > 1.f ? roi_h : 1.f;
+  const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
+  const int gh = grid_of(roi_h), gw = grid_of(roi_w);
+  const int cnt = gh * gw;
+  const float count = (float)(cnt > 1 ? cnt : 1);
+  const float* img = map + (long long)b * height * width * pitch;
+  const float ybase = sh + ph * bin_h, xbase = sw + pw * bin_w;
+  int ylo, yhi, xlo, xhi;
+  sample_range(ybase, bin_h, gh, (float)height, &ylo, &yhi);
+  sample_range(xbase, bin_w, gw, (float)width, &xlo, &xhi);
+  float acc = 0.f;
+  for (int iy = ylo; iy <= yhi; ++iy) {
+    const float yy = ybase + ((float)(iy + .5f)) * bin_h / (float)gh;
+    for (int ix = xlo; ix <= xhi; ++ix) {
+      const float xx = xbase + ((float)(ix + .5f)) * bin_w / (float)gw;
+      acc += bilinear_nhwc(img, pitch, height, width, c, yy, xx);
+    }
+  }
+  return acc / count;
+}
+
+// one output of torchvision.ops.ps_roi_align(sampling_ratio=-1): input channel c_in = (c_out*P+ph)*P+pw
+__device__ float ps_sample(const float* map, long long pitch, int height, int width, const float* roi, float scale,
+                           int c_in, int ph, int pw) {
+#pragma clang fp contract(off)
+  const int b = (int)roi[0];
+  const float sw = roi[1] * scale - 0.5f, sh = roi[2] * scale - 0.5f;
+  const float ew = roi[3] * scale - 0.5f, eh = roi[4] * scale - 0.5f;
+  const float roi_w = ew - sw, roi_h = eh - sh;
+  const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
+  const float hstart = (float)ph * bin_h + sh;
+  const float wstart = (float)pw * bin_w + sw;
+  const int gh = grid_of(roi_h), gw = grid_of(roi_w);
+  const float count = (float)(gh * gw);
+  const float* img = map + (long long)b * height * width * pitch;
+  int ylo, yhi, xlo, xhi;
+  sample_range(hstart, bin_h, gh, (float)height, &ylo, &yhi);
+  sample_range(wstart, bin_w, gw, (float)width, &xlo, &xhi);
+  float out_sum = 0.f;
+  for (int iy = ylo; iy <= yhi; ++iy) {
+    const float y = hstart + ((float)(iy + .5f)) * bin_h / (float)gh;
+    for (int ix = xlo; ix <= xhi; ++ix) {
+      const float x = wstart + ((float)(ix + .5f)) * bin_w / (float)gw;
+      out_sum += bilinear_nhwc(img, pitch, height, width, c_in, y, x);
+    }
+  }
+  return out_sum / count;
+}
+
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* map, long long pitch, int h, int w, int c,
+                                                        const float* rois, int k, float scale, float* out,
+                                                        int ps) {
+  const long long total = (long long)k * c * PP / (ps ? PP : 1);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int pw = (int)(idx % P);
+    const int ph = (int)((idx / P) % P);
+    const int cc = (int)((idx / PP) % (ps ? c / PP : c));
+    const int r = (int)(idx / ((long long)PP * (ps ? c / PP : c)));
+    out[idx] = ps ? ps_sample(map, pitch, h, w, rois + 5 * r, scale, (cc * P + ph) * P + pw, ph, pw)
+                  : roi_sample(map, pitch, h, w, rois + 5 * r, scale, cc, ph, pw);
+  }
+}
+
+// ---- proposal assembly --------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gather_class_boxes_kernel(const float* det, const int* count, int n,
+                                                                  int max_det, int num_classes, int class_idx,
+                                                                  int class_num, float* boxes, int* total) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int width = 7 + num_classes, cols = 8 + class_num;
+  if (t == 0) s_base = 0;
+  __syncthreads();
+  for (int img = 0; img < n; ++img) {
+    const int cnt = count[img];
+    for (int k0 = 0; k0 < cnt; k0 += 1024) {
+      const int k = k0 + t;
+      const float* d = det + ((long long)img * max_det + (k < cnt ? k : 0)) * width;
+      const bool take = (k < cnt) && (d[6] == (float)class_idx);
+      const unsigned long long m = __ballot(take);
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave[wv] = __popcll(m);
+      __syncthreads();
+      int woff = 0, all = 0;
+      for (int q = 0; q < 16; ++q) {
+        if (q < wv) woff += s_wave[q];
+        all += s_wave[q];
+      }
+      const int base = s_base;
+      if (take) {
+        float* o = boxes + (long long)(base + woff + before) * cols;
+        o[0] = (float)img;
+        for (int c = 0; c < 7 + class_num; ++c) o[1 + c] = d[c];
+      }
+      __syncthreads();
+      if (t == 0) s_base = base + all;
+      __syncthreads();
+    }
+  }
+  if (t == 0) *total = s_base;
+}
+
+// ---- fused RoI pooling + heads ---------------------------------------------------------------------
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.1f * v; }
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
+  __shared__ float s_feat[RPB][2 * FEAT];  // [r][0:490] image (PS-RoIAlign), [490:980] radar (RoIAlign)
+  __shared__ float s_hid[RPB][HID];
+  __shared__ float s_small[RPB][16];       // 0-3 reg, 4-5 cls logits(0,1), 6-15 radar conv
+  __shared__ float s_roi[RPB][5];
+
+  const int t = threadIdx.x;
+  const int n_img = *d.n_img;
+  const int total = n_img + d.n_radar;
+  const int k0 = blockIdx.x * RPB;
+  if (k0 >= total) return;
+  const int nr = (total - k0 < RPB) ? total - k0 : RPB;
+
+  if (t < RPB * 5) {
+    const int r = t / 5, c = t % 5;
+    float v = 0.f;
+    if (r < nr) {
+      const int k = k0 + r;
+      v = (k < n_img) ? d.img_boxes[(long long)k * d.box_cols + c] : d.radar_boxes[(long long)(k - n_img) * 5 + c];
+    }
+    s_roi[r][c] = v;
+  }
+  __syncthreads();
+
+  // phase A: pooled features
+  for (int idx = t; idx < nr * 2 * FEAT; idx += 256) {
+    const int r = idx / (2 * FEAT), f = idx % (2 * FEAT);
+    float v;
+    if (f < FEAT) {
+      const int pw = f % P, ph = (f / P) % P;
+      v = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_roi[r], d.spatial_scale, f, ph, pw);
+    } else {
+      const int g = f - FEAT;
+      const int pw = g % P, ph = (g / P) % P, c = g / PP;
+      v = roi_sample(d.radar_map, d.radar_pitch, d.fh, d.fw, s_roi[r], d.spatial_scale, c, ph, pw);
+    }
+    s_feat[r][f] = v;
+  }
+  __syncthreads();
+
+  // phase B: net0 (490 -> 256) + LeakyReLU; thread t = hidden unit t, all RoIs of the workgroup
+  {
+    float acc[RPB];
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) acc[r] = 0.f;
+    for (int k = 0; k < FEAT; ++k) {
+      const float w = d.wts.w0t[k * HID + t];
+#pragma unroll
+      for (int r = 0; r < RPB; ++r) acc[r] = fmaf(w, s_feat[r][k], acc[r]);
+    }
+    const float b = d.wts.b0[t];
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) s_hid[r][t] = leaky(acc[r] + b);
+  }
+  __syncthreads();
+
+  // phase C: the small dot products: (r, j) with j < 6 -> net1 rows 0-3 / net2 rows 0-1 over the
+  // hidden vector; 6 <= j < 16 -> radar_net 7x7 conv output j-6 over the pooled radar feature
+  {
+    const int r = t >> 5, j = t & 31;
+    if (r < nr && j < 16) {
+      float acc = 0.f;
+      if (j < 6) {
+        const float* wrow = (j < 4) ? d.wts.w1 + j * HID : d.wts.w2 + (j - 4) * HID;
+        for (int k = 0; k < HID; ++k) acc = fmaf(wrow[k], s_hid[r][k], acc);
+        acc += (j < 4) ? d.wts.b1[j] : d.wts.b2[j - 4];
+      } else {
+        const float* wrow = d.wts.rw + (j - 6) * FEAT;
+        for (int k = 0; k < FEAT; ++k) acc = fmaf(wrow[k], s_feat[r][FEAT + k], acc);
+      }
+      s_small[r][j] = acc;
+    }
+  }
+  __syncthreads();
+
+  // phase D: one thread per RoI - scalar tail
+  if (t < nr) {
+    const int r = t, k = k0 + r;
+    const float* sm = s_small[r];
+    const float cls0 = sigmoidf(sm[4]), cls1 = sigmoidf(sm[5]);
+    float rad = d.wts.rb2[0];
+#pragma unroll
+    for (int o = 0; o < C_OUT; ++o) rad = fmaf(d.wts.rw2[o], leaky(sm[6 + o] * d.wts.rscale[o] + d.wts.rshift[o]), rad);
+    const float radar_conf = sigmoidf(rad);
+    const float conf = sigmoidf(radar_conf + cls0);  // sigmoid applied twice on purpose (quirk q2)
+    const bool is_img = k < n_img;
+    float p;
+    float c6, c7;
+    if (is_img) {
+      const float* bx = d.img_boxes + (long long)k * d.box_cols;
+      const float yolo0 = bx[5], yolo1 = bx[8];
+      // ensemble_head: stack -> fc1 (2->32) + leaky -> flatten(64) -> fc2 (64->2) -> softmax; column 0 (q1)
+      float o0 = d.wts.e2b[0], o1 = d.wts.e2b[1];
+#pragma unroll 4
+      for (int u = 0; u < 32; ++u) {
+        const float wa = d.wts.e1w[2 * u], wb = d.wts.e1w[2 * u + 1], bb = d.wts.e1b[u];
+        const float h0 = leaky(wa * conf + wb * yolo0 + bb);
+        const float h1 = leaky(wa * cls1 + wb * yolo1 + bb);
+        o0 += d.wts.e2w[u] * h0 + d.wts.e2w[32 + u] * h1;
+        o1 += d.wts.e2w[64 + u] * h0 + d.wts.e2w[96 + u] * h1;
+      }
+      const float m = fmaxf(o0, o1);
+      const float e0 = expf(o0 - m), e1 = expf(o1 - m);
+      p = e0 / (e0 + e1);
+      c6 = bx[6];
+      c7 = bx[7];
+    } else {
+      p = conf;
+      c6 = cls1;
+      c7 = 0.f;
+    }
+    d.regress_out[4 * k + 0] = sm[0];
+    d.regress_out[4 * k + 1] = sm[1];
+    d.regress_out[4 * k + 2] = sm[2];
+    d.regress_out[4 * k + 3] = sm[3];
+    d.refine_out[2 * k + 0] = conf;
+    d.refine_out[2 * k + 1] = cls1;
+    d.mask1_out[k] = p;
+    const float thr = is_img ? d.thr_img : d.thr_radar;
+    d.keep[k] = (p > thr) ? 1 : 0;
+    d.sort_key[k] = is_img ? p : p / 5.f;
+    float x1 = s_roi[r][1], y1 = s_roi[r][2], x2 = s_roi[r][3], y2 = s_roi[r][4];
+    if (d.regress) {  // box_regress, my_models.py:378-391
+      const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2, bw = x2 - x1, bh = y2 - y1;
+      const float nx = sm[0] * bw + cx, ny = sm[1] * bh + cy;
+      const float nw = expf(sm[2]) * bw, nh = expf(sm[3]) * bh;
+      x1 = nx - nw / 2; y1 = ny - nh / 2; x2 = nx + nw / 2; y2 = ny + nh / 2;
+    }
+    float* o = d.out_rows + 8ll * k;
+    o[0] = s_roi[r][0]; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = p; o[6] = c6; o[7] = c7;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int me_gather_class_boxes_f32(const float* det, const int32_t* count, int32_t n, int32_t max_det,
+                              int32_t num_classes, int32_t class_idx, int32_t class_num, float* boxes,
+                              int32_t* total, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(det && count && boxes && total, ME_E_NULLPTR, "me_gather_class_boxes_f32: null pointer");
+  ME_REQUIRE(n > 0 && max_det > 0 && num_classes >= 1 && class_num >= 0 && class_num <= num_classes, ME_E_BADARG,
+             "me_gather_class_boxes_f32: bad dimensions");
+  hipLaunchKernelGGL(gather_class_boxes_kernel, dim3(1), dim3(1024), 0, stream, det, count, n, max_det, num_classes,
+                     class_idx, class_num, boxes, total);
+  return me::check_launch("gather_class_boxes_kernel");
+}
+
+int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(d, ME_E_NULLPTR, "me_roi_heads_f32: null descriptor");
+  ME_REQUIRE(d->img_map && d->radar_map && d->img_boxes && d->n_img, ME_E_NULLPTR, "me_roi_heads_f32: null input");
+  ME_REQUIRE(d->n_radar == 0 || d->radar_boxes, ME_E_NULLPTR, "me_roi_heads_f32: null radar_boxes");
+  ME_REQUIRE(d->regress_out && d->refine_out && d->mask1_out && d->out_rows && d->keep && d->sort_key, ME_E_NULLPTR,
+             "me_roi_heads_f32: null output");
+  const me_heads_weights& w = d->wts;
+  ME_REQUIRE(w.w0t && w.b0 && w.w1 && w.b1 && w.w2 && w.b2 && w.rw && w.rscale && w.rshift && w.rw2 && w.rb2 &&
+                 w.e1w && w.e1b && w.e2w && w.e2b,
+             ME_E_NULLPTR, "me_roi_heads_f32: null weight pointer");
+  ME_REQUIRE(d->n > 0 && d->fh > 0 && d->fw > 0 && d->n_img_cap >= 0 && d->n_radar >= 0 && d->box_cols >= 9,
+             ME_E_BADARG, "me_roi_heads_f32: bad dimensions");
+  ME_REQUIRE(d->img_pitch >= FEAT && d->radar_pitch >= C_OUT, ME_E_BADARG, "me_roi_heads_f32: map pitch too small");
+  const int cap = d->n_img_cap + d->n_radar;
+  if (cap == 0) return 0;
+  hipLaunchKernelGGL(roi_heads_kernel, dim3((cap + RPB - 1) / RPB), dim3(256), 0, stream, *d);
+  return me::check_launch("roi_heads_kernel");
+}
+
+static int launch_roi(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c, const float* rois,
+                      int32_t k, int32_t pooled, float scale, float* out, void* stream_, int ps) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(map && out && (rois || k == 0), ME_E_NULLPTR, "me_roi_align_f32: null pointer");
+  ME_REQUIRE(pooled == P, ME_E_BADARG, "me_roi_align_f32: only 7x7 pooling is built (my_models.py:495-496)");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && pitch >= c && k >= 0, ME_E_BADARG, "me_roi_align_f32: bad dims");
+  ME_REQUIRE(!ps || c % PP == 0, ME_E_BADARG, "me_ps_roi_align_f32: channels %% 49 != 0");
+  if (k == 0) return 0;
+  const long long total = (long long)k * c * PP / (ps ? PP : 1);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, map, (long long)pitch, h, w, c,
+                     rois, k, scale, out, ps);
+  return me::check_launch("roi_align_kernel");
+}
+
+int me_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c, const float* rois,
+                     int32_t k, int32_t pooled, float spatial_scale, float* out, void* stream) {
+  return launch_roi(map, pitch, n, h, w, c, rois, k, pooled, spatial_scale, out, stream, 0);
+}
+
+int me_ps_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                        const float* rois, int32_t k, int32_t pooled, float spatial_scale, float* out, void* stream) {
+  return launch_roi(map, pitch, n, h, w, c, rois, k, pooled, spatial_scale, out, stream, 1);
+}
+
+}  // extern "C"

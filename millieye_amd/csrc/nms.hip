@@ -1,0 +1,370 @@
+// nms.hip - confidence filter + class-aware greedy NMS on the GPU (gfx950).
+//
+// Replaces non_max_suppression_cpp (module3_our_dataset/utils/utils.py:337-378) and the
+// torchvision batched_nms / nms it calls (semantics: SURVEY.md Appendix C, restated bit for
+// bit in oracle/tv_ops.c).  Integer / index work is bit-exact with that oracle: the IoU
+// arithmetic below uses the same operation order with FP contraction off, comparisons are
+// written as the C++ std::max / std::min the CPU kernel uses (NaN behaviour included).
+//
+// Pipeline per call (three launches + one 4*n byte memset):
+//   nms_prep    one thread per prediction row: conf >= thr filter, xywh->xyxy, class
+//               max/argmax, append candidate {raw box, key, label, cls_conf} (wave-aggregated
+//               atomic append; order does not matter, the key carries the row index).
+//   nms_select  one 1024-thread workgroup per image: max-coordinate reduction (the batched_nms
+//               offset trick), then greedy selection: repeatedly take the alive candidate with
+//               the highest (score, lowest row) key - a 64-lane shuffle + LDS reduction - and
+//               suppress every alive candidate whose IoU with it exceeds the threshold.  Each
+//               thread owns <= 32 candidates and keeps their alive bits in one register.
+//               Stops after max_det winners (the reference keeps keep[:200]).
+//   nms_emit    gathers the kept rows into det[n, max_det, 7+C].
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int SEL_THREADS = 1024;
+constexpr int MAX_ROWS = 32768;  // 32 candidates per thread
+
+struct NmsWs {
+  float4* raw;               // [n][cap] raw xyxy
+  float4* off;               // [n][cap] boxes + label*(max+1)
+  unsigned long long* key;   // [n][cap] (sortable(score) << 32) | ~row
+  float* label;              // [n][cap]
+  float* clsconf;            // [n][cap]
+  int* keep_slot;            // [n][cap_keep] candidate slot of every winner
+  int* cand_count;           // [n]
+  int cap;
+};
+
+__host__ __device__ inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+
+inline long long ws_bytes(int n, int rows) {
+  const long long cap = rows;
+  long long b = 0;
+  b += align_up((long long)n * cap * 16, 256) * 2;  // raw, off
+  b += align_up((long long)n * cap * 8, 256);       // key
+  b += align_up((long long)n * cap * 4, 256) * 3;   // label, clsconf, keep_slot
+  b += align_up((long long)n * 4, 256);             // cand_count
+  return b;
+}
+
+inline NmsWs carve(void* base, int n, int rows) {
+  NmsWs w;
+  char* p = reinterpret_cast<char*>(base);
+  const long long cap = rows;
+  w.cap = rows;
+  w.raw = reinterpret_cast<float4*>(p); p += align_up((long long)n * cap * 16, 256);
+  w.off = reinterpret_cast<float4*>(p); p += align_up((long long)n * cap * 16, 256);
+  w.key = reinterpret_cast<unsigned long long*>(p); p += align_up((long long)n * cap * 8, 256);
+  w.label = reinterpret_cast<float*>(p); p += align_up((long long)n * cap * 4, 256);
+  w.clsconf = reinterpret_cast<float*>(p); p += align_up((long long)n * cap * 4, 256);
+  w.keep_slot = reinterpret_cast<int*>(p); p += align_up((long long)n * cap * 4, 256);
+  w.cand_count = reinterpret_cast<int*>(p);
+  return w;
+}
+
+__device__ __forceinline__ unsigned sortable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned long long make_key(float score, int row) {
+  return ((unsigned long long)sortable(score) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)row);
+}
+
+// ---- prep -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_prep_kernel(float* pred, int rows, int num_classes, float conf_thresh,
+                                                       int writeback, NmsWs w) {
+#pragma clang fp contract(off)
+  const int img = blockIdx.y;
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const int per = 5 + num_classes;
+  float* p = pred + ((long long)img * rows + row) * per;
+  const float cx = p[0], cy = p[1], bw = p[2], bh = p[3], conf = p[4];
+  // xywh2xyxy (utils.py:68-74): half extents as w / 2
+  const float x1 = cx - bw / 2, y1 = cy - bh / 2, x2 = cx + bw / 2, y2 = cy + bh / 2;
+  if (writeback) {
+    p[0] = x1; p[1] = y1; p[2] = x2; p[3] = y2;
+  }
+  if (!(conf >= conf_thresh)) return;
+  // torch.max(1): first index of the maximum
+  float best = -INFINITY;
+  int arg = 0;
+  if (num_classes > 0) {
+    best = p[5];
+    for (int c = 1; c < num_classes; ++c) {
+      const float v = p[5 + c];
+      if (v > best || (v != v && best == best)) {  // NaN propagates like torch.max
+        best = v;
+        arg = c;
+      }
+    }
+  }
+  const int slot = atomicAdd(&w.cand_count[img], 1);
+  const long long o = (long long)img * w.cap + slot;
+  w.raw[o] = make_float4(x1, y1, x2, y2);
+  w.key[o] = make_key(conf, row);
+  w.label[o] = (float)arg;
+  w.clsconf[o] = best;
+}
+
+// explicit boxes (box_ops.nms / batched_nms): every box is a candidate, img = 0
+__global__ __launch_bounds__(256) void nms_prep_boxes_kernel(const float* boxes, const float* scores,
+                                                             const float* labels, int m, NmsWs w) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= m) return;
+  w.raw[row] = make_float4(boxes[4 * row], boxes[4 * row + 1], boxes[4 * row + 2], boxes[4 * row + 3]);
+  w.key[row] = make_key(scores[row], row);
+  w.label[row] = labels ? labels[row] : 0.f;
+  w.clsconf[row] = 0.f;
+  if (row == 0) w.cand_count[0] = m;
+}
+
+// ---- select -----------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFull), s, 64);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), s, 64);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// torchvision nms_cpu_kernel IoU test, literal operation order (std::max(a,b) = a < b ? b : a).
+__device__ __forceinline__ bool iou_exceeds(const float4 bi, float iarea, const float4 bj, float jarea, float thr) {
+#pragma clang fp contract(off)
+  const float xx1 = (bi.x < bj.x) ? bj.x : bi.x;
+  const float yy1 = (bi.y < bj.y) ? bj.y : bi.y;
+  const float xx2 = (bj.z < bi.z) ? bj.z : bi.z;
+  const float yy2 = (bj.w < bi.w) ? bj.w : bi.w;
+  const float dw = xx2 - xx1, dh = yy2 - yy1;
+  const float ww = (0.f < dw) ? dw : 0.f;
+  const float hh = (0.f < dh) ? dh : 0.f;
+  const float inter = ww * hh;
+  const float ovr = inter / (iarea + jarea - inter);
+  return ovr > thr;
+}
+
+__device__ __forceinline__ float box_area(const float4 b) {
+#pragma clang fp contract(off)
+  return (b.z - b.x) * (b.w - b.y);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int use_offsets, float iou_thresh,
+                                                                 int max_det, int* out_count) {
+#pragma clang fp contract(off)
+  __shared__ unsigned long long s_red[SEL_THREADS / 64];
+  __shared__ float s_redf[SEL_THREADS / 64];
+  __shared__ int s_redi[SEL_THREADS / 64];
+  __shared__ float4 s_wbox;
+  __shared__ float s_warea;
+  __shared__ float s_maxc;
+
+  const int img = blockIdx.x;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
+  const int cnt = w.cand_count[img];
+  if (cnt == 0) {
+    if (t == 0) out_count[img] = 0;
+    return;
+  }
+  const long long base = (long long)img * w.cap;
+
+  // ---- offsets: boxes + label * (boxes.max() + 1)  (batched_nms) --------------------------
+  float maxc = 0.f;
+  if (use_offsets) {
+    float m = -INFINITY;
+    int nan = 0;
+    for (int j = t; j < cnt; j += SEL_THREADS) {
+      const float4 b = w.raw[base + j];
+      nan |= (b.x != b.x) | (b.y != b.y) | (b.z != b.z) | (b.w != b.w);
+      m = fmaxf(m, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      m = fmaxf(m, __shfl_xor(m, s, 64));
+      nan |= __shfl_xor(nan, s, 64);
+    }
+    if (lane == 0) {
+      s_redf[wv] = m;
+      s_redi[wv] = nan;
+    }
+    __syncthreads();
+    if (t == 0) {
+      float mm = s_redf[0];
+      int nn = s_redi[0];
+      for (int k = 1; k < SEL_THREADS / 64; ++k) {
+        mm = fmaxf(mm, s_redf[k]);
+        nn |= s_redi[k];
+      }
+      s_maxc = nn ? NAN : mm;
+    }
+    __syncthreads();
+    maxc = s_maxc;
+  }
+  unsigned alive = 0;
+  {
+    const float mp1 = maxc + 1.f;
+    int i = 0;
+    for (int j = t; j < cnt; j += SEL_THREADS, ++i) {
+      float4 b = w.raw[base + j];
+      if (use_offsets) {
+        const float o = w.label[base + j] * mp1;
+        b.x = b.x + o; b.y = b.y + o; b.z = b.z + o; b.w = b.w + o;
+      }
+      w.off[base + j] = b;
+      alive |= (1u << i);
+    }
+  }
+  // each thread only ever re-reads the w.off entries it wrote itself -> no barrier needed
+
+  int kept = 0;
+  bool have_winner = false;
+  float4 wbox = make_float4(0.f, 0.f, 0.f, 0.f);
+  float warea = 0.f;
+  while (true) {
+    unsigned long long best = 0ull;
+    int best_i = -1;
+    {
+      unsigned bits = alive;
+      while (bits) {
+        const int i = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const int j = t + i * SEL_THREADS;
+        if (have_winner) {
+          const float4 b = w.off[base + j];
+          if (iou_exceeds(wbox, warea, b, box_area(b), iou_thresh)) {
+            alive &= ~(1u << i);
+            continue;
+          }
+        }
+        const unsigned long long k = w.key[base + j];
+        if (k > best) {
+          best = k;
+          best_i = i;
+        }
+      }
+    }
+    unsigned long long g = wave_max_u64(best);
+    if (lane == 0) s_red[wv] = g;
+    __syncthreads();
+    g = s_red[0];
+#pragma unroll
+    for (int k = 1; k < SEL_THREADS / 64; ++k) g = s_red[k] > g ? s_red[k] : g;
+    if (g == 0ull) break;  // nothing alive (uniform)
+    if (best == g) {       // unique owner: keys embed the row index
+      const int j = t + best_i * SEL_THREADS;
+      alive &= ~(1u << best_i);
+      const float4 b = w.off[base + j];
+      s_wbox = b;
+      s_warea = box_area(b);
+      w.keep_slot[base + kept] = j;
+    }
+    __syncthreads();
+    wbox = s_wbox;
+    warea = s_warea;
+    have_winner = true;
+    ++kept;
+    if (kept >= max_det) break;
+  }
+  if (t == 0) out_count[img] = kept;
+}
+
+// ---- emit -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void nms_emit_kernel(const float* pred, int rows, int num_classes, int max_det,
+                                                       NmsWs w, const int* count, float* det) {
+  const int img = blockIdx.y, k = blockIdx.x;
+  if (k >= count[img]) return;
+  const long long base = (long long)img * w.cap;
+  const int slot = w.keep_slot[base + k];
+  const unsigned long long key = w.key[base + slot];
+  const int row = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+  const int per = 5 + num_classes, width = 7 + num_classes;
+  const float* p = pred + ((long long)img * rows + row) * per;
+  float* d = det + ((long long)img * max_det + k) * width;
+  const float4 b = w.raw[base + slot];
+  for (int c = threadIdx.x; c < width; c += 128) {
+    float v;
+    if (c == 0) v = b.x;
+    else if (c == 1) v = b.y;
+    else if (c == 2) v = b.z;
+    else if (c == 3) v = b.w;
+    else if (c == 4) v = p[4];
+    else if (c == 5) v = w.clsconf[base + slot];
+    else if (c == 6) v = w.label[base + slot];
+    else v = p[5 + (c - 7)];
+    d[c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void nms_emit_indices_kernel(NmsWs w, const int* count, long long* keep) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= count[0]) return;
+  const int slot = w.keep_slot[k];
+  const unsigned long long key = w.key[slot];
+  keep[k] = (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t me_nms_workspace_bytes(int32_t n, int32_t rows) {
+  if (n <= 0 || rows <= 0) return 0;
+  return ws_bytes(n, rows);
+}
+
+int me_nms_batched_f32(const me_nms_desc* d, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(d && d->pred && d->det && d->count && d->workspace, ME_E_NULLPTR, "me_nms_batched_f32: null pointer");
+  ME_REQUIRE(d->n > 0 && d->rows > 0 && d->num_classes >= 0 && d->max_det > 0, ME_E_BADARG,
+             "me_nms_batched_f32: bad dimensions");
+  ME_REQUIRE(d->rows <= MAX_ROWS, ME_E_TOOBIG, "me_nms_batched_f32: rows %d > capacity %d", d->rows, MAX_ROWS);
+  ME_REQUIRE(d->n <= 65535, ME_E_TOOBIG, "me_nms_batched_f32: batch too large");
+  ME_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 255u) == 0, ME_E_ALIGN,
+             "me_nms_batched_f32: workspace not 256-byte aligned");
+  NmsWs w = carve(d->workspace, d->n, d->rows);
+  ME_HIP(hipMemsetAsync(w.cand_count, 0, sizeof(int) * d->n, stream));
+  hipLaunchKernelGGL(nms_prep_kernel, dim3((d->rows + 255) / 256, d->n), dim3(256), 0, stream, d->pred, d->rows,
+                     d->num_classes, d->conf_thresh, d->writeback_xyxy, w);
+  int rc = me::check_launch("nms_prep_kernel");
+  if (rc) return rc;
+  const int max_det = d->max_det < d->rows ? d->max_det : d->rows;
+  hipLaunchKernelGGL(nms_select_kernel, dim3(d->n), dim3(SEL_THREADS), 0, stream, w, 1, d->iou_thresh, max_det,
+                     d->count);
+  rc = me::check_launch("nms_select_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_emit_kernel, dim3(max_det, d->n), dim3(128), 0, stream, d->pred, d->rows, d->num_classes,
+                     d->max_det, w, d->count, d->det);
+  return me::check_launch("nms_emit_kernel");
+}
+
+int me_nms_boxes_f32(const float* boxes, const float* scores, const float* labels, int32_t m, float iou_thresh,
+                     int64_t* keep, int32_t* keep_count, void* workspace, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(keep_count, ME_E_NULLPTR, "me_nms_boxes_f32: null keep_count");
+  if (m == 0) {  // batched_nms on an empty set returns an empty index tensor
+    ME_HIP(hipMemsetAsync(keep_count, 0, sizeof(int32_t), stream));
+    return 0;
+  }
+  ME_REQUIRE(boxes && scores && keep && workspace, ME_E_NULLPTR, "me_nms_boxes_f32: null pointer");
+  ME_REQUIRE(m > 0 && m <= MAX_ROWS, ME_E_TOOBIG, "me_nms_boxes_f32: m %d outside (0, %d]", m, MAX_ROWS);
+  ME_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, ME_E_ALIGN,
+             "me_nms_boxes_f32: workspace not 256-byte aligned");
+  NmsWs w = carve(workspace, 1, m);
+  hipLaunchKernelGGL(nms_prep_boxes_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, boxes, scores, labels, m, w);
+  int rc = me::check_launch("nms_prep_boxes_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, w, labels ? 1 : 0, iou_thresh, m,
+                     keep_count);
+  rc = me::check_launch("nms_select_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_emit_indices_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, w, keep_count,
+                     reinterpret_cast<long long*>(keep));
+  return me::check_launch("nms_emit_indices_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,510 @@
+"""Host-side planner / executor of the Darknet graph on the HIP library.
+
+``Darknet.forward`` of the reference (``module3_our_dataset/yolov3/models.py:247-267``) is a
+Python loop that dispatches one library op per cfg module and keeps every activation
+alive.  Here the cfg graph is compiled once per input shape into a short list of
+``libmillieye_hip`` launches:
+
+* conv + BN(eval) + LeakyReLU + bias are one kernel (``me_conv2d_f32``), with the
+  ``[shortcut]`` add and a following ``[upsample]`` fused into its epilogue when nobody
+  else reads the intermediate;
+* ``[route]`` concatenation is free: the producers write straight into channel slices of
+  one wider NHWC buffer (pitched stores), single-source routes are aliases;
+* activations live in one arena with liveness-based reuse (only tensors that a later
+  ``[route]``/``[shortcut]`` reads stay alive), so the working set of Darknet-53 at batch 8
+  stays inside the 256 MiB Infinity Cache instead of the reference's ~2.5 GB;
+* each ``[yolo]`` decode writes its rows directly at its offset of the final
+  ``[N, R, 5+C]`` tensor (no ``torch.cat``).
+
+Nothing in this file computes: it owns shapes, pointers and launch order.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+__all__ = ["DarknetEngine", "ConvWeights", "pick_tap_module"]
+
+_ALIGN = 64  # floats (256 bytes)
+
+
+def _resolve(idx, current):
+    """darknet layer reference -> absolute module index (negative = relative to ``current``)."""
+    idx = int(idx)
+    return current + idx if idx < 0 else idx
+
+
+def pick_tap_module(module_defs):
+    """Index of the module whose output is ``Darknet.featuremap``.
+
+    Reference rule (models.py:254-255): the ``nn.Sequential`` whose first child is named
+    ``conv_8`` - i.e. module 8 when it is convolutional (true for the tiny cfgs).  For cfgs where
+    module 8 is not a convolution (yolov3.cfg: a shortcut) the reference raises AttributeError;
+    documented extension: the last 256-filter convolution before the second
+    ``[yolo]`` block (yolov3.cfg module 91: 512->256 @ stride 16) - the only tensor compatible
+    with ``cnn_layers_1((256, 490))`` and ``spatial_scale = 1/16`` (my_models.py:427,495).
+    Returns ``None`` when no such module exists."""
+    if len(module_defs) > 8 and module_defs[8]["type"] == "convolutional":
+        return 8
+    yolos = [i for i, d in enumerate(module_defs) if d["type"] == "yolo"]
+    if len(yolos) < 2:
+        return None
+    tap = None
+    for i in range(yolos[0] + 1, yolos[1]):
+        d = module_defs[i]
+        if d["type"] == "convolutional" and int(d["filters"]) == 256:
+            tap = i
+    return tap
+
+
+class ConvWeights:
+    """Packed device copies of one conv block's parameters (weights OHWI, folded scale/shift).
+
+    The ``nn.Parameter``s of the module tree stay the source of truth (state_dict / optimizer /
+    checkpoint compatibility); this object re-packs them in place
+    whenever their version counters or storage change, so descriptor pointers stay valid."""
+
+    def __init__(self, conv, bn=None):
+        self.conv, self.bn = conv, bn
+        self.wgt = self.scale = self.shift = None
+        self._stamp = None
+
+    def _sources(self):
+        ts = [self.conv.weight]
+        if self.conv.bias is not None:
+            ts.append(self.conv.bias)
+        if self.bn is not None:
+            ts += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        return ts
+
+    def stamp(self):
+        return tuple((t.data_ptr(), t._version) for t in self._sources())
+
+    def refresh(self, device):
+        stamp = self.stamp()
+        if stamp == self._stamp and self.wgt is not None and self.wgt.device == device:
+            return False
+        with torch.no_grad():
+            w = self.conv.weight.detach().to(device=device, dtype=torch.float32)
+            packed = w.permute(0, 2, 3, 1).contiguous()
+            cout = w.shape[0]
+            if self.bn is not None:
+                g = self.bn.weight.detach().to(device, torch.float64)
+                b = self.bn.bias.detach().to(device, torch.float64)
+                mean = self.bn.running_mean.detach().to(device, torch.float64)
+                var = self.bn.running_var.detach().to(device, torch.float64)
+                scale = g / torch.sqrt(var + self.bn.eps)
+                shift = b - mean * scale
+                if self.conv.bias is not None:
+                    shift = shift + self.conv.bias.detach().to(device, torch.float64) * scale
+            else:
+                scale = torch.ones(cout, dtype=torch.float64, device=device)
+                if self.conv.bias is not None:
+                    shift = self.conv.bias.detach().to(device, torch.float64)
+                else:
+                    shift = torch.zeros(cout, dtype=torch.float64, device=device)
+            scale, shift = scale.to(torch.float32), shift.to(torch.float32)
+            realloc = self.wgt is None or self.wgt.device != device or self.wgt.shape != packed.shape
+            if realloc:
+                self.wgt, self.scale, self.shift = packed, scale.contiguous(), shift.contiguous()
+            else:  # keep the pointers the plans hold
+                self.wgt.copy_(packed)
+                self.scale.copy_(scale)
+                self.shift.copy_(shift)
+        self._stamp = stamp
+        return "realloc" if realloc else True
+
+
+class _Tensor:
+    __slots__ = ("h", "w", "c", "parent", "chan_off", "producers", "readers", "offset", "pinned", "external")
+
+    def __init__(self, h, w, c):
+        self.h, self.w, self.c = h, w, c
+        self.parent = None
+        self.chan_off = 0
+        self.producers = []
+        self.readers = []
+        self.offset = None
+        self.pinned = False
+        self.external = False  # the network input (NCHW, caller owned)
+
+    def root(self):
+        t, off = self, 0
+        while t.parent is not None:
+            off += t.chan_off
+            t = t.parent
+        return t, off
+
+
+class _Plan:
+    pass
+
+
+class DarknetEngine:
+    """Compiled execution of a :class:`millieye_amd.yolov3.models.Darknet` module tree."""
+
+    def __init__(self, model):
+        self.model = model
+        self._plans = {}
+        self._weights = {}
+        self.tap_module = pick_tap_module(model.module_defs)
+
+    # ---------------------------------------------------------------------------------- weights
+    def _conv_weights(self, i):
+        cw = self._weights.get(i)
+        if cw is None:
+            seq = self.model.module_list[i]
+            conv = seq[0]
+            bn = seq[1] if isinstance(seq[1] if len(seq) > 1 else None, torch.nn.BatchNorm2d) else None
+            cw = ConvWeights(conv, bn)
+            self._weights[i] = cw
+        return cw
+
+    def refresh_weights(self, device):
+        for i, d in enumerate(self.model.module_defs):
+            if d["type"] == "convolutional":
+                seq = self.model.module_list[i]
+                if len(seq) > 1 and isinstance(seq[1], torch.nn.BatchNorm2d) and seq[1].training:
+                    raise NotImplementedError(
+                        "Darknet BatchNorm in training mode (batch statistics) is not on the accelerated "
+                        "inference path; call model.eval() (the reference keeps base_detector.eval(), "
+                        "module3_our_dataset/train.py:170)")
+                if self._conv_weights(i).refresh(device) == "realloc" and self._plans:
+                    self._plans.clear()  # descriptors hold the old pointers
+
+    # ---------------------------------------------------------------------------------- planning
+    def _build(self, n, h, w, device):
+        defs = self.model.module_defs
+        L = len(defs)
+        hyper_c = int(self.model.hyperparams["channels"])
+
+        # who reads layer k?
+        readers = [[] for _ in range(L)]
+        srcs = [None] * L
+        for i, d in enumerate(defs):
+            t = d["type"]
+            if t in ("convolutional", "upsample", "maxpool", "yolo"):
+                srcs[i] = [i - 1]
+            elif t == "route":
+                srcs[i] = [_resolve(x, i) for x in d["layers"].split(",")]
+            elif t == "shortcut":
+                srcs[i] = [i - 1, _resolve(d["from"], i)]
+            else:
+                raise ValueError(f"unsupported cfg block [{t}] at module {i}")
+            for s in srcs[i]:
+                if s >= 0:
+                    readers[s].append(i)
+        tap = self.tap_module
+
+        tensors = []
+
+        def new_tensor(hh, ww, cc):
+            t = _Tensor(hh, ww, cc)
+            tensors.append(t)
+            return t
+
+        t_in = new_tensor(h, w, hyper_c)
+        t_in.external = True
+        out = [None] * L  # layer index -> _Tensor
+        ops = []  # dicts
+        fused_away = set()
+        yolo_rows = []
+        i = 0
+        while i < L:
+            d = defs[i]
+            t = d["type"]
+            if t == "convolutional":
+                x = t_in if i == 0 else out[i - 1]
+                if x is None:
+                    raise RuntimeError(f"module {i} reads a fused-away tensor")
+                k, s = int(d["size"]), int(d["stride"])
+                pad = (k - 1) // 2
+                cout = int(d["filters"])
+                ho = (x.h + 2 * pad - k) // s + 1
+                wo = (x.w + 2 * pad - k) // s + 1
+                act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
+                op = dict(kind="conv", module=i, x=x, res=None, k=k, s=s, pad=pad, act=act, ups=1, ho=ho, wo=wo)
+                nxt = defs[i + 1] if i + 1 < L else None
+                only_next = readers[i] == [i + 1] and i != tap
+                if (nxt is not None and nxt["type"] == "shortcut" and only_next and x.c > 4
+                        and srcs[i + 1][0] == i and out[srcs[i + 1][1]] is not None
+                        and srcs[i + 1][1] != i):
+                    res = out[srcs[i + 1][1]]
+                    if (res.h, res.w, res.c) == (ho, wo, cout):
+                        y = new_tensor(ho, wo, cout)
+                        op["res"] = res
+                        op["y"] = y
+                        op["covers"] = (i, i + 1)
+                        out[i + 1] = y
+                        fused_away.add(i)
+                        ops.append(op)
+                        i += 2
+                        continue
+                if (nxt is not None and nxt["type"] == "upsample" and int(nxt["stride"]) == 2 and only_next
+                        and x.c > 4):
+                    y = new_tensor(ho * 2, wo * 2, cout)
+                    op["ups"] = 2
+                    op["y"] = y
+                    op["covers"] = (i, i + 1)
+                    out[i + 1] = y
+                    fused_away.add(i)
+                    ops.append(op)
+                    i += 2
+                    continue
+                y = new_tensor(ho, wo, cout)
+                op["y"] = y
+                op["covers"] = (i,)
+                out[i] = y
+                ops.append(op)
+            elif t == "maxpool":
+                x = out[i - 1]
+                k, s = int(d["size"]), int(d["stride"])
+                zero_ext = (k == 2 and s == 1)
+                pad = (k - 1) // 2
+                ext = 1 if zero_ext else 0
+                ho = (x.h + ext + 2 * pad - k) // s + 1
+                wo = (x.w + ext + 2 * pad - k) // s + 1
+                y = new_tensor(ho, wo, x.c)
+                ops.append(dict(kind="pool", module=i, x=x, y=y, k=k, s=s, pad=pad, zero_ext=ext, ho=ho, wo=wo))
+                out[i] = y
+            elif t == "upsample":
+                x = out[i - 1]
+                f = int(d["stride"])
+                y = new_tensor(x.h * f, x.w * f, x.c)
+                ops.append(dict(kind="upsample", module=i, x=x, y=y, f=f))
+                out[i] = y
+            elif t == "shortcut":
+                a, b = out[srcs[i][0]], out[srcs[i][1]]
+                y = new_tensor(a.h, a.w, a.c)
+                ops.append(dict(kind="add", module=i, a=a, b=b, y=y))
+                out[i] = y
+            elif t == "route":
+                parts = [out[s] for s in srcs[i]]
+                if any(p is None for p in parts):
+                    raise RuntimeError(f"route {i} reads a fused-away tensor")
+                if len(parts) == 1:
+                    out[i] = parts[0]
+                else:
+                    cat = new_tensor(parts[0].h, parts[0].w, sum(p.c for p in parts))
+                    off = 0
+                    for p in parts:
+                        if (p.h, p.w) != (cat.h, cat.w):
+                            raise ValueError(f"route {i}: spatial size mismatch")
+                        if p.parent is None and not p.external and p is not cat and not _in_family(cat, p):
+                            p.parent, p.chan_off = cat, off
+                        else:  # already part of another concat: materialise a copy
+                            piece = new_tensor(p.h, p.w, p.c)
+                            piece.parent, piece.chan_off = cat, off
+                            ops.append(dict(kind="copy", module=i, x=p, y=piece))
+                        off += p.c
+                    out[i] = cat
+            elif t == "yolo":
+                x = out[i - 1]
+                if x.h != x.w or h != w:
+                    raise ValueError("YOLO decode needs square inputs (the reference uses one grid_size)")
+                yl = self.model.module_list[i][0]
+                na, nc = yl.num_anchors, yl.num_classes
+                if x.c != na * (nc + 5):
+                    raise ValueError(f"yolo {i}: {x.c} channels != {na}*({nc}+5)")
+                ops.append(dict(kind="yolo", module=i, x=x, layer=yl, g=x.h, row_offset=sum(yolo_rows)))
+                yolo_rows.append(na * x.h * x.h)
+                out[i] = None  # decoded rows are never routed
+            i += 1
+
+        # liveness (op index granularity)
+        for oi, op in enumerate(ops):
+            for key in ("x", "res", "a", "b"):
+                tt = op.get(key)
+                if tt is not None:
+                    tt.readers.append(oi)
+            if op.get("y") is not None:
+                op["y"].producers.append(oi)
+        tap_tensor = out[tap] if tap is not None and tap < L else None
+        if tap_tensor is not None:
+            tap_tensor.pinned = True
+
+        fam = {}
+        for tt in tensors:
+            if tt.external:
+                continue
+            root, _ = tt.root()
+            first, last, pin = fam.get(id(root), (10 ** 9, -1, False))
+            if tt.producers:
+                first = min(first, min(tt.producers))
+            if tt.readers:
+                last = max(last, max(tt.readers))
+            pin = pin or tt.pinned
+            fam[id(root)] = (first, last, pin)
+        roots = []
+        for tt in tensors:
+            if tt.external or tt.parent is not None or id(tt) not in fam:
+                continue
+            first, last, pin = fam[id(tt)]
+            if first == 10 ** 9:
+                continue  # never produced (should not happen)
+            if pin:
+                last = len(ops)
+            last = max(last, first)
+            size = -(-(n * tt.h * tt.w * tt.c) // _ALIGN) * _ALIGN
+            roots.append((first, last, size, tt))
+        roots.sort(key=lambda r: (r[0], -r[2]))
+        placed = []  # (offset, size, first, last)
+        total = 0
+        for first, last, size, tt in roots:
+            busy = sorted((o, s) for (o, s, f, l) in placed if not (l < first or f > last))
+            off = 0
+            for o, s in busy:
+                if off + size <= o:
+                    break
+                off = max(off, o + s)
+            tt.offset = off
+            placed.append((off, size, first, last))
+            total = max(total, off + size)
+
+        plan = _Plan()
+        plan.n, plan.h, plan.w = n, h, w
+        plan.arena = torch.empty(max(total, _ALIGN), dtype=torch.float32, device=device)
+        plan.arena_floats = total
+        plan.rows = sum(yolo_rows)
+        plan.num_classes = None
+        base = plan.arena.data_ptr()
+
+        def view(tt):
+            root, coff = tt.root()
+            return base + 4 * (root.offset + coff), root.c
+
+        lib = hip.lib()
+        launches = []
+        plan.input_descs = []
+        plan.yolo_descs = []
+        plan.conv_descs = []
+        flops = 0
+        for op in ops:
+            kind = op["kind"]
+            if kind == "conv":
+                cw = self._conv_weights(op["module"])
+                x, y = op["x"], op["y"]
+                dsc = hip.ConvDesc()
+                if x.external:
+                    dsc.x, dsc.x_pitch, dsc.x_nchw = None, x.c, 1
+                    plan.input_descs.append(dsc)
+                else:
+                    dsc.x, dsc.x_pitch = view(x)
+                    dsc.x_nchw = 0
+                dsc.wgt, dsc.scale, dsc.shift = cw.wgt.data_ptr(), cw.scale.data_ptr(), cw.shift.data_ptr()
+                if op["res"] is not None:
+                    dsc.res, dsc.res_pitch = view(op["res"])
+                else:
+                    dsc.res, dsc.res_pitch = None, 0
+                dsc.y, dsc.y_pitch = view(y)
+                dsc.n, dsc.h, dsc.w, dsc.cin = n, x.h, x.w, x.c
+                dsc.cout, dsc.ksize, dsc.stride, dsc.pad = cw.wgt.shape[0], op["k"], op["s"], op["pad"]
+                dsc.ho, dsc.wo, dsc.act, dsc.upsample, dsc.tile = op["ho"], op["wo"], op["act"], op["ups"], 0
+                launches.append((lib.me_conv2d_f32, (C.byref(dsc),), dsc, f"conv{op['module']}"))
+                plan.conv_descs.append((op["module"], dsc))
+                flops += 2 * n * op["ho"] * op["wo"] * dsc.cout * op["k"] * op["k"] * x.c
+            elif kind == "pool":
+                x, y = op["x"], op["y"]
+                dsc = hip.PoolDesc()
+                dsc.x, dsc.x_pitch = view(x)
+                dsc.y, dsc.y_pitch = view(y)
+                dsc.n, dsc.h, dsc.w, dsc.c = n, x.h, x.w, x.c
+                dsc.size, dsc.stride, dsc.pad, dsc.zero_ext = op["k"], op["s"], (0 if op["zero_ext"] else op["pad"]), \
+                    op["zero_ext"]
+                dsc.ho, dsc.wo = op["ho"], op["wo"]
+                launches.append((lib.me_maxpool_f32, (C.byref(dsc),), dsc, f"pool{op['module']}"))
+            elif kind == "upsample":
+                x, y = op["x"], op["y"]
+                (xp, xpitch), (yp, ypitch) = view(x), view(y)
+                launches.append((lib.me_upsample_f32, (xp, xpitch, yp, ypitch, n, x.h, x.w, x.c, op["f"]), None,
+                                 f"upsample{op['module']}"))
+            elif kind == "add":
+                a, b, y = op["a"], op["b"], op["y"]
+                (ap, apitch), (bp, bpitch), (yp, ypitch) = view(a), view(b), view(y)
+                launches.append((lib.me_add_f32, (ap, apitch, bp, bpitch, yp, ypitch, n * a.h * a.w, a.c), None,
+                                 f"add{op['module']}"))
+            elif kind == "copy":
+                x, y = op["x"], op["y"]
+                (xp, xpitch), (yp, ypitch) = view(x), view(y)
+                launches.append((lib.me_copy_f32, (xp, xpitch, yp, ypitch, n * x.h * x.w, x.c), None,
+                                 f"copy{op['module']}"))
+            elif kind == "yolo":
+                x, yl = op["x"], op["layer"]
+                dsc = hip.YoloDesc()
+                dsc.x, dsc.x_pitch = view(x)
+                dsc.out = None
+                dsc.n, dsc.g, dsc.num_anchors, dsc.num_classes = n, op["g"], yl.num_anchors, yl.num_classes
+                dsc.rows_total, dsc.row_offset = plan.rows, op["row_offset"]
+                stride = h / op["g"]
+                dsc.stride = stride
+                for k, (aw, ah) in enumerate(yl.anchors):
+                    dsc.anchors[2 * k] = aw / stride
+                    dsc.anchors[2 * k + 1] = ah / stride
+                plan.num_classes = yl.num_classes
+                plan.yolo_descs.append(dsc)
+                launches.append((lib.me_yolo_decode_f32, (C.byref(dsc),), dsc, f"yolo{op['module']}"))
+                # side effects the reference's YOLOLayer.forward has (models.py:135-156)
+                yl.img_dim = h
+                yl.grid_size = op["g"]
+                yl.stride = stride
+        plan.launches = launches
+        plan.conv_flops = flops
+        if tap_tensor is not None:
+            root, coff = tap_tensor.root()
+            pitch = root.c
+            plan.tap = torch.as_strided(
+                plan.arena, (n, tap_tensor.c, tap_tensor.h, tap_tensor.w),
+                (tap_tensor.h * tap_tensor.w * pitch, 1, tap_tensor.w * pitch, pitch), root.offset + coff)
+            plan.tap_ptr, plan.tap_pitch = base + 4 * (root.offset + coff), pitch
+            plan.tap_shape = (tap_tensor.h, tap_tensor.w, tap_tensor.c)
+        else:
+            plan.tap = None
+        return plan
+
+    def plan_for(self, x):
+        n, _, h, w = x.shape
+        key = (n, h, w, x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._build(n, h, w, x.device)
+            self._plans[key] = plan
+            if len(self._plans) > 8:  # multiscale callers: keep the arena count bounded
+                self._plans.pop(next(iter(self._plans)))
+        return plan
+
+    # ---------------------------------------------------------------------------------- execution
+    def run(self, x):
+        """x: CUDA fp32 NCHW [N,C,H,W].  Returns (plan, yolo_outputs [N,R,5+C]); the feature tap is
+        ``plan.tap`` (a view into the plan's arena, valid until the next ``run`` of that plan)."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            raise hip.MeError("Darknet input must be a 4-D CUDA float32 tensor [N,C,H,W]; this path has no CPU "
+                              "fallback (the CPU restatement is oracle/, test infrastructure only)")
+        x = x.contiguous()
+        self.refresh_weights(x.device)
+        plan = self.plan_for(x)
+        yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
+                               device=x.device)
+        xp = x.data_ptr()
+        for dsc in plan.input_descs:
+            dsc.x = xp
+        yp = yolo_out.data_ptr()
+        for dsc in plan.yolo_descs:
+            dsc.out = yp
+        stream = hip.stream_ptr()
+        for fn, args, _keep, name in plan.launches:
+            rc = fn(*args, stream)
+            if rc != 0:
+                hip.check(rc, name)
+        plan.last_input = x  # keep the caller's tensor alive until the stream has consumed it
+        return plan, yolo_out
+
+
+def _in_family(cat, p):
+    """True if ``cat`` is (transitively) a slice of ``p`` - guards against cyclic concat parents."""
+    t = cat
+    while t is not None:
+        if t is p:
+            return True
+        t = t.parent
+    return False

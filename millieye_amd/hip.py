@@ -1,0 +1,335 @@
+"""ctypes binding of ``libmillieye_hip.so`` (C ABI: ``include/millieye_hip.h``).
+
+This is the whole Python<->native boundary: struct mirrors, a lazy loader that fails
+loudly when the library is missing, and thin tensor-level wrappers used by the host-side
+modules.  PyTorch supplies device memory (``tensor.data_ptr()``) and the current HIP
+stream; nothing here computes.
+
+The library is built in-tree by ``__graft_entry__.build()`` (``hipcc --offload-arch=gfx950``)
+as ``millieye_amd/libmillieye_hip.so``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+__all__ = ["lib", "available", "default_device", "MeError"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmillieye_hip.so")
+
+ACT_LINEAR, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
+
+
+class MeError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wgt", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("res", C.c_void_p), ("y", C.c_void_p),
+        ("x_pitch", C.c_int64), ("res_pitch", C.c_int64), ("y_pitch", C.c_int64),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32),
+        ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32),
+        ("act", C.c_int32), ("upsample", C.c_int32), ("x_nchw", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p),
+        ("x_pitch", C.c_int64), ("y_pitch", C.c_int64),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
+        ("size", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("zero_ext", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32),
+    ]
+
+
+class YoloDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("out", C.c_void_p),
+        ("x_pitch", C.c_int64),
+        ("n", C.c_int32), ("g", C.c_int32), ("num_anchors", C.c_int32), ("num_classes", C.c_int32),
+        ("rows_total", C.c_int32), ("row_offset", C.c_int32),
+        ("stride", C.c_float),
+        ("anchors", C.c_float * 16),
+    ]
+
+
+class NmsDesc(C.Structure):
+    _fields_ = [
+        ("pred", C.c_void_p), ("det", C.c_void_p), ("count", C.c_void_p), ("workspace", C.c_void_p),
+        ("n", C.c_int32), ("rows", C.c_int32), ("num_classes", C.c_int32), ("max_det", C.c_int32),
+        ("conf_thresh", C.c_float), ("iou_thresh", C.c_float),
+        ("writeback_xyxy", C.c_int32),
+    ]
+
+
+class HeadsWeights(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in (
+        "w0t", "b0", "w1", "b1", "w2", "b2", "rw", "rscale", "rshift", "rw2", "rb2", "e1w", "e1b", "e2w", "e2b")]
+
+
+class HeadsDesc(C.Structure):
+    _fields_ = [
+        ("img_map", C.c_void_p), ("radar_map", C.c_void_p),
+        ("img_pitch", C.c_int64), ("radar_pitch", C.c_int64),
+        ("n", C.c_int32), ("fh", C.c_int32), ("fw", C.c_int32),
+        ("spatial_scale", C.c_float),
+        ("img_boxes", C.c_void_p), ("n_img", C.c_void_p),
+        ("n_img_cap", C.c_int32), ("box_cols", C.c_int32),
+        ("radar_boxes", C.c_void_p),
+        ("n_radar", C.c_int32),
+        ("thr_img", C.c_float), ("thr_radar", C.c_float),
+        ("regress", C.c_int32),
+        ("wts", HeadsWeights),
+        ("regress_out", C.c_void_p), ("refine_out", C.c_void_p), ("mask1_out", C.c_void_p),
+        ("out_rows", C.c_void_p), ("keep", C.c_void_p), ("sort_key", C.c_void_p),
+    ]
+
+
+_STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights}
+
+# name -> (restype, argtypes); every symbol include/millieye_hip.h declares
+SIGNATURES = {
+    "me_abi_version": (C.c_int, []),
+    "me_last_error": (C.c_char_p, []),
+    "me_device_query": (C.c_int, [C.POINTER(C.c_int32)] * 3),
+    "me_sizeof": (C.c_int32, [C.c_int32]),
+    "me_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "me_conv2d_flops": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "me_maxpool_f32": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p]),
+    "me_upsample_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_void_p]),
+    "me_add_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                             C.c_int32, C.c_void_p]),
+    "me_copy_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "me_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_void_p]),
+    "me_yolo_decode_f32": (C.c_int, [C.POINTER(YoloDesc), C.c_void_p]),
+    "me_nms_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "me_nms_batched_f32": (C.c_int, [C.POINTER(NmsDesc), C.c_void_p]),
+    "me_nms_boxes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "me_gather_class_boxes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "me_roi_heads_f32": (C.c_int, [C.POINTER(HeadsDesc), C.c_void_p]),
+    "me_roi_align_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "me_ps_roi_align_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen the library, bind every declared symbol, verify the ABI.  Raises ``MeError``
+    (never falls back) when the library is missing or does not match this binding."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MeError(
+            f"{path} not found: the HIP library is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    try:
+        lib_ = C.CDLL(path)
+    except OSError as exc:  # e.g. no ROCm runtime
+        raise MeError(f"cannot load {path}: {exc}") from exc
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib_, name)
+        except AttributeError as exc:
+            raise MeError(f"{path} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib_.me_abi_version() != 1:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 1")
+    for which, struct in _STRUCTS.items():
+        if lib_.me_sizeof(which) != C.sizeof(struct):
+            raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
+                          f"ctypes {C.sizeof(struct)}")
+    _lib = lib_
+    return _lib
+
+
+def lib():
+    return load()
+
+
+def available():
+    """True when the library is built AND a GPU is visible."""
+    return os.path.exists(LIB_PATH) and torch.cuda.is_available()
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise MeError("no HIP device visible: millieye_amd runs its hot path on MI355X only "
+                      "(the CPU restatement lives in oracle/ and is test infrastructure)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().me_last_error().decode("utf-8", "replace")
+        raise MeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda_f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise MeError(f"{name} must be a CUDA float32 tensor (got {type(t).__name__}"
+                      f"{'' if not isinstance(t, torch.Tensor) else f' {t.device} {t.dtype}'})")
+
+
+# --------------------------------------------------------------------------------------
+# tensor-level wrappers (stand-alone use + tests); the detector engine builds descriptors itself
+# --------------------------------------------------------------------------------------
+def pack_conv_weight(weight):
+    """OIHW -> [cout][ky][kx][cin] contiguous fp32 (the layout me_conv2d_f32 reads)."""
+    return weight.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+
+
+def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
+           x_nchw=False, tile=0):
+    """x_nhwc: [N,H,W,Cin] contiguous (or NCHW [N,Cin,H,W] when ``x_nchw``).  Returns NHWC
+    [N,Ho*up,Wo*up,Cout]."""
+    _require_cuda_f32(x_nhwc, "x")
+    if x_nchw:
+        n, cin, h, w = x_nhwc.shape
+    else:
+        n, h, w, cin = x_nhwc.shape
+    cout = wgt_packed.shape[0]
+    ho = (h + 2 * pad - ksize) // stride + 1
+    wo = (w + 2 * pad - ksize) // stride + 1
+    if out is None:
+        out = torch.empty((n, ho * upsample, wo * upsample, cout), device=x_nhwc.device, dtype=torch.float32)
+    d = ConvDesc()
+    d.x, d.wgt, d.scale, d.shift = x_nhwc.data_ptr(), wgt_packed.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    d.res = residual.data_ptr() if residual is not None else None
+    d.y = out.data_ptr()
+    d.x_pitch = cin
+    d.res_pitch = residual.shape[-1] if residual is not None else 0
+    d.y_pitch = out.shape[-1]
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+    d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, stride, pad, ho, wo
+    d.act, d.upsample, d.x_nchw, d.tile = act, upsample, 1 if x_nchw else 0, tile
+    check(lib().me_conv2d_f32(C.byref(d), stream_ptr()), "me_conv2d_f32")
+    return out
+
+
+def maxpool(x_nhwc, size, stride, zero_ext=False):
+    _require_cuda_f32(x_nhwc, "x")
+    n, h, w, c = x_nhwc.shape
+    pad = 0 if zero_ext else (size - 1) // 2
+    ext = 1 if zero_ext else 0
+    ho = (h + ext + 2 * pad - size) // stride + 1
+    wo = (w + ext + 2 * pad - size) // stride + 1
+    out = torch.empty((n, ho, wo, c), device=x_nhwc.device, dtype=torch.float32)
+    d = PoolDesc()
+    d.x, d.y, d.x_pitch, d.y_pitch = x_nhwc.data_ptr(), out.data_ptr(), c, c
+    d.n, d.h, d.w, d.c = n, h, w, c
+    d.size, d.stride, d.pad, d.zero_ext, d.ho, d.wo = size, stride, pad, ext, ho, wo
+    check(lib().me_maxpool_f32(C.byref(d), stream_ptr()), "me_maxpool_f32")
+    return out
+
+
+def upsample(x_nhwc, factor):
+    _require_cuda_f32(x_nhwc, "x")
+    n, h, w, c = x_nhwc.shape
+    out = torch.empty((n, h * factor, w * factor, c), device=x_nhwc.device, dtype=torch.float32)
+    check(lib().me_upsample_f32(x_nhwc.data_ptr(), c, out.data_ptr(), c, n, h, w, c, factor, stream_ptr()),
+          "me_upsample_f32")
+    return out
+
+
+def nhwc_to_nchw(x_nhwc):
+    _require_cuda_f32(x_nhwc, "x")
+    n, h, w, c = x_nhwc.shape
+    out = torch.empty((n, c, h, w), device=x_nhwc.device, dtype=torch.float32)
+    check(lib().me_nhwc_to_nchw_f32(x_nhwc.data_ptr(), c, out.data_ptr(), n, h, w, c, stream_ptr()),
+          "me_nhwc_to_nchw_f32")
+    return out
+
+
+def yolo_decode(x_nhwc, anchors, num_classes, img_dim, out=None, rows_total=None, row_offset=0):
+    """x_nhwc [N,G,G,A*(5+C)] -> rows of out [N,rows_total,5+C] (reference YOLOLayer decode)."""
+    _require_cuda_f32(x_nhwc, "x")
+    n, g, _, ch = x_nhwc.shape
+    na = len(anchors)
+    if rows_total is None:
+        rows_total = na * g * g
+    if out is None:
+        out = torch.empty((n, rows_total, 5 + num_classes), device=x_nhwc.device, dtype=torch.float32)
+    d = YoloDesc()
+    d.x, d.out, d.x_pitch = x_nhwc.data_ptr(), out.data_ptr(), ch
+    d.n, d.g, d.num_anchors, d.num_classes = n, g, na, num_classes
+    d.rows_total, d.row_offset = rows_total, row_offset
+    stride = img_dim / g
+    d.stride = stride
+    for k, (aw, ah) in enumerate(anchors):
+        d.anchors[2 * k] = aw / stride
+        d.anchors[2 * k + 1] = ah / stride
+    check(lib().me_yolo_decode_f32(C.byref(d), stream_ptr()), "me_yolo_decode_f32")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    off = (-ws.data_ptr()) % 256
+    return ws.data_ptr() + off, ws
+
+
+def nms_batched(pred, conf_thresh, iou_thresh, max_det, writeback_xyxy=True):
+    """pred [N,R,5+C] (modified in place when ``writeback_xyxy``) -> (det [N,max_det,7+C],
+    count int32 [N]) on the device; rows >= count are unspecified."""
+    _require_cuda_f32(pred, "prediction")
+    if not pred.is_contiguous():
+        raise MeError("prediction must be contiguous")
+    n, rows, per = pred.shape
+    nc = per - 5
+    det = torch.empty((n, max_det, 7 + nc), device=pred.device, dtype=torch.float32)
+    count = torch.empty((n,), device=pred.device, dtype=torch.int32)
+    if n == 0 or rows == 0:
+        return det, count.zero_()
+    nbytes = lib().me_nms_workspace_bytes(n, rows)
+    ws_ptr, _keep = _workspace(nbytes, pred.device)
+    d = NmsDesc()
+    d.pred, d.det, d.count, d.workspace = pred.data_ptr(), det.data_ptr(), count.data_ptr(), ws_ptr
+    d.n, d.rows, d.num_classes, d.max_det = n, rows, nc, max_det
+    d.conf_thresh, d.iou_thresh, d.writeback_xyxy = conf_thresh, iou_thresh, 1 if writeback_xyxy else 0
+    check(lib().me_nms_batched_f32(C.byref(d), stream_ptr()), "me_nms_batched_f32")
+    return det, count
+
+
+def nms_indices(boxes, scores, idxs, iou_threshold):
+    """torchvision-style ``nms`` / ``batched_nms``: int64 kept indices, descending score."""
+    src = boxes.device
+    dev = boxes if boxes.is_cuda else boxes.to(default_device())
+    m = dev.shape[0]
+    if m == 0:
+        return torch.empty((0,), dtype=torch.int64, device=src)
+    b = dev.to(torch.float32).contiguous()
+    s = scores.to(b.device, torch.float32).contiguous()
+    lab = idxs.to(b.device, torch.float32).contiguous() if idxs is not None else None
+    keep = torch.empty((m,), dtype=torch.int64, device=b.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=b.device)
+    ws_ptr, _keep = _workspace(lib().me_nms_workspace_bytes(1, m), b.device)
+    check(lib().me_nms_boxes_f32(b.data_ptr(), s.data_ptr(), lab.data_ptr() if lab is not None else None, m,
+                                 float(iou_threshold), keep.data_ptr(), cnt.data_ptr(), ws_ptr, stream_ptr()),
+          "me_nms_boxes_f32")
+    return keep[: int(cnt.item())].to(src)

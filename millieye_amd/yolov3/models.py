@@ -1,0 +1,255 @@
+"""``Darknet(cfg)`` - the YOLOv3 / yolov3-tiny detector, executed by HIP kernels.
+
+Host-side mirror of ``module3_our_dataset/yolov3/models.py`` (identical copies live in
+``module2_mixed/yolov3/models.py``): same constructor, same attributes (``module_defs``,
+``hyperparams``, ``module_list``, ``yolo_layers``, ``img_size``, ``seen``, ``header_info``,
+``featuremap``), same ``forward(x, targets=None)`` return tuples and the same darknet
+``.weights`` reader / writer.
+
+What differs is *execution*: the module tree below only **holds parameters** under the
+reference's exact names (``module_list.{i}.conv_{i}.weight``,
+``module_list.{i}.batch_norm_{i}.running_mean`` ... so ``state_dict`` / ``load_state_dict`` /
+``weights_init_normal`` / freeze-by-name keep working).  ``forward`` never
+calls those torch modules - it hands the graph to :class:`millieye_amd.engine.DarknetEngine`,
+which launches fused gfx950 kernels from ``libmillieye_hip.so``.
+"""
+from __future__ import division
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..engine import DarknetEngine
+from ..utils.parse_config import parse_model_config, parse_data_config  # noqa: F401 (re-export)
+from ..utils.utils import build_targets, to_cpu  # noqa: F401 (re-export, reference :9-10)
+
+__all__ = ["create_modules", "Upsample", "EmptyLayer", "YOLOLayer", "Darknet",
+           "parse_model_config", "parse_data_config"]
+
+
+class Upsample(nn.Module):
+    """Parameter-less marker for ``[upsample]`` (reference :82-92).  Executed as a fused conv
+    epilogue or ``me_upsample_f32``; ``forward`` exists for API completeness only."""
+
+    def __init__(self, scale_factor, mode="nearest"):
+        super().__init__()
+        self.scale_factor = scale_factor
+        self.mode = mode
+
+    def forward(self, x):
+        from .. import hip
+        if self.mode != "nearest":
+            raise NotImplementedError("only nearest-neighbour upsampling exists in darknet cfgs")
+        nhwc = x.permute(0, 2, 3, 1).contiguous()
+        return hip.upsample(nhwc, int(self.scale_factor)).permute(0, 3, 1, 2)
+
+
+class EmptyLayer(nn.Module):
+    """Placeholder for ``[route]`` / ``[shortcut]`` (reference :95-99)."""
+
+
+class YOLOLayer(nn.Module):
+    """Detection layer bookkeeping (reference :102-232).
+
+    Holds anchors / class count / loss hyper-parameters; the inference decode
+    (``me_yolo_decode_f32``) is issued by the engine as part of the whole-network launch list.
+    ``metrics`` must exist: ``Darknet`` finds its yolo layers by that attribute (reference :241)."""
+
+    def __init__(self, anchors, num_classes, img_dim=416):
+        super().__init__()
+        self.anchors = anchors
+        self.num_anchors = len(anchors)
+        self.num_classes = num_classes
+        self.ignore_thres = 0.5
+        self.mse_loss = nn.MSELoss()
+        self.bce_loss = nn.BCELoss()
+        self.obj_scale = 1
+        self.noobj_scale = 100
+        self.metrics = {}
+        self.img_dim = img_dim
+        self.grid_size = 0
+
+    def forward(self, x, targets=None, img_dim=None):
+        """Stand-alone decode of one raw detection map ``x`` [N, A*(5+C), G, G] (NCHW, as the
+        reference passes it).  Inference only; returns ``(output [N, A*G*G, 5+C], 0)``."""
+        from .. import hip
+        if targets is not None:
+            raise NotImplementedError(_TRAIN_MSG)
+        self.img_dim = img_dim if img_dim is not None else self.img_dim
+        self.grid_size = x.size(2)
+        self.stride = self.img_dim / self.grid_size
+        nhwc = x.permute(0, 2, 3, 1).contiguous()
+        return hip.yolo_decode(nhwc, self.anchors, self.num_classes, self.img_dim), 0
+
+
+_TRAIN_MSG = ("Darknet.forward(x, targets): the YOLO loss / detector backward (SURVEY.md section 8a row a6) is not "
+              "built yet - no m2/m3 script trains the detector (it is frozen: train.py:170, featuremap and "
+              "yolo_outputs are detached at models.py:255,266)")
+
+
+def _conv_block(index, spec, in_channels):
+    seq = nn.Sequential()
+    bn = int(spec["batch_normalize"])
+    filters = int(spec["filters"])
+    k = int(spec["size"])
+    seq.add_module(f"conv_{index}", nn.Conv2d(in_channels, filters, kernel_size=k, stride=int(spec["stride"]),
+                                              padding=(k - 1) // 2, bias=not bn))
+    if bn:
+        seq.add_module(f"batch_norm_{index}", nn.BatchNorm2d(filters, momentum=0.9, eps=1e-5))
+    if spec["activation"] == "leaky":
+        seq.add_module(f"leaky_{index}", nn.LeakyReLU(0.1))
+    return seq, filters
+
+
+def _maxpool_block(index, spec, in_channels):
+    seq = nn.Sequential()
+    k, s = int(spec["size"]), int(spec["stride"])
+    if k == 2 and s == 1:
+        seq.add_module(f"_debug_padding_{index}", nn.ZeroPad2d((0, 1, 0, 1)))
+    seq.add_module(f"maxpool_{index}", nn.MaxPool2d(kernel_size=k, stride=s, padding=int((k - 1) // 2)))
+    return seq, in_channels
+
+
+def create_modules(module_defs):
+    """cfg blocks -> ``(hyperparams, nn.ModuleList)`` with the reference's child names
+    (reference :12-79).  Pops the ``[net]`` block off ``module_defs`` like the reference."""
+    hyperparams = module_defs.pop(0)
+    widths = [int(hyperparams["channels"])]  # widths[1 + i] = output channels of module i
+    module_list = nn.ModuleList()
+    for index, spec in enumerate(module_defs):
+        kind = spec["type"]
+        if kind == "convolutional":
+            seq, filters = _conv_block(index, spec, widths[-1])
+        elif kind == "maxpool":
+            seq, filters = _maxpool_block(index, spec, widths[-1])
+        elif kind == "upsample":
+            seq = nn.Sequential()
+            seq.add_module(f"upsample_{index}", Upsample(scale_factor=int(spec["stride"]), mode="nearest"))
+            filters = widths[-1]
+        elif kind == "route":
+            seq = nn.Sequential()
+            seq.add_module(f"route_{index}", EmptyLayer())
+            filters = sum(widths[1:][int(l)] for l in spec["layers"].split(","))
+        elif kind == "shortcut":
+            seq = nn.Sequential()
+            seq.add_module(f"shortcut_{index}", EmptyLayer())
+            filters = widths[1:][int(spec["from"])]
+        elif kind == "yolo":
+            seq = nn.Sequential()
+            flat = [int(v) for v in spec["anchors"].split(",")]
+            pairs = [(flat[j], flat[j + 1]) for j in range(0, len(flat), 2)]
+            chosen = [pairs[int(m)] for m in spec["mask"].split(",")]
+            seq.add_module(f"yolo_{index}", YOLOLayer(chosen, int(spec["classes"]), int(hyperparams["height"])))
+            filters = widths[-1]
+        else:
+            raise ValueError(f"unsupported cfg block [{kind}] (module {index})")
+        module_list.append(seq)
+        widths.append(filters)
+    return hyperparams, module_list
+
+
+class Darknet(nn.Module):
+    """YOLOv3 object detector (reference :235-352), forward on MI355X."""
+
+    def __init__(self, config_path, img_size=416):
+        super().__init__()
+        self.module_defs = parse_model_config(config_path)
+        self.hyperparams, self.module_list = create_modules(self.module_defs)
+        self.yolo_layers = [layer[0] for layer in self.module_list if hasattr(layer[0], "metrics")]
+        self.img_size = img_size
+        self.seen = 0
+        self.header_info = np.array([0, 0, 0, self.seen, 0], dtype=np.int32)
+        # not a submodule / not in state_dict: plain attribute via object.__setattr__
+        object.__setattr__(self, "_engine", None)
+
+    # -- execution -----------------------------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            object.__setattr__(self, "_engine", DarknetEngine(self))
+        return self._engine
+
+    @property
+    def featuremap_module(self):
+        """Module index tapped as ``featuremap`` (8 = the reference's ``conv_8``; see
+        :func:`millieye_amd.engine.pick_tap_module` for the Darknet-53 extension)."""
+        return self.engine.tap_module
+
+    @featuremap_module.setter
+    def featuremap_module(self, index):
+        self.engine.tap_module = index
+        self.engine._plans.clear()
+
+    def _run(self, x):
+        """Internal: (plan, yolo_outputs) without cloning the feature tap (used by Network)."""
+        return self.engine.run(x)
+
+    def forward(self, x, targets=None):
+        if targets is not None:
+            raise NotImplementedError(_TRAIN_MSG)
+        plan, yolo_outputs = self._run(x)
+        if plan.tap is not None:
+            # fresh tensor per call like the reference's ``x.detach()`` of a fresh activation;
+            # memory stays channels-last (NHWC), shape is the reference's [N,256,S/16,S/16]
+            self.featuremap = plan.tap.clone()
+        if not hasattr(self, "featuremap"):
+            # same failure the reference has for cfgs without a ``conv_8`` child
+            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+        return self.featuremap, yolo_outputs
+
+    # -- darknet .weights I/O (reference :269-352) ---------------------------------------------
+    def _conv_blocks(self, stop=None):
+        for i, (spec, module) in enumerate(zip(self.module_defs, self.module_list)):
+            if stop is not None and i == stop:
+                return
+            if spec["type"] == "convolutional":
+                yield spec, module
+
+    def load_darknet_weights(self, weights_path):
+        """5 x int32 header, then per conv: [bn.bias, bn.weight, bn.running_mean, bn.running_var]
+        or [conv.bias], then conv.weight (OIHW), all float32."""
+        with open(weights_path, "rb") as fh:
+            header = np.fromfile(fh, dtype=np.int32, count=5)
+            self.header_info = header
+            self.seen = header[3]
+            stream = np.fromfile(fh, dtype=np.float32)
+        cutoff = None
+        if "darknet53.conv.74" in weights_path:
+            cutoff = 75
+        if "yolov3-tiny.conv.15" in weights_path:
+            cutoff = 15
+        cursor = 0
+
+        def take(dst):
+            nonlocal cursor
+            count = dst.numel()
+            dst.data.copy_(torch.from_numpy(stream[cursor: cursor + count]).view_as(dst))
+            cursor += count
+
+        for spec, module in self._conv_blocks(stop=cutoff):
+            conv = module[0]
+            if spec["batch_normalize"]:
+                bn = module[1]
+                for dst in (bn.bias, bn.weight, bn.running_mean, bn.running_var):
+                    take(dst)
+            else:
+                take(conv.bias)
+            take(conv.weight)
+
+    def save_darknet_weights(self, path, cutoff=-1):
+        """Inverse of :meth:`load_darknet_weights`; ``cutoff`` slices ``module_defs[:cutoff]``
+        exactly like the reference (so the default -1 drops the last module)."""
+        with open(path, "wb") as fp:
+            self.header_info[3] = self.seen
+            self.header_info.tofile(fp)
+            for spec, module in zip(self.module_defs[:cutoff], self.module_list[:cutoff]):
+                if spec["type"] != "convolutional":
+                    continue
+                conv = module[0]
+                if spec["batch_normalize"]:
+                    bn = module[1]
+                    for src in (bn.bias, bn.weight, bn.running_mean, bn.running_var):
+                        src.data.cpu().numpy().tofile(fp)
+                else:
+                    conv.bias.data.cpu().numpy().tofile(fp)
+                conv.weight.data.cpu().numpy().tofile(fp)

@@ -1,0 +1,114 @@
+"""ORACLE (test infrastructure - never imported by the product path).
+
+CPU restatement, in stock PyTorch fp32 ops, of the reference detector forward:
+
+  * cfg parsing            module3_our_dataset/utils/parse_config.py:3-21
+  * conv/BN/leaky blocks   module3_our_dataset/yolov3/models.py:22-41
+  * maxpool (+ zero pad)   models.py:43-49        * upsample  models.py:82-92
+  * route / shortcut       models.py:256-260      * YOLO decode models.py:132-179
+  * Darknet.forward        models.py:247-267 (returns featuremap, yolo_outputs)
+
+It is a *functional* evaluator: ``darknet_forward(cfg_text, state_dict, x)`` walks the parsed
+blocks and applies ``torch.nn.functional`` ops to tensors taken from a state dict with the
+reference's key names - the same library calls (MKLDNN conv, native batch_norm ...) the
+reference's CPU path ends up in, so it doubles as the timed CPU baseline in bench.py
+(``cpu_baseline.kind = "port"``).
+
+Pinning: tests/golden/darknet_*.npz were produced by importing the real reference
+(tests/golden/make_golden.py, Appendix-E recipe) on the same deterministic weights/inputs;
+tests/test_oracle_golden.py checks this file against them.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def parse_cfg_text(text):
+    """cfg text -> list of dict blocks ([net] first).  Values stay strings; convolutional blocks
+    default ``batch_normalize`` to integer 0 (reference parse_config.py:14-15)."""
+    blocks = []
+    for raw in text.split("\n"):
+        line = raw.strip()
+        if not line or line.startswith("#"):
+            continue
+        if line.startswith("["):
+            blocks.append({"type": line[1:-1].rstrip()})
+            if blocks[-1]["type"] == "convolutional":
+                blocks[-1]["batch_normalize"] = 0
+        else:
+            k, v = line.split("=")
+            blocks[-1][k.rstrip()] = v.strip()
+    return blocks
+
+
+def yolo_decode(x, anchors, num_classes, img_dim):
+    """Reference YOLOLayer inference branch (models.py:132-179) on an NCHW map."""
+    n, g = x.size(0), x.size(2)
+    na = len(anchors)
+    pred = x.view(n, na, num_classes + 5, g, g).permute(0, 1, 3, 4, 2).contiguous()
+    sx = torch.sigmoid(pred[..., 0])
+    sy = torch.sigmoid(pred[..., 1])
+    tw, th = pred[..., 2], pred[..., 3]
+    conf = torch.sigmoid(pred[..., 4])
+    cls = torch.sigmoid(pred[..., 5:])
+    stride = img_dim / g
+    gx = torch.arange(g).repeat(g, 1).view(1, 1, g, g).float()
+    gy = torch.arange(g).repeat(g, 1).t().view(1, 1, g, g).float()
+    scaled = torch.tensor([(aw / stride, ah / stride) for aw, ah in anchors], dtype=torch.float32)
+    aw = scaled[:, 0:1].view(1, na, 1, 1)
+    ah = scaled[:, 1:2].view(1, na, 1, 1)
+    boxes = torch.empty(pred[..., :4].shape, dtype=torch.float32)
+    boxes[..., 0] = sx + gx
+    boxes[..., 1] = sy + gy
+    boxes[..., 2] = torch.exp(tw) * aw
+    boxes[..., 3] = torch.exp(th) * ah
+    return torch.cat((boxes.view(n, -1, 4) * stride, conf.view(n, -1, 1), cls.view(n, -1, num_classes)), -1)
+
+
+def _anchors_of(block):
+    flat = [int(v) for v in block["anchors"].split(",")]
+    pairs = [(flat[i], flat[i + 1]) for i in range(0, len(flat), 2)]
+    return [pairs[int(m)] for m in block["mask"].split(",")]
+
+
+def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list.", return_layers=False):
+    """Evaluate the detector.  ``state_dict`` keys: ``{prefix}{i}.conv_{i}.weight`` etc.
+    Returns ``(featuremap or None, yolo_outputs [N,R,5+C])`` (+ per-module outputs on request)."""
+    blocks = parse_cfg_text(cfg_text)[1:]
+    img_dim = x.shape[2]
+    outs, yolo = [], []
+    feat = None
+    with torch.no_grad():
+        for i, b in enumerate(blocks):
+            kind = b["type"]
+            if kind == "convolutional":
+                k = int(b["size"])
+                w = state_dict[f"{prefix}{i}.conv_{i}.weight"]
+                bias = state_dict.get(f"{prefix}{i}.conv_{i}.bias")
+                x = F.conv2d(x, w, bias, stride=int(b["stride"]), padding=(k - 1) // 2)
+                if int(b["batch_normalize"]):
+                    p = f"{prefix}{i}.batch_norm_{i}."
+                    x = F.batch_norm(x, state_dict[p + "running_mean"], state_dict[p + "running_var"],
+                                     state_dict[p + "weight"], state_dict[p + "bias"], False, 0.9, 1e-5)
+                if b["activation"] == "leaky":
+                    x = F.leaky_relu(x, 0.1)
+                if i == tap_module:
+                    feat = x
+            elif kind == "maxpool":
+                k, s = int(b["size"]), int(b["stride"])
+                if k == 2 and s == 1:
+                    x = F.pad(x, (0, 1, 0, 1), value=0.0)
+                x = F.max_pool2d(x, k, s, (k - 1) // 2)
+            elif kind == "upsample":
+                x = F.interpolate(x, scale_factor=int(b["stride"]), mode="nearest")
+            elif kind == "route":
+                x = torch.cat([outs[int(l)] for l in b["layers"].split(",")], 1)
+            elif kind == "shortcut":
+                x = outs[-1] + outs[int(b["from"])]
+            elif kind == "yolo":
+                x = yolo_decode(x, _anchors_of(b), int(b["classes"]), img_dim)
+                yolo.append(x)
+            else:
+                raise ValueError(kind)
+            outs.append(x)
+    res = (feat, torch.cat(yolo, 1))
+    return res + (outs,) if return_layers else res
