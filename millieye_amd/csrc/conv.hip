@@ -327,9 +327,9 @@ struct TileCfg {
 // id 1..4; BK = 16 for all (LDS 2*(BM+BN)*20*4 B: 40 KiB for 128x128 -> 3-4 workgroups per CU)
 const TileCfg kTiles[] = {
     {1, 128, 128, 1.00f},
-    {2, 128, 64, 0.92f},
-    {3, 64, 64, 0.80f},
-    {4, 128, 32, 0.72f},
+    {2, 128, 64, 0.95f},
+    {3, 64, 64, 0.85f},
+    {4, 128, 32, 0.75f},
 };
 
 template <int BM, int BN, int BK, int WR, int WC>
@@ -356,14 +356,18 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
 
 int pick_tile(const ConvP& p) {
   // one "round" = every CU holding 2 workgroups; estimate rounds * tile work / efficiency
+  // makespan model: the busiest CU gets ceil(blocks / 256) workgroups; co-resident workgroups
+  // share its matrix pipe, whose utilisation grows with the number of waves per SIMD
+  // (measured round 1: ~0.55 with one workgroup per CU, ~0.75 with two, ~0.85 with three+).
+  static const double kUtil[4] = {0.55, 0.55, 0.75, 0.85};
   int best = 1;
   double best_cost = 1e300;
   for (const TileCfg& t : kTiles) {
     const long long tm = (p.M + t.bm - 1) / t.bm, tn = (p.cout + t.bn - 1) / t.bn;
     const long long blocks = tm * tn;
-    const double rounds = (double)((blocks + 511) / 512);
-    // below one full round the chip is not filled: cost is still one tile latency
-    const double cost = rounds * (double)t.bm * t.bn / t.eff;
+    const long long per_cu = (blocks + 255) / 256;
+    const double util = kUtil[per_cu > 3 ? 3 : per_cu] * t.eff;
+    const double cost = (double)per_cu * t.bm * t.bn / util;
     if (cost < best_cost) {
       best_cost = cost;
       best = t.id;

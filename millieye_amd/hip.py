@@ -333,3 +333,26 @@ def nms_indices(boxes, scores, idxs, iou_threshold):
                                  float(iou_threshold), keep.data_ptr(), cnt.data_ptr(), ws_ptr, stream_ptr()),
           "me_nms_boxes_f32")
     return keep[: int(cnt.item())].to(src)
+
+
+def _roi(fn_name, map_nhwc, rois, pooled, spatial_scale, ps):
+    _require_cuda_f32(map_nhwc, "map")
+    n, h, w, c = map_nhwc.shape
+    r = rois.to(map_nhwc.device, torch.float32).contiguous()
+    k = r.shape[0]
+    cout = c // (pooled * pooled) if ps else c
+    out = torch.empty((k, cout, pooled, pooled), device=map_nhwc.device, dtype=torch.float32)
+    fn = getattr(lib(), fn_name)
+    check(fn(map_nhwc.data_ptr(), c, n, h, w, c, r.data_ptr() if k else None, k, pooled, float(spatial_scale),
+             out.data_ptr(), stream_ptr()), fn_name)
+    return out
+
+
+def roi_align(map_nhwc, rois, pooled=7, spatial_scale=1.0 / 16):
+    """torchvision.ops.roi_align(aligned=False, sampling_ratio=-1) on an NHWC map -> [K,C,7,7]."""
+    return _roi("me_roi_align_f32", map_nhwc, rois, pooled, spatial_scale, False)
+
+
+def ps_roi_align(map_nhwc, rois, pooled=7, spatial_scale=1.0 / 16):
+    """torchvision.ops.ps_roi_align(sampling_ratio=-1) on an NHWC map -> [K,C/49,7,7]."""
+    return _roi("me_ps_roi_align_f32", map_nhwc, rois, pooled, spatial_scale, True)

@@ -1,0 +1,399 @@
+"""milliEye fusion network (stage 3): YOLO proposals + radar proposals -> refined detections.
+
+Host-side mirror of ``module3_our_dataset/my_models.py``: ``define_yolo``, ``init_yolo``,
+``Network(base_detector, conf_thresh)`` with the reference's attributes / children
+(``base_detector``, ``img_cnn_layers``, ``radar_cnn_layers``, ``refinement_head``,
+``ensemble_head``) and parameter names, and
+``forward(images, maps, radar_boxes_location, model_mode=0, targets=None)``.
+
+Execution: the sub-modules are parameter containers; ``forward`` stays on the GPU from the
+frames to the final ``[m, 8]`` rows (the reference bounces through the host three times,
+my_models.py:457,470,520):
+
+    Darknet engine -> me_nms_batched_f32 -> me_gather_class_boxes_f32
+      -> me_conv2d_f32 (1x1 256->490 score map; radar CNN 3->32->64->128->10)
+      -> me_roi_heads_f32 (PS-RoIAlign + RoIAlign + refinement head + ensemble head + box regress)
+      -> one compaction / ordering step and a single host sync for the data-dependent row count.
+"""
+import ctypes as C
+import random  # noqa: F401  (the reference's negative sampling uses python's RNG; training tail)
+
+import numpy as np  # noqa: F401
+import torch
+from torch import nn
+
+from . import hip
+from .engine import ConvWeights
+from .utils.utils import *  # noqa: F401,F403  (reference re-exports its utils through this module)
+from .utils.utils import xywh2xyxy, xyxy2xywh, bbox_iou
+from .yolov3.models import Darknet
+
+__all__ = ["define_yolo", "init_yolo", "cnn_layers_1", "cnn_layers_3", "ensemble_head", "refinement_head",
+           "FocalLoss", "obtain_iou_labels", "box_regress", "regression_loss", "Network"]
+
+_DETECTIONS_PER_IMG = 200  # non_max_suppression_cpp default (utils/utils.py:337)
+_NMS_THRESH = 0.5
+
+
+def define_yolo(model_def):
+    """cfg path -> :class:`Darknet` (reference my_models.py:13-24)."""
+    return Darknet(model_def)
+
+
+def init_yolo(model, weights_path):
+    """Load detector weights: darknet ``.weights``, ultralytics ``.pt`` (positional copy of
+    ``["model"]``), or a plain ``state_dict`` checkpoint (reference my_models.py:27-44)."""
+    if weights_path.endswith(".weights"):
+        model.load_darknet_weights(weights_path)
+    elif weights_path.endswith(".pt"):
+        param = torch.load(weights_path)["model"]
+        own = model.state_dict()
+        names = list(param)
+        for i, name in enumerate(own):
+            own[name] = param[names[i]]
+        model.load_state_dict(own)
+    else:
+        model.load_state_dict(torch.load(weights_path))
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers (names / shapes / construction order = reference, so default-init RNG
+# consumption, weights_init_normal and checkpoints line up)
+# --------------------------------------------------------------------------------------------------
+class cnn_layers_1(nn.Module):
+    """1x1 conv + BN + LeakyReLU stack producing the RoI score maps (reference :47-77)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.net = nn.Sequential()
+        for i in range(len(channels) - 1):
+            self.net.add_module(f"conv_{i}", nn.Conv2d(channels[i], channels[i + 1], kernel_size=(1, 1), stride=(1, 1)))
+            self.net.add_module(f"batch_norm_{i}", nn.BatchNorm2d(channels[i + 1], momentum=0.1))
+            self.net.add_module(f"leaky_{i}", nn.LeakyReLU(0.1))
+
+    def forward(self, x):
+        raise RuntimeError("cnn_layers_1 is executed by Network.forward through me_conv2d_f32")
+
+
+class cnn_layers_3(nn.Module):
+    """Radar heat-map CNN 3->32->64->128->10 + sigmoid (reference :130-157)."""
+
+    def __init__(self):
+        super().__init__()
+
+        def block(cin, cout):
+            return [nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1), nn.BatchNorm2d(cout, momentum=0.1),
+                    nn.LeakyReLU(0.1)]
+
+        self.conv1 = nn.Sequential(*block(3, 32))
+        self.conv2 = nn.Sequential(*block(32, 64))
+        self.conv3 = nn.Sequential(*block(64, 128), nn.Conv2d(128, 10, kernel_size=1, stride=1))
+
+    def forward(self, x):
+        raise RuntimeError("cnn_layers_3 is executed by Network.forward through me_conv2d_f32")
+
+
+class ensemble_head(nn.Module):
+    """(refinement vector, yolo vector) -> 2-way softmax (reference :176-210)."""
+
+    def __init__(self, channels, activation_softmax=True):
+        super().__init__()
+        self.activation_softmax = activation_softmax
+        self.fc1 = nn.Sequential(nn.Linear(channels[0], channels[1]), nn.LeakyReLU(0.1))
+        self.fc2 = nn.Sequential(nn.Linear(channels[2], channels[3]))
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, refinement_vector, yolo_vector):
+        raise RuntimeError("ensemble_head is fused into me_roi_heads_f32")
+
+
+class refinement_head(nn.Module):
+    """RoI features -> box regression + (confidence, class) vector (reference :213-284).
+    ``net3`` / ``fusion_head`` exist in the reference's state_dict but are never used."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.count = 0
+        tmp = 49
+        self.net0 = nn.Sequential(nn.Linear(channels[0], channels[1]), nn.LeakyReLU(0.1))
+        self.net1 = nn.Sequential(nn.Linear(channels[1], 4))
+        self.net2 = nn.Sequential(nn.Linear(channels[1], 13), nn.Sigmoid())
+        self.net3 = nn.Sequential(nn.Linear(channels[1], tmp), nn.Sigmoid())
+        self.radar_net = nn.Sequential(
+            nn.Conv2d(10, 10, kernel_size=7, stride=1, padding=0),
+            nn.BatchNorm2d(10, momentum=0.1),
+            nn.LeakyReLU(0.1),
+            nn.Conv2d(10, 1, kernel_size=1, stride=1, padding=0),
+            nn.Sigmoid(),
+        )
+        self.fusion_head = nn.Sequential(nn.Linear(2 * tmp, 1), nn.Sigmoid())
+
+    def forward(self, radar_maps, img_maps):
+        raise RuntimeError("refinement_head is fused into me_roi_heads_f32")
+
+
+# --------------------------------------------------------------------------------------------------
+# losses / helpers of the training tail (reference :287-408) - host-side float code
+# --------------------------------------------------------------------------------------------------
+class FocalLoss(nn.Module):
+    """alpha-balanced focal loss on one-hot labels (reference :287-314)."""
+
+    def __init__(self, device, alpha, gamma=2, reduction="sum"):
+        super().__init__()
+        self.alpha, self.gamma, self.reduction, self.device = alpha, gamma, reduction, device
+
+    def forward(self, inputs, labels):
+        alpha_pos = torch.full((labels.shape[0], 1), self.alpha).to(self.device)
+        alpha_neg = torch.full((labels.shape[0], 1), 1 - self.alpha).to(self.device)
+        alpha = torch.where(labels[:, 1:2] == 1, alpha_pos, alpha_neg)
+        probs = (inputs * labels).sum(1).view(-1, 1)
+        batch_loss = -alpha * (torch.pow((1 - probs), self.gamma)) * probs.log()
+        if self.reduction == "mean":
+            return batch_loss.mean()
+        return batch_loss.sum()
+
+
+def obtain_iou_labels(boxes, targets, multi_boxes=True):
+    """Max IoU (+1 convention) of every box with the same-image, same-class targets
+    (reference :317-375, incl. quirk q5; the reference's ``b.txt`` debug file is not written)."""
+    image_index, pred_classes, pred_boxes = boxes[:, :1], boxes[:, 1:2], boxes[:, 2:]
+    detected = []
+    iou_labels = torch.zeros((len(image_index), 1))
+    target_location = torch.zeros((len(image_index), 4))
+    for box_i in range(len(boxes)):
+        sel = (targets[:, 0] == image_index[box_i]) & (targets[:, 1] == pred_classes[box_i])
+        if not bool(sel.any()):
+            continue
+        target_boxes = targets[sel][:, 2:]
+        ious = bbox_iou(pred_boxes[box_i].unsqueeze(0), target_boxes)
+        if len(ious) > 0:
+            iou, target_index = ious.max(0)
+            if (target_index not in detected) or multi_boxes:
+                iou_labels[box_i] = iou
+                target_location[box_i] = target_boxes[target_index]
+                if iou > 0.7:
+                    detected += [target_index]
+    return iou_labels, target_location
+
+
+def box_regress(regress_param, roi_location):
+    """Apply (dx, dy, dw, dh) to xyxy RoIs (reference :378-391)."""
+    x, y, w, h = xyxy2xywh(roi_location).t()
+    xr = regress_param[:, 0] * w + x
+    yr = regress_param[:, 1] * h + y
+    wr = torch.exp(regress_param[:, 2]) * w
+    hr = torch.exp(regress_param[:, 3]) * h
+    return xywh2xyxy(torch.stack((xr, yr, wr, hr), 1))
+
+
+def regression_loss(regress_param, target_location, roi_location):
+    """SmoothL1 (sum) on the encoded regression targets (reference :394-408)."""
+    x, y, w, h = xyxy2xywh(roi_location).t()
+    xt, yt, wt, ht = xyxy2xywh(target_location).t()
+    p01 = torch.stack(((xt - x) / (w + 1e-16), (yt - y) / (h + 1e-16)), -1)
+    p23 = torch.stack((torch.log(wt / w + 1e-16), torch.log(ht / h + 1e-16)), -1)
+    loss_xy = torch.nn.SmoothL1Loss(reduction="sum")(p01, regress_param[:, :2])
+    loss_wh = torch.nn.SmoothL1Loss(reduction="sum")(p23, regress_param[:, 2:])
+    return loss_xy, loss_wh
+
+
+# --------------------------------------------------------------------------------------------------
+class _HeadPack:
+    """Device copies of the small head weights in the layouts ``me_roi_heads_f32`` reads."""
+
+    def __init__(self, net):
+        self.net = net
+        self._stamp = None
+        self.t = {}
+
+    def _sources(self):
+        rh, eh = self.net.refinement_head, self.net.ensemble_head
+        bn = rh.radar_net[1]
+        return [rh.net0[0].weight, rh.net0[0].bias, rh.net1[0].weight, rh.net1[0].bias, rh.net2[0].weight,
+                rh.net2[0].bias, rh.radar_net[0].weight, rh.radar_net[0].bias, bn.weight, bn.bias, bn.running_mean,
+                bn.running_var, rh.radar_net[3].weight, rh.radar_net[3].bias, eh.fc1[0].weight, eh.fc1[0].bias,
+                eh.fc2[0].weight, eh.fc2[0].bias]
+
+    def refresh(self, device):
+        stamp = tuple((t.data_ptr(), t._version) for t in self._sources()) + (str(device),)
+        if stamp == self._stamp:
+            return self.t
+        rh, eh = self.net.refinement_head, self.net.ensemble_head
+        f = dict(device=device, dtype=torch.float32)
+        with torch.no_grad():
+            bn = rh.radar_net[1]
+            rscale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            rshift = (rh.radar_net[0].bias.double() - bn.running_mean.double()) * rscale + bn.bias.double()
+            self.t = dict(
+                w0t=rh.net0[0].weight.detach().t().contiguous().to(**f), b0=rh.net0[0].bias.detach().to(**f),
+                w1=rh.net1[0].weight.detach().contiguous().to(**f), b1=rh.net1[0].bias.detach().to(**f),
+                w2=rh.net2[0].weight.detach().contiguous().to(**f), b2=rh.net2[0].bias.detach().to(**f),
+                rw=rh.radar_net[0].weight.detach().reshape(10, 490).contiguous().to(**f),
+                rscale=rscale.to(**f), rshift=rshift.to(**f),
+                rw2=rh.radar_net[3].weight.detach().reshape(10).contiguous().to(**f),
+                rb2=rh.radar_net[3].bias.detach().reshape(1).to(**f),
+                e1w=eh.fc1[0].weight.detach().contiguous().to(**f), e1b=eh.fc1[0].bias.detach().to(**f),
+                e2w=eh.fc2[0].weight.detach().contiguous().to(**f), e2b=eh.fc2[0].bias.detach().to(**f),
+            )
+        self._stamp = stamp
+        return self.t
+
+
+class Network(nn.Module):
+    """milliEye stage-3 network (reference my_models.py:411-641)."""
+
+    def __init__(self, base_detector, conf_thresh):
+        super().__init__()
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.conf_thresh = conf_thresh
+        self.seen = 0
+        self.iou_thresh = (0.3, 0.7)
+        self.alpha = 0.75
+        self.balance_factor = 5
+        self.loss_lambda = (6, 1)
+        self.refine_threshold_img, self.refine_threshold_radar = 0, 0
+        self.class_num = 1
+        self.class_idx = 0
+
+        self.base_detector = base_detector.eval()
+        self.img_cnn_layers = cnn_layers_1((256, 490))
+        self.radar_cnn_layers = cnn_layers_3()
+        self.refinement_head = refinement_head((490, 256, 128, self.class_num + 1))
+        self.ensemble_head = ensemble_head((2, 32, 32 * (1 + self.class_num), 2))
+
+        object.__setattr__(self, "_packs", None)
+
+    # ---------------------------------------------------------------------------------- helpers
+    def _get_packs(self):
+        if self._packs is None:
+            rc = self.radar_cnn_layers
+            packs = dict(
+                img=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1]),
+                r1=ConvWeights(rc.conv1[0], rc.conv1[1]),
+                r2=ConvWeights(rc.conv2[0], rc.conv2[1]),
+                r3=ConvWeights(rc.conv3[0], rc.conv3[1]),
+                r4=ConvWeights(rc.conv3[3], None),
+                heads=_HeadPack(self),
+            )
+            object.__setattr__(self, "_packs", packs)
+        return self._packs
+
+    def _check_eval(self):
+        bns = [self.img_cnn_layers.net[1], self.radar_cnn_layers.conv1[1], self.radar_cnn_layers.conv2[1],
+               self.radar_cnn_layers.conv3[1], self.refinement_head.radar_net[1]]
+        if any(b.training for b in bns):
+            raise NotImplementedError(
+                "Network.forward in train() mode (batch-statistics BatchNorm + the stage-3 loss/backward, "
+                "SURVEY.md rows a17/K14) is not built yet; call model.eval() for inference")
+
+    @staticmethod
+    def _conv(x_ptr, x_pitch, x_nchw, n, h, w, cin, cw, ksize, pad, act, out):
+        d = hip.ConvDesc()
+        d.x, d.x_pitch, d.x_nchw = x_ptr, x_pitch, 1 if x_nchw else 0
+        d.wgt, d.scale, d.shift, d.res, d.res_pitch = cw.wgt.data_ptr(), cw.scale.data_ptr(), cw.shift.data_ptr(), None, 0
+        d.y, d.y_pitch = out.data_ptr(), out.shape[-1]
+        d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cw.wgt.shape[0]
+        d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, 1, pad, h, w
+        d.act, d.upsample, d.tile = act, 1, 0
+        hip.check(hip.lib().me_conv2d_f32(C.byref(d), hip.stream_ptr()), "me_conv2d_f32")
+        return out
+
+    # ---------------------------------------------------------------------------------- forward
+    def forward(self, images, maps, radar_boxes_location, model_mode=0, targets=None):
+        """See the reference docstring (my_models.py:434-450).  Returns ``output [m, 8]`` rows
+        ``(image_i, x1, y1, x2, y2, object_conf, class_score, class_pred)`` sorted by confidence.
+
+        Compat rule: ``train.py:185`` passes ``targets`` in the ``model_mode`` slot; a
+        tensor there is therefore taken as ``targets`` with mode 0."""
+        if isinstance(model_mode, torch.Tensor):
+            targets, model_mode = model_mode, 0
+        if targets is not None:
+            raise NotImplementedError("the stage-3 training tail (loss + backward) is not built yet "
+                                      "(SURVEY.md rows a17 / K14)")
+        if not images.is_cuda:
+            raise hip.MeError("Network.forward needs CUDA tensors (MI355X); there is no CPU fallback")
+        dev = images.device
+        n = images.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        # ---- candidate boxes from the base detector (reference :454-473), all on device
+        plan, yolo_out = self.base_detector._run(images)
+        det, cnt = hip.nms_batched(yolo_out, float(self.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
+                                   writeback_xyxy=False)
+        num_classes = yolo_out.shape[2] - 5
+        cols = 8 + self.class_num
+        cap_img = n * _DETECTIONS_PER_IMG
+        img_boxes = torch.empty((cap_img, cols), **f32)
+        n_img_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+        lib = hip.lib()
+        hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
+                                                int(self.class_idx), int(self.class_num), img_boxes.data_ptr(),
+                                                n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
+        if model_mode == 1:  # yolo only
+            return img_boxes[: int(n_img_dev.item()), :8]
+        if model_mode == 2:  # radar only: permanent, like the reference (quirk q3)
+            self.refine_threshold_img = 1
+
+        # ---- score maps (reference :486-487)
+        self._check_eval()
+        if plan.tap is None:
+            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+        packs = self._get_packs()
+        for key in ("img", "r1", "r2", "r3", "r4"):
+            packs[key].refresh(dev)
+        fh, fw, fc = plan.tap_shape
+        roi_score_map = torch.empty((n, fh, fw, 490), **f32)
+        self._conv(plan.tap_ptr, plan.tap_pitch, False, n, fh, fw, fc, packs["img"], 1, 0, hip.ACT_LEAKY, roi_score_map)
+        maps = maps.contiguous()
+        if not (maps.is_cuda and maps.dtype == torch.float32):
+            raise hip.MeError("radar maps must be CUDA float32 [N,3,h,w]")
+        mh, mw = maps.shape[2], maps.shape[3]
+        t1 = torch.empty((n, mh, mw, 32), **f32)
+        t2 = torch.empty((n, mh, mw, 64), **f32)
+        t3 = torch.empty((n, mh, mw, 128), **f32)
+        radar_score_map = torch.empty((n, mh, mw, 12), **f32)  # 10 channels, pitch 12
+        self._conv(maps.data_ptr(), 3, True, n, mh, mw, 3, packs["r1"], 3, 1, hip.ACT_LEAKY, t1)
+        self._conv(t1.data_ptr(), 32, False, n, mh, mw, 32, packs["r2"], 3, 1, hip.ACT_LEAKY, t2)
+        self._conv(t2.data_ptr(), 64, False, n, mh, mw, 64, packs["r3"], 3, 1, hip.ACT_LEAKY, t3)
+        self._conv(t3.data_ptr(), 128, False, n, mh, mw, 128, packs["r4"], 1, 0, hip.ACT_SIGMOID, radar_score_map)
+        if (mh, mw) != (fh, fw):
+            # the reference hands both maps to RoI ops with the same spatial_scale; a size mismatch is
+            # legal there (demo feeds 32x32, quirk q15) - the pooling kernel takes per-map sizes
+            raise NotImplementedError("radar map size != feature map size (demo-only configuration, quirk q15)")
+
+        # ---- RoIs: image proposals then radar proposals (reference :490-492)
+        if len(radar_boxes_location) > 0:
+            radar_boxes_location[:, 1:] *= images.shape[-1]  # in place on the caller's tensor, like the reference
+        n_radar = int(radar_boxes_location.shape[0])
+        rb = radar_boxes_location.to(**f32).contiguous() if n_radar else None
+        cap = cap_img + n_radar
+        regress = torch.empty((cap, 4), **f32)
+        refine = torch.empty((cap, 2), **f32)
+        mask1 = torch.empty((cap,), **f32)
+        rows = torch.empty((cap, 8), **f32)
+        keep = torch.zeros((cap,), device=dev, dtype=torch.uint8)
+        key = torch.empty((cap,), **f32)
+
+        hw = packs["heads"].refresh(dev)
+        d = hip.HeadsDesc()
+        d.img_map, d.radar_map = roi_score_map.data_ptr(), radar_score_map.data_ptr()
+        d.img_pitch, d.radar_pitch = 490, 12
+        d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16
+        d.img_boxes, d.n_img, d.n_img_cap, d.box_cols = img_boxes.data_ptr(), n_img_dev.data_ptr(), cap_img, cols
+        d.radar_boxes, d.n_radar = (rb.data_ptr() if n_radar else None), n_radar
+        d.thr_img, d.thr_radar = float(self.refine_threshold_img), float(self.refine_threshold_radar)
+        d.regress = 0 if model_mode == 2 else 1
+        for name in ("w0t", "b0", "w1", "b1", "w2", "b2", "rw", "rscale", "rshift", "rw2", "rb2", "e1w", "e1b", "e2w",
+                     "e2b"):
+            setattr(d.wts, name, hw[name].data_ptr())
+        d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
+        d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
+        hip.check(lib.me_roi_heads_f32(C.byref(d), hip.stream_ptr()), "me_roi_heads_f32")
+        self.refinement_head.count += 1
+
+        # ---- keep positives, order by confidence (reference :517-539); the one host sync
+        idx = torch.nonzero(keep, as_tuple=False).flatten()
+        order = torch.sort(key[idx], descending=True, stable=True).indices
+        output = rows[idx[order]]
+        self._last = dict(regress=regress, refine=refine, mask1=mask1, n_img=n_img_dev, img_boxes=img_boxes)
+        return output

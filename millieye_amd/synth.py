@@ -12,7 +12,7 @@ bounded to +-6 sigma, exact in float64, which is all a weight init needs.
 """
 import numpy as np
 
-__all__ = ["tag_seed", "uniform", "normal", "fill_state_dict", "trained_like_"]
+__all__ = ["tag_seed", "uniform", "normal", "fill_state_dict", "fill_darknet_", "trained_like_"]
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -108,12 +108,110 @@ def fill_state_dict(module, tag, conv_std=None, linear_std=None, bn_weight=(0.8,
     return module
 
 
+def fill_darknet_(darknet, tag):
+    """Deterministic Darknet weights whose activations stay O(1) through all 75 conv layers.
+
+    A plain He init explodes through Darknet-53 (23 residual adds, BN in eval mode with unit
+    running variance does not normalise anything): outputs reach 1e4 and every sigmoid of the
+    YOLO heads saturates, which would make parity tests blind.  A trained checkpoint does not do
+    that because each BatchNorm's running variance matches the variance of its input.  This
+    routine emulates that without running the network: it propagates the second moment ``q`` of
+    the activations through the cfg graph analytically (conv: var = fan_in * std_w^2 * q; leaky:
+    x0.505; shortcut: sum; route: channel-weighted mean) and sets every BN's ``running_var`` to
+    the predicted variance of its conv output (x U(0.8, 1.25)), so each block re-normalises.
+    """
+    import torch
+
+    defs = darknet.module_defs
+    q = [None] * len(defs)  # second moment of each module's output
+    q_in = 1.0 / 3.0        # frames are U[0,1)
+    chans = [int(darknet.hyperparams["channels"])]
+    with torch.no_grad():
+        for i, d in enumerate(defs):
+            kind = d["type"]
+            prev = q[i - 1] if i > 0 else q_in
+            if kind == "convolutional":
+                seq = darknet.module_list[i]
+                conv = seq[0]
+                cout, cin, kh, kw = conv.weight.shape
+                fan_in = cin * kh * kw
+                std = (2.0 / fan_in) ** 0.5
+                k = f"{tag}/module_list.{i}"
+                conv.weight.copy_(torch.from_numpy(normal(k + ".w", (cout, cin, kh, kw), 0.0, std)))
+                var_c = fan_in * std * std * prev
+                if int(d["batch_normalize"]):
+                    bn = seq[1]
+                    bn.weight.copy_(torch.from_numpy(uniform(k + ".g", (cout,), 0.8, 1.2)))
+                    bn.bias.copy_(torch.from_numpy(normal(k + ".b", (cout,), 0.0, 0.1)))
+                    bn.running_mean.copy_(torch.from_numpy(normal(k + ".m", (cout,), 0.0, 0.1 * var_c ** 0.5)))
+                    bn.running_var.copy_(torch.from_numpy(uniform(k + ".v", (cout,), 0.8 * var_c, 1.25 * var_c)))
+                    bn.num_batches_tracked.zero_()
+                    out_q = 1.08  # E[g^2] * E[var_c / running_var] + bias^2
+                else:
+                    conv.bias.copy_(torch.from_numpy(normal(k + ".cb", (cout,), 0.0, 0.1)))
+                    out_q = var_c + 0.01
+                if d["activation"] == "leaky":
+                    out_q *= 0.505
+                q[i] = out_q
+                chans.append(cout)
+            elif kind == "maxpool":
+                q[i] = prev * 1.6  # max of four positively correlated samples
+                chans.append(chans[-1])
+            elif kind == "upsample":
+                q[i] = prev
+                chans.append(chans[-1])
+            elif kind == "route":
+                idx = [int(v) for v in d["layers"].split(",")]
+                idx = [i + v if v < 0 else v for v in idx]
+                cs = [chans[1:][j] for j in idx]
+                q[i] = sum(q[j] * c for j, c in zip(idx, cs)) / sum(cs)
+                chans.append(sum(cs))
+            elif kind == "shortcut":
+                frm = int(d["from"])
+                j = i + frm if frm < 0 else frm
+                q[i] = q[i - 1] + q[j]
+                chans.append(chans[-1])
+            elif kind == "yolo":
+                q[i] = prev
+                chans.append(chans[-1])
+    return darknet
+
+
+def fill_network_(net, tag, trained_like=True):
+    """Deterministic weights for a whole fusion ``Network`` (product or reference instance - the
+    module / parameter names are identical): calibrated detector (+ trained-like detection
+    convs), He-style heads with non-trivial BatchNorm statistics."""
+    fill_darknet_(net.base_detector, tag + "/det")
+    if trained_like:
+        trained_like_(net.base_detector, tag + "/det/trained")
+    for name in ("img_cnn_layers", "radar_cnn_layers", "refinement_head", "ensemble_head"):
+        fill_state_dict(getattr(net, name), f"{tag}/{name}")
+    return net
+
+
+def radar_inputs(tag, n, side, boxes_per_image=2, density=0.02):
+    """Synthetic radar heat maps ``[n,3,side,side]`` (about ``density`` non-zeros in [0,1], the
+    measured sparsity of real maps) and radar box proposals ``[n*b,5]`` =
+    (image_i, x1, y1, x2, y2) in [0,1] units with x1 < x2, y1 < y2."""
+    m = uniform(tag + "/maps", (n, 3, side, side))
+    mask = uniform(tag + "/mask", (n, 3, side, side)) < density
+    maps = np.where(mask, m, 0.0).astype(np.float32)
+    c = uniform(tag + "/bc", (n * boxes_per_image, 2), 0.2, 0.8)
+    half = uniform(tag + "/bs", (n * boxes_per_image, 2), 0.05, 0.2)
+    idx = np.repeat(np.arange(n, dtype=np.float32), boxes_per_image)[:, None]
+    boxes = np.concatenate([idx, c - half, c + half], 1).astype(np.float32)
+    return maps, boxes
+
+
 def _is_bn(sd, key):
     stem = key.rsplit(".", 1)[0]
     return (stem + ".running_var") in sd
 
 
-def trained_like_(darknet, tag="trained", obj_bias=-4.0, obj_std=2.0, wh_std=0.5, cls_bias=-2.0):
+_DET_GAIN = {107: [4.0, 1.93, 1.34], 24: [0.30, 0.36]}  # yolov3.cfg / yolov3-tiny cfgs
+
+
+def trained_like_(darknet, tag="trained", obj_bias=-4.0, obj_std=2.0, wh_std=0.5, cls_bias=-2.0, gains=None):
     """Give the detection convolutions of a ``Darknet`` (in place) the output statistics of
     a *trained* detector: objectness logits around
     ``obj_bias`` so that only a few percent of rows pass ``conf_thresh``, ``tw/th`` ~
@@ -126,6 +224,11 @@ def trained_like_(darknet, tag="trained", obj_bias=-4.0, obj_std=2.0, wh_std=0.5
     import torch
 
     defs = darknet.module_defs
+    if gains is None:
+        # measured std of unit-scale detection logits on fill_darknet_ weights at 416x416
+        # (the backbone's activations drift upward a little): per [yolo] block, cfg order
+        gains = _DET_GAIN.get(len(defs), [1.0] * 8)
+    yolo_no = 0
     for i, d in enumerate(defs):
         if d["type"] != "yolo":
             continue
@@ -133,8 +236,10 @@ def trained_like_(darknet, tag="trained", obj_bias=-4.0, obj_std=2.0, wh_std=0.5
         num_classes = int(d["classes"])
         per = num_classes + 5
         cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        gain = gains[yolo_no]
+        yolo_no += 1
         with torch.no_grad():
-            w = normal(f"{tag}/det{i}/w", tuple(conv.weight.shape), 0.0, 1.0 / (cin ** 0.5))
+            w = normal(f"{tag}/det{i}/w", tuple(conv.weight.shape), 0.0, 1.0 / (cin ** 0.5) / gain)
             b = np.zeros(cout, dtype=np.float32)
             scale = np.ones(cout, dtype=np.float32)
             for a in range(cout // per):

@@ -1,0 +1,130 @@
+"""CPU (-m "not gpu"): pin the ORACLE to the reference's own outputs (tests/golden/*.npz were
+produced by the imported reference, tests/golden/make_golden.py).  Exact equality is expected
+for the detector (same torch ops on the same machine class) - a loose 1e-5 is allowed so a
+different torch / BLAS build on the GPU box's host cannot turn this red."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from millieye_amd import cfgs, synth
+from oracle import darknet_ref, network_ref
+from tests.golden.make_golden import CASES_DARKNET, NETWORK_CASES
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+def _close(a, b, tol=TOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size:
+        err = np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+        assert err <= tol, err
+
+
+def _product_darknet(cfg):
+    from millieye_amd.yolov3.models import Darknet
+    from tests.parity_helpers import cfg_path
+    return Darknet(cfg_path(cfg)).eval()
+
+
+@pytest.mark.parametrize("name,cfg,n,s,stride", CASES_DARKNET)
+def test_darknet_oracle_matches_reference(name, cfg, n, s, stride):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    model = _product_darknet(cfg)  # product module tree only as a state-dict holder (same key names)
+    synth.fill_darknet_(model, name)
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    fm, yolo = darknet_ref.darknet_forward(cfgs.KNOWN[cfg](), model.state_dict(), x, tap_module=8)
+    assert tuple(yolo.shape) == tuple(g["yolo_shape"])
+    _close(yolo.numpy()[:, ::stride], g["yolo"])
+    assert abs(yolo.double().sum().item() - float(g["yolo_sum"])) <= 1e-6 * max(1.0, abs(float(g["yolo_sum"])))
+    if "fm" in g.files:
+        assert tuple(fm.shape) == tuple(g["fm_shape"])
+        _close(fm.numpy()[:, ::stride], g["fm"])
+    else:
+        assert fm is None  # yolov3.cfg: module 8 is a shortcut -> the reference has no featuremap
+
+
+def test_config0_shapes():
+    """BASELINE configs[0]: yolov3-tiny (80 classes) 416x416 batch 1 on CPU."""
+    g = np.load(os.path.join(GOLD, "darknet_tinycoco_s416_n1.npz"))
+    assert tuple(g["fm_shape"]) == (1, 256, 26, 26) and tuple(g["yolo_shape"]) == (1, 2535, 85)
+
+
+def _network_inputs(name, n, s):
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    maps, rboxes = synth.radar_inputs(name + "/radar", n, s // 16)
+    return x, torch.from_numpy(maps), torch.from_numpy(rboxes)
+
+
+@pytest.mark.parametrize("name,cfg,n,s,conf", NETWORK_CASES)
+def test_network_oracle_matches_reference(name, cfg, n, s, conf):
+    from millieye_amd.my_models import Network, define_yolo
+    from tests.parity_helpers import cfg_path
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = Network(define_yolo(cfg_path(cfg)), conf).eval()  # state-dict holder
+    synth.fill_network_(net, name)
+    sd = net.state_dict()
+    x, maps, rboxes = _network_inputs(name, n, s)
+    text = cfgs.KNOWN[cfg]()
+    run = lambda mode, rb, **kw: network_ref.network_forward(text, sd, x, maps, rb, mode, conf_thresh=conf, **kw)
+    _close(run(1, rboxes).numpy(), g["mode1"])
+    _close(run(0, rboxes).numpy(), g["mode0"])
+    _close(run(0, torch.zeros((0, 5))).numpy(), g["mode0_noradar"])
+    _close(run(2, rboxes).numpy(), g["mode2"])
+    _close(run(0, rboxes, thr_img=1).numpy(), g["mode0_after_mode2"])  # quirk q3 state carried over
+
+
+def test_nms_wrapper_oracle_matches_reference():
+    name = "nms_r300"
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    n, rows, nc = 2, 300, 12
+    parts = [synth.uniform(name + "/c", (n, rows, 2), 0, 416), synth.uniform(name + "/s", (n, rows, 2), 8, 160),
+             synth.uniform(name + "/o", (n, rows, 1), 0, 1), synth.uniform(name + "/k", (n, rows, nc), 0, 1)]
+    pred = torch.from_numpy(np.concatenate(parts, -1).astype(np.float32))
+    res = network_ref.nms_cpp(pred, 0.6)
+    for i, r in enumerate(res):
+        ref = g[f"img{i}"]
+        got = r.numpy() if r is not None else np.zeros((0, 7 + nc), np.float32)
+        assert np.array_equal(got, ref)
+    assert network_ref.nms_cpp(pred, 1.5) == [None, None]
+
+
+def test_metrics_host_code_matches_reference():
+    """Row a18: the product's host-side metric code against the reference's outputs (bit-for-bit)."""
+    from millieye_amd.utils import utils as U  # imports millieye_amd.hip lazily-safe (no GPU call here)
+    name = "metrics_synth"
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    rng_boxes = synth.uniform(name + "/b", (3, 40, 4), 0, 300)
+    outputs = []
+    for i in range(3):
+        b = rng_boxes[i]
+        xyxy = np.stack([np.minimum(b[:, 0], b[:, 2]), np.minimum(b[:, 1], b[:, 3]),
+                         np.maximum(b[:, 0], b[:, 2]) + 5, np.maximum(b[:, 1], b[:, 3]) + 5], 1)
+        conf = np.sort(synth.uniform(f"{name}/c{i}", (40,), 0, 1))[::-1]
+        score = synth.uniform(f"{name}/s{i}", (40,), 0, 1)
+        label = np.floor(synth.uniform(f"{name}/l{i}", (40,), 0, 3))
+        outputs.append(torch.from_numpy(np.concatenate([xyxy, conf[:, None], score[:, None], label[:, None]], 1)
+                                        .astype(np.float32)))
+    outputs[1] = None
+    tg = []
+    for i in (0, 2):
+        o = outputs[i].numpy()
+        for j in range(0, 40, 5):
+            tg.append([i, o[j, 6], o[j, 0] + 2, o[j, 1] - 1, o[j, 2] + 1, o[j, 3] + 2])
+    tg.append([1, 0, 10, 10, 50, 50])
+    targets = torch.tensor(tg, dtype=torch.float32)
+    stats = U.get_batch_statistics(outputs, targets, iou_threshold=0.5)
+    tp = np.concatenate([s[0] for s in stats])
+    sc = np.concatenate([s[1].numpy() for s in stats])
+    lb = np.concatenate([s[2].numpy() for s in stats])
+    assert np.array_equal(tp, g["tp"]) and tp.sum() > 0
+    p, r, ap, f1, cls, (pc, rc) = U.ap_per_class(tp, sc, lb, targets[:, 1].tolist())
+    for got, key in ((p, "p"), (r, "r"), (ap, "ap"), (f1, "f1"), (cls, "cls"), (pc, "pc"), (rc, "rc")):
+        assert np.array_equal(np.asarray(got), g[key]), key
+    assert np.array_equal(U.bbox_iou(outputs[0][:1, :4], outputs[0][:, :4]).numpy(), g["iou"])
+    assert U.compute_ap(np.array([0.1, 0.4, 0.4, 0.9]), np.array([1.0, 0.8, 0.6, 0.5])) == float(g["ap_simple"])
+    # known-answer: 3-point PR curve by hand: (0.5-0)*1 + (1-0.5)*0.5 = 0.75
+    assert abs(U.compute_ap(np.array([0.5, 1.0]), np.array([1.0, 0.5])) - 0.75) < 1e-12
