@@ -1,0 +1,6 @@
+import os, sys  # noqa: E401
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _bootstrap  # noqa: F401,E402
+from millieye_amd.utils.utils import *  # noqa: F401,F403,E402
+from millieye_amd.utils.utils import (torch, np, nn, F, tqdm, plt, patches, math, time, Variable,  # noqa: F401,E402
+                                      box_ops)

@@ -1,0 +1,85 @@
+"""Evaluation harness: ``evaluate(model, ...)`` -> (precision, recall, AP, f1, ap_class, box_stat, pr_curve).
+
+Host-side mirror of ``module3_our_dataset/test_fusion.py:24-115``.  The
+reference builds ``MyDataset(...)`` inside ``evaluate``; the dataset (jpg / txt / radar pkl
+files, ``utils/datasets.py``) is the *input producer* and outside this round's scope, so
+``evaluate`` takes the batches from ``dataloader`` when one is passed, and otherwise imports
+``utils.datasets.MyDataset`` (the caller's own module, exactly as the reference does) to build it.
+
+Per batch: ``mode_selection`` -> ``model(imgs, radar_maps, radar_boxes, mode)`` (all device work:
+detector, NMS, heads) -> regroup ``[m,8]`` rows per image -> ``get_batch_statistics``; finally
+``ap_per_class``.  The metric code is host-side by design (row a18)."""
+from __future__ import division
+
+import numpy as np
+import torch
+
+from .utils.utils import ap_per_class, get_batch_statistics, xywh2xyxy
+
+try:
+    import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+
+__all__ = ["mode_selection", "evaluate", "regroup_outputs"]
+
+
+def mode_selection(mode, img, paths):
+    """mode in [millieye, yolo, radar, auto]; auto -> fusion iff the batch is dark (quirk q14)."""
+    if mode in [0, 1, 2]:
+        return mode
+    if mode == 3:
+        return 0 if img.mean() < 0.1 else 1
+
+
+def regroup_outputs(outputs, batch_size):
+    """``[m,8]`` rows (image_i first) -> list of ``[n_i,7]`` CPU tensors / ``None`` per image, row order
+    kept (reference test_fusion.py:80-87, vectorised: one device->host copy instead of m)."""
+    rows = outputs.to(torch.device("cpu"))
+    grouped = [None for _ in range(batch_size)]
+    if rows.shape[0] == 0:
+        return grouped
+    idx = rows[:, 0].int()
+    for i in range(batch_size):
+        sel = rows[idx == i]
+        if sel.shape[0]:
+            grouped[i] = sel[:, 1:]
+    return grouped
+
+
+def evaluate(model, mode, model_mode, illumination, iou_thresh, nms_thresh, img_size, batch_size, test_list,
+             dataloader=None):
+    model.eval()
+    if dataloader is None:
+        from utils.datasets import MyDataset  # the caller's input producer (reference :48)
+
+        dataset = MyDataset(mode=mode, illumination=illumination, augment=False, multiscale=False,
+                            test_list=test_list, dataset_folder="../data/our_dataset")
+        dataloader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=4,
+                                                 pin_memory=True, collate_fn=dataset.collate_fn)
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    labels = []
+    sample_metrics = []
+    box_stat = dict(before=[1], after=[1])
+    it = dataloader if tqdm is None else tqdm.tqdm(dataloader, desc="Detecting objects")
+    for (paths, imgs, targets, radar_boxes, radar_maps) in it:
+        with torch.no_grad():
+            imgs = imgs.to(device)
+            radar_maps = radar_maps.to(device)
+            radar_boxes = radar_boxes.to(device)
+            mode_now = mode_selection(model_mode, imgs, paths)
+            outputs = model(imgs, radar_maps, radar_boxes, mode_now)
+            outputs_reshape = regroup_outputs(outputs, len(imgs))
+            for image_pred in outputs_reshape:
+                box_stat["after"].append(len(image_pred) if image_pred is not None else 0)
+        labels += targets[:, 1].tolist()
+        targets[:, 2:] = xywh2xyxy(targets[:, 2:])
+        targets[:, 2:] *= img_size
+        sample_metrics += get_batch_statistics(outputs_reshape, targets, iou_threshold=iou_thresh)
+
+    if sample_metrics == []:
+        true_positives, pred_scores, pred_labels, labels = np.array([0]), np.array([1]), np.array([1]), np.array([1])
+    else:
+        true_positives, pred_scores, pred_labels = [np.concatenate(x, 0) for x in list(zip(*sample_metrics))]
+    precision, recall, AP, f1, ap_class, pr_curve = ap_per_class(true_positives, pred_scores, pred_labels, labels)
+    return precision, recall, AP, f1, ap_class, box_stat, pr_curve
