@@ -439,6 +439,10 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
     case 2: return launch_igemm<128, 64, 16, 2, 2>(p, stream);
     case 3: return launch_igemm<64, 64, 16, 2, 2>(p, stream);
     case 4: return launch_igemm<128, 32, 16, 4, 1>(p, stream);
+    // experimental configurations (forced ids only, see tools/conv_bench.py)
+    case 5: return launch_igemm<128, 128, 32, 2, 2>(p, stream);
+    case 6: return launch_igemm<256, 128, 16, 4, 1>(p, stream);
+    case 7: return launch_igemm<256, 64, 16, 4, 1>(p, stream);
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_f32: unknown tile id %d", tile);
   }
   return 0;

@@ -355,7 +355,7 @@ int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
 static int launch_roi(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c, const float* rois,
                       int32_t k, int32_t pooled, float scale, float* out, void* stream_, int ps) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  ME_REQUIRE(map && out && (rois || k == 0), ME_E_NULLPTR, "me_roi_align_f32: null pointer");
+  ME_REQUIRE(map && (out || k == 0) && (rois || k == 0), ME_E_NULLPTR, "me_roi_align_f32: null pointer");
   ME_REQUIRE(pooled == P, ME_E_BADARG, "me_roi_align_f32: only 7x7 pooling is built (my_models.py:495-496)");
   ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && pitch >= c && k >= 0, ME_E_BADARG, "me_roi_align_f32: bad dims");
   ME_REQUIRE(!ps || c % PP == 0, ME_E_BADARG, "me_ps_roi_align_f32: channels %% 49 != 0");

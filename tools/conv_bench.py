@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Micro-benchmark of me_conv2d_f32 on Darknet-53 layer shapes (tuning aid, GPU box only).
+
+    python tools/conv_bench.py [--batch 8] [--tiles 0,1,2,3,4] [--reps 20] [--only 3x3]
+
+Prints one line per (layer shape, tile id): microseconds, TFLOP/s, fraction of the 157.3 TF fp32 MFMA peak.
+tile 0 = the library's own choice."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# (name, H(=W) of the input, cin, cout, ksize, stride) - the distinct conv shapes of yolov3.cfg @416
+SHAPES = [
+    ("s2 32->64 @416", 416, 32, 64, 3, 2),
+    ("1x1 64->32 @208", 208, 64, 32, 1, 1),
+    ("3x3 32->64 @208", 208, 32, 64, 3, 1),
+    ("1x1 128->64 @104", 104, 128, 64, 1, 1),
+    ("3x3 64->128 @104", 104, 64, 128, 3, 1),
+    ("1x1 256->128 @52", 52, 256, 128, 1, 1),
+    ("3x3 128->256 @52", 52, 128, 256, 3, 1),
+    ("1x1 512->256 @26", 26, 512, 256, 1, 1),
+    ("3x3 256->512 @26", 26, 256, 512, 3, 1),
+    ("1x1 1024->512 @13", 13, 1024, 512, 1, 1),
+    ("3x3 512->1024 @13", 13, 512, 1024, 3, 1),
+    ("1x1 1024->255 @13", 13, 1024, 255, 1, 1),
+    ("1x1 768->256 @26", 26, 768, 256, 1, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--tiles", default="0,1,2,3,4")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import __graft_entry__ as g
+    g.build()
+    from millieye_amd import hip
+
+    lib = hip.lib()
+    tiles = [int(t) for t in args.tiles.split(",")]
+    dev = "cuda"
+    for name, hw, cin, cout, k, s in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        n = args.batch
+        pad = (k - 1) // 2
+        ho = (hw + 2 * pad - k) // s + 1
+        x = torch.randn((n, hw, hw, cin), device=dev)
+        w = torch.randn((cout, k, k, cin), device=dev) * 0.05
+        sc = torch.ones(cout, device=dev)
+        sh = torch.zeros(cout, device=dev)
+        y = torch.empty((n, ho, ho, cout), device=dev)
+        d = hip.ConvDesc()
+        d.x, d.wgt, d.scale, d.shift, d.res, d.y = x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr()
+        d.x_pitch, d.res_pitch, d.y_pitch = cin, 0, cout
+        d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.pad, d.ho, d.wo = n, hw, hw, cin, cout, k, s, pad, ho, ho
+        d.act, d.upsample, d.x_nchw = 1, 1, 0
+        flops = lib.me_conv2d_flops(d)
+        row = []
+        for t in tiles:
+            d.tile = t
+            stream = hip.stream_ptr()
+            for _ in range(3):
+                hip.check(lib.me_conv2d_f32(C.byref(d), stream), "conv")
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.reps):
+                lib.me_conv2d_f32(C.byref(d), stream)
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) * 1e3 / args.reps
+            tf = flops / us / 1e6
+            row.append(f"t{t}: {us:8.1f} us {tf:6.1f} TF ({tf / 157.3:4.0%})")
+        print(f"{name:22s} n={n:<3d} {flops / 1e9:7.2f} GF | " + " | ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
