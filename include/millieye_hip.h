@@ -77,8 +77,16 @@ typedef struct me_conv_desc {
   int32_t upsample; /* 1 or 2 */
   int32_t x_nchw;   /* 0 / 1 */
   int32_t tile;     /* 0 = auto; else force a tile config id (testing / tuning) */
+  int32_t split_k;  /* 0 = auto; 1 = never split; k > 1 forces k K-splits (needs the workspace) */
+  void* workspace;  /* optional scratch for deterministic split-K slabs (256-byte aligned), or NULL */
+  int64_t workspace_bytes;
 } me_conv_desc;
 int me_conv2d_f32(const me_conv_desc* d, void* stream);
+/* scratch the automatic plan would like for this descriptor (0 = none). Small-M layers (13x13, 26x26
+ * maps at small batch) are split along K so that every CU gets work; partial sums go to
+ * workspace[split][n*ho*wo][cout] and a second launch reduces them in a FIXED order (bit-reproducible)
+ * before applying the same fused epilogue.  Without a workspace the call never splits. */
+int64_t me_conv2d_workspace_bytes(const me_conv_desc* d);
 /* algorithmic FLOPs (2*MAC) of the descriptor - used by bench.py for the roofline */
 int64_t me_conv2d_flops(const me_conv_desc* d);
 

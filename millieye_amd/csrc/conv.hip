@@ -36,6 +36,9 @@ struct ConvP {
   int cs;      // channel chunks per tap = ceil(cin / BK)
   int stages;  // ks*ks*cs
   int tiles_m, tiles_n;
+  float* partial;  // split-K slabs [splitk][M][cout] (raw accumulators), or nullptr
+  int splitk;      // number of K splits (grid.y)
+  int sps;         // K stages per split
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -119,7 +122,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
   }
 
   float4 a_reg[A_IT], b_reg[B_IT];
-  int tap = 0, cc = 0;  // stage -> (tap, channel chunk)
+  // split-K: this workgroup accumulates K stages [s_begin, s_end) of its tile
+  const int sid = blockIdx.y;
+  const int s_begin = sid * p.sps;
+  const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
+  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;  // stage -> (tap, channel chunk)
 
   auto load_stage = [&]() {
     const int ky = tap / p.ks, kx = tap - ky * p.ks;
@@ -173,9 +180,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
   const int a_frag = (wr * TM + r32) * LP + 4 * hh;
   const int b_frag = (wc * TN + r32) * LP + 4 * hh;
 
-  for (int s = 0; s < p.stages; ++s) {
-    const int buf = s & 1;
-    const bool more = (s + 1 < p.stages);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    const bool more = (s + 1 < s_end);
     if (more) load_stage();  // global loads in flight while the matrix cores work on `buf`
     const float* Ab = As + buf * BM * LP + a_frag;
     const float* Bb = Bs + buf * BN * LP + b_frag;
@@ -204,6 +211,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
 
   // ---- fused epilogue -------------------------------------------------------------------
   // 32x32 C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+  if (p.splitk > 1) {  // raw partial sums; conv_splitk_reduce_f32 applies the epilogue
+    float* slab = p.partial + (long long)sid * p.M * p.cout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = n0 + wc * TN + j * 32 + r32;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (co < p.cout && m < p.M) slab[(long long)m * p.cout + co] = acc[i][j][e];
+        }
+    }
+    return;
+  }
   const int hw = p.ho * p.wo;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -234,6 +256,35 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
           p.y[(base + W2 + 1) * p.y_pitch + co] = v;
         }
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-K second pass: sum the slabs in a fixed order (deterministic), then the fused epilogue.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_splitk_reduce_f32(ConvP p) {
+  const long long total = (long long)p.M * p.cout;
+  const int hw = p.ho * p.wo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int co = (int)(idx % p.cout);
+    const int m = (int)(idx / p.cout);
+    float a = p.partial[idx];
+    for (int k = 1; k < p.splitk; ++k) a += p.partial[(long long)k * total + idx];
+    float v = apply_act(a * p.scale[co] + p.shift[co], p.act);
+    if (p.res) v += p.res[(long long)m * p.res_pitch + co];
+    if (p.ups == 1) {
+      p.y[(long long)m * p.y_pitch + co] = v;
+    } else {
+      const int nimg = m / hw;
+      const int rem = m - nimg * hw;
+      const int oy = rem / p.wo, ox = rem - oy * p.wo;
+      const int W2 = p.wo * 2;
+      const long long base = ((long long)nimg * (p.ho * 2) + 2 * oy) * W2 + 2 * ox;
+      p.y[(base)*p.y_pitch + co] = v;
+      p.y[(base + 1) * p.y_pitch + co] = v;
+      p.y[(base + W2) * p.y_pitch + co] = v;
+      p.y[(base + W2 + 1) * p.y_pitch + co] = v;
     }
   }
 }
@@ -318,19 +369,86 @@ __global__ __launch_bounds__(256) void conv_smallcin_f32(ConvP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// host side: tile selection + launch
+// host side: (tile, split-K) planning + launch
 // ---------------------------------------------------------------------------------------------
 struct TileCfg {
-  int id, bm, bn;
-  float eff;
+  int id, bm, bn, bk;
+  int occ;    // workgroups resident per CU (LDS / register limited)
+  float eff;  // steady-state efficiency of the tile shape relative to 128x128
 };
-// id 1..4; BK = 16 for all (LDS 2*(BM+BN)*20*4 B: 40 KiB for 128x128 -> 3-4 workgroups per CU)
+// BK = 16: LDS 2*(BM+BN)*20*4 B (40 KiB for 128x128)
 const TileCfg kTiles[] = {
-    {1, 128, 128, 1.00f},
-    {2, 128, 64, 0.95f},
-    {3, 64, 64, 0.85f},
-    {4, 128, 32, 0.75f},
+    {1, 128, 128, 16, 3, 1.00f},
+    {2, 128, 64, 16, 5, 0.90f},
+    {3, 64, 64, 16, 8, 0.85f},
+    {4, 128, 32, 16, 7, 0.75f},
 };
+const TileCfg kExtraTiles[] = {  // forced ids only (tools/conv_bench.py)
+    {5, 128, 128, 32, 2, 1.0f},
+    {6, 256, 128, 16, 1, 1.0f},
+    {7, 256, 64, 16, 3, 1.0f},
+};
+constexpr int kMaxSplit = 16;
+
+struct ConvPlan {
+  int tile;
+  int splitk;
+};
+
+const TileCfg* find_tile(int id) {
+  for (const TileCfg& t : kTiles)
+    if (t.id == id) return &t;
+  for (const TileCfg& t : kExtraTiles)
+    if (t.id == id) return &t;
+  return nullptr;
+}
+
+// Makespan model.  The busiest CU gets ceil(blocks / 256) workgroups; up to `occ` of them are
+// co-resident and share its matrix pipe, whose utilisation grows with the number of resident waves
+// (fitted to tools/conv_bench.py sweeps on MI355X, profiles/r01_conv_bench_*: 0.68 / 0.76 / 0.80 /
+// 0.84 for 1 / 2 / 3 / 4+ resident workgroups; rms error of the model 6 %).  Split-K multiplies the
+// number of workgroups, divides their length and adds a slab round trip that mostly stays in L2 /
+// Infinity Cache (~10 TB/s effective).
+ConvPlan plan_conv(const ConvP& p, int forced_tile, int max_split) {
+  static const double kUtil[5] = {0.68, 0.68, 0.76, 0.80, 0.84};
+  ConvPlan best{1, 1};
+  double best_cost = 1e300;
+  const double flop_per_clk_cu = 256.0;  // 4 SIMDs x 64 FLOP/clk (v_mfma_f32_32x32x2_f32)
+  auto consider = [&](const TileCfg& t) {
+    const long long tm = (p.M + t.bm - 1) / t.bm, tn = (p.cout + t.bn - 1) / t.bn;
+    const int cs = (p.cin + t.bk - 1) / t.bk;
+    const int stages = p.ks * p.ks * cs;
+    for (int split = 1; split <= max_split && split <= stages; ++split) {
+      const int sps = (stages + split - 1) / split;
+      if ((split - 1) * sps >= stages) continue;  // an empty split
+      const long long blocks = tm * tn * split;
+      const long long per_cu = (blocks + 255) / 256;
+      // cycles: full rounds of `occ` resident workgroups, then the remainder at its own utilisation;
+      // each workgroup is 2*BM*BN*BK*sps flops through one CU's matrix pipe
+      const double wg = 2.0 * t.bm * t.bn * t.bk * sps / flop_per_clk_cu;
+      const long long full = per_cu / t.occ, rem = per_cu % t.occ;
+      double cost = full * t.occ * wg / (kUtil[t.occ > 4 ? 4 : t.occ] * t.eff);
+      if (rem) cost += rem * wg / (kUtil[rem > 4 ? 4 : rem] * t.eff);
+      cost += 3000.0;  // prologue / epilogue latency of a workgroup chain
+      if (split > 1) {
+        const double bytes = (double)(split + 1) * p.M * p.cout * 4.0 * 2.0;
+        cost += bytes / 1.0e13 * 2.1e9 + 6000.0;  // slab traffic + the extra launch (~3 us)
+      }
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = ConvPlan{t.id, split};
+      }
+    }
+  };
+  if (forced_tile) {
+    const TileCfg* t = find_tile(forced_tile);
+    if (t) consider(*t);
+    best.tile = forced_tile;
+  } else {
+    for (const TileCfg& t : kTiles) consider(t);
+  }
+  return best;
+}
 
 template <int BM, int BN, int BK, int WR, int WC>
 int launch_igemm(ConvP& p, hipStream_t stream) {
@@ -338,6 +456,9 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
   p.stages = p.ks * p.ks * p.cs;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.cout + BN - 1) / BN;
+  if (p.splitk > p.stages) p.splitk = p.stages;
+  p.sps = (p.stages + p.splitk - 1) / p.splitk;
+  while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
   auto kern = conv_igemm_f32<BM, BN, BK, WR, WC>;
   if (lds > 64 * 1024) {
@@ -350,30 +471,37 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
   }
   const long long blocks = (long long)p.tiles_m * p.tiles_n;
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
-  return me::check_launch("conv_igemm_f32");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(256), lds, stream, p);
+  int rc = me::check_launch("conv_igemm_f32");
+  if (rc || p.splitk == 1) return rc;
+  long long rb = ((long long)p.M * p.cout + 255) / 256;
+  if (rb > 256 * 16) rb = 256 * 16;
+  hipLaunchKernelGGL(conv_splitk_reduce_f32, dim3((unsigned)rb), dim3(256), 0, stream, p);
+  return me::check_launch("conv_splitk_reduce_f32");
 }
 
-int pick_tile(const ConvP& p) {
-  // one "round" = every CU holding 2 workgroups; estimate rounds * tile work / efficiency
-  // makespan model: the busiest CU gets ceil(blocks / 256) workgroups; co-resident workgroups
-  // share its matrix pipe, whose utilisation grows with the number of waves per SIMD
-  // (measured round 1: ~0.55 with one workgroup per CU, ~0.75 with two, ~0.85 with three+).
-  static const double kUtil[4] = {0.55, 0.55, 0.75, 0.85};
-  int best = 1;
-  double best_cost = 1e300;
-  for (const TileCfg& t : kTiles) {
-    const long long tm = (p.M + t.bm - 1) / t.bm, tn = (p.cout + t.bn - 1) / t.bn;
-    const long long blocks = tm * tn;
-    const long long per_cu = (blocks + 255) / 256;
-    const double util = kUtil[per_cu > 3 ? 3 : per_cu] * t.eff;
-    const double cost = (double)per_cu * t.bm * t.bn / util;
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = t.id;
-    }
-  }
-  return best;
+int fill_params(const me_conv_desc* d, ConvP& p) {
+  ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_f32: null descriptor");
+  ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
+             "me_conv2d_f32: non-positive dimension");
+  ME_REQUIRE(d->ksize >= 1 && d->stride >= 1 && d->pad >= 0, ME_E_BADARG, "me_conv2d_f32: bad ksize/stride/pad");
+  const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1;
+  const int wo = (d->w + 2 * d->pad - d->ksize) / d->stride + 1;
+  ME_REQUIRE(ho == d->ho && wo == d->wo, ME_E_BADARG, "me_conv2d_f32: ho/wo (%d,%d) != derived (%d,%d)", d->ho,
+             d->wo, ho, wo);
+  ME_REQUIRE((long long)d->n * d->ho * d->wo < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: too many output pixels");
+  p.x = d->x; p.wgt = d->wgt; p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
+  p.x_pitch = d->x_pitch; p.res_pitch = d->res_pitch; p.y_pitch = d->y_pitch;
+  p.n = d->n; p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout; p.ks = d->ksize;
+  p.stride = d->stride; p.pad = d->pad; p.ho = d->ho; p.wo = d->wo; p.act = d->act; p.ups = d->upsample;
+  p.x_nchw = d->x_nchw;
+  p.M = d->n * d->ho * d->wo;
+  p.ktot = d->ksize * d->ksize * d->cin;
+  p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
+  p.partial = nullptr;
+  p.splitk = 1;
+  p.sps = 0;
+  return 0;
 }
 
 }  // namespace
@@ -385,31 +513,23 @@ int64_t me_conv2d_flops(const me_conv_desc* d) {
   return 2ll * d->n * d->ho * d->wo * (int64_t)d->cout * d->ksize * d->ksize * d->cin;
 }
 
+int64_t me_conv2d_workspace_bytes(const me_conv_desc* d) {
+  ConvP p;
+  if (!d || fill_params(d, p) != 0 || d->cin <= 4) return 0;
+  const ConvPlan plan = plan_conv(p, d->tile, d->split_k > 0 ? d->split_k : kMaxSplit);
+  const int split = d->split_k > 0 ? d->split_k : plan.splitk;
+  return split > 1 ? (int64_t)split * p.M * p.cout * (int64_t)sizeof(float) : 0;
+}
+
 int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_f32: null descriptor");
+  ConvP p;
+  int rc = fill_params(d, p);
+  if (rc) return rc;
   ME_REQUIRE(d->x && d->wgt && d->scale && d->shift && d->y, ME_E_NULLPTR, "me_conv2d_f32: null tensor pointer");
-  ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
-             "me_conv2d_f32: non-positive dimension");
-  ME_REQUIRE(d->ksize >= 1 && d->stride >= 1 && d->pad >= 0, ME_E_BADARG, "me_conv2d_f32: bad ksize/stride/pad");
-  const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1;
-  const int wo = (d->w + 2 * d->pad - d->ksize) / d->stride + 1;
-  ME_REQUIRE(ho == d->ho && wo == d->wo, ME_E_BADARG, "me_conv2d_f32: ho/wo (%d,%d) != derived (%d,%d)", d->ho,
-             d->wo, ho, wo);
   ME_REQUIRE(d->upsample == 1 || d->upsample == 2, ME_E_BADARG, "me_conv2d_f32: upsample must be 1 or 2");
   ME_REQUIRE(d->act >= 0 && d->act <= 2, ME_E_BADARG, "me_conv2d_f32: unknown activation %d", d->act);
-  ME_REQUIRE((long long)d->n * d->ho * d->wo < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: too many output pixels");
   ME_REQUIRE(d->y_pitch >= d->cout, ME_E_BADARG, "me_conv2d_f32: y_pitch < cout");
-
-  ConvP p;
-  p.x = d->x; p.wgt = d->wgt; p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
-  p.x_pitch = d->x_pitch; p.res_pitch = d->res_pitch; p.y_pitch = d->y_pitch;
-  p.n = d->n; p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout; p.ks = d->ksize;
-  p.stride = d->stride; p.pad = d->pad; p.ho = d->ho; p.wo = d->wo; p.act = d->act; p.ups = d->upsample;
-  p.x_nchw = d->x_nchw;
-  p.M = d->n * d->ho * d->wo;
-  p.ktot = d->ksize * d->ksize * d->cin;
-  p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
 
   if (d->cin <= 4) {
     ME_REQUIRE(d->ksize == 3, ME_E_BADARG, "me_conv2d_f32: cin <= 4 needs ksize 3 (direct stem kernel)");
@@ -432,18 +552,32 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   ME_REQUIRE(d->x_pitch >= d->cin && d->x_pitch % 4 == 0, ME_E_ALIGN, "me_conv2d_f32: x_pitch must be >= cin, %% 4");
   ME_REQUIRE(me::aligned16(d->x) && me::aligned16(d->wgt), ME_E_ALIGN, "me_conv2d_f32: x / wgt not 16-byte aligned");
   ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_f32: res_pitch < cout");
+  ME_REQUIRE(d->split_k >= 0 && d->split_k <= 64, ME_E_BADARG, "me_conv2d_f32: split_k out of range");
 
-  int tile = d->tile ? d->tile : pick_tile(p);
-  switch (tile) {
+  // split-K only when the caller supplied a workspace that can hold the slabs
+  const long long slab = (long long)p.M * p.cout * (long long)sizeof(float);
+  int max_split = 1;
+  if (d->workspace && d->workspace_bytes >= 2 * slab) {
+    const long long fit = d->workspace_bytes / slab;
+    max_split = fit < kMaxSplit ? (int)fit : kMaxSplit;
+  }
+  ConvPlan plan = plan_conv(p, d->tile, max_split);
+  if (d->split_k > 0) {
+    ME_REQUIRE(d->split_k == 1 || (d->workspace && d->workspace_bytes >= d->split_k * slab), ME_E_BADARG,
+               "me_conv2d_f32: split_k=%d needs a workspace of %lld bytes", d->split_k, d->split_k * slab);
+    plan.splitk = d->split_k;
+  }
+  p.splitk = plan.splitk;
+  p.partial = reinterpret_cast<float*>(d->workspace);
+  switch (plan.tile) {
     case 1: return launch_igemm<128, 128, 16, 2, 2>(p, stream);
     case 2: return launch_igemm<128, 64, 16, 2, 2>(p, stream);
     case 3: return launch_igemm<64, 64, 16, 2, 2>(p, stream);
     case 4: return launch_igemm<128, 32, 16, 4, 1>(p, stream);
-    // experimental configurations (forced ids only, see tools/conv_bench.py)
     case 5: return launch_igemm<128, 128, 32, 2, 2>(p, stream);
     case 6: return launch_igemm<256, 128, 16, 4, 1>(p, stream);
     case 7: return launch_igemm<256, 64, 16, 4, 1>(p, stream);
-    default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_f32: unknown tile id %d", tile);
+    default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_f32: unknown tile id %d", plan.tile);
   }
   return 0;
 }

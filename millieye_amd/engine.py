@@ -401,6 +401,7 @@ class DarknetEngine:
                 dsc.n, dsc.h, dsc.w, dsc.cin = n, x.h, x.w, x.c
                 dsc.cout, dsc.ksize, dsc.stride, dsc.pad = cw.wgt.shape[0], op["k"], op["s"], op["pad"]
                 dsc.ho, dsc.wo, dsc.act, dsc.upsample, dsc.tile = op["ho"], op["wo"], op["act"], op["ups"], 0
+                dsc.split_k, dsc.workspace, dsc.workspace_bytes = 0, None, 0
                 launches.append((lib.me_conv2d_f32, (C.byref(dsc),), dsc, f"conv{op['module']}"))
                 plan.conv_descs.append((op["module"], dsc))
                 flops += 2 * n * op["ho"] * op["wo"] * dsc.cout * op["k"] * op["k"] * x.c
@@ -448,6 +449,15 @@ class DarknetEngine:
                 yl.img_dim = h
                 yl.grid_size = op["g"]
                 yl.stride = stride
+        # shared scratch for the deterministic split-K slabs (launches are serial on one stream)
+        need = max([lib.me_conv2d_workspace_bytes(C.byref(d)) for _m, d in plan.conv_descs] + [0])
+        plan.conv_ws = None
+        if need > 0:
+            plan.conv_ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
+            ws_ptr = plan.conv_ws.data_ptr() + (-plan.conv_ws.data_ptr()) % 256
+            for _m, d in plan.conv_descs:
+                if lib.me_conv2d_workspace_bytes(C.byref(d)) > 0:
+                    d.workspace, d.workspace_bytes = ws_ptr, need
         plan.launches = launches
         plan.conv_flops = flops
         if tap_tensor is not None:

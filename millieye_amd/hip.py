@@ -34,6 +34,8 @@ class ConvDesc(C.Structure):
         ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("ho", C.c_int32), ("wo", C.c_int32),
         ("act", C.c_int32), ("upsample", C.c_int32), ("x_nchw", C.c_int32), ("tile", C.c_int32),
+        ("split_k", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -100,6 +102,7 @@ SIGNATURES = {
     "me_sizeof": (C.c_int32, [C.c_int32]),
     "me_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "me_conv2d_flops": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "me_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "me_maxpool_f32": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p]),
     "me_upsample_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
@@ -198,7 +201,7 @@ def pack_conv_weight(weight):
 
 
 def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-           x_nchw=False, tile=0):
+           x_nchw=False, tile=0, split_k=0):
     """x_nhwc: [N,H,W,Cin] contiguous (or NCHW [N,Cin,H,W] when ``x_nchw``).  Returns NHWC
     [N,Ho*up,Wo*up,Cout]."""
     _require_cuda_f32(x_nhwc, "x")
@@ -220,7 +223,12 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     d.y_pitch = out.shape[-1]
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, stride, pad, ho, wo
-    d.act, d.upsample, d.x_nchw, d.tile = act, upsample, 1 if x_nchw else 0, tile
+    d.act, d.upsample, d.x_nchw, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, tile, split_k
+    need = lib().me_conv2d_workspace_bytes(C.byref(d))
+    keep = None
+    if need > 0:
+        ws_ptr, keep = _workspace(need, x_nhwc.device, slot="conv")
+        d.workspace, d.workspace_bytes = ws_ptr, need
     check(lib().me_conv2d_f32(C.byref(d), stream_ptr()), "me_conv2d_f32")
     return out
 
@@ -284,8 +292,8 @@ def yolo_decode(x_nhwc, anchors, num_classes, img_dim, out=None, rows_total=None
 _ws_cache = {}
 
 
-def _workspace(nbytes, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def _workspace(nbytes, device, slot="nms"):
+    key = (slot, device.index if device.index is not None else torch.cuda.current_device())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)

@@ -294,7 +294,11 @@ class Network(nn.Module):
         d.y, d.y_pitch = out.data_ptr(), out.shape[-1]
         d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cw.wgt.shape[0]
         d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, 1, pad, h, w
-        d.act, d.upsample, d.tile = act, 1, 0
+        d.act, d.upsample, d.tile, d.split_k = act, 1, 0, 0
+        need = hip.lib().me_conv2d_workspace_bytes(C.byref(d))
+        if need > 0:
+            d.workspace, _keep = hip._workspace(need, out.device, slot="conv")
+            d.workspace_bytes = need
         hip.check(hip.lib().me_conv2d_f32(C.byref(d), hip.stream_ptr()), "me_conv2d_f32")
         return out
 

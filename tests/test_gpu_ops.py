@@ -16,7 +16,7 @@ def _t(tag, shape, lo=-1.0, hi=1.0):
     return torch.from_numpy(synth.uniform(tag, shape, lo, hi))
 
 
-def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, tile=0, nchw_in=False):
+def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, tile=0, nchw_in=False, split_k=0):
     x = _t(tag + "x", (n, cin, h, w))
     wgt = torch.from_numpy(synth.normal(tag + "w", (cout, cin, k, k), 0, (2.0 / (cin * k * k)) ** 0.5))
     scale = _t(tag + "s", (cout,), 0.5, 1.5)
@@ -37,7 +37,7 @@ def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, t
     xd = x.to(dev) if nchw_in else x.permute(0, 2, 3, 1).contiguous().to(dev)
     got = hip.conv2d(xd, hip.pack_conv_weight(wgt).to(dev), scale.to(dev), shift.to(dev), k, s, pad, act,
                      residual=res.permute(0, 2, 3, 1).contiguous().to(dev) if res is not None else None,
-                     upsample=ups, x_nchw=nchw_in, tile=tile)
+                     upsample=ups, x_nchw=nchw_in, tile=tile, split_k=split_k)
     torch.cuda.synchronize()
     return assert_close(got.cpu().permute(0, 3, 1, 2), ref, TOL, tag)
 
@@ -59,6 +59,31 @@ def test_conv_variants(hip_lib):
     _conv_case(hip, "sig", 1, 26, 26, 128, 10, 1, 1, 2)                # radar head: 1x1 + sigmoid, cout 10
     _conv_case(hip, "k1big", 1, 26, 26, 256, 490, 1, 1, 1)             # cnn_layers_1 256->490
     _conv_case(hip, "odd", 1, 7, 5, 16, 40, 3, 1, 1)                   # tiny spatial, cin 16
+
+
+@pytest.mark.parametrize("split", [2, 3, 9])
+def test_conv_split_k_is_exact_and_deterministic(hip_lib, split):
+    """Small-M layers are split along K (slabs + ordered reduce): same 1e-3 bar, bit-reproducible,
+    and the fused epilogue (residual / upsample / activation) must survive the second pass."""
+    from millieye_amd import hip
+    _conv_case(hip, f"sk{split}", 2, 13, 13, 64, 96, 3, 1, 1, residual=True, split_k=split)
+    _conv_case(hip, f"sku{split}", 1, 13, 13, 48, 40, 3, 1, 1, ups=2, split_k=split, tile=3)
+    x = _t("skx", (2, 13, 13, 128)).cuda()
+    w = torch.from_numpy(synth.normal("skw", (256, 3, 3, 128), 0, 0.03)).cuda()
+    s = torch.ones(256).cuda()
+    b = torch.zeros(256).cuda()
+    a1 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, split_k=split)
+    a2 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, split_k=split)
+    assert torch.equal(a1, a2), "split-K must be run-to-run deterministic"
+    a0 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, split_k=1)
+    assert_close(a1.cpu(), a0.cpu(), 1e-4, "split vs unsplit")
+
+
+def test_conv_auto_plan_matches_reference_on_small_maps(hip_lib):
+    """Darknet-53's 13x13 / 26x26 layers at batch 8: the automatic (tile, split) plan."""
+    from millieye_amd import hip
+    _conv_case(hip, "auto13", 8, 13, 13, 512, 1024, 3, 1, 1)
+    _conv_case(hip, "auto13k1", 8, 13, 13, 1024, 512, 1, 1, 1)
 
 
 def test_conv_stem_smallcin(hip_lib):

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--tiles", default="0,1,2,3,4")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--splits", default="0", help="comma list of split_k values (0 = auto)")
     args = ap.parse_args()
     import __graft_entry__ as g
     g.build()
@@ -65,8 +66,12 @@ def main():
         d.act, d.upsample, d.x_nchw = 1, 1, 0
         flops = lib.me_conv2d_flops(d)
         row = []
-        for t in tiles:
-            d.tile = t
+        ws = torch.empty(256 * 1024 * 1024, dtype=torch.uint8, device=dev)
+        d.workspace, d.workspace_bytes = ws.data_ptr() + (-ws.data_ptr()) % 256, ws.numel() - 256
+        for t, sk in [(t, sk) for t in tiles for sk in [int(v) for v in args.splits.split(",")]]:
+            d.tile, d.split_k = t, sk
+            if sk > 1 and sk * n * ho * ho * cout * 4 > ws.numel() - 256:
+                continue
             stream = hip.stream_ptr()
             for _ in range(3):
                 hip.check(lib.me_conv2d_f32(C.byref(d), stream), "conv")
@@ -78,7 +83,7 @@ def main():
             torch.cuda.synchronize()
             us = a.elapsed_time(b) * 1e3 / args.reps
             tf = flops / us / 1e6
-            row.append(f"t{t}: {us:8.1f} us {tf:6.1f} TF ({tf / 157.3:4.0%})")
+            row.append(f"t{t}/k{sk}: {us:7.1f} us {tf:5.1f} TF ({tf / 157.3:4.0%})")
         print(f"{name:22s} n={n:<3d} {flops / 1e9:7.2f} GF | " + " | ".join(row), flush=True)
 
 
