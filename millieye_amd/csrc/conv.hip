@@ -50,7 +50,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM MFMA kernel
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WR, int WC>
+// ABL (ablation, tuning only): 0 = production kernel; 1 = global loads / LDS refills skipped after
+// the first stage (matrix pipe + LDS reads + barriers only); 2 = MFMAs skipped (memory side only).
+template <int BM, int BN, int BK, int WR, int WC, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int TM = BM / WR, TN = BN / WC;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
   for (int s = s_begin; s < s_end; ++s) {
     const int buf = (s - s_begin) & 1;
     const bool more = (s + 1 < s_end);
-    if (more) load_stage();  // global loads in flight while the matrix cores work on `buf`
+    if (more && ABL != 1) load_stage();  // global loads in flight while the matrix cores work on `buf`
     const float* Ab = As + buf * BM * LP + a_frag;
     const float* Bb = Bs + buf * BN * LP + b_frag;
 #pragma unroll
@@ -199,19 +201,237 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+          if (ABL == 2) {  // keep the fragment reads alive without touching the matrix pipe
+            asm volatile("" ::"v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w), "v"(bf[j].x), "v"(bf[j].y),
+                         "v"(bf[j].z), "v"(bf[j].w));
+            continue;
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (more) store_stage(buf ^ 1);
+    if (more && ABL != 1) store_stage(buf ^ 1);
     __syncthreads();
   }
 
   // ---- fused epilogue -------------------------------------------------------------------
   // 32x32 C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
   if (p.splitk > 1) {  // raw partial sums; conv_splitk_reduce_f32 applies the epilogue
+    float* slab = p.partial + (long long)sid * p.M * p.cout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = n0 + wc * TN + j * 32 + r32;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (co < p.cout && m < p.M) slab[(long long)m * p.cout + co] = acc[i][j][e];
+        }
+    }
+    return;
+  }
+  const int hw = p.ho * p.wo;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + wc * TN + j * 32 + r32;
+    const bool co_ok = co < p.cout;
+    const float sc = co_ok ? p.scale[co] : 0.f;
+    const float sh = co_ok ? p.shift[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int m = m0 + wr * TM + i * 32 + row;
+        if (!co_ok || m >= p.M) continue;
+        float v = apply_act(acc[i][j][e] * sc + sh, p.act);
+        if (p.res) v += p.res[(long long)m * p.res_pitch + co];
+        if (p.ups == 1) {
+          p.y[(long long)m * p.y_pitch + co] = v;
+        } else {
+          const int nimg = m / hw;
+          const int rem = m - nimg * hw;
+          const int oy = rem / p.wo, ox = rem - oy * p.wo;
+          const int W2 = p.wo * 2;
+          const long long base = ((long long)nimg * (p.ho * 2) + 2 * oy) * W2 + 2 * ox;
+          p.y[(base)*p.y_pitch + co] = v;
+          p.y[(base + 1) * p.y_pitch + co] = v;
+          p.y[(base + W2) * p.y_pitch + co] = v;
+          p.y[(base + W2 + 1) * p.y_pitch + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM MFMA kernel, LDS-DMA edition (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS
+// without a VGPR round trip, three K stages are in flight (two behind a counted s_waitcnt
+// vmcnt), one raw s_barrier per stage.  LDS rows are unpadded 64 B (BK = 16 floats); the
+// DMA destination is lane-linear (wave-uniform base + lane * 16 B), so the bank-conflict swizzle
+// lives on the per-lane SOURCE address: the 16-byte slot q of row R is stored at slot
+// q ^ ((R >> 2) & 3) and ds_read_b128 applies the same XOR (conflict-free for its 16-lane groups).
+// Padding taps / ragged rows read from a zero block in global memory.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) float g_zero_block[16];
+
+template <int BM, int BN, int WR, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvP p) {
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  constexpr int BK = 16, NST = 3;
+  constexpr int TM = BM / WR, TN = BN / WC;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int GA = BM / 16, G = (BM + BN) / 16;  // 16-row groups (1 KiB each): A first, then B
+  constexpr int LPW = (G + 3) / 4;                  // DMA instructions per wave per stage
+  constexpr int STAGE_F = LPW * 4 * 256;            // floats per stage buffer (incl. dummy groups)
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int r32 = lane & 31, hh = lane >> 5;
+
+  int tile_m, tile_n;
+  {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_n = wg % p.tiles_n;
+    tile_m = wg / p.tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // per-lane source bookkeeping for this wave's groups g = wave + 4 * j
+  const int lrow = lane >> 2;  // row inside the 16-row group
+  int g_iy0[LPW], g_ix0[LPW], g_pix0[LPW], g_q[LPW];
+  long long g_boff[LPW];
+  int g_kind[LPW];  // 0 = A rows, 1 = B rows (valid cout), 2 = always zero
+#pragma unroll
+  for (int j = 0; j < LPW; ++j) {
+    const int g = wave + 4 * j;
+    const int row = g * 16 + lrow;                       // row inside the (A|B) stage image
+    const int q = (lane & 3) ^ ((row >> 2) & 3);         // source 16-byte chunk for this LDS slot
+    g_q[j] = 4 * q;
+    g_iy0[j] = g_ix0[j] = g_pix0[j] = 0;
+    g_boff[j] = 0;
+    if (g < GA) {
+      g_kind[j] = 0;
+      const int m = m0 + row;
+      if (m < p.M) {
+        const int hw = p.ho * p.wo;
+        const int nimg = m / hw;
+        const int rem = m - nimg * hw;
+        const int oy = rem / p.wo, ox = rem - oy * p.wo;
+        g_iy0[j] = oy * p.stride - p.pad;
+        g_ix0[j] = ox * p.stride - p.pad;
+        g_pix0[j] = nimg * p.h * p.w;
+      } else {
+        g_iy0[j] = -(1 << 28);
+      }
+    } else if (g < G) {
+      const int co = n0 + (row - BM);
+      g_kind[j] = (co < p.cout) ? 1 : 2;
+      g_boff[j] = (long long)co * p.ktot + 4 * q;
+    } else {
+      g_kind[j] = 2;  // dummy group: keeps the per-wave DMA count uniform for the counted vmcnt
+    }
+  }
+
+  const int sid = blockIdx.y;
+  const int s_begin = sid * p.sps;
+  const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
+  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;
+
+  auto issue_stage = [&](int slot) {
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    const int c0 = cc * BK;
+    const int koff = tap * p.cin + c0;
+    const unsigned stage_lds = lds_base + (unsigned)slot * (STAGE_F * 4u);
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+      const float* src = g_zero_block;
+      if (g_kind[j] == 0) {
+        const int iy = g_iy0[j] + ky, ix = g_ix0[j] + kx;
+        if (((unsigned)iy < (unsigned)p.h) && ((unsigned)ix < (unsigned)p.w) && (c0 + g_q[j] < p.cin))
+          src = p.x + (long long)(g_pix0[j] + iy * p.w + ix) * p.x_pitch + (c0 + g_q[j]);
+      } else if (g_kind[j] == 1) {
+        if (c0 + g_q[j] < p.cin) src = p.wgt + g_boff[j] + koff;
+      }
+      // LDS byte address of this group's 1 KiB image: wave-uniform; hardware adds lane * 16 B.
+      // Issued through inline asm so that hipcc does not track the DMA (it would drain it with
+      // s_waitcnt vmcnt(0) in front of every ds_read); completion is counted by hand below.
+      const unsigned dst = __builtin_amdgcn_readfirstlane(stage_lds + (unsigned)(wave + 4 * j) * 1024u);
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src), "s"(dst)
+          : "memory");
+    }
+    if (++cc == p.cs) {
+      cc = 0;
+      ++tap;
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nstages = s_end - s_begin;
+  issue_stage(0);
+  if (nstages > 1) issue_stage(1);
+
+  const int sw = (r32 >> 2) & 3;
+  const int a_row = (wr * TM + r32) * BK;
+  const int b_row = (BM + wc * TN + r32) * BK;
+  const int off0 = ((0 + hh) ^ sw) * 4, off1 = ((2 + hh) ^ sw) * 4;
+
+  for (int s = 0; s < nstages; ++s) {
+    // stage s landed? (the only younger DMAs are those of stage s+1)
+    if (s + 1 < nstages)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's stage-s DMAs landed; everyone finished reading stage s-1
+    asm volatile("" ::: "memory");
+    if (s + 2 < nstages) issue_stage((s + 2) % NST);  // refills the slot stage s-1 just vacated
+    const float* Ab = smem + (s % NST) * STAGE_F + a_row;
+    const float* Bb = smem + (s % NST) * STAGE_F + b_row;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int off = half ? off1 : off0;
+      float4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + off);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue (same as conv_igemm_f32) --------------------------------------------------
+  if (p.splitk > 1) {
     float* slab = p.partial + (long long)sid * p.M * p.cout;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -385,8 +605,13 @@ const TileCfg kTiles[] = {
 };
 const TileCfg kExtraTiles[] = {  // forced ids only (tools/conv_bench.py)
     {5, 128, 128, 32, 2, 1.0f},
-    {6, 256, 128, 16, 1, 1.0f},
     {7, 256, 64, 16, 3, 1.0f},
+    {21, 128, 128, 16, 3, 1.0f},
+    {22, 128, 64, 16, 4, 0.9f},
+    {23, 64, 64, 16, 6, 0.85f},
+    {24, 128, 32, 16, 5, 0.75f},
+    {11, 128, 128, 16, 3, 1.0f},
+    {12, 128, 128, 16, 3, 1.0f},
 };
 constexpr int kMaxSplit = 16;
 
@@ -450,7 +675,7 @@ ConvPlan plan_conv(const ConvP& p, int forced_tile, int max_split) {
   return best;
 }
 
-template <int BM, int BN, int BK, int WR, int WC>
+template <int BM, int BN, int BK, int WR, int WC, int ABL = 0>
 int launch_igemm(ConvP& p, hipStream_t stream) {
   p.cs = (p.cin + BK - 1) / BK;
   p.stages = p.ks * p.ks * p.cs;
@@ -460,7 +685,7 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
   p.sps = (p.stages + p.splitk - 1) / p.splitk;
   while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-  auto kern = conv_igemm_f32<BM, BN, BK, WR, WC>;
+  auto kern = conv_igemm_f32<BM, BN, BK, WR, WC, ABL>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -473,6 +698,30 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(256), lds, stream, p);
   int rc = me::check_launch("conv_igemm_f32");
+  if (rc || p.splitk == 1) return rc;
+  long long rb = ((long long)p.M * p.cout + 255) / 256;
+  if (rb > 256 * 16) rb = 256 * 16;
+  hipLaunchKernelGGL(conv_splitk_reduce_f32, dim3((unsigned)rb), dim3(256), 0, stream, p);
+  return me::check_launch("conv_splitk_reduce_f32");
+}
+
+template <int BM, int BN, int WR, int WC>
+int launch_dma(ConvP& p, hipStream_t stream) {
+  constexpr int BK = 16;
+  p.cs = (p.cin + BK - 1) / BK;
+  p.stages = p.ks * p.ks * p.cs;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.cout + BN - 1) / BN;
+  if (p.splitk > p.stages) p.splitk = p.stages;
+  p.sps = (p.stages + p.splitk - 1) / p.splitk;
+  while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;
+  constexpr int LPW = ((BM + BN) / 16 + 3) / 4;
+  const size_t lds = (size_t)3 * LPW * 4 * 256 * sizeof(float);
+  auto kern = conv_igemm_dma_f32<BM, BN, WR, WC>;
+  const long long blocks = (long long)p.tiles_m * p.tiles_n;
+  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(256), lds, stream, p);
+  int rc = me::check_launch("conv_igemm_dma_f32");
   if (rc || p.splitk == 1) return rc;
   long long rb = ((long long)p.M * p.cout + 255) / 256;
   if (rb > 256 * 16) rb = 256 * 16;
@@ -575,8 +824,13 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
     case 3: return launch_igemm<64, 64, 16, 2, 2>(p, stream);
     case 4: return launch_igemm<128, 32, 16, 4, 1>(p, stream);
     case 5: return launch_igemm<128, 128, 32, 2, 2>(p, stream);
-    case 6: return launch_igemm<256, 128, 16, 4, 1>(p, stream);
     case 7: return launch_igemm<256, 64, 16, 4, 1>(p, stream);
+    case 21: return launch_dma<128, 128, 2, 2>(p, stream);  // LDS-DMA editions of tiles 1-4
+    case 22: return launch_dma<128, 64, 2, 2>(p, stream);
+    case 23: return launch_dma<64, 64, 2, 2>(p, stream);
+    case 24: return launch_dma<128, 32, 4, 1>(p, stream);
+    case 11: return launch_igemm<128, 128, 16, 2, 2, 1>(p, stream);  // ablations of tile 1 (wrong results!)
+    case 12: return launch_igemm<128, 128, 16, 2, 2, 2>(p, stream);
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_f32: unknown tile id %d", plan.tile);
   }
   return 0;

@@ -42,12 +42,15 @@ def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, t
     return assert_close(got.cpu().permute(0, 3, 1, 2), ref, TOL, tag)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 21, 22, 23, 24])
 def test_conv3x3_every_tile(hip_lib, tile):
     from millieye_amd import hip
     # ragged M (n*h*w = 2*13*11 = 286) and ragged cout (not a tile multiple), cin not a BK multiple
     _conv_case(hip, f"c3t{tile}", 2, 13, 11, 24, 72, 3, 1, 1, tile=tile)
     _conv_case(hip, f"c3t{tile}b", 1, 26, 26, 64, 160, 3, 1, 1, tile=tile)
+    _conv_case(hip, f"c3t{tile}c", 2, 16, 16, 32, 64, 3, 2, 1, tile=tile, residual=False)   # stride 2
+    _conv_case(hip, f"c3t{tile}d", 1, 13, 13, 40, 255, 1, 1, 0, tile=tile)                  # 1x1, one K stage + ragged
+    _conv_case(hip, f"c3t{tile}e", 2, 13, 13, 64, 96, 3, 1, 1, residual=True, split_k=3, tile=tile)
 
 
 def test_conv_variants(hip_lib):

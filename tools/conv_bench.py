@@ -40,7 +40,12 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--splits", default="0", help="comma list of split_k values (0 = auto)")
+    ap.add_argument("--custom", default="", help="extra shape 'hw,cin,cout,k,stride' (square input)")
     args = ap.parse_args()
+    if args.custom:
+        hw_, ci_, co_, k_, s_ = (int(v) for v in args.custom.split(","))
+        SHAPES.append((f"custom {k_}x{k_} {ci_}->{co_} @{hw_}", hw_, ci_, co_, k_, s_))
+        args.only = args.only or "custom"
     import __graft_entry__ as g
     g.build()
     from millieye_amd import hip
