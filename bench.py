@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--cfg", default="yolov3")
-    ap.add_argument("--workload", default="detector", choices=["detector", "full"])
+    ap.add_argument("--workload", default="full", choices=["detector", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
@@ -96,10 +96,10 @@ def conv_roofline(model, x, steps):
     return achieved, total_ms * 1e3 / launches, launches, total_flops / launches, per_layer
 
 
-def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s):
+def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s, radar=None):
     """The oracle (stock torch CPU ops = the reference's CPU path, pinned by tests/golden) timed on the
     host cores: a bounded sample of the same workload (batch-1 passes of the same cfg / size)."""
-    from oracle import darknet_ref
+    from oracle import darknet_ref, network_ref
 
     # torch's intra-op pool at os.cpu_count() threads is far from optimal on a many-core host
     # (256 threads on 13x13 maps: 60 s per frame); pick the best thread count on a probe conv so
@@ -121,17 +121,27 @@ def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s):
     cores = best[1]
     torch.set_num_threads(cores)
     x1 = frames_cpu[:1]
+    if radar is None:
+        def one_pass():
+            darknet_ref.darknet_forward(cfg_text, state_dict, x1, tap_module=tap)
+        what = "detector forward (oracle/darknet_ref.py"
+    else:
+        maps1, boxes1, conf = radar[0][:1], radar[1][radar[1][:, 0] == 0], radar[2]
+
+        def one_pass():
+            network_ref.network_forward(cfg_text, state_dict, x1, maps1, boxes1, 0, conf_thresh=conf, tap_module=tap)
+        what = "Network.forward mode 0: detector + NMS + RoI heads (oracle/network_ref.py + tv_ops.c"
     t0 = time.perf_counter()
-    darknet_ref.darknet_forward(cfg_text, state_dict, x1, tap_module=tap)  # warm-up (also bounds one pass)
+    one_pass()  # warm-up (also bounds one pass)
     one = time.perf_counter() - t0
     reps = max(1, min(10, int(budget_s / max(one, 1e-3)) - 1))
     t0 = time.perf_counter()
     for _ in range(reps):
-        darknet_ref.darknet_forward(cfg_text, state_dict, x1, tap_module=tap)
+        one_pass()
     dt = (time.perf_counter() - t0) / reps
     return {"value": round(1.0 / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} batch-1 passes of {args.cfg} {args.size}x{args.size} fp32 detector forward "
-                      f"(oracle/darknet_ref.py, torch {torch.__version__} CPU, {cores} threads)"}
+            "sample": f"{reps} batch-1 passes of {args.cfg} {args.size}x{args.size} fp32 {what}, "
+                      f"torch {torch.__version__} CPU, {cores} threads)"}
 
 
 def main():
@@ -148,18 +158,39 @@ def main():
     from millieye_amd.yolov3.models import Darknet
 
     batch = args.batch or (8 if args.workload == "detector" else 32)
+    conf_thresh = 0.2
     cfg_path = cfgs.write_cfg(args.cfg, os.path.join("/tmp", f"millieye_bench_cfg_{os.getuid()}_{rank}"))
-    model = Darknet(cfg_path).eval()
-    synth.fill_darknet_(model, "bench/" + args.cfg)
-    synth.trained_like_(model, "bench/" + args.cfg + "/trained")
-    state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
-    model = model.to(dev)
     frames_cpu = torch.from_numpy(synth.uniform(f"bench/frames/{rank}", (batch, 3, args.size, args.size)))
     x = frames_cpu.to(dev)
+    radar = None
+    if args.workload == "detector":
+        model = Darknet(cfg_path).eval()
+        synth.fill_darknet_(model, "bench/" + args.cfg)
+        synth.trained_like_(model, "bench/" + args.cfg + "/trained")
+        state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+        model = model.to(dev)
+        net = None
 
-    def step():
-        with torch.no_grad():
-            return model(x)
+        def step():
+            with torch.no_grad():
+                return model(x)
+    else:
+        from millieye_amd.my_models import Network
+        net = Network(Darknet(cfg_path), conf_thresh).eval()
+        synth.fill_network_(net, "bench/" + args.cfg)
+        state_cpu = {k: v.clone() for k, v in net.state_dict().items()}
+        net = net.to(dev)
+        model = net.base_detector
+        maps_np, boxes_np = synth.radar_inputs(f"bench/radar/{rank}", batch, args.size // 16, boxes_per_image=2)
+        maps_cpu, boxes_cpu = torch.from_numpy(maps_np), torch.from_numpy(boxes_np)
+        maps_d, boxes_d = maps_cpu.to(dev), boxes_cpu.to(dev)
+        radar = (maps_cpu, boxes_cpu, conf_thresh)
+        last = {}
+
+        def step():
+            with torch.no_grad():
+                last["out"] = net(x, maps_d, boxes_d.clone(), 0)  # forward scales the radar boxes in place
+            return last["out"]
 
     for _ in range(args.warmup):
         step()
@@ -197,9 +228,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.cfg}.cfg Darknet-53 {args.size}x{args.size} fp32 inference, batch={batch} per GPU "
-                            f"({args.workload}: Darknet.forward -> featuremap + yolo_outputs), synthetic frames U[0,1), "
-                            f"deterministic trained-like weights",
+                "workload": f"{args.cfg}.cfg {args.size}x{args.size} fp32 inference, batch={batch} per GPU, "
+                            + ("Darknet.forward -> featuremap + yolo_outputs" if args.workload == "detector" else
+                               "full milliEye: Darknet.forward -> NMS -> Network.forward mode 0 (R-CNN head + radar "
+                               "fusion, 2 radar boxes/frame) -> output rows")
+                            + ", synthetic frames U[0,1), deterministic trained-like weights",
+                "stage": args.workload,
                 "batch_per_gpu": batch,
                 "global_batch": batch * world,
                 "img_size": args.size,
@@ -223,7 +257,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from millieye_amd.engine import pick_tap_module
             out["cpu_baseline"] = cpu_baseline(args, frames_cpu, state_cpu, cfgs.KNOWN[args.cfg](),
-                                               pick_tap_module(model.module_defs), args.cpu_seconds)
+                                               pick_tap_module(model.module_defs), args.cpu_seconds, radar)
+        if net is not None:
+            out["config"]["output_rows_last_step"] = int(last["out"].shape[0])
         if os.environ.get("BENCH_LAYERS"):
             for mod, flops, ms in per_layer:
                 print(f"[layer] conv{mod}: {flops / 1e9:.3f} GF {ms * 1e3:.1f} us {flops / ms / 1e9:.1f} TF/s",

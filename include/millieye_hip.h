@@ -216,6 +216,7 @@ typedef struct me_heads_weights {
   const float* e1b;   /* [32] */
   const float* e2w;   /* ensemble_head.fc2.0.weight [2][64] */
   const float* e2b;   /* [2] */
+  const float* rb;    /* radar_net.0.bias [10] - training mode only (inference folds it into rshift) */
 } me_heads_weights;
 
 typedef struct me_heads_desc {
@@ -238,8 +239,75 @@ typedef struct me_heads_desc {
   float* out_rows;
   uint8_t* keep;
   float* sort_key;
+  /* training mode (all four non-NULL): the launch stops after the pooled features / hidden layer /
+   * small dot products and stores them for the backward pass instead of running the scalar tail:
+   * save_feat_img [cap,490], save_feat_rad [cap,490], save_hidden [cap,256] (post LeakyReLU),
+   * save_small [cap,16] = (reg0..3, z2_0, z2_1, rconv0..9) with biases added, pre-activation.
+   * The tail then runs as me_heads_tail_f32 once the RoI-wise BatchNorm statistics are known. */
+  float* save_feat_img;
+  float* save_feat_rad;
+  float* save_hidden;
+  float* save_small;
 } me_heads_desc;
 int me_roi_heads_f32(const me_heads_desc* d, void* stream);
+
+/* scalar tail of the heads for `k` RoIs from a saved `small` [k,16] block (training forward; identical
+ * arithmetic to the fused inference tail).  d->wts.rscale/rshift must hold the radar_net BatchNorm as an
+ * affine on rconv (batch statistics in train mode); reads d->img_boxes / n_img / radar_boxes, writes
+ * regress_out, refine_out, mask1_out, out_rows, keep, sort_key. */
+int me_heads_tail_f32(const me_heads_desc* d, const float* small, int32_t k, void* stream);
+
+/* per-RoI loss terms and gradient seeds of the stage-3 objective (my_models.py:606-635):
+ *   focal (alpha, gamma=2, sum) on [1-p, p] for rows with in_focal, BCE(sum)/lambda on conf for rows with
+ *   in_conf; label_pos marks IoU-positive rows.  terms [k,2] = (focal_i, bce_i) (sum them with
+ *   me_colsum_f32); seed_p [k] = dL/dp, seed_conf [k] = dL/dconf (already divided by lambda). */
+int me_heads_loss_f32(const float* mask1, const float* refine, const uint8_t* label_pos, const uint8_t* in_focal,
+                      const uint8_t* in_conf, int32_t k, float alpha, float conf_lambda, float* terms,
+                      float* seed_p, float* seed_conf, void* stream);
+
+/* backward of the scalar tail, one thread per RoI.  Inputs: saved small [k,16], refine [k,2], mask1 [k],
+ * seeds, d (weights incl. rscale/rshift, img_boxes, n_img).  Outputs (row k = RoI k):
+ *   g_o [k,2] dL/d(fc2 logits), g_hpre [k,64] dL/d(fc1 pre-activation), h_act [k,64] fc1 activations,
+ *   xin [k,4] = (refine0, yolo0, refine1, yolo1), g_z2 [k,2] dL/d(net2 logits 0,1),
+ *   g_rl [k,10] dL/d(radar_net LeakyReLU output), rl [k,10] that output, g_rlogit [k] dL/d(1x1 logit). */
+int me_heads_tail_bwd_f32(const me_heads_desc* d, const float* small, const float* refine, const float* mask1,
+                          const float* seed_p, const float* seed_conf, int32_t k, float* g_o, float* g_hpre,
+                          float* h_act, float* xin, float* g_z2, float* g_rl, float* rl, float* g_rlogit,
+                          void* stream);
+
+/* ---- generic training building blocks (millieye_amd/csrc/train.hip) ----------------------- */
+/* C[m,n] = alpha * op(A) * op(B) + beta * C, row-major with leading dimensions; op = transpose if
+ * trans_* != 0 (A is stored [k,m] then).  Sequential K reduction per element: bit-reproducible. */
+int me_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float* a,
+                int64_t lda, const float* b, int64_t ldb, float beta, float* c, int64_t ldc, void* stream);
+int me_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, void* stream);
+/* nn.BatchNorm2d in training mode over rows of x[rows, channels] (NHWC maps: rows = n*h*w):
+ * batch mean / biased variance, y = act((x-mean)*rstd*gamma+beta), running stats updated in place
+ * (momentum, unbiased variance) when running_mean != NULL.  workspace: me_bn_workspace_bytes(channels). */
+int64_t me_bn_workspace_bytes(int32_t channels);
+int me_bn_train_fwd_f32(const float* x, int64_t ldx, int32_t rows, int32_t channels, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        int32_t act, float* y, int64_t ldy, float* save_mean, float* save_var, float* save_rstd,
+                        void* workspace, void* stream);
+/* dy is the gradient w.r.t. the ACTIVATED output; dx / dgamma / dbeta may be NULL. */
+int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
+                        const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
+                        int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* workspace,
+                        void* stream);
+/* dx = dy * act'(y) from the activation output y (sigmoid / leaky) */
+int me_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx, int64_t lddx, int64_t rows,
+                   int32_t channels, int32_t act, void* stream);
+/* dW[cout][ky][kx][cin] = sum_pixels dy * x(shifted), NHWC operands (the packed-weight layout of me_conv2d_f32).
+ * (The data gradient of a stride-1 conv is me_conv2d_f32 itself on the 180-degree rotated, transposed weights.) */
+int me_conv_wgrad_f32(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n,
+                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
+                      void* stream);
+/* RoI pooling backward: grad_out [k,c_out,7,7] scattered (atomicAdd) into the zero-filled NHWC grad_map */
+int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
+                         int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch, void* stream);
+int me_ps_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
+                            int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
+                            void* stream);
 
 /* stand-alone RoI ops (tests, training path): out [k, c_out, 7, 7] dense */
 int me_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c,

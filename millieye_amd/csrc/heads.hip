@@ -183,6 +183,61 @@ __global__ __launch_bounds__(1024) void gather_class_boxes_kernel(const float* d
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.1f * v; }
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
+// scalar tail of one RoI (shared by the fused inference kernel and me_heads_tail_f32)
+__device__ void tail_one(const me_heads_desc& d, const float* sm, const float* roi, int k, int n_img) {
+  const float cls0 = sigmoidf(sm[4]), cls1 = sigmoidf(sm[5]);
+  float rad = d.wts.rb2[0];
+#pragma unroll
+  for (int o = 0; o < C_OUT; ++o) rad = fmaf(d.wts.rw2[o], leaky(sm[6 + o] * d.wts.rscale[o] + d.wts.rshift[o]), rad);
+  const float radar_conf = sigmoidf(rad);
+  const float conf = sigmoidf(radar_conf + cls0);  // sigmoid applied twice on purpose (quirk q2)
+  const bool is_img = k < n_img;
+  float p;
+  float c6, c7;
+  if (is_img) {
+    const float* bx = d.img_boxes + (long long)k * d.box_cols;
+    const float yolo0 = bx[5], yolo1 = bx[8];
+    // ensemble_head: stack -> fc1 (2->32) + leaky -> flatten(64) -> fc2 (64->2) -> softmax; column 0 (q1)
+    float o0 = d.wts.e2b[0], o1 = d.wts.e2b[1];
+#pragma unroll 4
+    for (int u = 0; u < 32; ++u) {
+      const float wa = d.wts.e1w[2 * u], wb = d.wts.e1w[2 * u + 1], bb = d.wts.e1b[u];
+      const float h0 = leaky(wa * conf + wb * yolo0 + bb);
+      const float h1 = leaky(wa * cls1 + wb * yolo1 + bb);
+      o0 += d.wts.e2w[u] * h0 + d.wts.e2w[32 + u] * h1;
+      o1 += d.wts.e2w[64 + u] * h0 + d.wts.e2w[96 + u] * h1;
+    }
+    const float m = fmaxf(o0, o1);
+    const float e0 = expf(o0 - m), e1 = expf(o1 - m);
+    p = e0 / (e0 + e1);
+    c6 = bx[6];
+    c7 = bx[7];
+  } else {
+    p = conf;
+    c6 = cls1;
+    c7 = 0.f;
+  }
+  d.regress_out[4 * k + 0] = sm[0];
+  d.regress_out[4 * k + 1] = sm[1];
+  d.regress_out[4 * k + 2] = sm[2];
+  d.regress_out[4 * k + 3] = sm[3];
+  d.refine_out[2 * k + 0] = conf;
+  d.refine_out[2 * k + 1] = cls1;
+  d.mask1_out[k] = p;
+  const float thr = is_img ? d.thr_img : d.thr_radar;
+  d.keep[k] = (p > thr) ? 1 : 0;
+  d.sort_key[k] = is_img ? p : p / 5.f;
+  float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+  if (d.regress) {  // box_regress, my_models.py:378-391
+    const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2, bw = x2 - x1, bh = y2 - y1;
+    const float nx = sm[0] * bw + cx, ny = sm[1] * bh + cy;
+    const float nw = expf(sm[2]) * bw, nh = expf(sm[3]) * bh;
+    x1 = nx - nw / 2; y1 = ny - nh / 2; x2 = nx + nw / 2; y2 = ny + nh / 2;
+  }
+  float* o = d.out_rows + 8ll * k;
+  o[0] = roi[0]; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = p; o[6] = c6; o[7] = c7;
+}
+
 __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
   __shared__ float s_feat[RPB][2 * FEAT];  // [r][0:490] image (PS-RoIAlign), [490:980] radar (RoIAlign)
   __shared__ float s_hid[RPB][HID];
@@ -258,61 +313,130 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
   }
   __syncthreads();
 
+  if (d.save_small) {  // training mode: keep what the backward pass needs, the tail runs separately
+    for (int idx = t; idx < nr * 2 * FEAT; idx += 256) {
+      const int r = idx / (2 * FEAT), f = idx % (2 * FEAT);
+      if (f < FEAT) d.save_feat_img[(long long)(k0 + r) * FEAT + f] = s_feat[r][f];
+      else d.save_feat_rad[(long long)(k0 + r) * FEAT + (f - FEAT)] = s_feat[r][f];
+    }
+    for (int idx = t; idx < nr * HID; idx += 256) d.save_hidden[(long long)(k0 + idx / HID) * HID + idx % HID] = s_hid[idx / HID][idx % HID];
+    if (t < nr * 16) {
+      const int r = t / 16, j = t % 16;
+      d.save_small[(long long)(k0 + r) * 16 + j] = s_small[r][j] + (j >= 6 ? d.wts.rb[j - 6] : 0.f);
+    }
+    return;
+  }
+
   // phase D: one thread per RoI - scalar tail
-  if (t < nr) {
-    const int r = t, k = k0 + r;
-    const float* sm = s_small[r];
-    const float cls0 = sigmoidf(sm[4]), cls1 = sigmoidf(sm[5]);
-    float rad = d.wts.rb2[0];
+  if (t < nr) tail_one(d, s_small[t], s_roi[t], k0 + t, n_img);
+}
+
+
+// ---- training: stand-alone tail, loss terms, tail backward -----------------------------------------
+__global__ __launch_bounds__(256) void heads_tail_kernel(me_heads_desc d, const float* small, int k) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const int n_img = *d.n_img;
+  float roi[5];
+  for (int c = 0; c < 5; ++c)
+    roi[c] = (i < n_img) ? d.img_boxes[(long long)i * d.box_cols + c] : d.radar_boxes[(long long)(i - n_img) * 5 + c];
+  tail_one(d, small + 16ll * i, roi, i, n_img);
+}
+
+__global__ __launch_bounds__(256) void heads_loss_kernel(const float* mask1, const float* refine,
+                                                         const uint8_t* label_pos, const uint8_t* in_focal,
+                                                         const uint8_t* in_conf, int k, float alpha, float lam,
+                                                         float* terms, float* seed_p, float* seed_conf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const bool pos = label_pos[i] != 0;
+  float focal = 0.f, dp = 0.f;
+  if (in_focal[i]) {  // FocalLoss(alpha, gamma=2, "sum") on [1-p, p] vs one-hot (my_models.py:287-314, 610)
+    const float p = mask1[i];
+    const float pt = pos ? p : 1.f - p;
+    const float a = pos ? alpha : 1.f - alpha;
+    const float lg = logf(pt);
+    focal = -a * (1.f - pt) * (1.f - pt) * lg;
+    const float dpt = a * (2.f * (1.f - pt) * lg - (1.f - pt) * (1.f - pt) / pt);
+    dp = pos ? dpt : -dpt;
+  }
+  float bce = 0.f, dc = 0.f;
+  if (in_conf[i]) {  // nn.BCELoss(reduction="sum") / lambda (my_models.py:614-619, 635); log clamped at -100
+    const float x = refine[2 * i];
+    const float y = pos ? 1.f : 0.f;
+    const float l1 = fmaxf(logf(x), -100.f), l0 = fmaxf(logf(1.f - x), -100.f);
+    bce = -(y * l1 + (1.f - y) * l0) / lam;
+    dc = (x - y) / fmaxf((1.f - x) * x, 1e-12f) / lam;
+  }
+  terms[2 * i] = focal;
+  terms[2 * i + 1] = bce;
+  seed_p[i] = dp;
+  seed_conf[i] = dc;
+}
+
+__global__ __launch_bounds__(256) void heads_tail_bwd_kernel(me_heads_desc d, const float* small, const float* refine,
+                                                             const float* mask1, const float* seed_p,
+                                                             const float* seed_conf, int k, float* g_o, float* g_hpre,
+                                                             float* h_act, float* xin, float* g_z2, float* g_rl,
+                                                             float* rl_out, float* g_rlogit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const int n_img = *d.n_img;
+  const float* sm = small + 16ll * i;
+  const float conf = refine[2 * i], cls1 = refine[2 * i + 1];
+  const float cls0 = sigmoidf(sm[4]);
+  float rl[C_OUT], rpre[C_OUT];
+  float rad = d.wts.rb2[0];
 #pragma unroll
-    for (int o = 0; o < C_OUT; ++o) rad = fmaf(d.wts.rw2[o], leaky(sm[6 + o] * d.wts.rscale[o] + d.wts.rshift[o]), rad);
-    const float radar_conf = sigmoidf(rad);
-    const float conf = sigmoidf(radar_conf + cls0);  // sigmoid applied twice on purpose (quirk q2)
-    const bool is_img = k < n_img;
-    float p;
-    float c6, c7;
-    if (is_img) {
-      const float* bx = d.img_boxes + (long long)k * d.box_cols;
-      const float yolo0 = bx[5], yolo1 = bx[8];
-      // ensemble_head: stack -> fc1 (2->32) + leaky -> flatten(64) -> fc2 (64->2) -> softmax; column 0 (q1)
-      float o0 = d.wts.e2b[0], o1 = d.wts.e2b[1];
-#pragma unroll 4
-      for (int u = 0; u < 32; ++u) {
-        const float wa = d.wts.e1w[2 * u], wb = d.wts.e1w[2 * u + 1], bb = d.wts.e1b[u];
-        const float h0 = leaky(wa * conf + wb * yolo0 + bb);
-        const float h1 = leaky(wa * cls1 + wb * yolo1 + bb);
-        o0 += d.wts.e2w[u] * h0 + d.wts.e2w[32 + u] * h1;
-        o1 += d.wts.e2w[64 + u] * h0 + d.wts.e2w[96 + u] * h1;
-      }
-      const float m = fmaxf(o0, o1);
-      const float e0 = expf(o0 - m), e1 = expf(o1 - m);
-      p = e0 / (e0 + e1);
-      c6 = bx[6];
-      c7 = bx[7];
-    } else {
-      p = conf;
-      c6 = cls1;
-      c7 = 0.f;
+  for (int o = 0; o < C_OUT; ++o) {
+    rpre[o] = sm[6 + o] * d.wts.rscale[o] + d.wts.rshift[o];
+    rl[o] = leaky(rpre[o]);
+    rad = fmaf(d.wts.rw2[o], rl[o], rad);
+  }
+  const float rconf = sigmoidf(rad);
+  float d_conf = seed_conf[i], d_cls1 = 0.f;
+  float go0 = 0.f, go1 = 0.f;
+  float* gh = g_hpre + 64ll * i;
+  float* ha = h_act + 64ll * i;
+  if (i < n_img) {
+    const float* bx = d.img_boxes + (long long)i * d.box_cols;
+    const float yolo0 = bx[5], yolo1 = bx[8];
+    const float p = mask1[i];
+    // p = softmax(o)[0]: dp/do0 = p (1 - p), dp/do1 = -p (1 - p)
+    go0 = seed_p[i] * p * (1.f - p);
+    go1 = -go0;
+    float d_r0 = 0.f, d_r1 = 0.f;
+    for (int u = 0; u < 32; ++u) {
+      const float wa = d.wts.e1w[2 * u], wb = d.wts.e1w[2 * u + 1], bb = d.wts.e1b[u];
+      const float pre0 = wa * conf + wb * yolo0 + bb, pre1 = wa * cls1 + wb * yolo1 + bb;
+      ha[u] = leaky(pre0);
+      ha[32 + u] = leaky(pre1);
+      const float dh0 = d.wts.e2w[u] * go0 + d.wts.e2w[64 + u] * go1;
+      const float dh1 = d.wts.e2w[32 + u] * go0 + d.wts.e2w[96 + u] * go1;
+      const float dp0 = pre0 > 0.f ? dh0 : 0.1f * dh0, dp1 = pre1 > 0.f ? dh1 : 0.1f * dh1;
+      gh[u] = dp0;
+      gh[32 + u] = dp1;
+      d_r0 += dp0 * wa;
+      d_r1 += dp1 * wa;
     }
-    d.regress_out[4 * k + 0] = sm[0];
-    d.regress_out[4 * k + 1] = sm[1];
-    d.regress_out[4 * k + 2] = sm[2];
-    d.regress_out[4 * k + 3] = sm[3];
-    d.refine_out[2 * k + 0] = conf;
-    d.refine_out[2 * k + 1] = cls1;
-    d.mask1_out[k] = p;
-    const float thr = is_img ? d.thr_img : d.thr_radar;
-    d.keep[k] = (p > thr) ? 1 : 0;
-    d.sort_key[k] = is_img ? p : p / 5.f;
-    float x1 = s_roi[r][1], y1 = s_roi[r][2], x2 = s_roi[r][3], y2 = s_roi[r][4];
-    if (d.regress) {  // box_regress, my_models.py:378-391
-      const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2, bw = x2 - x1, bh = y2 - y1;
-      const float nx = sm[0] * bw + cx, ny = sm[1] * bh + cy;
-      const float nw = expf(sm[2]) * bw, nh = expf(sm[3]) * bh;
-      x1 = nx - nw / 2; y1 = ny - nh / 2; x2 = nx + nw / 2; y2 = ny + nh / 2;
-    }
-    float* o = d.out_rows + 8ll * k;
-    o[0] = s_roi[r][0]; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = p; o[6] = c6; o[7] = c7;
+    d_conf += d_r0;
+    d_cls1 = d_r1;
+    xin[4 * i + 0] = conf; xin[4 * i + 1] = yolo0; xin[4 * i + 2] = cls1; xin[4 * i + 3] = yolo1;
+  } else {
+    for (int u = 0; u < 64; ++u) { gh[u] = 0.f; ha[u] = 0.f; }
+    xin[4 * i + 0] = xin[4 * i + 1] = xin[4 * i + 2] = xin[4 * i + 3] = 0.f;
+  }
+  g_o[2 * i] = go0;
+  g_o[2 * i + 1] = go1;
+  const float d_s = d_conf * conf * (1.f - conf);  // conf = sigmoid(rconf + cls0)
+  g_z2[2 * i] = d_s * cls0 * (1.f - cls0);
+  g_z2[2 * i + 1] = d_cls1 * cls1 * (1.f - cls1);
+  const float d_rlogit = d_s * rconf * (1.f - rconf);
+  g_rlogit[i] = d_rlogit;
+#pragma unroll
+  for (int o = 0; o < C_OUT; ++o) {
+    g_rl[10ll * i + o] = d_rlogit * d.wts.rw2[o];
+    rl_out[10ll * i + o] = rl[o];
   }
 }
 
@@ -346,6 +470,9 @@ int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
   ME_REQUIRE(d->n > 0 && d->fh > 0 && d->fw > 0 && d->n_img_cap >= 0 && d->n_radar >= 0 && d->box_cols >= 9,
              ME_E_BADARG, "me_roi_heads_f32: bad dimensions");
   ME_REQUIRE(d->img_pitch >= FEAT && d->radar_pitch >= C_OUT, ME_E_BADARG, "me_roi_heads_f32: map pitch too small");
+  const bool train = d->save_small || d->save_feat_img || d->save_feat_rad || d->save_hidden;
+  ME_REQUIRE(!train || (d->save_small && d->save_feat_img && d->save_feat_rad && d->save_hidden && w.rb), ME_E_NULLPTR,
+             "me_roi_heads_f32: training mode needs all four save_* pointers and wts.rb");
   const int cap = d->n_img_cap + d->n_radar;
   if (cap == 0) return 0;
   hipLaunchKernelGGL(roi_heads_kernel, dim3((cap + RPB - 1) / RPB), dim3(256), 0, stream, *d);
@@ -376,6 +503,45 @@ int me_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int3
 int me_ps_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c,
                         const float* rois, int32_t k, int32_t pooled, float spatial_scale, float* out, void* stream) {
   return launch_roi(map, pitch, n, h, w, c, rois, k, pooled, spatial_scale, out, stream, 1);
+}
+
+int me_heads_tail_f32(const me_heads_desc* d, const float* small, int32_t k, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(d && small && d->n_img && d->img_boxes, ME_E_NULLPTR, "me_heads_tail_f32: null pointer");
+  ME_REQUIRE(d->regress_out && d->refine_out && d->mask1_out && d->out_rows && d->keep && d->sort_key, ME_E_NULLPTR,
+             "me_heads_tail_f32: null output");
+  ME_REQUIRE(k >= 0, ME_E_BADARG, "me_heads_tail_f32: negative k");
+  if (k == 0) return 0;
+  hipLaunchKernelGGL(heads_tail_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, *d, small, k);
+  return me::check_launch("heads_tail_kernel");
+}
+
+int me_heads_loss_f32(const float* mask1, const float* refine, const uint8_t* label_pos, const uint8_t* in_focal,
+                      const uint8_t* in_conf, int32_t k, float alpha, float conf_lambda, float* terms, float* seed_p,
+                      float* seed_conf, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(k >= 0, ME_E_BADARG, "me_heads_loss_f32: negative k");
+  if (k == 0) return 0;
+  ME_REQUIRE(mask1 && refine && label_pos && in_focal && in_conf && terms && seed_p && seed_conf, ME_E_NULLPTR,
+             "me_heads_loss_f32: null pointer");
+  hipLaunchKernelGGL(heads_loss_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, mask1, refine, label_pos,
+                     in_focal, in_conf, k, alpha, conf_lambda, terms, seed_p, seed_conf);
+  return me::check_launch("heads_loss_kernel");
+}
+
+int me_heads_tail_bwd_f32(const me_heads_desc* d, const float* small, const float* refine, const float* mask1,
+                          const float* seed_p, const float* seed_conf, int32_t k, float* g_o, float* g_hpre,
+                          float* h_act, float* xin, float* g_z2, float* g_rl, float* rl, float* g_rlogit,
+                          void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(k >= 0, ME_E_BADARG, "me_heads_tail_bwd_f32: negative k");
+  if (k == 0) return 0;
+  ME_REQUIRE(d && small && refine && mask1 && seed_p && seed_conf && g_o && g_hpre && h_act && xin && g_z2 && g_rl &&
+                 rl && g_rlogit && d->n_img && d->img_boxes,
+             ME_E_NULLPTR, "me_heads_tail_bwd_f32: null pointer");
+  hipLaunchKernelGGL(heads_tail_bwd_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, *d, small, refine, mask1,
+                     seed_p, seed_conf, k, g_o, g_hpre, h_act, xin, g_z2, g_rl, rl, g_rlogit);
+  return me::check_launch("heads_tail_bwd_kernel");
 }
 
 }  // extern "C"

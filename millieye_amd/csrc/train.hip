@@ -1,0 +1,492 @@
+// train.hip - building blocks of the stage-3 training step (gfx950), fp32.
+//
+// The reference trains the fusion heads through torch autograd (module3_our_dataset/train.py:185-191,
+// loss assembled in my_models.py:545-639).  Gradients reach: ensemble_head.fc1/fc2, refinement_head
+// (net0, net2 rows 0-1, radar_net), img_cnn_layers (through ps_roi_align backward) and
+// radar_cnn_layers (through roi_align backward); the detector is frozen and detached.
+// This file provides the native kernels that training step is assembled from
+// (millieye_amd/train_path.py owns the fixed graph and the order of launches):
+//
+//   me_gemm_f32            C = op(A) * op(B) (+C)      Linear / 1x1-conv forward, dgrad and wgrad
+//   me_colsum_f32          bias gradients
+//   me_bn_train_fwd_f32    batch statistics + normalise + LeakyReLU, running-stat update
+//   me_bn_train_bwd_f32    dgamma, dbeta, dx (LeakyReLU backward fused)
+//   me_act_bwd_f32         sigmoid / leaky backward (elementwise)
+//   me_conv_wgrad_f32      3x3 / 1x1 weight gradient (NHWC gather, no im2col)
+//   me_roi_align_bwd_f32 / me_ps_roi_align_bwd_f32   atomic scatter (torchvision backward semantics)
+//
+// These layers are tiny next to the detector (0.3 GFLOP/frame forward): the kernels favour
+// simplicity and determinism (no atomics except the RoI scatters, which torchvision also does
+// with atomics) over peak throughput; none of them is on the inference path.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// GEMM: C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C.  Row-major, leading dimensions.
+// 64x64 tile, 256 threads, 4x4 outputs per thread, K step 16 through LDS.  Reduction over K is
+// sequential per output element -> bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, long long lda,
+                                                   const float* __restrict__ B, long long ldb, float* C,
+                                                   long long ldc, int M, int N, int K, float alpha, float beta) {
+  __shared__ float As[16][64 + 1];
+  __shared__ float Bs[16][64 + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int kk = TA ? idx / 64 : idx % 16, mm = TA ? idx % 64 : idx / 16;
+      const int m = m0 + mm, k = k0 + kk;
+      float v = 0.f;
+      if (m < M && k < K) v = TA ? A[(long long)k * lda + m] : A[(long long)m * lda + k];
+      As[kk][mm] = v;
+    }
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int kk = TB ? idx % 16 : idx / 64, nn = TB ? idx / 16 : idx % 64;
+      const int n = n0 + nn, k = k0 + kk;
+      float v = 0.f;
+      if (n < N && k < K) v = TB ? B[(long long)n * ldb + k] : B[(long long)k * ldb + n];
+      Bs[kk][nn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m < M && n < N) {
+        float* c = C + (long long)m * ldc + n;
+        *c = alpha * acc[i][j] + (beta != 0.f ? beta * *c : 0.f);
+      }
+    }
+}
+
+// column sums of X[rows, cols] (pitch ld): out[c] = sum_r X[r][c]; one workgroup per 64 columns,
+// fixed-order tree -> deterministic
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long ld, int rows, int cols,
+                                                     float* out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = part; r < rows; r += 4) s += X[(long long)r * ld + c];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm (training mode) over rows of X[rows, C] (pitch ld).
+//   stats: mean[c], var[c] (biased) - two-level fixed-order reduction (64 row-chunks)
+//   fwd:   y = act((x - mean) * rstd * gamma + beta);  running stats updated like nn.BatchNorm2d
+//          (momentum m: running = (1-m)*running + m*stat, unbiased variance for running_var)
+//   bwd:   g = dy * act'(y);  dbeta = sum g;  dgamma = sum g * xhat;
+//          dx = gamma * rstd * (g - dbeta/rows - xhat * dgamma/rows)
+// ---------------------------------------------------------------------------------------------
+constexpr int BN_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ X, long long ld, int rows, int C,
+                                                         const float* __restrict__ G, long long ldg,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, float* p0, float* p1) {
+  // forward use (G == nullptr): p0 = sum x, p1 = sum x^2 over this block's row chunk
+  // backward use: p0 = sum g, p1 = sum g * xhat with g = dy * act'(bn output)
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  if (c >= C) return;
+  const int per = (rows + BN_CHUNKS - 1) / BN_CHUNKS;
+  const int r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  double s0 = 0.0, s1 = 0.0;
+  if (G == nullptr) {
+    for (int r = r0; r < r1; ++r) {
+      const float x = X[(long long)r * ld + c];
+      s0 += x;
+      s1 += (double)x * x;
+    }
+  } else {
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    for (int r = r0; r < r1; ++r) {
+      const float xh = (X[(long long)r * ld + c] - mu) * rs;
+      float g = G[(long long)r * ldg + c];
+      if (act == ME_ACT_LEAKY) g = (xh * ga + be > 0.f) ? g : 0.1f * g;
+      s0 += g;
+      s1 += (double)g * xh;
+    }
+  }
+  p0[(long long)chunk * C + c] = (float)s0;
+  p1[(long long)chunk * C + c] = (float)s1;
+}
+
+__global__ __launch_bounds__(256) void bn_finish_stats_kernel(const float* p0, const float* p1, int rows, int C,
+                                                              float eps, float momentum, float* mean, float* var,
+                                                              float* rstd, float* running_mean, float* running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < BN_CHUNKS; ++k) {
+    s0 += p0[(long long)k * C + c];
+    s1 += p1[(long long)k * C + c];
+  }
+  const double mu = s0 / rows;
+  double v = s1 / rows - mu * mu;
+  if (v < 0.0) v = 0.0;
+  mean[c] = (float)mu;
+  var[c] = (float)v;
+  rstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+  if (running_mean) {
+    const double unb = rows > 1 ? v * rows / (rows - 1) : v;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ X, long long ld, int rows, int C,
+                                                       const float* mean, const float* rstd, const float* gamma,
+                                                       const float* beta, int act, float* Y, long long ldy) {
+  const long long total = (long long)rows * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    float v = (X[r * ld + c] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    if (act == ME_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
+    Y[r * ldy + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ X, long long ld,
+                                                           const float* __restrict__ G, long long ldg, int rows,
+                                                           int C, const float* mean, const float* rstd,
+                                                           const float* gamma, const float* beta, int act,
+                                                           const float* p0, const float* p1, float* dgamma,
+                                                           float* dbeta, float* DX, long long lddx) {
+  // p0[c] / p1[c] hold the channel sums (bn_reduce_partials_kernel folded the chunk partials, fixed order)
+  const long long total = (long long)rows * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    const double s0 = p0[c], s1 = p1[c];
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    const float xh = (X[r * ld + c] - mu) * rs;
+    float g = G[r * ldg + c];
+    if (act == ME_ACT_LEAKY) g = (xh * ga + be > 0.f) ? g : 0.1f * g;
+    if (DX) DX[r * lddx + c] = ga * rs * (g - (float)(s0 / rows) - xh * (float)(s1 / rows));
+    if (r == 0) {
+      if (dbeta) dbeta[c] = (float)s0;
+      if (dgamma) dgamma[c] = (float)s1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_reduce_partials_kernel(float* p0, float* p1, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < BN_CHUNKS; ++k) {
+    s0 += p0[(long long)k * C + c];
+    s1 += p1[(long long)k * C + c];
+  }
+  p0[c] = (float)s0;
+  p1[c] = (float)s1;
+}
+
+// elementwise activation backward: dx = dy * act'(y) given the activation OUTPUT y
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ Y, long long ldy,
+                                                      const float* __restrict__ G, long long ldg, float* DX,
+                                                      long long lddx, long long rows, int C, int act) {
+  const long long total = rows * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    const float y = Y[r * ldy + c];
+    float g = G[r * ldg + c];
+    if (act == ME_ACT_SIGMOID) g *= y * (1.f - y);
+    else if (act == ME_ACT_LEAKY) g = y > 0.f ? g : 0.1f * g;
+    DX[r * lddx + c] = g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv weight gradient: dW[co][ky][kx][ci] = sum_p dY[p][co] * X[p + tap][ci]  (stride 1/2, zero pad)
+// one workgroup = 64 co x 64 ci for one tap; pixels stream through LDS 16 at a time.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ X, long long xp,
+                                                         const float* __restrict__ DY, long long dyp, float* DW,
+                                                         int n, int h, int w, int cin, int cout, int ks, int stride,
+                                                         int pad, int ho, int wo) {
+  __shared__ float Ys[16][64 + 1];
+  __shared__ float Xs[16][64 + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int tap = blockIdx.z, ky = tap / ks, kx = tap - ky * ks;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+  const int P = n * ho * wo;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int p0 = 0; p0 < P; p0 += 16) {
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int pp = idx / 64, cc = idx % 64;
+      const int p = p0 + pp;
+      float vy = 0.f, vx = 0.f;
+      if (p < P) {
+        if (co0 + cc < cout) vy = DY[(long long)p * dyp + co0 + cc];
+        const int nimg = p / (ho * wo);
+        const int rem = p - nimg * ho * wo;
+        const int oy = rem / wo, ox = rem - oy * wo;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w && ci0 + cc < cin)
+          vx = X[((long long)(nimg * h + iy) * w + ix) * xp + ci0 + cc];
+      }
+      Ys[pp][cc] = vy;
+      Xs[pp][cc] = vx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Ys[pp][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Xs[pp][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + ty * 4 + i, ci = ci0 + tx * 4 + j;
+      if (co < cout && ci < cin) DW[((long long)co * ks * ks + tap) * cin + ci] = acc[i][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoI pooling backward (torchvision roi_align / ps_roi_align backward semantics, oracle/tv_ops.c):
+// every sample scatters grad * w / count to its four bilinear corners with atomicAdd.
+// grad_map is NHWC [n,h,w,c] (pitch), zero-filled by the caller.
+// ---------------------------------------------------------------------------------------------
+constexpr int P7 = 7;
+
+__device__ __forceinline__ int grid_of7(float extent) {
+  const float g = ceilf(extent / (float)P7);
+  if (!(g < 1.0e9f)) return (g != g) ? 0 : 1000000000;
+  if (g < -1.0e9f) return -1000000000;
+  return (int)g;
+}
+
+__device__ __forceinline__ void scatter_bilinear(float* gmap, long long pitch, int height, int width, int c, float y,
+                                                 float x, float gval) {
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return;
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+  atomicAdd(gmap + ((long long)y_low * width + x_low) * pitch + c, gval * (hy * hx));
+  atomicAdd(gmap + ((long long)y_low * width + x_high) * pitch + c, gval * (hy * lx));
+  atomicAdd(gmap + ((long long)y_high * width + x_low) * pitch + c, gval * (ly * hx));
+  atomicAdd(gmap + ((long long)y_high * width + x_high) * pitch + c, gval * (ly * lx));
+}
+
+__global__ __launch_bounds__(256) void roi_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                      int k, int c, int h, int w, float scale, float* gmap,
+                                                      long long pitch, int ps) {
+  // gout: [k, c_out, 7, 7] with c_out = ps ? c/49 : c
+  const int cout = ps ? c / 49 : c;
+  const long long total = (long long)k * cout * 49;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int pw = (int)(idx % P7), ph = (int)((idx / P7) % P7);
+    const int cc = (int)((idx / 49) % cout);
+    const int r = (int)(idx / (49ll * cout));
+    const float* roi = rois + 5 * r;
+    const int b = (int)roi[0];
+    const float off = ps ? 0.5f : 0.0f;
+    const float sw = roi[1] * scale - off, sh = roi[2] * scale - off;
+    const float ew = roi[3] * scale - off, eh = roi[4] * scale - off;
+    float roi_w = ew - sw, roi_h = eh - sh;
+    if (!ps) {
+      roi_w = roi_w > 1.f ? roi_w : 1.f;
+      roi_h = roi_h > 1.f ? roi_h : 1.f;
+    }
+    const float bin_h = roi_h / (float)P7, bin_w = roi_w / (float)P7;
+    const int gh = grid_of7(roi_h), gw = grid_of7(roi_w);
+    if (gh <= 0 || gw <= 0 || gh > 4096 || gw > 4096) continue;
+    const float count = (float)(gh * gw);
+    const float g = gout[idx];
+    const int ch = ps ? (cc * P7 + ph) * P7 + pw : cc;
+    float* gimg = gmap + (long long)b * h * w * pitch;
+    const float ybase = ps ? ((float)ph * bin_h + sh) : (sh + ph * bin_h);
+    const float xbase = ps ? ((float)pw * bin_w + sw) : (sw + pw * bin_w);
+    for (int iy = 0; iy < gh; ++iy) {
+      const float yy = ybase + ((float)(iy + .5f)) * bin_h / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float xx = xbase + ((float)(ix + .5f)) * bin_w / (float)gw;
+        scatter_bilinear(gimg, pitch, h, w, ch, yy, xx, g / count);
+      }
+    }
+  }
+}
+
+inline unsigned grid1d(long long work) {
+  long long b = (work + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int me_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float* a,
+                int64_t lda, const float* b, int64_t ldb, float beta, float* c, int64_t ldc, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(m >= 0 && n >= 0 && k >= 0, ME_E_BADARG, "me_gemm_f32: negative dimension");
+  if (m == 0 || n == 0) return 0;
+  ME_REQUIRE(c && (k == 0 || (a && b)), ME_E_NULLPTR, "me_gemm_f32: null pointer");
+  dim3 grid((n + 63) / 64, (m + 63) / 64);
+  ME_REQUIRE(grid.y <= 65535, ME_E_TOOBIG, "me_gemm_f32: M too large");
+  const long long la = lda, lb = ldb, lc = ldc;
+  if (!trans_a && !trans_b)
+    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, a, la, b, lb, c, lc, m, n, k, alpha, beta);
+  else if (trans_a && !trans_b)
+    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, stream, a, la, b, lb, c, lc, m, n, k, alpha, beta);
+  else if (!trans_a && trans_b)
+    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, stream, a, la, b, lb, c, lc, m, n, k, alpha, beta);
+  else
+    hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, a, la, b, lb, c, lc, m, n, k, alpha, beta);
+  return me::check_launch("gemm_kernel");
+}
+
+int me_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float* out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(out && (x || rows == 0), ME_E_NULLPTR, "me_colsum_f32: null pointer");
+  ME_REQUIRE(rows >= 0 && cols > 0, ME_E_BADARG, "me_colsum_f32: bad dimensions");
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, stream, x, (long long)ld, rows, cols, out);
+  return me::check_launch("colsum_kernel");
+}
+
+int64_t me_bn_workspace_bytes(int32_t channels) { return (int64_t)2 * BN_CHUNKS * channels * sizeof(float); }
+
+int me_bn_train_fwd_f32(const float* x, int64_t ldx, int32_t rows, int32_t channels, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        int32_t act, float* y, int64_t ldy, float* save_mean, float* save_var, float* save_rstd,
+                        void* workspace, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(x && gamma && beta && y && save_mean && save_var && save_rstd && workspace, ME_E_NULLPTR,
+             "me_bn_train_fwd_f32: null pointer");
+  ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_bn_train_fwd_f32: bad dimensions");
+  float* p0 = reinterpret_cast<float*>(workspace);
+  float* p1 = p0 + (long long)BN_CHUNKS * channels;
+  const unsigned cb = (channels + 255) / 256;
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
+                     (const float*)nullptr, 0ll, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, 0, p0, p1);
+  hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, rows, channels, eps, momentum,
+                     save_mean, save_var, save_rstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid1d((long long)rows * channels)), dim3(256), 0, stream, x,
+                     (long long)ldx, rows, channels, save_mean, save_rstd, gamma, beta, act, y, (long long)ldy);
+  return me::check_launch("bn_train_fwd");
+}
+
+int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
+                        const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
+                        int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* workspace,
+                        void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(x && dy && gamma && beta && save_mean && save_rstd && workspace, ME_E_NULLPTR,
+             "me_bn_train_bwd_f32: null pointer");
+  ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_bn_train_bwd_f32: bad dimensions");
+  float* p0 = reinterpret_cast<float*>(workspace);
+  float* p1 = p0 + (long long)BN_CHUNKS * channels;
+  const unsigned cb = (channels + 255) / 256;
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
+                     dy, (long long)lddy, save_mean, save_rstd, gamma, beta, act, p0, p1);
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, channels);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d((long long)rows * channels)), dim3(256), 0, stream, x,
+                     (long long)ldx, dy, (long long)lddy, rows, channels, save_mean, save_rstd, gamma, beta, act, p0,
+                     p1, dgamma, dbeta, dx, (long long)lddx);
+  return me::check_launch("bn_train_bwd");
+}
+
+int me_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx, int64_t lddx, int64_t rows,
+                   int32_t channels, int32_t act, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(y && dy && dx, ME_E_NULLPTR, "me_act_bwd_f32: null pointer");
+  ME_REQUIRE(rows >= 0 && channels > 0, ME_E_BADARG, "me_act_bwd_f32: bad dimensions");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(rows * channels)), dim3(256), 0, stream, y, (long long)ldy, dy,
+                     (long long)lddy, dx, (long long)lddx, (long long)rows, channels, act);
+  return me::check_launch("act_bwd_kernel");
+}
+
+int me_conv_wgrad_f32(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n,
+                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
+                      void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(x && dy && dw, ME_E_NULLPTR, "me_conv_wgrad_f32: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0,
+             ME_E_BADARG, "me_conv_wgrad_f32: bad dimensions");
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+  dim3 grid((cin + 63) / 64, (cout + 63) / 64, ksize * ksize);
+  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy, (long long)dy_pitch, dw,
+                     n, h, w, cin, cout, ksize, stride, pad, ho, wo);
+  return me::check_launch("conv_wgrad_kernel");
+}
+
+static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w, int32_t c,
+                          int32_t pooled, float scale, float* gmap, int64_t pitch, void* stream_, int ps) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(gmap && (k == 0 || (gout && rois)), ME_E_NULLPTR, "me_roi_align_bwd_f32: null pointer");
+  ME_REQUIRE(pooled == 7 && n > 0 && h > 0 && w > 0 && c > 0 && pitch >= c && k >= 0, ME_E_BADARG,
+             "me_roi_align_bwd_f32: bad dimensions");
+  ME_REQUIRE(!ps || c % 49 == 0, ME_E_BADARG, "me_ps_roi_align_bwd_f32: channels %% 49 != 0");
+  if (k == 0) return 0;
+  const long long total = (long long)k * (ps ? c / 49 : c) * 49;
+  hipLaunchKernelGGL(roi_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, stream, gout, rois, k, c, h, w, scale, gmap,
+                     (long long)pitch, ps);
+  return me::check_launch("roi_bwd_kernel");
+}
+
+int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
+                         int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
+                         void* stream) {
+  return launch_roi_bwd(grad_out, rois, k, n, h, w, c, pooled, spatial_scale, grad_map, pitch, stream, 0);
+}
+
+int me_ps_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
+                            int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
+                            void* stream) {
+  return launch_roi_bwd(grad_out, rois, k, n, h, w, c, pooled, spatial_scale, grad_map, pitch, stream, 1);
+}
+
+}  // extern "C"

@@ -71,7 +71,8 @@ class NmsDesc(C.Structure):
 
 class HeadsWeights(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in (
-        "w0t", "b0", "w1", "b1", "w2", "b2", "rw", "rscale", "rshift", "rw2", "rb2", "e1w", "e1b", "e2w", "e2b")]
+        "w0t", "b0", "w1", "b1", "w2", "b2", "rw", "rscale", "rshift", "rw2", "rb2", "e1w", "e1b", "e2w", "e2b",
+        "rb")]
 
 
 class HeadsDesc(C.Structure):
@@ -89,6 +90,8 @@ class HeadsDesc(C.Structure):
         ("wts", HeadsWeights),
         ("regress_out", C.c_void_p), ("refine_out", C.c_void_p), ("mask1_out", C.c_void_p),
         ("out_rows", C.c_void_p), ("keep", C.c_void_p), ("sort_key", C.c_void_p),
+        ("save_feat_img", C.c_void_p), ("save_feat_rad", C.c_void_p), ("save_hidden", C.c_void_p),
+        ("save_small", C.c_void_p),
     ]
 
 
@@ -119,6 +122,28 @@ SIGNATURES = {
     "me_gather_class_boxes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "me_roi_heads_f32": (C.c_int, [C.POINTER(HeadsDesc), C.c_void_p]),
+    "me_heads_tail_f32": (C.c_int, [C.POINTER(HeadsDesc), C.c_void_p, C.c_int32, C.c_void_p]),
+    "me_heads_loss_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
+                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "me_heads_tail_bwd_f32": (C.c_int, [C.POINTER(HeadsDesc)] + [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 9),
+    "me_gemm_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
+                              C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "me_bn_workspace_bytes": (C.c_int64, [C.c_int32]),
+    "me_bn_train_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "me_bn_train_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "me_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                 C.c_int32, C.c_int32, C.c_void_p]),
+    "me_conv_wgrad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "me_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_ps_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "me_roi_align_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "me_ps_roi_align_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -311,9 +311,9 @@ class Network(nn.Module):
         tensor there is therefore taken as ``targets`` with mode 0."""
         if isinstance(model_mode, torch.Tensor):
             targets, model_mode = model_mode, 0
-        if targets is not None:
-            raise NotImplementedError("the stage-3 training tail (loss + backward) is not built yet "
-                                      "(SURVEY.md rows a17 / K14)")
+        if targets is not None:  # training call: (loss, output, metric, radar_attention), reference :545-641
+            from .train_path import forward_train
+            return forward_train(self, images, maps, radar_boxes_location, targets)
         if not images.is_cuda:
             raise hip.MeError("Network.forward needs CUDA tensors (MI355X); there is no CPU fallback")
         dev = images.device

@@ -1,0 +1,400 @@
+"""Stage-3 training step of ``Network.forward(..., targets)`` on the HIP library.
+
+Reference: ``module3_our_dataset/my_models.py:545-639`` (labels, sampling, focal + BCE losses) on top
+of the train-mode forward of the heads, differentiated by torch autograd (``train.py:185-191``).
+Here the graph is fixed, so forward and backward are explicit launch sequences over
+``libmillieye_hip`` (``csrc/train.hip``, ``csrc/heads.hip``, ``csrc/conv.hip``); autograd only sees one
+:class:`torch.autograd.Function` whose inputs are the head parameters, so ``loss.backward()`` /
+``optimizer.step()`` / ``requires_grad=False`` freezing (``train.py:146-149``) behave as in the reference.
+
+What gets a gradient: ``ensemble_head.fc1/fc2``, ``refinement_head.net0``,
+``net2`` (rows 0-1; the other rows are zero), ``radar_net``; ``img_cnn_layers`` through the PS-RoIAlign
+backward; ``radar_cnn_layers`` through the RoIAlign backward.  ``net1`` (regression loss is excluded from the
+loss, my_models.py:635), ``net3`` and ``fusion_head`` (never used) get ``None`` like in the reference.
+The detector is frozen and detached (models.py:255,266).
+
+Host-side parts are the ones that are host-side in the reference too: IoU labelling
+(``obtain_iou_labels``, a python loop over boxes) and negative sampling with python's ``random``.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+
+from . import hip
+from .engine import ConvWeights
+
+_EPS = 1e-5
+_MOM = 0.1
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, alpha=1.0, beta=0.0):
+    hip.check(hip.lib().me_gemm_f32(int(ta), int(tb), m, n, k, alpha, _ptr(a), lda, _ptr(b), ldb, beta, _ptr(c), ldc,
+                                    hip.stream_ptr()), "me_gemm_f32")
+
+
+def _colsum(x, ld, rows, cols, out):
+    hip.check(hip.lib().me_colsum_f32(_ptr(x), ld, rows, cols, _ptr(out), hip.stream_ptr()), "me_colsum_f32")
+
+
+def _f32(dev, *shape):
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+class _BnState:
+    def __init__(self, c, dev):
+        self.mean, self.var, self.rstd = _f32(dev, c), _f32(dev, c), _f32(dev, c)
+
+
+def _bn_fwd(x, ldx, rows, c, bn, act, y, ldy, ws):
+    st = _BnState(c, x.device)
+    if rows == 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, {c}]")
+    hip.check(hip.lib().me_bn_train_fwd_f32(_ptr(x), ldx, rows, c, _ptr(bn.weight), _ptr(bn.bias), float(bn.eps),
+                                            float(bn.momentum), _ptr(bn.running_mean), _ptr(bn.running_var), act,
+                                            _ptr(y), ldy, _ptr(st.mean), _ptr(st.var), _ptr(st.rstd), ws,
+                                            hip.stream_ptr()), "me_bn_train_fwd_f32")
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return st
+
+
+def _bn_bwd(x, ldx, dy, lddy, rows, c, bn, st, act, dx, lddx, ws):
+    dg, db = _f32(x.device, c), _f32(x.device, c)
+    hip.check(hip.lib().me_bn_train_bwd_f32(_ptr(x), ldx, _ptr(dy), lddy, rows, c, _ptr(bn.weight), _ptr(bn.bias),
+                                            _ptr(st.mean), _ptr(st.rstd), act, _ptr(dx), lddx, _ptr(dg), _ptr(db), ws,
+                                            hip.stream_ptr()), "me_bn_train_bwd_f32")
+    return dg, db
+
+
+def _conv(x, x_pitch, n, h, w, cin, wgt, scale, shift, k, pad, act, out):
+    d = hip.ConvDesc()
+    d.x, d.x_pitch, d.x_nchw = _ptr(x), x_pitch, 0
+    d.wgt, d.scale, d.shift, d.res, d.res_pitch = _ptr(wgt), _ptr(scale), _ptr(shift), None, 0
+    d.y, d.y_pitch = _ptr(out), out.shape[-1]
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, wgt.shape[0]
+    d.ksize, d.stride, d.pad, d.ho, d.wo = k, 1, pad, h, w
+    d.act, d.upsample, d.tile, d.split_k = act, 1, 0, 1
+    hip.check(hip.lib().me_conv2d_f32(C.byref(d), hip.stream_ptr()), "me_conv2d_f32")
+    return out
+
+
+def _wgrad(x, x_pitch, dy, dy_pitch, n, h, w, cin, cout, k, pad):
+    dw = _f32(x.device, cout, k, k, cin)
+    hip.check(hip.lib().me_conv_wgrad_f32(_ptr(x), x_pitch, _ptr(dy), dy_pitch, _ptr(dw), n, h, w, cin, cout, k, 1,
+                                          pad, hip.stream_ptr()), "me_conv_wgrad_f32")
+    return dw.permute(0, 3, 1, 2).contiguous()  # OHWI -> OIHW (the parameter's layout)
+
+
+def head_parameters(net):
+    """Fixed order of every non-detector parameter (the autograd inputs of the training step)."""
+    return [p for name, p in net.named_parameters() if not name.startswith("base_detector.")]
+
+
+def _head_names(net):
+    return [name for name, _ in net.named_parameters() if not name.startswith("base_detector.")]
+
+
+class _StageThree(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, *params):
+        ctx.state = state
+        return state["loss"].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = _backward(ctx.state, grad_out)
+        names = ctx.state["names"]
+        return (None,) + tuple(grads.get(n) for n in names)
+
+
+def forward_train(net, images, maps, radar_boxes_location, targets):
+    """Returns ``(loss, output, metric, radar_attention)`` like the reference's training call."""
+    from .my_models import _DETECTIONS_PER_IMG, _NMS_THRESH, obtain_iou_labels
+    from .utils.utils import xywh2xyxy
+
+    if not images.is_cuda:
+        raise hip.MeError("Network.forward needs CUDA tensors (MI355X); there is no CPU fallback")
+    dev = images.device
+    lib = hip.lib()
+    n = images.shape[0]
+    size = images.shape[-1]
+    f32 = dict(device=dev, dtype=torch.float32)
+    rh, eh = net.refinement_head, net.ensemble_head
+    head_bns = [net.img_cnn_layers.net[1], net.radar_cnn_layers.conv1[1], net.radar_cnn_layers.conv2[1],
+                net.radar_cnn_layers.conv3[1], rh.radar_net[1]]
+    if not all(b.training for b in head_bns):
+        raise NotImplementedError("Network.forward(targets=...) needs the heads in train() mode (batch-statistics "
+                                  "BatchNorm), as module3_our_dataset/train.py:169 sets them")
+
+    # ---- frozen detector, NMS, proposal assembly (no grad) -------------------------------------------
+    with torch.no_grad():
+        plan, yolo_out = net.base_detector._run(images)
+        det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
+                                   writeback_xyxy=False)
+        num_classes = yolo_out.shape[2] - 5
+        cols = 8 + net.class_num
+        cap_img = n * _DETECTIONS_PER_IMG
+        img_boxes = torch.empty((cap_img, cols), **f32)
+        n_img_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+        hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
+                                                int(net.class_idx), int(net.class_num), img_boxes.data_ptr(),
+                                                n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
+        n_img = int(n_img_dev.item())  # the labelling below is host work anyway (reference :556)
+        if plan.tap is None:
+            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+        fh, fw, fc = plan.tap_shape
+        fm = plan.tap.permute(0, 2, 3, 1).contiguous()  # NHWC copy: the arena is reused by the next forward
+        if len(radar_boxes_location) > 0:
+            radar_boxes_location[:, 1:] *= size
+        n_radar = int(radar_boxes_location.shape[0])
+        rb = radar_boxes_location.to(**f32).contiguous() if n_radar else torch.zeros((0, 5), **f32)
+        k = n_img + n_radar
+        pix = n * fh * fw
+        ws_t = torch.empty(int(lib.me_bn_workspace_bytes(512)) + 256, dtype=torch.uint8, device=dev)
+        ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256
+
+        # ---- image score map: conv1x1 (+bias) -> BN(train) -> leaky ---------------------------------
+        icl = net.img_cnn_layers.net
+        w_img = icl[0].weight.detach().reshape(490, fc).contiguous()
+        ones490, b_img = torch.ones(490, **f32), icl[0].bias.detach().contiguous()
+        z1 = _f32(dev, pix, 490)
+        _conv(fm, fc, n, fh, fw, fc, w_img.view(490, 1, 1, fc), ones490, b_img, 1, 0, hip.ACT_LINEAR, z1.view(n, fh, fw, 490))
+        a1 = _f32(dev, pix, 490)
+        st_img = _bn_fwd(z1, 490, pix, 490, icl[1], hip.ACT_LEAKY, a1, 490, ws)
+
+        # ---- radar CNN (train-mode BN) ---------------------------------------------------------------
+        rc = net.radar_cnn_layers
+        maps = maps.to(**f32)
+        mh, mw = maps.shape[2], maps.shape[3]
+        if (mh, mw) != (fh, fw):
+            raise NotImplementedError("radar map size != feature map size (demo-only configuration, quirk q15)")
+        x0 = maps.permute(0, 2, 3, 1).contiguous()  # NHWC, 3 channels
+        radar = {"x0": x0}
+        prev, prev_c = x0, 3
+        for li, seq in enumerate((rc.conv1, rc.conv2, rc.conv3), start=1):
+            conv, bn = seq[0], seq[1]
+            cout = conv.weight.shape[0]
+            wp = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+            c_raw = _f32(dev, n, mh, mw, cout)
+            _conv(prev, prev_c, n, mh, mw, prev_c, wp, torch.ones(cout, **f32), conv.bias.detach().contiguous(), 3, 1,
+                  hip.ACT_LINEAR, c_raw)
+            r_act = _f32(dev, n, mh, mw, cout)
+            st = _bn_fwd(c_raw, cout, pix, cout, bn, hip.ACT_LEAKY, r_act, cout, ws)
+            radar[f"c{li}"], radar[f"r{li}"], radar[f"st{li}"] = c_raw, r_act, st
+            prev, prev_c = r_act, cout
+        conv4 = rc.conv3[3]
+        w4 = conv4.weight.detach().reshape(10, 128).contiguous()
+        r4 = _f32(dev, n, mh, mw, 10)
+        _conv(prev, 128, n, mh, mw, 128, w4.view(10, 1, 1, 128), torch.ones(10, **f32), conv4.bias.detach().contiguous(),
+              1, 0, hip.ACT_SIGMOID, r4)
+        radar["r4"] = r4
+
+        # ---- heads, part A: pooling + net0 + small dot products (saved for backward) -----------------
+        cap = max(k, 1)
+        feat_img, feat_rad = _f32(dev, cap, 490), _f32(dev, cap, 490)
+        hidden, small = _f32(dev, cap, 256), _f32(dev, cap, 16)
+        regress, refine, mask1 = _f32(dev, cap, 4), _f32(dev, cap, 2), _f32(dev, cap)
+        rows, key = _f32(dev, cap, 8), _f32(dev, cap)
+        keep = torch.zeros((cap,), device=dev, dtype=torch.uint8)
+        wts = dict(
+            w0t=rh.net0[0].weight.detach().t().contiguous(), b0=rh.net0[0].bias.detach().contiguous(),
+            w1=rh.net1[0].weight.detach().contiguous(), b1=rh.net1[0].bias.detach().contiguous(),
+            w2=rh.net2[0].weight.detach().contiguous(), b2=rh.net2[0].bias.detach().contiguous(),
+            rw=rh.radar_net[0].weight.detach().reshape(10, 490).contiguous(),
+            rb=rh.radar_net[0].bias.detach().contiguous(),
+            rscale=torch.ones(10, **f32), rshift=torch.zeros(10, **f32),
+            rw2=rh.radar_net[3].weight.detach().reshape(10).contiguous(),
+            rb2=rh.radar_net[3].bias.detach().reshape(1).contiguous(),
+            e1w=eh.fc1[0].weight.detach().contiguous(), e1b=eh.fc1[0].bias.detach().contiguous(),
+            e2w=eh.fc2[0].weight.detach().contiguous(), e2b=eh.fc2[0].bias.detach().contiguous())
+        d = hip.HeadsDesc()
+        d.img_map, d.radar_map, d.img_pitch, d.radar_pitch = a1.data_ptr(), r4.data_ptr(), 490, 10
+        d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16
+        d.img_boxes, d.n_img, d.n_img_cap, d.box_cols = img_boxes.data_ptr(), n_img_dev.data_ptr(), n_img, cols
+        d.radar_boxes, d.n_radar = (rb.data_ptr() if n_radar else None), n_radar
+        d.thr_img, d.thr_radar = float(net.refine_threshold_img), float(net.refine_threshold_radar)
+        d.regress = 1
+        for name, t in wts.items():
+            setattr(d.wts, name, t.data_ptr())
+        d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
+        d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
+        d.save_feat_img, d.save_feat_rad = feat_img.data_ptr(), feat_rad.data_ptr()
+        d.save_hidden, d.save_small = hidden.data_ptr(), small.data_ptr()
+        if k > 0:
+            hip.check(lib.me_roi_heads_f32(C.byref(d), hip.stream_ptr()), "me_roi_heads_f32")
+        rh.count += 1
+
+        # ---- radar_net BatchNorm over the RoIs, then the scalar tail ----------------------------------
+        bn_r = rh.radar_net[1]
+        st_r = None
+        if k > 0:
+            dummy = _f32(dev, k, 10)
+            st_r = _bn_fwd(small[:, 6:], 16, k, 10, bn_r, hip.ACT_LINEAR, dummy, 10, ws)
+            rscale = bn_r.weight.detach() * st_r.rstd
+            rshift = bn_r.bias.detach() - st_r.mean * rscale
+            wts["rscale"], wts["rshift"] = rscale.contiguous(), rshift.contiguous()
+            d.wts.rscale, d.wts.rshift = wts["rscale"].data_ptr(), wts["rshift"].data_ptr()
+            hip.check(lib.me_heads_tail_f32(C.byref(d), small.data_ptr(), k, hip.stream_ptr()), "me_heads_tail_f32")
+
+        # ---- output rows (same ordering rule as inference, reference :517-539) -------------------------
+        idx = torch.nonzero(keep[:k], as_tuple=False).flatten()
+        order = torch.sort(key[:k][idx], descending=True, stable=True).indices
+        output = rows[idx[order]]
+
+        # ---- labels on the host (reference :545-604) ---------------------------------------------------
+        targets[:, 2:] = xywh2xyxy(targets[:, 2:])
+        targets[:, 2:] *= images.shape[3]
+        ib = img_boxes[:n_img]
+        boxes_cpu = torch.cat((torch.cat((ib[:, :1], ib[:, 7:8], ib[:, 1:5]), 1),
+                               torch.cat((rb[:, :1], torch.zeros((n_radar, 1), **f32), rb[:, 1:5]), 1)), 0).cpu()
+        iou_labels, _target_location = obtain_iou_labels(boxes_cpu, targets.cpu(), net.iou_thresh)
+        pos_filter = (iou_labels > net.iou_thresh[1]).flatten()
+        neg_filter = (iou_labels < net.iou_thresh[0]).flatten()
+        positive_masks = keep[:k].bool().cpu()
+        conf_1 = torch.cat((ib[:, 5], refine[n_img:k, 0])).cpu()
+        conf_2 = mask1[:k].cpu()
+        flat = iou_labels.flatten()
+        confs = dict(conf_1_pos=conf_1[flat > 0.5], conf_1_neg=conf_1[flat < 0.5], conf_2_pos=conf_2[flat > 0.5],
+                     conf_2_neg=conf_2[flat < 0.5])
+        metric = dict(total=len(iou_labels), true=pos_filter.sum(), positive=positive_masks.sum(),
+                      tp=(positive_masks * pos_filter).sum().float(), conf=confs)
+        pos_idx = np.where(pos_filter)[0]
+        neg_idx = np.where(neg_filter)[0]
+        top_k = min(len(pos_idx) * net.balance_factor, len(neg_idx))
+        sample_filter = pos_filter.clone()
+        selected = neg_idx[random.sample(range(len(neg_idx)), k=top_k)]  # python RNG, like the reference (q7)
+        sample_filter[selected] = True
+        in_conf = sample_filter.clone()
+        in_focal = sample_filter.clone()
+        in_focal[n_img:] = False
+        lab_d = pos_filter.to(torch.uint8).to(dev)
+        foc_d, cnf_d = in_focal.to(torch.uint8).to(dev), in_conf.to(torch.uint8).to(dev)
+
+        # ---- loss terms + gradient seeds ----------------------------------------------------------------
+        terms, seed_p, seed_c = _f32(dev, cap, 2), _f32(dev, cap), _f32(dev, cap)
+        sums = torch.zeros(2, **f32)
+        if k > 0:
+            hip.check(lib.me_heads_loss_f32(mask1.data_ptr(), refine.data_ptr(), lab_d.data_ptr(), foc_d.data_ptr(),
+                                            cnf_d.data_ptr(), k, float(net.alpha), float(net.loss_lambda[0]),
+                                            terms.data_ptr(), seed_p.data_ptr(), seed_c.data_ptr(), hip.stream_ptr()),
+                      "me_heads_loss_f32")
+            _colsum(terms, 2, k, 2, sums)
+        loss_value = sums[0] + sums[1]  # masks_loss + conf_loss / lambda (reference :635)
+        radar_attention = r4[..., :1].permute(0, 3, 1, 2).contiguous()
+
+    state = dict(net=net, names=_head_names(net), loss=loss_value, n=n, fh=fh, fw=fw, fc=fc, pix=pix, k=k, n_img=n_img,
+                 n_radar=n_radar, fm=fm, z1=z1, a1=a1, st_img=st_img, radar=radar, feat_img=feat_img,
+                 feat_rad=feat_rad, hidden=hidden, small=small, refine=refine, mask1=mask1, seed_p=seed_p,
+                 seed_c=seed_c, desc=d, keepalive=(wts, img_boxes, n_img_dev, rb, regress, rows, keep, key), st_r=st_r,
+                 ws=(ws, ws_t), w_img=w_img, w4=w4, rois=torch.cat((ib[:, :5], rb), 0).contiguous(),
+                 losses=dict(masks_loss=sums[0], conf_loss=sums[1]))
+    loss = _StageThree.apply(state, *head_parameters(net))
+    net._last_train = state
+    return loss, output, metric, radar_attention
+
+
+def _backward(S, grad_out):
+    """Manual backward of the stage-3 graph; returns {parameter name: gradient}."""
+    net, dev = S["net"], S["fm"].device
+    lib = hip.lib()
+    f32 = dict(device=dev, dtype=torch.float32)
+    k, n_img, n, fh, fw, fc, pix = S["k"], S["n_img"], S["n"], S["fh"], S["fw"], S["fc"], S["pix"]
+    rh, eh, rc = net.refinement_head, net.ensemble_head, net.radar_cnn_layers
+    ws = S["ws"][0]
+    G = {}
+    with torch.no_grad():
+        if k == 0:
+            return G
+        g = grad_out.to(**f32).reshape(())
+        seed_p, seed_c = S["seed_p"][:k] * g, S["seed_c"][:k] * g
+        d = S["desc"]
+        g_o, g_hpre, h_act, xin = _f32(dev, k, 2), _f32(dev, k, 64), _f32(dev, k, 64), _f32(dev, k, 4)
+        g_z2, g_rl, rl, g_rlogit = _f32(dev, k, 2), _f32(dev, k, 10), _f32(dev, k, 10), _f32(dev, k, 1)
+        hip.check(lib.me_heads_tail_bwd_f32(C.byref(d), S["small"].data_ptr(), S["refine"].data_ptr(),
+                                            S["mask1"].data_ptr(), seed_p.data_ptr(), seed_c.data_ptr(), k,
+                                            g_o.data_ptr(), g_hpre.data_ptr(), h_act.data_ptr(), xin.data_ptr(),
+                                            g_z2.data_ptr(), g_rl.data_ptr(), rl.data_ptr(), g_rlogit.data_ptr(),
+                                            hip.stream_ptr()), "me_heads_tail_bwd_f32")
+        # ---- ensemble head ------------------------------------------------------------------------------
+        dw = torch.zeros((2, 64), **f32); _gemm(1, 0, 2, 64, k, g_o, 2, h_act, 64, dw, 64)
+        db = _f32(dev, 2); _colsum(g_o, 2, k, 2, db)
+        G["ensemble_head.fc2.0.weight"], G["ensemble_head.fc2.0.bias"] = dw, db
+        dw = torch.zeros((32, 2), **f32); _gemm(1, 0, 32, 2, 2 * k, g_hpre, 32, xin, 2, dw, 2)
+        db = _f32(dev, 32); _colsum(g_hpre, 32, 2 * k, 32, db)
+        G["ensemble_head.fc1.0.weight"], G["ensemble_head.fc1.0.bias"] = dw, db
+        # ---- radar_net: 1x1, BN over RoIs (+leaky), 7x7 conv ---------------------------------------------
+        dw = torch.zeros((1, 10), **f32); _gemm(1, 0, 1, 10, k, g_rlogit, 1, rl, 10, dw, 10)
+        db = _f32(dev, 1); _colsum(g_rlogit, 1, k, 1, db)
+        G["refinement_head.radar_net.3.weight"], G["refinement_head.radar_net.3.bias"] = dw.view(1, 10, 1, 1), db
+        bn_r = rh.radar_net[1]
+        g_rconv = _f32(dev, k, 10)
+        dg, dbt = _bn_bwd(S["small"][:, 6:], 16, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10, ws)
+        G["refinement_head.radar_net.1.weight"], G["refinement_head.radar_net.1.bias"] = dg, dbt
+        dw = torch.zeros((10, 490), **f32); _gemm(1, 0, 10, 490, k, g_rconv, 10, S["feat_rad"], 490, dw, 490)
+        db = _f32(dev, 10); _colsum(g_rconv, 10, k, 10, db)
+        G["refinement_head.radar_net.0.weight"], G["refinement_head.radar_net.0.bias"] = dw.view(10, 10, 7, 7), db
+        wr = rh.radar_net[0].weight.detach().reshape(10, 490).contiguous()
+        d_prad = _f32(dev, k, 490); _gemm(0, 0, k, 490, 10, g_rconv, 10, wr, 490, d_prad, 490)
+        # ---- net2 (rows 0, 1) and net0 -----------------------------------------------------------------------
+        w2 = rh.net2[0].weight.detach().contiguous()
+        dw2 = torch.zeros((13, 256), **f32); _gemm(1, 0, 2, 256, k, g_z2, 2, S["hidden"], 256, dw2, 256)
+        db2 = torch.zeros(13, **f32); _colsum(g_z2, 2, k, 2, db2)
+        G["refinement_head.net2.0.weight"], G["refinement_head.net2.0.bias"] = dw2, db2
+        dt = _f32(dev, k, 256); _gemm(0, 0, k, 256, 2, g_z2, 2, w2, 256, dt, 256)
+        g_pre = _f32(dev, k, 256)
+        hip.check(lib.me_act_bwd_f32(S["hidden"].data_ptr(), 256, dt.data_ptr(), 256, g_pre.data_ptr(), 256, k, 256,
+                                     hip.ACT_LEAKY, hip.stream_ptr()), "me_act_bwd_f32")
+        dw0 = torch.zeros((256, 490), **f32); _gemm(1, 0, 256, 490, k, g_pre, 256, S["feat_img"], 490, dw0, 490)
+        db0 = _f32(dev, 256); _colsum(g_pre, 256, k, 256, db0)
+        G["refinement_head.net0.0.weight"], G["refinement_head.net0.0.bias"] = dw0, db0
+        w0 = rh.net0[0].weight.detach().contiguous()
+        d_pimg = _f32(dev, k, 490); _gemm(0, 0, k, 490, 256, g_pre, 256, w0, 490, d_pimg, 490)
+        # ---- RoI pooling backward (atomic scatter) ----------------------------------------------------------
+        rois = S["rois"]
+        d_a1 = torch.zeros((pix, 490), **f32)
+        d_r4 = torch.zeros((pix, 10), **f32)
+        hip.check(lib.me_ps_roi_align_bwd_f32(d_pimg.data_ptr(), rois.data_ptr(), k, n, fh, fw, 490, 7, 1.0 / 16,
+                                              d_a1.data_ptr(), 490, hip.stream_ptr()), "me_ps_roi_align_bwd_f32")
+        hip.check(lib.me_roi_align_bwd_f32(d_prad.data_ptr(), rois.data_ptr(), k, n, fh, fw, 10, 7, 1.0 / 16,
+                                           d_r4.data_ptr(), 10, hip.stream_ptr()), "me_roi_align_bwd_f32")
+        # ---- image score map: BN(+leaky) backward, 1x1 conv weight / bias gradient -------------------------
+        icl = net.img_cnn_layers.net
+        dz1 = _f32(dev, pix, 490)
+        dg, dbt = _bn_bwd(S["z1"], 490, d_a1, 490, pix, 490, icl[1], S["st_img"], hip.ACT_LEAKY, dz1, 490, ws)
+        G["img_cnn_layers.net.batch_norm_0.weight"], G["img_cnn_layers.net.batch_norm_0.bias"] = dg, dbt
+        dw = torch.zeros((490, fc), **f32); _gemm(1, 0, 490, fc, pix, dz1, 490, S["fm"], fc, dw, fc)
+        db = _f32(dev, 490); _colsum(dz1, 490, pix, 490, db)
+        G["img_cnn_layers.net.conv_0.weight"], G["img_cnn_layers.net.conv_0.bias"] = dw.view(490, fc, 1, 1), db
+        # ---- radar CNN ---------------------------------------------------------------------------------------
+        R = S["radar"]
+        dc4 = _f32(dev, pix, 10)
+        hip.check(lib.me_act_bwd_f32(R["r4"].data_ptr(), 10, d_r4.data_ptr(), 10, dc4.data_ptr(), 10, pix, 10,
+                                     hip.ACT_SIGMOID, hip.stream_ptr()), "me_act_bwd_f32")
+        dw = torch.zeros((10, 128), **f32); _gemm(1, 0, 10, 128, pix, dc4, 10, R["r3"], 128, dw, 128)
+        db = _f32(dev, 10); _colsum(dc4, 10, pix, 10, db)
+        G["radar_cnn_layers.conv3.3.weight"], G["radar_cnn_layers.conv3.3.bias"] = dw.view(10, 128, 1, 1), db
+        d_act = _f32(dev, pix, 128); _gemm(0, 0, pix, 128, 10, dc4, 10, S["w4"], 128, d_act, 128)
+        mh, mw = fh, fw
+        for li, seq, cin in ((3, rc.conv3, 64), (2, rc.conv2, 32), (1, rc.conv1, 3)):
+            conv, bn = seq[0], seq[1]
+            cout = conv.weight.shape[0]
+            dc = _f32(dev, pix, cout)
+            dg, dbt = _bn_bwd(R[f"c{li}"], cout, d_act, cout, pix, cout, bn, R[f"st{li}"], hip.ACT_LEAKY, dc, cout, ws)
+            G[f"radar_cnn_layers.conv{li}.1.weight"], G[f"radar_cnn_layers.conv{li}.1.bias"] = dg, dbt
+            x_in = R["x0"] if li == 1 else R[f"r{li - 1}"]
+            G[f"radar_cnn_layers.conv{li}.0.weight"] = _wgrad(x_in, cin, dc, cout, n, mh, mw, cin, cout, 3, 1)
+            db = _f32(dev, cout); _colsum(dc, cout, pix, cout, db)
+            G[f"radar_cnn_layers.conv{li}.0.bias"] = db
+            if li > 1:  # data gradient = the forward conv kernel on the rotated, transposed weights
+                wd = conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()  # [cin][ky][kx][cout]
+                d_prev = _f32(dev, n, mh, mw, cin)
+                _conv(dc, cout, n, mh, mw, cout, wd, torch.ones(cin, **f32), torch.zeros(cin, **f32), 3, 1,
+                      hip.ACT_LINEAR, d_prev)
+                d_act = d_prev.view(pix, cin)
+    return G

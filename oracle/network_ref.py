@@ -178,3 +178,136 @@ def network_forward(cfg_text, sd, images, maps, radar_boxes, model_mode=0, conf_
                             roi_score_map=roi_score_map, radar_score_map=radar_score_map,
                             crop_img=crop_img, crop_radar=crop_radar, radar_boxes=radar_boxes, boxes=boxes)
     return output
+
+
+# ---------------------------------------------------------------------------------------------------
+# training step (reference my_models.py:433-641 with targets, train-mode heads, frozen eval detector)
+# ---------------------------------------------------------------------------------------------------
+def focal_loss(inputs, labels, alpha, gamma=2):
+    """FocalLoss(alpha, gamma, reduction='sum'), my_models.py:287-314."""
+    alpha_t = torch.where(labels[:, 1:2] == 1, torch.full((labels.shape[0], 1), alpha),
+                          torch.full((labels.shape[0], 1), 1 - alpha))
+    probs = (inputs * labels).sum(1).view(-1, 1)
+    return (-alpha_t * torch.pow(1 - probs, gamma) * probs.log()).sum()
+
+
+def obtain_iou_labels(boxes, targets, multi_boxes=True):
+    """my_models.py:317-375 (multi_boxes is always truthy at the call site: quirk q5)."""
+    image_index, pred_classes, pred_boxes = boxes[:, :1], boxes[:, 1:2], boxes[:, 2:]
+    detected = []
+    iou_labels = torch.zeros((len(image_index), 1))
+    target_location = torch.zeros((len(image_index), 4))
+    for i in range(len(boxes)):
+        sel = (targets[:, 0] == image_index[i]) & (targets[:, 1] == pred_classes[i])
+        if not bool(sel.any()):
+            continue
+        tb = targets[sel][:, 2:]
+        ious = bbox_iou_plus1(pred_boxes[i].unsqueeze(0), tb)
+        if len(ious) > 0:
+            iou, ti = ious.max(0)
+            if (ti not in detected) or multi_boxes:
+                iou_labels[i] = iou
+                target_location[i] = tb[ti]
+                if iou > 0.7:
+                    detected += [ti]
+    return iou_labels, target_location
+
+
+def _bn_train(x, P, B, prefix):
+    return F.batch_norm(x, B[prefix + "running_mean"], B[prefix + "running_var"], P[prefix + "weight"],
+                        P[prefix + "bias"], True, 0.1, 1e-5)
+
+
+def network_train_step(cfg_text, sd, images, maps, radar_boxes, targets, conf_thresh=0.2, class_idx=0, class_num=1,
+                       tap_module=8, iou_thresh=(0.3, 0.7), alpha=0.75, balance_factor=5, loss_lambda=(6, 1)):
+    """One training forward + backward on CPU autograd.  ``sd``: full Network state dict.  ``targets`` [q,6]
+    (image_i, class, cx, cy, w, h in [0,1]) is NOT modified.  Python's ``random`` must be seeded by the
+    caller (negative sampling, quirk q7).  Returns dict(loss, masks_loss, conf_loss, output, grads{name: tensor},
+    buffers{name: updated running stat}, internals)."""
+    det_sd = {k[len("base_detector."):]: v for k, v in sd.items() if k.startswith("base_detector.")}
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+         if not k.startswith("base_detector.") and v.dtype == torch.float32 and "running_" not in k}
+    B = {k: v.clone() for k, v in sd.items() if "running_" in k and not k.startswith("base_detector.")}
+    with torch.no_grad():
+        feature_map, output_tensor = darknet_ref.darknet_forward(cfg_text, det_sd, images, tap_module=tap_module)
+        detections = nms_cpp(output_tensor, conf_thresh)
+        img_boxes = []
+        for image_i, det in enumerate(detections):
+            if det is not None:
+                det = det[det[:, 6] == class_idx]
+                if len(det) > 0:
+                    b = torch.zeros((len(det), 8 + class_num))
+                    b[:, 0] = image_i
+                    b[:, 1:] = det[:, :7 + class_num]
+                    img_boxes.append(b)
+        img_boxes = torch.cat(img_boxes, 0) if img_boxes else torch.empty((0, 8 + class_num))
+    num_img = len(img_boxes)
+    p = "img_cnn_layers.net."
+    x = F.conv2d(feature_map, P[p + "conv_0.weight"], P[p + "conv_0.bias"])
+    roi_score_map = F.leaky_relu(_bn_train(x, P, B, p + "batch_norm_0."), 0.1)
+    x = maps
+    for name in ("conv1", "conv2", "conv3"):
+        q = f"radar_cnn_layers.{name}."
+        x = F.conv2d(x, P[q + "0.weight"], P[q + "0.bias"], padding=1)
+        x = F.leaky_relu(_bn_train(x, P, B, q + "1."), 0.1)
+    radar_score_map = torch.sigmoid(F.conv2d(x, P["radar_cnn_layers.conv3.3.weight"], P["radar_cnn_layers.conv3.3.bias"]))
+    radar_boxes = radar_boxes.clone()
+    if len(radar_boxes) > 0:
+        radar_boxes[:, 1:] *= images.shape[-1]
+    box_locations = torch.cat((img_boxes[:, :5], radar_boxes), 0)
+    crop_img = tv_ops.ps_roi_align(roi_score_map, box_locations, (7, 7), spatial_scale=1. / 16)
+    crop_radar = tv_ops.roi_align(radar_score_map, box_locations, (7, 7), spatial_scale=1. / 16)
+    r = "refinement_head."
+    t = F.leaky_relu(F.linear(crop_img.flatten(start_dim=1), P[r + "net0.0.weight"], P[r + "net0.0.bias"]), 0.1)
+    regress_param = F.linear(t, P[r + "net1.0.weight"], P[r + "net1.0.bias"])
+    class_vector = torch.sigmoid(F.linear(t, P[r + "net2.0.weight"], P[r + "net2.0.bias"]))
+    rr = F.conv2d(crop_radar, P[r + "radar_net.0.weight"], P[r + "radar_net.0.bias"])
+    rr = F.leaky_relu(_bn_train(rr, P, B, r + "radar_net.1."), 0.1)
+    rr = torch.sigmoid(F.conv2d(rr, P[r + "radar_net.3.weight"], P[r + "radar_net.3.bias"]))
+    confidence = torch.sigmoid(rr.squeeze(-1).squeeze(-1) + class_vector[:, :1])
+    refinement_vector = torch.cat((confidence, class_vector[:, 1:2]), -1)
+    radar_rows = torch.cat((radar_boxes, refinement_vector[num_img:], torch.zeros((len(radar_boxes), 1)),
+                            refinement_vector[num_img:, 1:]), -1)
+    boxes = torch.cat((img_boxes, radar_rows), 0)
+    yolo_vector = torch.cat((img_boxes[:, 5:6], img_boxes[:, 8:]), 1).detach()
+    xx = torch.stack((refinement_vector[:num_img], yolo_vector), -1)
+    xx = F.leaky_relu(F.linear(xx, P["ensemble_head.fc1.0.weight"], P["ensemble_head.fc1.0.bias"]), 0.1)
+    masks_img = torch.softmax(F.linear(xx.flatten(start_dim=1), P["ensemble_head.fc2.0.weight"],
+                                       P["ensemble_head.fc2.0.bias"]), dim=1)
+    masks = torch.cat((masks_img[:, :1], refinement_vector[num_img:, :1]), 0)
+    masks = torch.cat((1 - masks, masks), -1)
+    positive = torch.cat((masks[:num_img, 1] > 0, masks[num_img:, 1] > 0), 0)
+    with torch.no_grad():
+        output = torch.cat((boxes[positive, :1], box_regress(regress_param[positive], boxes[positive, 1:5]),
+                            masks[positive, 1:], boxes[positive, 6:8]), -1)
+        masks_tmp = masks.clone()
+        masks_tmp[num_img:, 1] /= 5
+        output = output[torch.sort(masks_tmp[positive, 1], descending=True, stable=True).indices]
+    tg = targets.clone()
+    tg[:, 2:] = xywh2xyxy(tg[:, 2:])
+    tg[:, 2:] *= images.shape[3]
+    boxes_cpu = torch.cat((boxes[:, :1], boxes[:, 7:8], boxes[:, 1:5]), 1).detach()
+    iou_labels, _ = obtain_iou_labels(boxes_cpu, tg, iou_thresh)
+    pos_filter = (iou_labels > iou_thresh[1]).flatten()
+    neg_filter = (iou_labels < iou_thresh[0]).flatten()
+    pos_idx = np.where(pos_filter)[0]
+    neg_idx = np.where(neg_filter)[0]
+    top_k = min(len(pos_idx) * balance_factor, len(neg_idx))
+    label_onehot = torch.tensor([1.0, 0.0]).repeat(masks.shape[0], 1)
+    for i in pos_idx:
+        label_onehot[i] = torch.tensor([0.0, 1.0])
+    sample_filter = pos_filter.clone()
+    selected = neg_idx[random.sample(range(len(neg_idx)), k=top_k)]
+    sample_filter[selected] = True
+    lab = label_onehot[:num_img][sample_filter[:num_img]]
+    oh = masks[:num_img][sample_filter[:num_img]]
+    masks_loss = focal_loss(oh, lab, alpha)
+    conf_label = torch.zeros(len(boxes_cpu))
+    conf_label[pos_idx] = 1.0
+    conf_loss = F.binary_cross_entropy(refinement_vector[sample_filter, 0], conf_label[sample_filter], reduction="sum")
+    loss = masks_loss + conf_loss / loss_lambda[0]
+    loss.backward()
+    grads = {k: (v.grad.clone() if v.grad is not None else None) for k, v in P.items()}
+    return dict(loss=loss.detach(), masks_loss=masks_loss.detach(), conf_loss=conf_loss.detach(), output=output,
+                grads=grads, buffers=B, n_pos=int(pos_filter.sum()), n_sampled=int(sample_filter.sum()),
+                num_img=num_img, refinement_vector=refinement_vector.detach(), masks=masks.detach())

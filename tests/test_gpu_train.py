@@ -1,0 +1,210 @@
+"""-m gpu: the stage-3 training step.  Per-kernel parity of the training building blocks against torch
+CPU autograd / the oracle's torchvision backward, then the whole step (loss, every parameter gradient,
+BatchNorm running statistics, optimizer step) against oracle/network_ref.network_train_step and the
+reference's own golden numbers (tests/golden/train_*.npz).  Tolerance 1e-3 relative to the tensor's scale."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from millieye_amd import cfgs, synth
+from tests import parity_helpers as ph
+from tests.golden.make_golden import TRAIN_CASE, train_inputs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _t(tag, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(synth.uniform(tag, shape, lo, hi))
+
+
+def _rel(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return float((got - ref).abs().max() / max(1e-12, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_and_colsum(hip_lib, ta, tb):
+    from millieye_amd import hip, train_path as tp
+    m, n, k = 70, 130, 45
+    a = _t("ga", (k, m) if ta else (m, k))
+    b = _t("gb", (n, k) if tb else (k, n))
+    ref = (a.t() if ta else a) @ (b.t() if tb else b)
+    c = torch.full((m, n), 7.0).cuda()
+    tp._gemm(ta, tb, m, n, k, a.cuda(), a.shape[1], b.cuda(), b.shape[1], c, n)
+    assert _rel(c, ref) < 1e-5
+    tp._gemm(ta, tb, m, n, k, a.cuda(), a.shape[1], b.cuda(), b.shape[1], c, n, alpha=0.5, beta=2.0)
+    assert _rel(c, 2.5 * ref) < 1e-5
+    out = torch.empty(n).cuda()
+    tp._colsum(c, n, m, n, out)
+    assert _rel(out, (2.5 * ref).sum(0)) < 1e-5
+
+
+def test_bn_train_forward_backward(hip_lib):
+    from millieye_amd import hip, train_path as tp
+    rows, c = 5408, 70
+    x = _t("bnx", (rows, c), -2, 3)
+    bn = torch.nn.BatchNorm2d(c, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(_t("bng", (c,), 0.5, 1.5))
+        bn.bias.copy_(_t("bnb", (c,), -0.5, 0.5))
+        bn.running_mean.copy_(_t("bnm", (c,)))
+        bn.running_var.copy_(_t("bnv", (c,), 0.5, 1.5))
+    ref_bn = torch.nn.BatchNorm2d(c, momentum=0.1)
+    ref_bn.load_state_dict(bn.state_dict())
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(ref_bn(xr.t().reshape(1, c, rows, 1)), 0.1)
+    dy = _t("bndy", (rows, c))
+    yr.backward(dy.t().reshape(1, c, rows, 1))
+    bn = bn.cuda()
+    ws_t = torch.empty(int(hip.lib().me_bn_workspace_bytes(c)) + 256, dtype=torch.uint8, device="cuda")
+    ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256
+    xd, y = x.cuda(), torch.empty((rows, c)).cuda()
+    st = tp._bn_fwd(xd, c, rows, c, bn, hip.ACT_LEAKY, y, c, ws)
+    assert _rel(y, yr.reshape(c, rows).t()) < 1e-4
+    assert _rel(bn.running_mean, ref_bn.running_mean) < 1e-5 and _rel(bn.running_var, ref_bn.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    dx = torch.empty((rows, c)).cuda()
+    dg, db = tp._bn_bwd(xd, c, dy.cuda(), c, rows, c, bn, st, hip.ACT_LEAKY, dx, c, ws)
+    assert _rel(dx, xr.grad) < 1e-3 and _rel(dg, ref_bn.weight.grad) < 1e-3 and _rel(db, ref_bn.bias.grad) < 1e-3
+
+
+@pytest.mark.parametrize("cin,cout,k", [(3, 32, 3), (32, 64, 3), (64, 128, 3), (128, 10, 1)])
+def test_conv_wgrad_and_dgrad(hip_lib, cin, cout, k):
+    from millieye_amd import hip, train_path as tp
+    n, h, w = 2, 10, 12
+    pad = (k - 1) // 2
+    x = _t(f"wx{cin}", (n, cin, h, w)).requires_grad_(True)
+    wt = _t(f"ww{cin}", (cout, cin, k, k), -0.2, 0.2).requires_grad_(True)
+    y = F.conv2d(x, wt, None, 1, pad)
+    dy = _t(f"wdy{cin}", tuple(y.shape))
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dw = tp._wgrad(xd, cin, dyd, cout, n, h, w, cin, cout, k, pad)
+    assert _rel(dw, wt.grad) < 1e-4
+    if cout % 4 == 0 and cin > 4:  # data gradient through the forward kernel on rotated / transposed weights
+        wd = wt.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().cuda()
+        dx = torch.empty((n, h, w, cin)).cuda()
+        tp._conv(dyd, cout, n, h, w, cout, wd, torch.ones(cin).cuda(), torch.zeros(cin).cuda(), k, pad, hip.ACT_LINEAR, dx)
+        assert _rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-4
+
+
+def test_roi_backward_vs_oracle(hip_lib):
+    from millieye_amd import hip
+    from oracle import tv_ops
+    n, h, w, k = 2, 10, 10, 24
+    size = 160.0
+    c = synth.uniform("rbc", (k, 2), 0.1 * size, 0.9 * size)
+    half = synth.uniform("rbh", (k, 2), 3.0, 0.4 * size)
+    idx = np.floor(synth.uniform("rbi", (k, 1), 0, n))
+    rois = torch.from_numpy(np.concatenate([idx, c - half, c + half], 1).astype(np.float32))
+    for ps, ch in ((False, 10), (True, 490)):
+        m = _t(f"rbm{ch}", (n, ch, h, w)).requires_grad_(True)
+        out = (tv_ops.ps_roi_align if ps else tv_ops.roi_align)(m, rois, (7, 7), 1 / 16)
+        g = _t(f"rbg{ch}", tuple(out.shape))
+        out.backward(g)
+        gmap = torch.zeros((n, h, w, ch)).cuda()
+        gd, rd = g.cuda(), rois.cuda()  # keep the device copies alive across the asynchronous launch
+        fn = hip.lib().me_ps_roi_align_bwd_f32 if ps else hip.lib().me_roi_align_bwd_f32
+        hip.check(fn(gd.data_ptr(), rd.data_ptr(), k, n, h, w, ch, 7, 1.0 / 16, gmap.data_ptr(), ch,
+                     hip.stream_ptr()), "roi bwd")
+        torch.cuda.synchronize()
+        assert _rel(gmap.permute(0, 3, 1, 2), m.grad) < 1e-4
+
+
+def _build(name, cfg, conf):
+    from millieye_amd.my_models import Network, define_yolo
+    net = Network(define_yolo(ph.cfg_path(cfg)), conf)
+    synth.fill_network_(net, name)
+    return net
+
+
+def test_training_step_vs_oracle_and_reference_golden(hip_lib):
+    from oracle import network_ref
+    name, cfg, n, s, conf, seed = TRAIN_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = _build(name, cfg, conf)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, maps, rboxes = train_inputs(name, n, s)
+    targets = torch.from_numpy(g["targets"])
+    random.seed(seed)
+    ref = network_ref.network_train_step(cfgs.KNOWN[cfg](), sd0, x, maps, rboxes, targets, conf_thresh=conf)
+
+    net = net.cuda()
+    net.train()
+    net.base_detector.eval()
+    random.seed(seed)
+    tg = targets.clone()
+    rb = rboxes.clone().cuda()
+    loss, output, metric, att = net(x.cuda(), maps.cuda(), rb, tg)  # train.py:185 call form (targets in mode slot)
+    assert torch.allclose(tg[:, 2:], network_ref.xywh2xyxy(targets[:, 2:]) * s, atol=1e-4), "targets mutate in place"
+    assert loss.requires_grad and tuple(att.shape) == (n, 1, s // 16, s // 16)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-3 * max(1.0, abs(float(ref["loss"]))), (float(loss), float(ref["loss"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * max(1.0, abs(float(g["loss"])))
+    assert int(metric["true"]) == int(g["n_pos"]) and metric["total"] == int(g["total"])
+    ph.assert_close(output.detach().cpu(), torch.from_numpy(g["output"]), 1e-3, "training-mode output rows")
+    checked = 0
+    for k, p in net.named_parameters():
+        if k.startswith("base_detector."):
+            assert p.grad is None
+            continue
+        rg = ref["grads"][k]
+        if rg is None:
+            assert p.grad is None, f"{k} must not receive a gradient"
+            continue
+        assert p.grad is not None, k
+        if float(rg.abs().max()) < 1e-5:
+            # mathematically zero gradient (a conv bias in front of a train-mode BatchNorm): noise on both
+            # sides - only require ours to be noise-sized as well
+            assert float(p.grad.abs().max()) < 1e-4, k
+            checked += 1
+            continue
+        err = _rel(p.grad, rg)
+        assert err < 2e-3, f"grad {k}: rel err {err:.2e}"
+        assert abs(float(p.grad.double().norm().cpu()) - float(g["gnorm/" + k])) <= 2e-3 * float(g["gnorm/" + k]) + 1e-9, k
+        checked += 1
+    assert checked >= 20
+    for k, v in net.state_dict().items():
+        if "running_" in k and not k.startswith("base_detector."):
+            assert _rel(v, torch.from_numpy(g["buf/" + k])) < 1e-3, k
+    # one optimizer step like train.py:163,188-191 must change exactly the tensors that got gradients
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
+    before = {k: v.clone() for k, v in net.named_parameters()}
+    opt.step()
+    changed = [k for k, v in net.named_parameters() if not torch.equal(v, before[k])]
+    assert "ensemble_head.fc1.0.weight" in changed and "radar_cnn_layers.conv1.0.weight" in changed
+    assert not any(k.startswith("base_detector.") for k in changed)
+    # the next forward picks the updated weights up (packed copies are refreshed by version counters)
+    net.eval()
+    with torch.no_grad():
+        out2 = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+    assert out2.shape[1] == 8
+
+
+def test_frozen_parameters_get_no_gradient(hip_lib):
+    """train.py:146-149 freezes the stage-2 tensors by requires_grad=False."""
+    name, cfg, n, s, conf, seed = TRAIN_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = _build(name, cfg, conf).cuda()
+    frozen = ["img_cnn_layers.net.conv_0.weight", "refinement_head.net0.0.weight", "refinement_head.net2.0.bias"]
+    for k, p in net.named_parameters():
+        if k in frozen:
+            p.requires_grad = False
+    net.train()
+    net.base_detector.eval()
+    x, maps, rboxes = train_inputs(name, n, s)
+    random.seed(seed)
+    loss, *_ = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0, torch.from_numpy(g["targets"]).clone())
+    loss.backward()
+    for k, p in net.named_parameters():
+        if k in frozen:
+            assert p.grad is None
+    assert net.ensemble_head.fc2[0].weight.grad is not None

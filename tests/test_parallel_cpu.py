@@ -1,0 +1,88 @@
+"""CPU (-m "not gpu"): the N>1 path - frame sharding / output merging and the flat-bucket SUM all-reduce,
+run as two real processes over gloo (127.0.0.1)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_and_merge_roundtrip():
+    from millieye_amd import parallel as par
+    n = 7
+    images = torch.arange(n * 3 * 4 * 4, dtype=torch.float32).view(n, 3, 4, 4)
+    maps = torch.arange(n * 3, dtype=torch.float32).view(n, 3, 1, 1)
+    rboxes = torch.tensor([[0, .1, .1, .2, .2], [3, .3, .3, .4, .4], [6, .5, .5, .6, .6], [6, .1, .2, .3, .4]])
+    targets = torch.tensor([[2, 0, .5, .5, .1, .1], [5, 0, .4, .4, .2, .2]])
+    world = 3
+    assert [par.shard_range(n, r, world) for r in range(world)] == [(0, 3), (3, 5), (5, 7)]
+    seen, outs, frames = 0, [], []
+    for r in range(world):
+        im, mp_, rb, tg = par.shard_batch(images, maps, rboxes, targets, r, world)
+        lo, hi = par.shard_range(n, r, world)
+        assert torch.equal(im, images[lo:hi]) and torch.equal(mp_, maps[lo:hi])
+        assert all(0 <= v < hi - lo for v in rb[:, 0].tolist() + tg[:, 0].tolist())
+        seen += len(rb)
+        rows = torch.zeros((len(rb), 8))
+        rows[:, 0] = rb[:, 0]
+        rows[:, 1:5] = rb[:, 1:]
+        outs.append(rows)
+        frames.append(hi - lo)
+    assert seen == len(rboxes)
+    merged = par.merge_outputs(outs, frames)
+    assert sorted(merged[:, 0].tolist()) == sorted(rboxes[:, 0].tolist())
+    assert torch.equal(merged[:, 1:5][merged[:, 0].argsort(stable=True)], rboxes[:, 1:][rboxes[:, 0].argsort(stable=True)])
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 2), torch.nn.Linear(2, 1))
+    model[2].weight.requires_grad = False  # frozen tensor: not part of the bucket
+    x = torch.arange(12, dtype=torch.float32).view(2, 6) + rank
+    model[1](model[0](x)).sum().backward() if rank == 0 else model[0](x).sum().backward()  # rank 1: layer 1 has no grad
+    nbytes = par.allreduce_gradients(model.parameters())
+    res = {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+    q.put((rank, nbytes, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_gradients_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, nbytes, res = q.get(timeout=120)
+        got[rank] = (nbytes, res)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: sum of the two ranks' local gradients
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 2), torch.nn.Linear(2, 1))
+    x0 = torch.arange(12, dtype=torch.float32).view(2, 6)
+    model[1](model[0](x0)).sum().backward()
+    model[0](x0 + 1).sum().backward()  # grads accumulate: rank 0 + rank 1
+    for rank in (0, 1):
+        nbytes, res = got[rank]
+        assert nbytes == 4 * (6 * 4 + 4 + 4 * 2 + 2)  # trainable tensors only, one flat fp32 bucket
+        for k, p in model.named_parameters():
+            if not p.requires_grad:
+                assert res[k] is None
+            else:
+                assert torch.allclose(res[k], p.grad, atol=1e-6), (rank, k)

