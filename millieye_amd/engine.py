@@ -377,6 +377,7 @@ class DarknetEngine:
         lib = hip.lib()
         launches = []
         plan.input_descs = []
+        plan.yolo_raw = []  # raw detection maps [n,g,g,A*(5+C)] (arena views) for the YOLO loss
         plan.yolo_descs = []
         plan.conv_descs = []
         flops = 0
@@ -444,6 +445,10 @@ class DarknetEngine:
                     dsc.anchors[2 * k + 1] = ah / stride
                 plan.num_classes = yl.num_classes
                 plan.yolo_descs.append(dsc)
+                xroot, xoff = x.root()
+                plan.yolo_raw.append(torch.as_strided(
+                    plan.arena, (n, x.h, x.w, x.c), (x.h * x.w * xroot.c, x.w * xroot.c, xroot.c, 1),
+                    xroot.offset + xoff))
                 launches.append((lib.me_yolo_decode_f32, (C.byref(dsc),), dsc, f"yolo{op['module']}"))
                 # side effects the reference's YOLOLayer.forward has (models.py:135-156)
                 yl.img_dim = h

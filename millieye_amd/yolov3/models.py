@@ -70,21 +70,74 @@ class YOLOLayer(nn.Module):
         self.grid_size = 0
 
     def forward(self, x, targets=None, img_dim=None):
-        """Stand-alone decode of one raw detection map ``x`` [N, A*(5+C), G, G] (NCHW, as the
-        reference passes it).  Inference only; returns ``(output [N, A*G*G, 5+C], 0)``."""
+        """Stand-alone use on one raw detection map ``x`` [N, A*(5+C), G, G] (NCHW, as the reference
+        passes it): returns ``(output [N, A*G*G, 5+C], 0)`` or, with ``targets``, ``(output, loss)``."""
         from .. import hip
-        if targets is not None:
-            raise NotImplementedError(_TRAIN_MSG)
         self.img_dim = img_dim if img_dim is not None else self.img_dim
         self.grid_size = x.size(2)
         self.stride = self.img_dim / self.grid_size
         nhwc = x.permute(0, 2, 3, 1).contiguous()
-        return hip.yolo_decode(nhwc, self.anchors, self.num_classes, self.img_dim), 0
+        output = hip.yolo_decode(nhwc, self.anchors, self.num_classes, self.img_dim)
+        if targets is None:
+            return output, 0
+        return output, self.loss_from_raw(nhwc, targets)
+
+    def loss_from_raw(self, raw_nhwc, targets):
+        """YOLO loss + metrics of this scale (reference :181-232) from the raw detection map
+        ``raw_nhwc`` [N, G, G, A*(5+C)] (any strides) and ``targets`` [m,6] = (image_i, class, cx, cy, w, h)
+        normalised to [0,1].  Device-side torch ops (anchor matching is index bookkeeping,
+        ``utils.utils.build_targets``); the value carries no gradient - the detector is frozen on this
+        path and its backward is not built."""
+        n, g = raw_nhwc.shape[0], raw_nhwc.shape[1]
+        dev = raw_nhwc.device
+        with torch.no_grad():
+            pred = raw_nhwc.reshape(n, g, g, self.num_anchors, self.num_classes + 5).permute(0, 3, 1, 2, 4)
+            x = torch.sigmoid(pred[..., 0])
+            y = torch.sigmoid(pred[..., 1])
+            w = pred[..., 2]
+            h = pred[..., 3]
+            pred_conf = torch.sigmoid(pred[..., 4])
+            pred_cls = torch.sigmoid(pred[..., 5:])
+            stride = self.img_dim / g
+            grid_x = torch.arange(g, device=dev).repeat(g, 1).view(1, 1, g, g).float()
+            grid_y = torch.arange(g, device=dev).repeat(g, 1).t().view(1, 1, g, g).float()
+            scaled_anchors = torch.tensor([(aw / stride, ah / stride) for aw, ah in self.anchors],
+                                          dtype=torch.float32, device=dev)
+            self.scaled_anchors = scaled_anchors
+            anchor_w = scaled_anchors[:, 0:1].view(1, self.num_anchors, 1, 1)
+            anchor_h = scaled_anchors[:, 1:2].view(1, self.num_anchors, 1, 1)
+            pred_boxes = torch.stack((x + grid_x, y + grid_y, torch.exp(w) * anchor_w, torch.exp(h) * anchor_h), -1)
+            targets = targets.to(dev)
+            iou_scores, class_mask, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf = build_targets(
+                pred_boxes=pred_boxes, pred_cls=pred_cls, target=targets, anchors=scaled_anchors,
+                ignore_thres=self.ignore_thres)
+            obj_mask, noobj_mask = obj_mask.bool(), noobj_mask.bool()
+            loss_x = self.mse_loss(x[obj_mask], tx[obj_mask])
+            loss_y = self.mse_loss(y[obj_mask], ty[obj_mask])
+            loss_w = self.mse_loss(w[obj_mask], tw[obj_mask])
+            loss_h = self.mse_loss(h[obj_mask], th[obj_mask])
+            loss_conf_obj = self.bce_loss(pred_conf[obj_mask], tconf[obj_mask])
+            loss_conf_noobj = self.bce_loss(pred_conf[noobj_mask], tconf[noobj_mask])
+            loss_conf = self.obj_scale * loss_conf_obj + self.noobj_scale * loss_conf_noobj
+            loss_cls = self.bce_loss(pred_cls[obj_mask], tcls[obj_mask])
+            total_loss = loss_x + loss_y + loss_w + loss_h + loss_conf + loss_cls
+            conf50 = (pred_conf > 0.5).float()
+            iou50 = (iou_scores > 0.5).float()
+            iou75 = (iou_scores > 0.75).float()
+            detected_mask = conf50 * class_mask * tconf
+            self.metrics = {
+                "loss": to_cpu(total_loss).item(), "x": to_cpu(loss_x).item(), "y": to_cpu(loss_y).item(),
+                "w": to_cpu(loss_w).item(), "h": to_cpu(loss_h).item(), "conf": to_cpu(loss_conf).item(),
+                "cls": to_cpu(loss_cls).item(), "cls_acc": to_cpu(100 * class_mask[obj_mask].mean()).item(),
+                "recall50": to_cpu(torch.sum(iou50 * detected_mask) / (obj_mask.sum() + 1e-16)).item(),
+                "recall75": to_cpu(torch.sum(iou75 * detected_mask) / (obj_mask.sum() + 1e-16)).item(),
+                "precision": to_cpu(torch.sum(iou50 * detected_mask) / (conf50.sum() + 1e-16)).item(),
+                "conf_obj": to_cpu(pred_conf[obj_mask].mean()).item(),
+                "conf_noobj": to_cpu(pred_conf[noobj_mask].mean()).item(), "grid_size": g,
+            }
+        return total_loss
 
 
-_TRAIN_MSG = ("Darknet.forward(x, targets): the YOLO loss / detector backward (SURVEY.md section 8a row a6) is not "
-              "built yet - no m2/m3 script trains the detector (it is frozen: train.py:170, featuremap and "
-              "yolo_outputs are detached at models.py:255,266)")
 
 
 def _conv_block(index, spec, in_channels):
@@ -185,8 +238,9 @@ class Darknet(nn.Module):
         return self.engine.run(x)
 
     def forward(self, x, targets=None):
-        if targets is not None:
-            raise NotImplementedError(_TRAIN_MSG)
+        """``(featuremap, yolo_outputs)``, or with ``targets`` ``(loss, featuremap, yolo_outputs)`` where
+        ``loss`` is the summed YOLO loss of every scale (reference :261-267).  The loss is a VALUE: the
+        detector backward is not built (no reference script trains the detector)."""
         plan, yolo_outputs = self._run(x)
         if plan.tap is not None:
             # fresh tensor per call like the reference's ``x.detach()`` of a fresh activation;
@@ -195,6 +249,12 @@ class Darknet(nn.Module):
         if not hasattr(self, "featuremap"):
             # same failure the reference has for cfgs without a ``conv_8`` child
             raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+        if targets is not None:
+            loss = 0
+            for layer, raw in zip(self.yolo_layers, plan.yolo_raw):
+                layer.img_dim = x.shape[2]
+                loss = loss + layer.loss_from_raw(raw, targets)
+            return loss, self.featuremap, yolo_outputs
         return self.featuremap, yolo_outputs
 
     # -- darknet .weights I/O (reference :269-352) ---------------------------------------------

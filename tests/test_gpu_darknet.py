@@ -60,3 +60,23 @@ def test_cpu_input_is_rejected_loudly(hip_lib):
     model = ph.make_darknet("yolov3-tiny-12").cuda()
     with pytest.raises(hip.MeError):
         model(ph.frames("cpu", 1, 96))
+
+
+def test_yolo_loss_value_vs_reference_golden(hip_lib):
+    """Darknet.forward(x, targets) -> (loss, featuremap, yolo_outputs): loss value and per-scale metrics
+    against the reference's own numbers (row a6; the value only - the detector backward is not built)."""
+    import os
+    import numpy as np
+    from millieye_amd import synth
+    from tests.golden.make_golden import YOLO_LOSS_CASE
+    name, cfg, n, s = YOLO_LOSS_CASE
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    model = ph.make_darknet(cfg, tag=name).cuda()
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s))).cuda()
+    loss, fm, yolo = model(x, torch.from_numpy(g["targets"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    for i, yl in enumerate(model.yolo_layers):
+        for k, v in yl.metrics.items():
+            ref = float(g[f"m{i}/{k}"])
+            assert abs(float(v) - ref) <= 1e-3 * max(1.0, abs(ref)), (i, k, v, ref)
+    assert tuple(fm.shape) == (n, 256, s // 16, s // 16) and yolo.shape[0] == n

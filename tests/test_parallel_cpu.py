@@ -80,9 +80,9 @@ def test_allreduce_gradients_gloo_world2():
     model[0](x0 + 1).sum().backward()  # grads accumulate: rank 0 + rank 1
     for rank in (0, 1):
         nbytes, res = got[rank]
-        assert nbytes == 4 * (6 * 4 + 4 + 4 * 2 + 2)  # trainable tensors only, one flat fp32 bucket
+        assert nbytes == 4 * (6 * 4 + 4 + 4 * 2 + 2 + 1)  # trainable tensors only, one flat fp32 bucket
         for k, p in model.named_parameters():
-            if not p.requires_grad:
-                assert res[k] is None
+            if not p.requires_grad or p.grad is None:
+                assert res[k] is None  # frozen, or no gradient on any rank
             else:
                 assert torch.allclose(res[k], p.grad, atol=1e-6), (rank, k)
