@@ -174,7 +174,7 @@ class DarknetEngine:
                     self._plans.clear()  # descriptors hold the old pointers
 
     # ---------------------------------------------------------------------------------- planning
-    def _build(self, n, h, w, device):
+    def _build(self, n, h, w, device, keep_raw=False):
         defs = self.model.module_defs
         L = len(defs)
         hyper_c = int(self.model.hyperparams["channels"])
@@ -323,6 +323,10 @@ class DarknetEngine:
         tap_tensor = out[tap] if tap is not None and tap < L else None
         if tap_tensor is not None:
             tap_tensor.pinned = True
+        if keep_raw:  # the YOLO loss reads the raw detection maps after the run: exempt them from reuse
+            for op in ops:
+                if op["kind"] == "yolo":
+                    op["x"].pinned = True
 
         fam = {}
         for tt in tensors:
@@ -477,19 +481,19 @@ class DarknetEngine:
             plan.tap = None
         return plan
 
-    def plan_for(self, x):
+    def plan_for(self, x, keep_raw=False):
         n, _, h, w = x.shape
-        key = (n, h, w, x.device.index)
+        key = (n, h, w, x.device.index, bool(keep_raw))
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._build(n, h, w, x.device)
+            plan = self._build(n, h, w, x.device, keep_raw)
             self._plans[key] = plan
             if len(self._plans) > 8:  # multiscale callers: keep the arena count bounded
                 self._plans.pop(next(iter(self._plans)))
         return plan
 
     # ---------------------------------------------------------------------------------- execution
-    def run(self, x):
+    def run(self, x, keep_raw=False):
         """x: CUDA fp32 NCHW [N,C,H,W].  Returns (plan, yolo_outputs [N,R,5+C]); the feature tap is
         ``plan.tap`` (a view into the plan's arena, valid until the next ``run`` of that plan)."""
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
@@ -497,7 +501,7 @@ class DarknetEngine:
                               "fallback (the CPU restatement is oracle/, test infrastructure only)")
         x = x.contiguous()
         self.refresh_weights(x.device)
-        plan = self.plan_for(x)
+        plan = self.plan_for(x, keep_raw)
         yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
                                device=x.device)
         xp = x.data_ptr()

@@ -233,15 +233,15 @@ class Darknet(nn.Module):
         self.engine.tap_module = index
         self.engine._plans.clear()
 
-    def _run(self, x):
+    def _run(self, x, keep_raw=False):
         """Internal: (plan, yolo_outputs) without cloning the feature tap (used by Network)."""
-        return self.engine.run(x)
+        return self.engine.run(x, keep_raw)
 
     def forward(self, x, targets=None):
         """``(featuremap, yolo_outputs)``, or with ``targets`` ``(loss, featuremap, yolo_outputs)`` where
         ``loss`` is the summed YOLO loss of every scale (reference :261-267).  The loss is a VALUE: the
         detector backward is not built (no reference script trains the detector)."""
-        plan, yolo_outputs = self._run(x)
+        plan, yolo_outputs = self._run(x, keep_raw=targets is not None)
         if plan.tap is not None:
             # fresh tensor per call like the reference's ``x.detach()`` of a fresh activation;
             # memory stays channels-last (NHWC), shape is the reference's [N,256,S/16,S/16]
