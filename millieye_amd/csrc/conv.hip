@@ -52,7 +52,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // ---------------------------------------------------------------------------------------------
 // ABL (ablation, tuning only): 0 = production kernel; 1 = global loads / LDS refills skipped after
 // the first stage (matrix pipe + LDS reads + barriers only); 2 = MFMAs skipped (memory side only).
-template <int BM, int BN, int BK, int WR, int WC, int ABL = 0>
+template <int BM, int BN, int BK, int WR, int WC, int ABL = 0, int PRIO = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int TM = BM / WR, TN = BN / WC;
@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
       const bool ok = ((unsigned)iy < (unsigned)p.h) && ((unsigned)ix < (unsigned)p.w) && (c0 + a_q[i] < p.cin);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
-        const float* src = p.x + (long long)(a_pix0[i] + iy * p.w + ix) * p.x_pitch + (c0 + a_q[i]);
-        v = *reinterpret_cast<const float4*>(src);
+        long long off = (long long)(a_pix0[i] + iy * p.w + ix) * p.x_pitch + (c0 + a_q[i]);
+        if (ABL == 3) off &= 0x3FFC;  // ablation: same instruction stream, every load L1/L2 resident (64 KiB)
+        v = *reinterpret_cast<const float4*>(p.x + off);
       }
       a_reg[i] = v;
     }
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
     if (more && ABL != 1) load_stage();  // global loads in flight while the matrix cores work on `buf`
     const float* Ab = As + buf * BM * LP + a_frag;
     const float* Bb = Bs + buf * BN * LP + b_frag;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);  // matrix phase outranks the other waves' load phases
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 8) {
       float4 af[MT], bf[NT];
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
     if (more && ABL != 1) store_stage(buf ^ 1);
     __syncthreads();
   }
@@ -278,15 +281,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
 // ---------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) float g_zero_block[16];
 
-template <int BM, int BN, int WR, int WC>
-__global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvP p) {
-  static_assert(WR * WC == 4, "4 waves per workgroup");
+template <int BM, int BN, int WR, int WC, int DPRIO = 0, int MINW = 1>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_dma_f32(ConvP p) {
+  constexpr int NW = WR * WC;  // waves per workgroup (4 or 8)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   constexpr int BK = 16, NST = 3;
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int MT = TM / 32, NT = TN / 32;
   constexpr int GA = BM / 16, G = (BM + BN) / 16;  // 16-row groups (1 KiB each): A first, then B
-  constexpr int LPW = (G + 3) / 4;                  // DMA instructions per wave per stage
-  constexpr int STAGE_F = LPW * 4 * 256;            // floats per stage buffer (incl. dummy groups)
+  constexpr int LPW = (G + NW - 1) / NW;            // DMA instructions per wave per stage
+  constexpr int STAGE_F = LPW * NW * 256;           // floats per stage buffer (incl. dummy groups)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
@@ -309,39 +313,45 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvP p) {
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // per-lane source bookkeeping for this wave's groups g = wave + 4 * j
+  // per-lane source bookkeeping for this wave's groups g = wave + 4 * j (A groups first, then B).
+  // Everything that does not depend on the K stage is hoisted: a lane pointer for (tap 0, channel 0),
+  // a 9-bit "tap is readable" mask and the channel limit; per stage only a wave-uniform offset is added.
+  static_assert(GA % NW == 0, "A groups must split evenly over the waves");
+  constexpr int LA = GA / NW;  // A-type DMA instructions per wave
   const int lrow = lane >> 2;  // row inside the 16-row group
-  int g_iy0[LPW], g_ix0[LPW], g_pix0[LPW], g_q[LPW];
-  long long g_boff[LPW];
-  int g_kind[LPW];  // 0 = A rows, 1 = B rows (valid cout), 2 = always zero
+  const float* g_ptr[LPW];
+  unsigned g_mask[LPW];
+  int g_qlim[LPW];
 #pragma unroll
   for (int j = 0; j < LPW; ++j) {
-    const int g = wave + 4 * j;
+    const int g = wave + NW * j;
     const int row = g * 16 + lrow;                       // row inside the (A|B) stage image
     const int q = (lane & 3) ^ ((row >> 2) & 3);         // source 16-byte chunk for this LDS slot
-    g_q[j] = 4 * q;
-    g_iy0[j] = g_ix0[j] = g_pix0[j] = 0;
-    g_boff[j] = 0;
-    if (g < GA) {
-      g_kind[j] = 0;
+    g_qlim[j] = p.cin - 4 * q;
+    g_mask[j] = 0;
+    g_ptr[j] = g_zero_block;
+    if (j < LA) {
       const int m = m0 + row;
       if (m < p.M) {
         const int hw = p.ho * p.wo;
         const int nimg = m / hw;
         const int rem = m - nimg * hw;
         const int oy = rem / p.wo, ox = rem - oy * p.wo;
-        g_iy0[j] = oy * p.stride - p.pad;
-        g_ix0[j] = ox * p.stride - p.pad;
-        g_pix0[j] = nimg * p.h * p.w;
-      } else {
-        g_iy0[j] = -(1 << 28);
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        unsigned mask = 0;
+        for (int ky = 0; ky < p.ks; ++ky)
+          for (int kx = 0; kx < p.ks; ++kx)
+            if ((unsigned)(iy0 + ky) < (unsigned)p.h && (unsigned)(ix0 + kx) < (unsigned)p.w)
+              mask |= 1u << (ky * p.ks + kx);
+        g_mask[j] = mask;
+        g_ptr[j] = p.x + ((long long)nimg * p.h * p.w + (long long)iy0 * p.w + ix0) * p.x_pitch + 4 * q;
       }
     } else if (g < G) {
       const int co = n0 + (row - BM);
-      g_kind[j] = (co < p.cout) ? 1 : 2;
-      g_boff[j] = (long long)co * p.ktot + 4 * q;
-    } else {
-      g_kind[j] = 2;  // dummy group: keeps the per-wave DMA count uniform for the counted vmcnt
+      if (co < p.cout) {
+        g_mask[j] = 0xFFFFFFFFu;
+        g_ptr[j] = p.wgt + (long long)co * p.ktot + 4 * q;
+      }
     }
   }
 
@@ -350,25 +360,21 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvP p) {
   const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
   int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;
 
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);  // SGPR
   auto issue_stage = [&](int slot) {
     const int ky = tap / p.ks, kx = tap - ky * p.ks;
     const int c0 = cc * BK;
-    const int koff = tap * p.cin + c0;
-    const unsigned stage_lds = lds_base + (unsigned)slot * (STAGE_F * 4u);
+    const long long a_off = (long long)(ky * p.w + kx) * p.x_pitch + c0;  // wave-uniform (scalar) offsets
+    const long long b_off = (long long)tap * p.cin + c0;
+    const unsigned stage_lds = wave_lds + (unsigned)slot * (STAGE_F * 4u);
 #pragma unroll
     for (int j = 0; j < LPW; ++j) {
-      const float* src = g_zero_block;
-      if (g_kind[j] == 0) {
-        const int iy = g_iy0[j] + ky, ix = g_ix0[j] + kx;
-        if (((unsigned)iy < (unsigned)p.h) && ((unsigned)ix < (unsigned)p.w) && (c0 + g_q[j] < p.cin))
-          src = p.x + (long long)(g_pix0[j] + iy * p.w + ix) * p.x_pitch + (c0 + g_q[j]);
-      } else if (g_kind[j] == 1) {
-        if (c0 + g_q[j] < p.cin) src = p.wgt + g_boff[j] + koff;
-      }
+      const bool ok = ((g_mask[j] >> tap) & 1u) && (c0 < g_qlim[j]);
+      const float* src = ok ? g_ptr[j] + (j < LA ? a_off : b_off) : g_zero_block;
       // LDS byte address of this group's 1 KiB image: wave-uniform; hardware adds lane * 16 B.
       // Issued through inline asm so that hipcc does not track the DMA (it would drain it with
       // s_waitcnt vmcnt(0) in front of every ds_read); completion is counted by hand below.
-      const unsigned dst = __builtin_amdgcn_readfirstlane(stage_lds + (unsigned)(wave + 4 * j) * 1024u);
+      const unsigned dst = stage_lds + (unsigned)j * (NW * 1024u);
       unsigned keep;
       asm volatile(
           "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -408,6 +414,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvP p) {
     __builtin_amdgcn_s_barrier();  // everyone's stage-s DMAs landed; everyone finished reading stage s-1
     asm volatile("" ::: "memory");
     if (s + 2 < nstages) issue_stage((s + 2) % NST);  // refills the slot stage s-1 just vacated
+    if (DPRIO) __builtin_amdgcn_s_setprio(1);
     const float* Ab = smem + (s % NST) * STAGE_F + a_row;
     const float* Bb = smem + (s % NST) * STAGE_F + b_row;
 #pragma unroll
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    if (DPRIO) __builtin_amdgcn_s_setprio(0);
   }
 
   // ---- epilogue (same as conv_igemm_f32) --------------------------------------------------
@@ -598,20 +606,18 @@ struct TileCfg {
 };
 // BK = 16: LDS 2*(BM+BN)*20*4 B (40 KiB for 128x128)
 const TileCfg kTiles[] = {
+    // LDS per workgroup = 3 stages x (BM + BN) x 64 B: 48 / 36 / 24 / 36 KiB
     {1, 128, 128, 16, 3, 1.00f},
-    {2, 128, 64, 16, 5, 0.90f},
-    {3, 64, 64, 16, 8, 0.85f},
-    {4, 128, 32, 16, 7, 0.75f},
+    {2, 128, 64, 16, 4, 0.95f},
+    {3, 64, 64, 16, 6, 0.85f},
+    {4, 128, 32, 16, 4, 0.75f},
 };
 const TileCfg kExtraTiles[] = {  // forced ids only (tools/conv_bench.py)
-    {5, 128, 128, 32, 2, 1.0f},
-    {7, 256, 64, 16, 3, 1.0f},
-    {21, 128, 128, 16, 3, 1.0f},
-    {22, 128, 64, 16, 4, 0.9f},
-    {23, 64, 64, 16, 6, 0.85f},
-    {24, 128, 32, 16, 5, 0.75f},
-    {11, 128, 128, 16, 3, 1.0f},
-    {12, 128, 128, 16, 3, 1.0f},
+    {5, 256, 128, 16, 2, 1.0f},  {6, 256, 128, 16, 1, 1.0f},
+    {21, 128, 128, 16, 3, 1.0f}, {22, 128, 64, 16, 4, 0.9f},  {51, 128, 128, 16, 3, 1.0f},
+    {52, 128, 64, 16, 5, 0.9f},  {53, 64, 64, 16, 8, 0.85f},  {54, 128, 32, 16, 7, 0.75f},
+    {55, 128, 128, 32, 2, 1.0f}, {31, 128, 128, 16, 3, 1.0f}, {11, 128, 128, 16, 3, 1.0f},
+    {12, 128, 128, 16, 3, 1.0f}, {13, 128, 128, 16, 3, 1.0f},
 };
 constexpr int kMaxSplit = 16;
 
@@ -675,7 +681,7 @@ ConvPlan plan_conv(const ConvP& p, int forced_tile, int max_split) {
   return best;
 }
 
-template <int BM, int BN, int BK, int WR, int WC, int ABL = 0>
+template <int BM, int BN, int BK, int WR, int WC, int ABL = 0, int PRIO = 0>
 int launch_igemm(ConvP& p, hipStream_t stream) {
   p.cs = (p.cin + BK - 1) / BK;
   p.stages = p.ks * p.ks * p.cs;
@@ -685,7 +691,7 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
   p.sps = (p.stages + p.splitk - 1) / p.splitk;
   while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-  auto kern = conv_igemm_f32<BM, BN, BK, WR, WC, ABL>;
+  auto kern = conv_igemm_f32<BM, BN, BK, WR, WC, ABL, PRIO>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -705,7 +711,7 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
   return me::check_launch("conv_splitk_reduce_f32");
 }
 
-template <int BM, int BN, int WR, int WC>
+template <int BM, int BN, int WR, int WC, int DPRIO = 0, int MINW = 1>
 int launch_dma(ConvP& p, hipStream_t stream) {
   constexpr int BK = 16;
   p.cs = (p.cin + BK - 1) / BK;
@@ -715,12 +721,21 @@ int launch_dma(ConvP& p, hipStream_t stream) {
   if (p.splitk > p.stages) p.splitk = p.stages;
   p.sps = (p.stages + p.splitk - 1) / p.splitk;
   while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;
-  constexpr int LPW = ((BM + BN) / 16 + 3) / 4;
-  const size_t lds = (size_t)3 * LPW * 4 * 256 * sizeof(float);
-  auto kern = conv_igemm_dma_f32<BM, BN, WR, WC>;
+  constexpr int NW = WR * WC;
+  constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
+  const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
+  auto kern = conv_igemm_dma_f32<BM, BN, WR, WC, DPRIO, MINW>;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      attr_set = true;
+    }
+  }
   const long long blocks = (long long)p.tiles_m * p.tiles_n;
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(64 * NW), lds, stream, p);
   int rc = me::check_launch("conv_igemm_dma_f32");
   if (rc || p.splitk == 1) return rc;
   long long rb = ((long long)p.M * p.cout + 255) / 256;
@@ -819,18 +834,25 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   p.splitk = plan.splitk;
   p.partial = reinterpret_cast<float*>(d->workspace);
   switch (plan.tile) {
-    case 1: return launch_igemm<128, 128, 16, 2, 2>(p, stream);
-    case 2: return launch_igemm<128, 64, 16, 2, 2>(p, stream);
-    case 3: return launch_igemm<64, 64, 16, 2, 2>(p, stream);
-    case 4: return launch_igemm<128, 32, 16, 4, 1>(p, stream);
-    case 5: return launch_igemm<128, 128, 32, 2, 2>(p, stream);
-    case 7: return launch_igemm<256, 64, 16, 4, 1>(p, stream);
-    case 21: return launch_dma<128, 128, 2, 2>(p, stream);  // LDS-DMA editions of tiles 1-4
-    case 22: return launch_dma<128, 64, 2, 2>(p, stream);
-    case 23: return launch_dma<64, 64, 2, 2>(p, stream);
-    case 24: return launch_dma<128, 32, 4, 1>(p, stream);
-    case 11: return launch_igemm<128, 128, 16, 2, 2, 1>(p, stream);  // ablations of tile 1 (wrong results!)
+    // production tiles: LDS-DMA pipeline + s_setprio around the matrix phase
+    case 1: return launch_dma<128, 128, 2, 2, 1>(p, stream);
+    case 2: return launch_dma<128, 64, 2, 2, 1>(p, stream);
+    case 3: return launch_dma<64, 64, 2, 2, 1>(p, stream);
+    case 4: return launch_dma<128, 32, 4, 1, 1>(p, stream);
+    // tuning / ablation variants (forced ids only, tools/conv_bench.py)
+    case 5: return launch_dma<256, 128, 4, 2, 1, 4>(p, stream);   // 8 waves (512 threads), 4 waves / SIMD
+    case 6: return launch_dma<256, 128, 4, 2, 1, 1>(p, stream);   // 8 waves, registers unconstrained
+    case 21: return launch_dma<128, 128, 2, 2, 0>(p, stream);  // DMA pipeline without s_setprio
+    case 22: return launch_dma<128, 64, 2, 2, 0>(p, stream);
+    case 51: return launch_igemm<128, 128, 16, 2, 2>(p, stream);  // register-staged, double-buffered LDS
+    case 52: return launch_igemm<128, 64, 16, 2, 2>(p, stream);
+    case 53: return launch_igemm<64, 64, 16, 2, 2>(p, stream);
+    case 54: return launch_igemm<128, 32, 16, 4, 1>(p, stream);
+    case 55: return launch_igemm<128, 128, 32, 2, 2>(p, stream);
+    case 31: return launch_igemm<128, 128, 16, 2, 2, 0, 1>(p, stream);  // register-staged + s_setprio
+    case 11: return launch_igemm<128, 128, 16, 2, 2, 1>(p, stream);     // ablations (wrong results!)
     case 12: return launch_igemm<128, 128, 16, 2, 2, 2>(p, stream);
+    case 13: return launch_igemm<128, 128, 16, 2, 2, 3>(p, stream);
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_f32: unknown tile id %d", plan.tile);
   }
   return 0;

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--splits", default="0", help="comma list of split_k values (0 = auto)")
+    ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed load before each measurement")
     ap.add_argument("--custom", default="", help="extra shape 'hw,cin,cout,k,stride' (square input)")
     args = ap.parse_args()
     if args.custom:
@@ -78,8 +79,16 @@ def main():
             if sk > 1 and sk * n * ho * ho * cout * 4 > ws.numel() - 256:
                 continue
             stream = hip.stream_ptr()
-            for _ in range(3):
-                hip.check(lib.me_conv2d_f32(C.byref(d), stream), "conv")
+            hip.check(lib.me_conv2d_f32(C.byref(d), stream), "conv")
+            torch.cuda.synchronize()
+            # the GPU needs ~100 ms of sustained load to reach its steady clocks: pre-warm every variant for
+            # the same wall time, otherwise the first one measured looks 15 % slower than it is
+            import time
+            t_end = time.perf_counter() + args.prewarm
+            while time.perf_counter() < t_end:
+                for _ in range(5):
+                    lib.me_conv2d_f32(C.byref(d), stream)
+                torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(args.reps):
