@@ -602,22 +602,21 @@ __global__ __launch_bounds__(256) void conv_smallcin_f32(ConvP p) {
 struct TileCfg {
   int id, bm, bn, bk;
   int occ;    // workgroups resident per CU (LDS / register limited)
+  int wps;    // waves per SIMD contributed by one resident workgroup (1 for 4-wave, 2 for 8-wave tiles)
   float eff;  // steady-state efficiency of the tile shape relative to 128x128
 };
-// BK = 16: LDS 2*(BM+BN)*20*4 B (40 KiB for 128x128)
 const TileCfg kTiles[] = {
-    // LDS per workgroup = 3 stages x (BM + BN) x 64 B: 48 / 36 / 24 / 36 KiB
-    {1, 128, 128, 16, 3, 1.00f},
-    {2, 128, 64, 16, 4, 0.95f},
-    {3, 64, 64, 16, 6, 0.85f},
-    {4, 128, 32, 16, 4, 0.75f},
+    // LDS per workgroup = 3 stages x (BM + BN) x 64 B: 48 / 36 / 24 / 36 / 72 KiB
+    {1, 128, 128, 16, 3, 1, 1.00f},
+    {2, 128, 64, 16, 4, 1, 0.95f},
+    {3, 64, 64, 16, 6, 1, 0.85f},
+    {4, 128, 32, 16, 4, 1, 0.75f},
 };
-const TileCfg kExtraTiles[] = {  // forced ids only (tools/conv_bench.py)
-    {5, 256, 128, 16, 2, 1.0f},  {6, 256, 128, 16, 1, 1.0f},
-    {21, 128, 128, 16, 3, 1.0f}, {22, 128, 64, 16, 4, 0.9f},  {51, 128, 128, 16, 3, 1.0f},
-    {52, 128, 64, 16, 5, 0.9f},  {53, 64, 64, 16, 8, 0.85f},  {54, 128, 32, 16, 7, 0.75f},
-    {55, 128, 128, 32, 2, 1.0f}, {31, 128, 128, 16, 3, 1.0f}, {11, 128, 128, 16, 3, 1.0f},
-    {12, 128, 128, 16, 3, 1.0f}, {13, 128, 128, 16, 3, 1.0f},
+const TileCfg kExtraTiles[] = {  // forced ids only (engine autotuner, tools/conv_bench.py)
+    {5, 256, 128, 16, 2, 2, 1.02f},  {6, 256, 128, 16, 1, 2, 1.0f},   {21, 128, 128, 16, 3, 1, 1.0f}, {22, 128, 64, 16, 4, 1, 0.9f},
+    {51, 128, 128, 16, 3, 1, 1.0f},  {52, 128, 64, 16, 5, 1, 0.9f},  {53, 64, 64, 16, 8, 1, 0.85f},
+    {54, 128, 32, 16, 7, 1, 0.75f},  {55, 128, 128, 32, 2, 1, 1.0f}, {31, 128, 128, 16, 3, 1, 1.0f},
+    {11, 128, 128, 16, 3, 1, 1.0f},  {12, 128, 128, 16, 3, 1, 1.0f}, {13, 128, 128, 16, 3, 1, 1.0f},
 };
 constexpr int kMaxSplit = 16;
 
@@ -658,12 +657,18 @@ ConvPlan plan_conv(const ConvP& p, int forced_tile, int max_split) {
       // each workgroup is 2*BM*BN*BK*sps flops through one CU's matrix pipe
       const double wg = 2.0 * t.bm * t.bn * t.bk * sps / flop_per_clk_cu;
       const long long full = per_cu / t.occ, rem = per_cu % t.occ;
-      double cost = full * t.occ * wg / (kUtil[t.occ > 4 ? 4 : t.occ] * t.eff);
-      if (rem) cost += rem * wg / (kUtil[rem > 4 ? 4 : rem] * t.eff);
+      auto util = [&](long long resident) {
+        const long long w = resident * t.wps;
+        return kUtil[w > 4 ? 4 : w] * t.eff;
+      };
+      double cost = full * t.occ * wg / util(t.occ);
+      if (rem) cost += rem * wg / util(rem);
       cost += 3000.0;  // prologue / epilogue latency of a workgroup chain
       if (split > 1) {
+        // slab round trip: stays in L2 / Infinity Cache (~10 TB/s) while small, HBM speed (~3 TB/s) beyond
         const double bytes = (double)(split + 1) * p.M * p.cout * 4.0 * 2.0;
-        cost += bytes / 1.0e13 * 2.1e9 + 6000.0;  // slab traffic + the extra launch (~3 us)
+        const double bw = bytes < 256.0e6 ? 1.0e13 : 3.0e12;
+        cost += bytes / bw * 2.1e9 + 6000.0;  // + the extra launch (~3 us)
       }
       if (cost < best_cost) {
         best_cost = cost;

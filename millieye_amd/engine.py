@@ -469,6 +469,8 @@ class DarknetEngine:
                     d.workspace, d.workspace_bytes = ws_ptr, need
         plan.launches = launches
         plan.conv_flops = flops
+        if _autotune_enabled():
+            _autotune(plan, lib)
         if tap_tensor is not None:
             root, coff = tap_tensor.root()
             pitch = root.c
@@ -517,6 +519,102 @@ class DarknetEngine:
                 hip.check(rc, name)
         plan.last_input = x  # keep the caller's tensor alive until the stream has consumed it
         return plan, yolo_out
+
+
+# ------------------------------------------------------------------------------------------ autotuner
+_TUNE_CACHE = {}
+_TUNE_TILES = (1, 2, 3, 4, 5)
+_TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
+
+
+def _autotune_enabled():
+    import os
+    return os.environ.get("MILLIEYE_AUTOTUNE", "1") not in ("0", "false", "off")
+
+
+def _autotune(plan, lib):
+    """Pick (tile, split_k) per MFMA conv layer by measuring the candidates on this GPU (HIP events on the
+    launch stream, clocks pre-warmed).  The analytic planner inside ``me_conv2d_f32`` is within ~6 % of the
+    best on average but misjudges the wave-quantisation of individual layers; measuring is cheap (about a
+    second per plan, outside any timed region) and cached per layer shape for the life of the process.
+    Every candidate computes the same convolution (parity tests cover all tiles and split-K)."""
+    import time
+
+    stream = hip.stream_ptr()
+    todo = []
+    for _m, d in plan.conv_descs:
+        if d.cin <= 4:
+            continue
+        key = (d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.upsample, bool(d.res))
+        hit = _TUNE_CACHE.get(key)
+        if hit is not None:
+            d.tile, d.split_k = hit
+        else:
+            todo.append((key, d))
+    def ensure_workspace(nbytes):
+        have = plan.conv_ws.numel() - 256 if plan.conv_ws is not None else 0
+        if nbytes > have:
+            plan.conv_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=plan.arena.device)
+            have = nbytes
+        ptr = plan.conv_ws.data_ptr() + (-plan.conv_ws.data_ptr()) % 256 if plan.conv_ws is not None else None
+        for _m2, d2 in plan.conv_descs:
+            if d2.cin > 4:
+                d2.workspace, d2.workspace_bytes = ptr, have
+        return have
+
+    def required():
+        return max([d2.split_k * d2.n * d2.ho * d2.wo * d2.cout * 4 for _m2, d2 in plan.conv_descs
+                    if d2.cin > 4 and d2.split_k > 1] + [0])
+
+    if not todo:
+        ensure_workspace(required())  # cached choices may need more scratch than the analytic plan asked for
+        return
+    ws_bytes = plan.conv_ws.numel() - 256 if plan.conv_ws is not None else 0
+    # one shared scratch big enough for 8 slabs of the smaller layers (bounded: 512 MiB)
+    need = 0
+    for _k, d in todo:
+        slab = d.n * d.ho * d.wo * d.cout * 4
+        if slab * 2 <= 512 * 2 ** 20:
+            need = max(need, min(8 * slab, 512 * 2 ** 20))
+    ws_bytes = ensure_workspace(max(need, required()))
+
+    def run(d, reps):
+        for _ in range(reps):
+            rc = lib.me_conv2d_f32(C.byref(d), stream)
+            if rc != 0:
+                return False
+        return True
+
+    # clock ramp-up on the first layer
+    t_end = time.perf_counter() + 0.3
+    d0 = todo[0][1]
+    d0.tile, d0.split_k = 0, 1
+    while time.perf_counter() < t_end:
+        run(d0, 5)
+        torch.cuda.synchronize()
+    for key, d in todo:
+        slab = d.n * d.ho * d.wo * d.cout * 4
+        stages = d.ksize * d.ksize * ((d.cin + 15) // 16)
+        best = (float("inf"), 0, 1)
+        for tile in _TUNE_TILES:
+            bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128)}[tile]
+            tiles = -(-d.n * d.ho * d.wo // bm) * -(-d.cout // bn)
+            for split in _TUNE_SPLITS:
+                if split > 1 and (split * slab > ws_bytes or tiles * split > 4096 or split > stages):
+                    continue
+                d.tile, d.split_k = tile, split
+                if not run(d, 2):
+                    continue
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                ok = run(d, 4)
+                b.record()
+                torch.cuda.synchronize()
+                if ok and a.elapsed_time(b) < best[0]:
+                    best = (a.elapsed_time(b), tile, split)
+        d.tile, d.split_k = best[1], best[2]
+        _TUNE_CACHE[key] = (best[1], best[2])
+    ensure_workspace(required())
 
 
 def _in_family(cat, p):
