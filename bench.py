@@ -97,6 +97,22 @@ def conv_roofline(model, x, steps):
     return achieved, total_ms * 1e3 / launches, launches, total_flops / launches, per_layer
 
 
+def conv_traffic(batch):
+    """HBM bytes per conv launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, two separate
+    passes over this same command; tools/pmc_traffic.py -> profiles/conv_traffic.json).  PMC counters cannot
+    be read from inside this process, so the committed measurement is reported when it matches the
+    configuration being run, else null."""
+    path = os.path.join(ROOT, "profiles", "conv_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        if int(t.get("batch", 32)) == batch:
+            return int(t["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s, radar=None):
     """The oracle (stock torch CPU ops = the reference's CPU path, pinned by tests/golden) timed on the
     host cores: a bounded sample of the same workload (batch-1 passes of the same cfg / size)."""
@@ -255,7 +271,7 @@ def main():
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": conv_traffic(batch),
                 "launches_per_step": launches,
                 "avg_launch_us": round(avg_us, 2),
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),

@@ -523,6 +523,7 @@ class DarknetEngine:
 
 # ------------------------------------------------------------------------------------------ autotuner
 _TUNE_CACHE = {}
+_TUNE_FILE_LOADED = [False]
 _TUNE_TILES = (1, 2, 3, 4, 5)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
 
@@ -530,6 +531,43 @@ _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
 def _autotune_enabled():
     import os
     return os.environ.get("MILLIEYE_AUTOTUNE", "1") not in ("0", "false", "off")
+
+
+def _tune_file():
+    import os
+    path = os.environ.get("MILLIEYE_TUNE_CACHE")
+    if path:
+        return path
+    base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
+    return os.path.join(base, "millieye_amd", "conv_tune.json")
+
+
+def _tune_load():
+    import json
+    import os
+    if _TUNE_FILE_LOADED[0]:
+        return
+    _TUNE_FILE_LOADED[0] = True
+    try:
+        with open(_tune_file()) as fh:
+            for k, v in json.load(fh).items():
+                _TUNE_CACHE[tuple(int(x) for x in k.split(","))] = (int(v[0]), int(v[1]))
+    except (OSError, ValueError):
+        pass
+
+
+def _tune_save():
+    import json
+    import os
+    path = _tune_file()
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as fh:
+            json.dump({",".join(str(int(x)) for x in k): list(v) for k, v in _TUNE_CACHE.items()}, fh)
+        os.replace(tmp, path)
+    except OSError:
+        pass  # the cache is an optimisation only
 
 
 def _autotune(plan, lib):
@@ -541,11 +579,12 @@ def _autotune(plan, lib):
     import time
 
     stream = hip.stream_ptr()
+    _tune_load()
     todo = []
     for _m, d in plan.conv_descs:
         if d.cin <= 4:
             continue
-        key = (d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.upsample, bool(d.res))
+        key = (d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.upsample, int(bool(d.res)))
         hit = _TUNE_CACHE.get(key)
         if hit is not None:
             d.tile, d.split_k = hit
@@ -615,6 +654,7 @@ def _autotune(plan, lib):
         d.tile, d.split_k = best[1], best[2]
         _TUNE_CACHE[key] = (best[1], best[2])
     ensure_workspace(required())
+    _tune_save()
 
 
 def _in_family(cat, p):

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""HBM traffic of the conv kernels from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a
+pass on gfx950: TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2).
+
+    python tools/pmc_traffic.py <fetch_results.db> <write_results.db> [kernel substring] > profiles/..json
+
+Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB
+(bytes = value * 1024); on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced read, so it
+is doubled; WRITE_SIZE is taken as is (uncalibrated)."""
+import json
+import sqlite3
+import sys
+
+
+def per_launch(db, counter, match):
+    cur = sqlite3.connect(db).cursor()
+    q = ("select sum(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?")
+    tot, n = cur.execute(q, (counter, f"%{match}%")).fetchone()
+    return (tot or 0.0), (n or 0)
+
+
+def main():
+    fetch_db, write_db = sys.argv[1], sys.argv[2]
+    match = sys.argv[3] if len(sys.argv) > 3 else "conv_igemm"
+    f, nf = per_launch(fetch_db, "FETCH_SIZE", match)
+    w, nw = per_launch(write_db, "WRITE_SIZE", match)
+    fetch_bytes = 2.0 * f * 1024.0 / max(nf, 1)
+    write_bytes = w * 1024.0 / max(nw, 1)
+    print(json.dumps({
+        "kernel_match": match, "launches_fetch_pass": nf, "launches_write_pass": nw,
+        "fetch_bytes_per_launch": round(fetch_bytes), "write_bytes_per_launch": round(write_bytes),
+        "hbm_bytes_per_launch": round(fetch_bytes + write_bytes),
+        "note": "FETCH_SIZE x2 (gfx950 half-count of wide reads), KiB -> bytes; WRITE_SIZE uncalibrated; "
+                "average over every conv_igemm launch of `python bench.py --steps 3 --warmup 1`",
+    }))
+
+
+if __name__ == "__main__":
+    main()
