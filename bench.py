@@ -10,6 +10,8 @@ communication.
 Workloads (``--workload``):
   detector  yolov3.cfg (Darknet-53) 416x416 fp32 forward -> (featuremap, yolo_outputs)   [BASELINE configs[1]]
   full      detector + NMS + R-CNN/radar-fusion heads (Network.forward, mode 0)          [metric's "+fusion"]
+  train     stage-3 training step: forward + loss + backward + one SUM all-reduce (RCCL) of the flat
+            gradient bucket + Adam step, batch 8 per GPU                                  [BASELINE configs[3] shape]
 """
 import argparse
 import json
@@ -35,7 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--cfg", default="yolov3")
-    ap.add_argument("--workload", default="full", choices=["detector", "full"])
+    ap.add_argument("--workload", default="full", choices=["detector", "full", "train"])
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed clock ramp-up before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
@@ -174,7 +176,7 @@ def main():
     from millieye_amd import cfgs, synth  # noqa: E402
     from millieye_amd.yolov3.models import Darknet
 
-    batch = args.batch or (8 if args.workload == "detector" else 32)
+    batch = args.batch or (32 if args.workload == "full" else 8)
     conf_thresh = 0.2
     cfg_path = cfgs.write_cfg(args.cfg, os.path.join("/tmp", f"millieye_bench_cfg_{os.getuid()}_{rank}"))
     frames_cpu = torch.from_numpy(synth.uniform(f"bench/frames/{rank}", (batch, 3, args.size, args.size)))
@@ -194,7 +196,9 @@ def main():
     else:
         from millieye_amd.my_models import Network
         net = Network(Darknet(cfg_path), conf_thresh).eval()
-        synth.fill_network_(net, "bench/" + args.cfg)
+        # class-0 logit clearly dominant (+3 vs -4) so that the class filter of Network.forward (class_idx 0,
+        # my_models.py:462) keeps a realistic number of image proposals per frame with random backbone weights
+        synth.fill_network_(net, "bench/" + args.cfg, cls0_bias=3.0, cls_bias=-4.0)
         state_cpu = {k: v.clone() for k, v in net.state_dict().items()}
         net = net.to(dev)
         model = net.base_detector
@@ -208,6 +212,36 @@ def main():
             with torch.no_grad():
                 last["out"] = net(x, maps_d, boxes_d.clone(), 0)  # forward scales the radar boxes in place
             return last["out"]
+
+        if args.workload == "train":
+            import random
+            from millieye_amd import parallel as par
+            from millieye_amd.train_path import head_parameters
+            random.seed(1234 + rank)
+            with torch.no_grad():  # targets = a few of the model's own detections, so IoU-positive samples exist
+                det = net(x, maps_d, boxes_d.clone(), 1).cpu()
+            tg = []
+            for i in range(batch):
+                rows_i = det[det[:, 0] == i]
+                for j in (0, 3):
+                    if j < len(rows_i):
+                        b = rows_i[j, 1:5] / args.size
+                        tg.append([i, 0, float((b[0] + b[2]) / 2), float((b[1] + b[3]) / 2), float(b[2] - b[0]) * 1.05,
+                                   float(b[3] - b[1]) * 0.95])
+            targets = torch.tensor(tg, dtype=torch.float32).reshape(-1, 6)
+            net.train()
+            net.base_detector.eval()
+            heads = head_parameters(net)
+            opt = torch.optim.Adam(heads, lr=5e-4)
+
+            def step():  # noqa: F811
+                loss, out_rows, _metric, _att = net(x, maps_d, boxes_d.clone(), targets.clone())
+                loss.backward()
+                last["bucket_bytes"] = par.allreduce_gradients(heads)
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                last["out"], last["loss"] = out_rows, loss.detach()
+                return out_rows
 
     # untimed pre-warm: the GPU needs a few hundred ms of sustained load to reach its steady clocks (the first
     # ~100 ms run ~15 % slower, measured with tools/conv_bench.py); serving throughput is the steady state
@@ -254,7 +288,9 @@ def main():
                 "workload": f"{args.cfg}.cfg {args.size}x{args.size} fp32 inference, batch={batch} per GPU, "
                             + ("Darknet.forward -> featuremap + yolo_outputs" if args.workload == "detector" else
                                "full milliEye: Darknet.forward -> NMS -> Network.forward mode 0 (R-CNN head + radar "
-                               "fusion, 2 radar boxes/frame) -> output rows")
+                               "fusion, 2 radar boxes/frame) -> output rows" if args.workload == "full" else
+                               "stage-3 training step: frozen detector + NMS + train-mode heads + focal/BCE loss + "
+                               "backward + SUM all-reduce of the flat gradient bucket + Adam step")
                             + ", synthetic frames U[0,1), deterministic trained-like weights",
                 "stage": args.workload,
                 "batch_per_gpu": batch,
@@ -277,12 +313,18 @@ def main():
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload != "train":
             from millieye_amd.engine import pick_tap_module
             out["cpu_baseline"] = cpu_baseline(args, frames_cpu, state_cpu, cfgs.KNOWN[args.cfg](),
                                                pick_tap_module(model.module_defs), args.cpu_seconds, radar)
         if net is not None:
             out["config"]["output_rows_last_step"] = int(last["out"].shape[0])
+            out["config"]["rois_last_step"] = int(getattr(net, "_last", {}).get("n_img", torch.zeros(1)).sum().item()) \
+                + batch * 2 if args.workload == "full" else int(net._last_train["k"])
+        if args.workload == "train":
+            out["config"]["grad_bucket_bytes"] = int(last.get("bucket_bytes", 0))
+            out["config"]["loss_last_step"] = round(float(last["loss"]), 5)
+            out["config"]["workload"] = out["config"]["workload"].replace("inference", "training (heads), inference (detector)")
         if os.environ.get("BENCH_LAYERS"):
             for mod, flops, ms in per_layer:
                 print(f"[layer] conv{mod}: {flops / 1e9:.3f} GF {ms * 1e3:.1f} us {flops / ms / 1e9:.1f} TF/s",

@@ -177,13 +177,13 @@ def fill_darknet_(darknet, tag):
     return darknet
 
 
-def fill_network_(net, tag, trained_like=True):
+def fill_network_(net, tag, trained_like=True, **trained_kwargs):
     """Deterministic weights for a whole fusion ``Network`` (product or reference instance - the
     module / parameter names are identical): calibrated detector (+ trained-like detection
     convs), He-style heads with non-trivial BatchNorm statistics."""
     fill_darknet_(net.base_detector, tag + "/det")
     if trained_like:
-        trained_like_(net.base_detector, tag + "/det/trained")
+        trained_like_(net.base_detector, tag + "/det/trained", **trained_kwargs)
     for name in ("img_cnn_layers", "radar_cnn_layers", "refinement_head", "ensemble_head"):
         fill_state_dict(getattr(net, name), f"{tag}/{name}")
     return net
@@ -211,7 +211,8 @@ def _is_bn(sd, key):
 _DET_GAIN = {107: [4.0, 1.93, 1.34], 24: [0.30, 0.36]}  # yolov3.cfg / yolov3-tiny cfgs
 
 
-def trained_like_(darknet, tag="trained", obj_bias=-4.0, obj_std=2.0, wh_std=0.5, cls_bias=-2.0, gains=None):
+def trained_like_(darknet, tag="trained", obj_bias=-4.0, obj_std=2.0, wh_std=0.5, cls_bias=-2.0, gains=None,
+                  cls0_bias=1.0):
     """Give the detection convolutions of a ``Darknet`` (in place) the output statistics of
     a *trained* detector: objectness logits around
     ``obj_bias`` so that only a few percent of rows pass ``conf_thresh``, ``tw/th`` ~
@@ -250,7 +251,7 @@ def trained_like_(darknet, tag="trained", obj_bias=-4.0, obj_std=2.0, wh_std=0.5
                 b[base + 4] = obj_bias
                 scale[base + 5: base + per] = 1.0
                 b[base + 5: base + per] = cls_bias
-                b[base + 5] = 1.0
+                b[base + 5] = cls0_bias
             w = w * scale[:, None, None, None]
             conv.weight.copy_(torch.from_numpy(w.astype(np.float32)))
             conv.bias.copy_(torch.from_numpy(b))

@@ -91,6 +91,34 @@ def _wgrad(x, x_pitch, dy, dy_pitch, n, h, w, cin, cout, k, pad):
     return dw.permute(0, 3, 1, 2).contiguous()  # OHWI -> OIHW (the parameter's layout)
 
 
+def iou_labels_vectorized(boxes, targets):
+    """Same result as ``my_models.obtain_iou_labels(boxes, targets, multi_boxes=<truthy>)`` (reference
+    my_models.py:317-375, quirk q5: the call site always passes a truthy ``multi_boxes``, so the ``detected``
+    bookkeeping never changes the outcome) without the per-box python loop: one ``[P, Q]`` IoU matrix (+1 pixel
+    convention, identical fp32 formula), masked to same-image / same-class targets, first-maximum per row."""
+    P, Q = boxes.shape[0], targets.shape[0]
+    iou_labels = torch.zeros((P, 1))
+    target_location = torch.zeros((P, 4))
+    if P == 0 or Q == 0:
+        return iou_labels, target_location
+    b, t = boxes[:, 2:6], targets[:, 2:6]
+    ix1 = torch.max(b[:, None, 0], t[None, :, 0])
+    iy1 = torch.max(b[:, None, 1], t[None, :, 1])
+    ix2 = torch.min(b[:, None, 2], t[None, :, 2])
+    iy2 = torch.min(b[:, None, 3], t[None, :, 3])
+    inter = torch.clamp(ix2 - ix1 + 1, min=0) * torch.clamp(iy2 - iy1 + 1, min=0)
+    a1 = ((b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1))[:, None]
+    a2 = ((t[:, 2] - t[:, 0] + 1) * (t[:, 3] - t[:, 1] + 1))[None, :]
+    iou = inter / (a1 + a2 - inter + 1e-16)
+    same = (boxes[:, None, 0] == targets[None, :, 0]) & (boxes[:, None, 1] == targets[None, :, 1])
+    masked = torch.where(same, iou, torch.full_like(iou, -1.0))
+    best, arg = masked.max(1)  # first maximum, like ious.max(0) over the filtered targets in target order
+    has = same.any(1)
+    iou_labels[has, 0] = best[has]
+    target_location[has] = t[arg[has]]
+    return iou_labels, target_location
+
+
 def head_parameters(net):
     """Fixed order of every non-detector parameter (the autograd inputs of the training step)."""
     return [p for name, p in net.named_parameters() if not name.startswith("base_detector.")]
@@ -115,7 +143,7 @@ class _StageThree(torch.autograd.Function):
 
 def forward_train(net, images, maps, radar_boxes_location, targets):
     """Returns ``(loss, output, metric, radar_attention)`` like the reference's training call."""
-    from .my_models import _DETECTIONS_PER_IMG, _NMS_THRESH, obtain_iou_labels
+    from .my_models import _DETECTIONS_PER_IMG, _NMS_THRESH
     from .utils.utils import xywh2xyxy
 
     if not images.is_cuda:
@@ -253,7 +281,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
         ib = img_boxes[:n_img]
         boxes_cpu = torch.cat((torch.cat((ib[:, :1], ib[:, 7:8], ib[:, 1:5]), 1),
                                torch.cat((rb[:, :1], torch.zeros((n_radar, 1), **f32), rb[:, 1:5]), 1)), 0).cpu()
-        iou_labels, _target_location = obtain_iou_labels(boxes_cpu, targets.cpu(), net.iou_thresh)
+        iou_labels, _target_location = iou_labels_vectorized(boxes_cpu, targets.cpu())
         pos_filter = (iou_labels > net.iou_thresh[1]).flatten()
         neg_filter = (iou_labels < net.iou_thresh[0]).flatten()
         positive_masks = keep[:k].bool().cpu()
