@@ -1,0 +1,184 @@
+"""Stage-3 training harness: the loop of ``module3_our_dataset/train.py``.
+
+The reference's loop lives under ``if __name__ == "__main__"`` (train.py:24-272); here it is a function
+so that a caller (or :func:`main`, which mirrors the script's command line) can drive it with any
+iterable of ``(paths, imgs, targets, radar_boxes, radar_maps)`` batches - the input producer
+(``utils/datasets.MyDataset``) is the caller's.  What is kept, line by line:
+
+* ``load_pretrained_module2`` - the stage-2 -> stage-3 tensor hand-over by *position* (train.py:113-141): the
+  tensors of the stage-2 checkpoint whose names are in ``NAMES_M2`` are collected in the checkpoint's own order
+  and assigned, in the model's ``state_dict`` order, to the names of ``NAMES_M3``; those parameters are then
+  frozen (``requires_grad = False``, train.py:143-147).
+* ``Adam(model.parameters(), lr=5e-4)`` created *after* freezing (train.py:161).
+* per epoch ``model.train(); model.base_detector.eval()`` (train.py:167-168); per batch
+  ``model(imgs, radar_maps, radar_boxes, targets.clone())`` - targets in the ``model_mode`` slot -
+  ``loss.backward()``; ``optimizer.step(); optimizer.zero_grad()`` when ``batches_done % gradient_accumulations == 0``
+  - so the very first step sees one batch of gradients, later ones two (train.py:185-191);
+  ``model.seen += imgs.size(0)`` (train.py:236).
+* ``checkpoints/{test_list}_ckpt_{epoch}.pth`` every ``checkpoint_interval`` epochs (train.py:238-239), then
+  ``evaluate(model, mode="test", model_mode=0, illumination=["L"], iou_thresh=0.5, nms_thresh=0.5, ...)`` every
+  ``evaluation_interval`` epochs (train.py:241-254).  ``evaluate`` leaves the model in ``eval()``; the next epoch
+  switches back, as in the reference.
+
+Added for MI355X: when ``torch.distributed`` is initialised every rank runs the loop on its shard of the batches
+and the accumulated gradients are SUM-all-reduced in one flat bucket right before ``optimizer.step()``
+(``millieye_amd/parallel.py``; losses are sums over RoIs, so SUM is the single-process gradient of the global batch).
+TensorBoard image dumps (train.py:196-219) are optional: pass a ``SummaryWriter``-like ``writer``.
+"""
+import argparse
+import datetime
+import os
+import time
+
+import torch
+
+from . import parallel
+from .test_fusion import evaluate as _evaluate
+
+NAMES_M3 = ["img_cnn_layers.net.conv_0.weight", "img_cnn_layers.net.conv_0.bias",
+            "img_cnn_layers.net.batch_norm_0.weight", "img_cnn_layers.net.batch_norm_0.bias",
+            "img_cnn_layers.net.batch_norm_0.running_mean", "img_cnn_layers.net.batch_norm_0.running_var",
+            "img_cnn_layers.net.batch_norm_0.num_batches_tracked",
+            "refinement_head.net0.0.weight", "refinement_head.net0.0.bias",
+            "refinement_head.net1.0.weight", "refinement_head.net1.0.bias",
+            "refinement_head.net2.0.weight", "refinement_head.net2.0.bias"]
+NAMES_M2 = [n.replace("img_cnn_layers.", "fcn_layers.") for n in NAMES_M3]
+
+
+def load_pretrained_module2(model, param, log=print):
+    """train.py:113-147.  ``param`` is the stage-2 ``state_dict``.  Returns the names that were frozen."""
+    module_list = model.state_dict()
+    tmp = [param[name] for name in list(param) if name in NAMES_M2]
+    for name in module_list:
+        if name in NAMES_M3:
+            module_list[name] = tmp.pop(0)
+    model.load_state_dict(module_list)
+    frozen = []
+    for name, p in model.named_parameters():
+        if name in NAMES_M3:
+            log(name)
+            p.requires_grad = False
+            frozen.append(name)
+    return frozen
+
+
+def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoint_interval=1, evaluation_interval=1,
+               test_list=4, img_size=416, batch_size=16, class_names=None, optimizer=None, evaluate_fn=_evaluate,
+               evaluate_kwargs=None, checkpoint_dir="checkpoints", writer=None, log=print):
+    """Runs the loop; returns ``dict(losses, steps, checkpoints, evaluations)`` (the reference only prints)."""
+    device = getattr(model, "device", torch.device("cuda"))
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    if optimizer is None:
+        optimizer = torch.optim.Adam(model.parameters(), lr=5e-4)
+    distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+    rank = torch.distributed.get_rank() if distributed else 0
+    history = dict(losses=[], steps=[], checkpoints=[], evaluations=[])
+
+    for epoch in range(epochs):
+        model.train()
+        model.base_detector.eval()
+        start_time = time.time()
+        for batch_i, (_, imgs, targets, radar_boxes, radar_maps) in enumerate(dataloader):
+            batches_done = len(dataloader) * epoch + batch_i
+            epoch_batches_left = len(dataloader) - (batch_i + 1)
+            imgs = imgs.to(device)
+            radar_maps = radar_maps.to(device)
+            radar_boxes = radar_boxes.to(device)
+
+            loss, outputs, metric, radar_attention = model(imgs, radar_maps, radar_boxes, targets.clone())
+            loss.backward()
+
+            if batches_done % gradient_accumulations == 0:
+                if distributed:
+                    parallel.allreduce_gradients([p for p in model.parameters() if p.requires_grad])
+                optimizer.step()
+                optimizer.zero_grad()
+                history["steps"].append(batches_done)
+
+            if writer is not None:
+                if batches_done % 50 == 0:
+                    writer.add_images("image", imgs, global_step=batches_done)
+                    writer.add_images("radar_attention", radar_attention[:, :3], global_step=batches_done)
+                writer.add_scalar("loss", loss, global_step=batches_done)
+                writer.add_scalar("precesion", metric["tp"] / metric["positive"], global_step=batches_done)
+                writer.add_scalar("recall", metric["tp"] / metric["true"], global_step=batches_done)
+
+            loss_value = loss.item()
+            history["losses"].append(loss_value)
+            time_left = datetime.timedelta(seconds=epoch_batches_left * (time.time() - start_time) / (batch_i + 1))
+            log("--- [Epoch %d/%d, Batch %d/%d] ---\nTotal loss: %s\n---- ETA %s\n"
+                % (epoch, epochs, batch_i, len(dataloader), loss_value, time_left))
+            model.seen += imgs.size(0)
+
+        if epoch % checkpoint_interval == 0 and rank == 0:
+            path = os.path.join(checkpoint_dir, f"{test_list}_ckpt_{epoch}.pth")
+            torch.save(model.state_dict(), path)
+            history["checkpoints"].append(path)
+
+        if epoch % evaluation_interval == 0 and evaluate_fn is not None:
+            log("\n---- Evaluating Model ----")
+            precision, recall, AP, f1, ap_class, _, _ = result = evaluate_fn(
+                model, mode="test", model_mode=0, illumination=["L"], iou_thresh=0.5, nms_thresh=0.5,
+                img_size=img_size, batch_size=batch_size, test_list=test_list, **(evaluate_kwargs or {}))
+            history["evaluations"].append(result)
+            if writer is not None:
+                writer.add_scalars("metrics", dict(val_precision=precision.mean(), val_recall=recall.mean(),
+                                                   val_mAP=AP.mean(), val_f1=f1.mean()), global_step=epoch)
+            rows = [["Index", "Class name", "AP"]]
+            for i, c in enumerate(ap_class):
+                rows.append([c, class_names[i] if class_names else str(c), "%.5f" % AP[i]])
+            log("\n".join(" | ".join(str(v) for v in r) for r in rows))
+            log(f"---- mAP {AP.mean()}")
+    return history
+
+
+def build_parser():
+    """The reference's command line (train.py:26-94), same names and defaults."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--gradient_accumulations", type=int, default=2)
+    p.add_argument("--n_cpu", type=int, default=16)
+    p.add_argument("--checkpoint_interval", type=int, default=1)
+    p.add_argument("--evaluation_interval", type=int, default=1)
+    p.add_argument("--multiscale_training", default=True)
+    p.add_argument("--conf_thresh", type=float, default=0.01)
+    p.add_argument("--img_size", type=int, default=416)
+    p.add_argument("--classes_path", type=str, default="config/exdark.names")
+    p.add_argument("--yolo_cfg", type=str, default="config/yolov3-tiny-12.cfg")
+    p.add_argument("--yolo_weights", type=str, default="weights/best_mixed.pt")
+    p.add_argument("--pretrained_module2", type=str, default="./weights/module2_best_mixed.pth")
+    p.add_argument("--checkpoint", type=str)
+    p.add_argument("--illumination", type=str, default=["H", "L"])
+    p.add_argument("--test_list", type=int, default=4)
+    return p
+
+
+def main(argv=None):
+    """``python -m millieye_amd.train`` - needs the caller's ``utils.datasets.MyDataset`` on ``sys.path`` (as the
+    reference script does, train.py:2,150)."""
+    from .my_models import Network, define_yolo, init_yolo
+    from .utils.utils import load_classes, weights_init_normal
+    from utils.datasets import MyDataset  # the caller's input producer
+
+    opt = build_parser().parse_args(argv)
+    class_names = load_classes(opt.classes_path)
+    model = Network(define_yolo(opt.yolo_cfg), opt.conf_thresh)
+    model = model.to(model.device)
+    if opt.checkpoint:
+        model.load_state_dict(torch.load(opt.checkpoint))
+    else:
+        model.apply(weights_init_normal)
+        init_yolo(model=model.base_detector, weights_path=opt.yolo_weights)
+    if opt.pretrained_module2:
+        load_pretrained_module2(model, torch.load(opt.pretrained_module2))
+    dataset = MyDataset(mode="train", illumination=opt.illumination, augment=False, multiscale=True)
+    dataloader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=True, num_workers=opt.n_cpu,
+                                             pin_memory=True, collate_fn=dataset.collate_fn)
+    train_loop(model, dataloader, epochs=opt.epochs, gradient_accumulations=opt.gradient_accumulations,
+               checkpoint_interval=opt.checkpoint_interval, evaluation_interval=opt.evaluation_interval,
+               test_list=opt.test_list, img_size=opt.img_size, batch_size=opt.batch_size, class_names=class_names)
+
+
+if __name__ == "__main__":
+    main()
