@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvP p) {
 // ---------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) float g_zero_block[16];
 
-template <int BM, int BN, int WR, int WC, int DPRIO = 0, int MINW = 1>
+// DABL (ablation, tuning only): 1 = every DMA reads the zero block (same instruction stream, memory system idle).
+template <int BM, int BN, int WR, int WC, int DPRIO = 0, int MINW = 1, int DABL = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_dma_f32(ConvP p) {
   constexpr int NW = WR * WC;  // waves per workgroup (4 or 8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_dma_f32(ConvP p
     const unsigned stage_lds = wave_lds + (unsigned)slot * (STAGE_F * 4u);
 #pragma unroll
     for (int j = 0; j < LPW; ++j) {
-      const bool ok = ((g_mask[j] >> tap) & 1u) && (c0 < g_qlim[j]);
+      const bool ok = DABL != 1 && ((g_mask[j] >> tap) & 1u) && (c0 < g_qlim[j]);
       const float* src = ok ? g_ptr[j] + (j < LA ? a_off : b_off) : g_zero_block;
       // LDS byte address of this group's 1 KiB image: wave-uniform; hardware adds lane * 16 B.
       // Issued through inline asm so that hipcc does not track the DMA (it would drain it with
@@ -417,23 +418,32 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_dma_f32(ConvP p
     if (DPRIO) __builtin_amdgcn_s_setprio(1);
     const float* Ab = smem + (s % NST) * STAGE_F + a_row;
     const float* Bb = smem + (s % NST) * STAGE_F + b_row;
+    // both halves' fragments are requested up front (the stage has landed), so the LDS latency of the
+    // second half hides behind the first half's MFMAs
+    float4 af[2][MT], bf[2][NT];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int off = half ? off1 : off0;
-      float4 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + off);
+      for (int i = 0; i < MT; ++i) af[half][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + off);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + off);
+      for (int j = 0; j < NT; ++j) bf[half][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the eight ds_reads ahead of the MFMAs (hipcc sinks them otherwise)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+    for (int half = 0; half < 2; ++half) {
+      // k-major issue order: consecutive MFMAs hit different accumulators (a dependent one is MT*NT later)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float4 av = af[half][i], bv = bf[half][j];
+            const float a = kk == 0 ? av.x : kk == 1 ? av.y : kk == 2 ? av.z : av.w;
+            const float b = kk == 0 ? bv.x : kk == 1 ? bv.y : kk == 2 ? bv.z : bv.w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
     }
     if (DPRIO) __builtin_amdgcn_s_setprio(0);
   }
@@ -455,6 +465,300 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_dma_f32(ConvP p
     return;
   }
   const int hw = p.ho * p.wo;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + wc * TN + j * 32 + r32;
+    const bool co_ok = co < p.cout;
+    const float sc = co_ok ? p.scale[co] : 0.f;
+    const float sh = co_ok ? p.shift[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int m = m0 + wr * TM + i * 32 + row;
+        if (!co_ok || m >= p.M) continue;
+        float v = apply_act(acc[i][j][e] * sc + sh, p.act);
+        if (p.res) v += p.res[(long long)m * p.res_pitch + co];
+        if (p.ups == 1) {
+          p.y[(long long)m * p.y_pitch + co] = v;
+        } else {
+          const int nimg = m / hw;
+          const int rem = m - nimg * hw;
+          const int oy = rem / p.wo, ox = rem - oy * p.wo;
+          const int W2 = p.wo * 2;
+          const long long base = ((long long)nimg * (p.ho * 2) + 2 * oy) * W2 + 2 * ox;
+          p.y[(base)*p.y_pitch + co] = v;
+          p.y[(base + 1) * p.y_pitch + co] = v;
+          p.y[(base + W2) * p.y_pitch + co] = v;
+          p.y[(base + W2 + 1) * p.y_pitch + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM MFMA kernel, buffer-addressed LDS-DMA edition (production).  Same tiling, LDS image,
+// swizzle and 3-stage pipeline as conv_igemm_dma_f32, but the stage loop carries (almost) no VALU / SALU
+// work: on gfx950 every non-MFMA instruction issued on a SIMD costs matrix-pipe time (measured with
+// tools/mfma_mix.hip: ~2 cycles per VALU op, ~3 per SALU op against 64 per v_mfma_f32_32x32x2_f32; the
+// global_load_lds version spends 53 VALU + 90 SALU per 32 MFMAs on 64-bit per-lane addresses, predicates
+// and M0 juggling = 15 % of the pipe).  Here each DMA is `buffer_load_dwordx4 v_off, rsrc, s_off offen lds`:
+//   * the per-lane byte offset v_off is fixed per (lane, tap): it only changes when the K walk moves to the
+//     next filter tap (2 VALU ops per A-type DMA, every cin/16 stages); weights never change theirs;
+//   * the per-stage part (tap position, channel chunk) is one SGPR offset per operand;
+//   * zero padding, ragged rows and ragged couts use the buffer range check: such lanes carry the offset
+//     0x80000000 >= num_records, the hardware writes zeros into LDS and touches no memory
+//     (tools/buflds_probe.hip: out-of-range lanes do zero-fill LDS, and s_off takes part in the check, so all real
+//     offsets + s_off stay below 2^31 - the host falls back to conv_igemm_dma_f32 otherwise);
+//   * M0 is saved / restored once per stage around all of the wave's DMAs.
+// Needs cin % 16 == 0 (no per-chunk channel predicate); other shapes use conv_igemm_dma_f32.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;
+
+__device__ __forceinline__ u32x4 make_rsrc(const void* base) {
+  const unsigned long long b = (unsigned long long)base;
+  u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);  // stride 0 (raw buffer)
+  r.z = kOobOffset;                                                      // num_records (bytes)
+  r.w = 0x00020000u;                                                     // gfx9 raw-buffer dword 3
+  return r;
+}
+
+// All of one wave's DMAs of one stage in a single asm block (M0 saved / restored once).  LA A-type loads
+// (descriptor ra, scalar offset sa) are followed by LPW - LA B-type loads (rb, sb); LDS destinations advance by STEP.
+template <int LPW, int LA, int STEP>
+__device__ __forceinline__ void dma_stage(const unsigned (&v)[LPW], u32x4 ra, u32x4 rb, unsigned sa, unsigned sb,
+                                          unsigned dst) {
+  unsigned keep;
+  static_assert(LPW >= 2 && LPW <= 4 && LA >= 1 && LA <= 2, "unsupported DMA shape");
+#define ME_DMA_HEAD "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+#define ME_DMA_NEXT "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\t"
+#define ME_DMA_A(i) "buffer_load_dwordx4 %[v" #i "], %[ra], %[sa] offen lds\n\t"
+#define ME_DMA_B(i) "buffer_load_dwordx4 %[v" #i "], %[rb], %[sb] offen lds\n\t"
+#define ME_DMA_TAIL "s_mov_b32 m0, %[k]"
+  if constexpr (LPW == 4 && LA == 2) {
+    asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_A(1) ME_DMA_NEXT ME_DMA_B(2) ME_DMA_NEXT ME_DMA_B(3) ME_DMA_TAIL
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
+                   [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3])
+                 : "memory", "scc");
+  } else if constexpr (LPW == 3 && LA == 2) {
+    asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_A(1) ME_DMA_NEXT ME_DMA_B(2) ME_DMA_TAIL
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
+                   [v1] "v"(v[1]), [v2] "v"(v[2])
+                 : "memory", "scc");
+  } else if constexpr (LPW == 2 && LA == 1) {
+    asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_B(1) ME_DMA_TAIL
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
+                   [v1] "v"(v[1])
+                 : "memory", "scc");
+  } else {
+    static_assert(LPW == 0, "add the (LPW, LA) combination");
+  }
+#undef ME_DMA_HEAD
+#undef ME_DMA_NEXT
+#undef ME_DMA_A
+#undef ME_DMA_B
+#undef ME_DMA_TAIL
+}
+
+template <int BM, int BN, int WR, int WC, int MINW = 1>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p) {
+  constexpr int NW = WR * WC;  // waves per workgroup (4 or 8)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  constexpr int BK = 16, NST = 3;
+  constexpr int TM = BM / WR, TN = BN / WC;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int GA = BM / 16, G = (BM + BN) / 16;  // 16-row groups (1 KiB each): A first, then B
+  constexpr int LPW = (G + NW - 1) / NW;            // DMA instructions per wave per stage
+  constexpr int LA = GA / NW;                       // ... of which A-type
+  constexpr int STAGE_F = LPW * NW * 256;           // floats per stage buffer (incl. dummy groups)
+  static_assert(GA % NW == 0, "A groups must split evenly over the waves");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int r32 = lane & 31, hh = lane >> 5;
+
+  int tile_m, tile_n;
+  {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_n = wg % p.tiles_n;
+    tile_m = wg / p.tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int hw = p.ho * p.wo;
+
+  // descriptors: A = activations rebased to the first image this tile touches, minus a bias of `pad` rows +
+  // `pad` pixels so that every lane's tap-0 offset is non-negative; B = the weight rows of this tile.
+  const int img0 = m0 / hw;
+  const long long img_elems = (long long)p.h * p.w * p.x_pitch;
+  const long long bias_elems = ((long long)p.pad * p.w + p.pad) * p.x_pitch;
+  const u32x4 rsrc_a = make_rsrc(p.x + (long long)img0 * img_elems - bias_elems);
+  const u32x4 rsrc_b = make_rsrc(p.wgt + (long long)n0 * p.ktot);
+
+  const int lrow = lane >> 2;  // row inside the 16-row group
+  unsigned v_base[LPW];        // in-range byte offset of (lane, tap 0 / k 0)
+  unsigned v_pad[LA];          // A-type: bit t set = tap t is padding (or the row is beyond M)
+  unsigned v_cur[LPW];         // what the DMA uses: v_base or kOobOffset
+#pragma unroll
+  for (int j = 0; j < LPW; ++j) {
+    const int g = wave + NW * j;
+    const int row = g * 16 + lrow;                // row inside the (A|B) stage image
+    const int q = (lane & 3) ^ ((row >> 2) & 3);  // source 16-byte chunk for this LDS slot
+    v_base[j] = kOobOffset;
+    if (j < LA) {
+      unsigned padmask = 0xFFFFFFFFu;
+      const int m = m0 + row;
+      if (m < p.M) {
+        const int nimg = m / hw;
+        const int rem = m - nimg * hw;
+        const int oy = rem / p.wo, ox = rem - oy * p.wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        unsigned ok = 0;
+        for (int ky = 0; ky < p.ks; ++ky)
+          for (int kx = 0; kx < p.ks; ++kx)
+            if ((unsigned)(iy0 + ky) < (unsigned)p.h && (unsigned)(ix0 + kx) < (unsigned)p.w)
+              ok |= 1u << (ky * p.ks + kx);
+        padmask = ~ok;
+        const long long e = (long long)(nimg - img0) * img_elems + ((long long)iy0 * p.w + ix0) * p.x_pitch + bias_elems;
+        v_base[j] = (unsigned)(e * 4) + 16u * q;
+      }
+      v_pad[j] = padmask;
+    } else if (g < G) {
+      const int co_local = row - BM;
+      if (n0 + co_local < p.cout) v_base[j] = (unsigned)co_local * (unsigned)p.ktot * 4u + 16u * q;
+    }
+    v_cur[j] = v_base[j];
+  }
+
+  const int sid = blockIdx.y;
+  const int s_begin = sid * p.sps;
+  const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
+  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;  // wave-uniform K walk of the *issue* side
+  int ky = tap / p.ks, kx = tap - ky * p.ks;
+  unsigned a_tap_off = 0, b_tap_off = 0;
+  auto enter_tap = [&]() {  // VALU work only here: once per filter tap
+#pragma unroll
+    for (int j = 0; j < LA; ++j) v_cur[j] = ((v_pad[j] >> tap) & 1u) ? kOobOffset : v_base[j];
+    a_tap_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 4);
+    b_tap_off = (unsigned)tap * (unsigned)p.cin * 4u;
+  };
+  enter_tap();
+
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);  // SGPR
+  auto issue_stage = [&](int slot) {
+    const unsigned c_off = (unsigned)cc * (BK * 4u);
+    dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_tap_off + c_off, b_tap_off + c_off,
+                                  wave_lds + (unsigned)slot * (STAGE_F * 4u));
+    if (++cc == p.cs) {
+      cc = 0;
+      ++tap;
+      if (++kx == p.ks) {
+        kx = 0;
+        ++ky;
+      }
+      enter_tap();
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nstages = s_end - s_begin;
+  issue_stage(0);
+  if (nstages > 1) issue_stage(1);
+
+  const int sw = (r32 >> 2) & 3;
+  const int a_row = (wr * TM + r32) * BK;
+  const int b_row = (BM + wc * TN + r32) * BK;
+  const int off0 = ((0 + hh) ^ sw) * 4, off1 = ((2 + hh) ^ sw) * 4;
+
+  auto compute_stage = [&](int slot) {
+    __builtin_amdgcn_s_setprio(1);
+    const float* Ab = smem + slot * STAGE_F + a_row;
+    const float* Bb = smem + slot * STAGE_F + b_row;
+    // both halves' fragments are requested up front (the stage has landed), so the LDS latency of the
+    // second half hides behind the first half's MFMAs
+    float4 af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int off = half ? off1 : off0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[half][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + off);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[half][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the ds_reads ahead of the MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      // k-major issue order: consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float4 av = af[half][i], bv = bf[half][j];
+            const float a = kk == 0 ? av.x : kk == 1 ? av.y : kk == 2 ? av.z : av.w;
+            const float b = kk == 0 ? bv.x : kk == 1 ? bv.y : kk == 2 ? bv.z : bv.w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  int slot = 0;  // s % NST
+  for (int s = 0; s + 1 < nstages; ++s) {
+    // stage s landed? (the only younger DMAs are those of stage s+1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's stage-s DMAs landed; everyone finished reading stage s-1
+    asm volatile("" ::: "memory");
+    const int refill = slot == 0 ? NST - 1 : slot - 1;  // (s + 2) % NST: the slot stage s-1 just vacated
+    if (s + 2 < nstages) issue_stage(refill);
+    compute_stage(slot);
+    slot = slot == NST - 1 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  compute_stage(slot);
+
+  // ---- epilogue (same as conv_igemm_dma_f32) ----------------------------------------------------
+  if (p.splitk > 1) {
+    float* slab = p.partial + (long long)sid * p.M * p.cout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = n0 + wc * TN + j * 32 + r32;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (co < p.cout && m < p.M) slab[(long long)m * p.cout + co] = acc[i][j][e];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int co = n0 + wc * TN + j * 32 + r32;
@@ -614,9 +918,11 @@ const TileCfg kTiles[] = {
 };
 const TileCfg kExtraTiles[] = {  // forced ids only (engine autotuner, tools/conv_bench.py)
     {5, 256, 128, 16, 2, 2, 1.02f},  {6, 256, 128, 16, 1, 2, 1.0f},   {21, 128, 128, 16, 3, 1, 1.0f}, {22, 128, 64, 16, 4, 1, 0.9f},
+    {23, 64, 64, 16, 8, 1, 0.85f},   {24, 128, 32, 16, 7, 1, 0.75f},  {25, 256, 128, 16, 2, 2, 1.02f},
     {51, 128, 128, 16, 3, 1, 1.0f},  {52, 128, 64, 16, 5, 1, 0.9f},  {53, 64, 64, 16, 8, 1, 0.85f},
     {54, 128, 32, 16, 7, 1, 0.75f},  {55, 128, 128, 32, 2, 1, 1.0f}, {31, 128, 128, 16, 3, 1, 1.0f},
     {11, 128, 128, 16, 3, 1, 1.0f},  {12, 128, 128, 16, 3, 1, 1.0f}, {13, 128, 128, 16, 3, 1, 1.0f},
+    {61, 128, 128, 16, 3, 1, 1.0f},  {65, 256, 128, 16, 2, 2, 1.0f},
 };
 constexpr int kMaxSplit = 16;
 
@@ -716,7 +1022,7 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
   return me::check_launch("conv_splitk_reduce_f32");
 }
 
-template <int BM, int BN, int WR, int WC, int DPRIO = 0, int MINW = 1>
+template <int BM, int BN, int WR, int WC, int DPRIO = 0, int MINW = 1, int DABL = 0>
 int launch_dma(ConvP& p, hipStream_t stream) {
   constexpr int BK = 16;
   p.cs = (p.cin + BK - 1) / BK;
@@ -729,7 +1035,7 @@ int launch_dma(ConvP& p, hipStream_t stream) {
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
   const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
-  auto kern = conv_igemm_dma_f32<BM, BN, WR, WC, DPRIO, MINW>;
+  auto kern = conv_igemm_dma_f32<BM, BN, WR, WC, DPRIO, MINW, DABL>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -742,6 +1048,54 @@ int launch_dma(ConvP& p, hipStream_t stream) {
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(64 * NW), lds, stream, p);
   int rc = me::check_launch("conv_igemm_dma_f32");
+  if (rc || p.splitk == 1) return rc;
+  long long rb = ((long long)p.M * p.cout + 255) / 256;
+  if (rb > 256 * 16) rb = 256 * 16;
+  hipLaunchKernelGGL(conv_splitk_reduce_f32, dim3((unsigned)rb), dim3(256), 0, stream, p);
+  return me::check_launch("conv_splitk_reduce_f32");
+}
+
+// Can conv_igemm_buf_f32 address this problem?  cin must be a multiple of 16 and every in-range byte offset
+// (+ the scalar stage offset) must stay below 2^31 (the descriptor's num_records).
+template <int BM>
+bool buf_addressable(const ConvP& p) {
+  if (p.cin % 16 != 0 || p.x_nchw) return false;
+  const long long hw = (long long)p.ho * p.wo;
+  const long long span_imgs = (BM - 1) / hw + 2;  // images one tile of BM consecutive output pixels can touch
+  const long long img_bytes = (long long)p.h * p.w * p.x_pitch * 4;
+  const long long tap_bytes = ((long long)p.ks * p.w + p.ks) * p.x_pitch * 4 + (long long)p.cin * 4;
+  const long long a_max = span_imgs * img_bytes + 2 * tap_bytes;
+  const long long b_max = 256ll * p.ktot * 4 + (long long)p.ktot * 4;
+  return a_max < (1ll << 31) && b_max < (1ll << 31) && (long long)p.x_pitch * 4 < (1ll << 31);
+}
+
+template <int BM, int BN, int WR, int WC, int MINW = 1>
+int launch_buf(ConvP& p, hipStream_t stream) {
+  if (!buf_addressable<BM>(p)) return launch_dma<BM, BN, WR, WC, 1, MINW>(p, stream);
+  constexpr int BK = 16;
+  p.cs = (p.cin + BK - 1) / BK;
+  p.stages = p.ks * p.ks * p.cs;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.cout + BN - 1) / BN;
+  if (p.splitk > p.stages) p.splitk = p.stages;
+  p.sps = (p.stages + p.splitk - 1) / p.splitk;
+  while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;
+  constexpr int NW = WR * WC;
+  constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
+  const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
+  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW>;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      attr_set = true;
+    }
+  }
+  const long long blocks = (long long)p.tiles_m * p.tiles_n;
+  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(64 * NW), lds, stream, p);
+  int rc = me::check_launch("conv_igemm_buf_f32");
   if (rc || p.splitk == 1) return rc;
   long long rb = ((long long)p.M * p.cout + 255) / 256;
   if (rb > 256 * 16) rb = 256 * 16;
@@ -839,16 +1193,22 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   p.splitk = plan.splitk;
   p.partial = reinterpret_cast<float*>(d->workspace);
   switch (plan.tile) {
-    // production tiles: LDS-DMA pipeline + s_setprio around the matrix phase
-    case 1: return launch_dma<128, 128, 2, 2, 1>(p, stream);
-    case 2: return launch_dma<128, 64, 2, 2, 1>(p, stream);
-    case 3: return launch_dma<64, 64, 2, 2, 1>(p, stream);
-    case 4: return launch_dma<128, 32, 4, 1, 1>(p, stream);
+    // production tiles: buffer-addressed LDS-DMA pipeline (falls back to conv_igemm_dma_f32 when cin % 16 != 0
+    // or the offsets do not fit the descriptor window)
+    case 1: return launch_buf<128, 128, 2, 2>(p, stream);
+    case 2: return launch_buf<128, 64, 2, 2>(p, stream);
+    case 3: return launch_buf<64, 64, 2, 2>(p, stream);
+    case 4: return launch_buf<128, 32, 4, 1>(p, stream);
+    case 5: return launch_buf<256, 128, 4, 2, 4>(p, stream);  // 8 waves (512 threads), 4 waves / SIMD
     // tuning / ablation variants (forced ids only, tools/conv_bench.py)
-    case 5: return launch_dma<256, 128, 4, 2, 1, 4>(p, stream);   // 8 waves (512 threads), 4 waves / SIMD
-    case 6: return launch_dma<256, 128, 4, 2, 1, 1>(p, stream);   // 8 waves, registers unconstrained
-    case 21: return launch_dma<128, 128, 2, 2, 0>(p, stream);  // DMA pipeline without s_setprio
-    case 22: return launch_dma<128, 64, 2, 2, 0>(p, stream);
+    case 21: return launch_dma<128, 128, 2, 2, 1>(p, stream);  // previous generation: global_load_lds + per-lane pointers
+    case 22: return launch_dma<128, 64, 2, 2, 1>(p, stream);
+    case 23: return launch_dma<64, 64, 2, 2, 1>(p, stream);
+    case 24: return launch_dma<128, 32, 4, 1, 1>(p, stream);
+    case 25: return launch_dma<256, 128, 4, 2, 1, 4>(p, stream);
+    case 6: return launch_dma<256, 128, 4, 2, 1, 1>(p, stream);      // 8 waves, registers unconstrained
+    case 61: return launch_dma<128, 128, 2, 2, 1, 1, 1>(p, stream);  // ablation: DMA sources = zero block
+    case 65: return launch_dma<256, 128, 4, 2, 1, 4, 1>(p, stream);
     case 51: return launch_igemm<128, 128, 16, 2, 2>(p, stream);  // register-staged, double-buffered LDS
     case 52: return launch_igemm<128, 64, 16, 2, 2>(p, stream);
     case 53: return launch_igemm<64, 64, 16, 2, 2>(p, stream);

@@ -244,6 +244,12 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     d.res = residual.data_ptr() if residual is not None else None
     d.y = out.data_ptr()
     d.x_pitch = cin
+    if not x_nchw and not x_nhwc.is_contiguous():
+        # a channel slice of a wider NHWC buffer (what a darknet [route] concat hands to the next conv)
+        pitch = x_nhwc.stride(2)
+        if x_nhwc.stride() != (h * w * pitch, w * pitch, pitch, 1):
+            raise MeError("x must be NHWC-contiguous or a channel slice of an NHWC-contiguous tensor")
+        d.x_pitch = pitch
     d.res_pitch = residual.shape[-1] if residual is not None else 0
     d.y_pitch = out.shape[-1]
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout

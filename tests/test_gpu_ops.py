@@ -16,7 +16,8 @@ def _t(tag, shape, lo=-1.0, hi=1.0):
     return torch.from_numpy(synth.uniform(tag, shape, lo, hi))
 
 
-def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, tile=0, nchw_in=False, split_k=0):
+def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, tile=0, nchw_in=False, split_k=0,
+               x_slice=0):
     x = _t(tag + "x", (n, cin, h, w))
     wgt = torch.from_numpy(synth.normal(tag + "w", (cout, cin, k, k), 0, (2.0 / (cin * k * k)) ** 0.5))
     scale = _t(tag + "s", (cout,), 0.5, 1.5)
@@ -35,6 +36,10 @@ def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, t
         ref = F.interpolate(ref, scale_factor=2, mode="nearest")
     dev = "cuda"
     xd = x.to(dev) if nchw_in else x.permute(0, 2, 3, 1).contiguous().to(dev)
+    if x_slice:  # the input is channels [x_slice, x_slice+cin) of a wider NHWC buffer (pitch > cin)
+        wide = torch.full((n, h, w, cin + 2 * x_slice), 7.0, device=dev)
+        wide[..., x_slice:x_slice + cin] = xd
+        xd = wide[..., x_slice:x_slice + cin]
     got = hip.conv2d(xd, hip.pack_conv_weight(wgt).to(dev), scale.to(dev), shift.to(dev), k, s, pad, act,
                      residual=res.permute(0, 2, 3, 1).contiguous().to(dev) if res is not None else None,
                      upsample=ups, x_nchw=nchw_in, tile=tile, split_k=split_k)
@@ -42,7 +47,22 @@ def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, t
     return assert_close(got.cpu().permute(0, 3, 1, 2), ref, TOL, tag)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 21, 51, 52, 53, 54])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_conv_buffer_addressed_kernel(hip_lib, tile):
+    """conv_igemm_buf_f32 (buffer_load ... lds with range-check zero padding): shapes that stress its addressing -
+    tiles spanning 2-3 images, borders on every side, channel-slice inputs (pitch > cin), cin = 16 (a new filter tap
+    every K stage), stride 2, 1x1, split-K starting mid-tap, residual + upsample epilogues."""
+    from millieye_amd import hip
+    _conv_case(hip, f"bk{tile}a", 5, 13, 13, 32, 96, 3, 1, 1, tile=tile)                        # 169 px / image
+    _conv_case(hip, f"bk{tile}b", 3, 7, 9, 16, 40, 3, 1, 1, tile=tile, x_slice=16)              # tiny maps, cs = 1
+    _conv_case(hip, f"bk{tile}c", 2, 26, 26, 64, 128, 3, 2, 1, tile=tile, x_slice=32)           # stride 2 + slice
+    _conv_case(hip, f"bk{tile}d", 2, 13, 13, 128, 255, 1, 1, 0, tile=tile)                      # 1x1, ragged cout
+    _conv_case(hip, f"bk{tile}e", 2, 13, 13, 48, 64, 3, 1, 1, residual=True, split_k=4, tile=tile)
+    _conv_case(hip, f"bk{tile}f", 1, 13, 13, 64, 48, 3, 1, 1, ups=2, split_k=5, tile=tile, x_slice=64)
+    _conv_case(hip, f"bk{tile}g", 1, 40, 24, 32, 32, 3, 1, 2, tile=tile)                        # sigmoid, h != w
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 51, 52, 53, 54])
 def test_conv3x3_every_tile(hip_lib, tile):
     from millieye_amd import hip
     # ragged M (n*h*w = 2*13*11 = 286) and ragged cout (not a tile multiple), cin not a BK multiple

@@ -79,10 +79,20 @@ def check(net, frozen, hist, tmpdir, loss_tol, param_atol, sum_tol, ap_tol, late
     assert losses.shape == g["losses"].shape
     assert np.all(np.abs(losses - g["losses"]) <= loss_tol * np.maximum(1.0, np.abs(g["losses"]))), (losses, g["losses"])
     # parameter sums after each optimizer step (same order as Adam's param group)
+    names = [k for k, _ in net.named_parameters()]
     numel = np.asarray([p.numel() for p in net.parameters()], dtype=np.float64)
     assert hist["step_sums"].shape == g["step_sums"].shape
-    assert np.all(np.abs(hist["step_sums"] - g["step_sums"]) <= sum_tol * numel + 1e-4), \
-        np.max(np.abs(hist["step_sums"] - g["step_sums"]) / numel)
+    per_elem = np.abs(hist["step_sums"] - g["step_sums"]) / numel  # mean drift per element, per step and tensor
+    # A conv bias that feeds a train-mode BatchNorm has a mathematically zero gradient: what autograd / our backward
+    # return for it is rounding noise, and Adam turns noise into +-lr steps.  Those tensors can only be bounded by
+    # lr * steps; every other tensor must track the reference closely on average.
+    noise = np.asarray([k.endswith(".bias") and ("radar_cnn_layers.conv" in k and k.split(".")[-2] == "0"
+                                                 or k == "refinement_head.radar_net.0.bias"
+                                                 or k == "img_cnn_layers.net.conv_0.bias") for k in names])
+    steps = np.arange(1, per_elem.shape[0] + 1)[:, None]
+    bound = np.where(noise[None, :], 2 * 5e-4 * steps, sum_tol)
+    bad = np.argwhere(per_elem > bound + 1e-4 / numel)
+    assert bad.size == 0, [(names[j], int(i), float(per_elem[i, j])) for i, j in bad]
     # the last checkpoint, tensor by tensor
     final = torch.load(os.path.join(str(tmpdir), "checkpoints", f"{c['test_list']}_ckpt_{c['epochs'] - 1}.pth"),
                        map_location="cpu")
