@@ -651,20 +651,23 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
   const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
   int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;  // wave-uniform K walk of the *issue* side
   int ky = tap / p.ks, kx = tap - ky * p.ks;
-  unsigned a_tap_off = 0, b_tap_off = 0;
-  auto enter_tap = [&]() {  // VALU work only here: once per filter tap
+  unsigned a_off = 0, b_off = 0;  // scalar byte offsets of the next stage to issue
+  auto enter_tap = [&]() {        // VALU work only here: once per filter tap
 #pragma unroll
     for (int j = 0; j < LA; ++j) v_cur[j] = ((v_pad[j] >> tap) & 1u) ? kOobOffset : v_base[j];
-    a_tap_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 4);
-    b_tap_off = (unsigned)tap * (unsigned)p.cin * 4u;
+    a_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 4);
+    b_off = (unsigned)tap * (unsigned)p.cin * 4u;
   };
   enter_tap();
+  a_off += (unsigned)cc * (BK * 4u);
+  b_off += (unsigned)cc * (BK * 4u);
 
+  constexpr unsigned STAGE_B = STAGE_F * 4u;
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);  // SGPR
-  auto issue_stage = [&](int slot) {
-    const unsigned c_off = (unsigned)cc * (BK * 4u);
-    dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_tap_off + c_off, b_tap_off + c_off,
-                                  wave_lds + (unsigned)slot * (STAGE_F * 4u));
+  auto issue_stage = [&](unsigned lds_dst) {
+    dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off, b_off, lds_dst);
+    a_off += BK * 4u;
+    b_off += BK * 4u;
     if (++cc == p.cs) {
       cc = 0;
       ++tap;
@@ -685,18 +688,16 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nstages = s_end - s_begin;
-  issue_stage(0);
-  if (nstages > 1) issue_stage(1);
+  issue_stage(wave_lds);
+  if (nstages > 1) issue_stage(wave_lds + STAGE_B);
 
   const int sw = (r32 >> 2) & 3;
-  const int a_row = (wr * TM + r32) * BK;
-  const int b_row = (BM + wc * TN + r32) * BK;
   const int off0 = ((0 + hh) ^ sw) * 4, off1 = ((2 + hh) ^ sw) * 4;
+  const float* a_frag = smem + (wr * TM + r32) * BK;        // this lane's A / B fragment rows in stage slot 0
+  const float* b_frag = smem + (BM + wc * TN + r32) * BK;
 
-  auto compute_stage = [&](int slot) {
-    __builtin_amdgcn_s_setprio(1);
-    const float* Ab = smem + slot * STAGE_F + a_row;
-    const float* Bb = smem + slot * STAGE_F + b_row;
+  auto compute_stage = [&](const float* Ab, const float* Bb) {
+    if (MT * NT >= 4) __builtin_amdgcn_s_setprio(1);
     // both halves' fragments are requested up front (the stage has landed), so the LDS latency of the
     // second half hides behind the first half's MFMAs
     float4 af[2][MT], bf[2][NT];
@@ -724,24 +725,39 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
           }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (MT * NT >= 4) __builtin_amdgcn_s_setprio(0);
   };
 
-  int slot = 0;  // s % NST
-  for (int s = 0; s + 1 < nstages; ++s) {
-    // stage s landed? (the only younger DMAs are those of stage s+1)
+  // Stage s lives in slot s % 3.  A "step" = wait for stage s (only stage s+1's DMAs are younger), barrier
+  // (everyone's stage-s DMAs landed, everyone finished reading stage s-1), refill the slot stage s-1 vacated with
+  // stage s+2, multiply stage s.  The bulk runs three steps per loop trip with compile-time slots (LDS offsets are
+  // immediates, ~19 scalar instructions per step); the last <= 4 stages go through the generic tail below.
+  auto step = [&](auto slot_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-    __builtin_amdgcn_s_barrier();  // everyone's stage-s DMAs landed; everyone finished reading stage s-1
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const int refill = slot == 0 ? NST - 1 : slot - 1;  // (s + 2) % NST: the slot stage s-1 just vacated
-    if (s + 2 < nstages) issue_stage(refill);
-    compute_stage(slot);
+    issue_stage(wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+    compute_stage(a_frag + SLOT * STAGE_F, b_frag + SLOT * STAGE_F);
+  };
+  int s = 0;
+  for (; s + 3 <= nstages - 2; s += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  int slot = 0;  // s is a multiple of 3 here
+  for (; s < nstages; ++s) {
+    if (s + 1 < nstages)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 2 < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);
+    compute_stage(a_frag + slot * STAGE_F, b_frag + slot * STAGE_F);
     slot = slot == NST - 1 ? 0 : slot + 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  compute_stage(slot);
 
   // ---- epilogue (same as conv_igemm_dma_f32) ----------------------------------------------------
   if (p.splitk > 1) {
