@@ -302,7 +302,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit-GEMM conv, all 3x3 / 1x1 layers)",
+                "kernel": "conv_igemm_buf_f32 (v_mfma_f32_32x32x2_f32 implicit-GEMM conv, all 3x3 / 1x1 layers)",
                 "achieved": round(ach, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
