@@ -317,6 +317,20 @@ int me_ps_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, i
                         const float* rois, int32_t k, int32_t pooled, float spatial_scale, float* out,
                         void* stream);
 
+/* ---- input producer (module3_our_dataset/utils/datasets.py) -------------------------------
+ * me_image_pad_resize_u8_f32: one decoded frame, uint8 HWC RGB [h,w,3] on the device -> float32 CHW [3,size,size]:
+ *   transforms.ToTensor() (datasets.py:203: /255), pad_to_square(img, 0) (:16-27, :211: the shorter side is padded
+ *   with floor(diff/2) before and the rest after), resize(img, size) = F.interpolate(mode="nearest") (:30-32, :317).
+ * me_radar_heatmap_f32: radar points -> the radar map of every frame of a batch.  points [total,4] float64 rows
+ *   (u, v, depth, velocity) of all frames back to back, offsets [n+1] the row range of frame i, sizes [n,2] the
+ *   original (w, h) of its image.  Per frame: plot_radar_heatmap(points.T, (w,h), radar_maps_size) (:59-106: count /
+ *   mean depth / mean |velocity| histograms in float64, np.histogram2d bin rules, range normalisation + clip),
+ *   ToTensor().float() (:267), pad_to_square (:270), F.interpolate(bilinear, align_corners=True) to
+ *   [3,map_size,map_size] (collate_fn :318-321).  out [n,3,map_size,map_size]. */
+int me_image_pad_resize_u8_f32(const uint8_t* src, int32_t h, int32_t w, float* dst, int32_t size, void* stream);
+int me_radar_heatmap_f32(const double* points, const int32_t* offsets, const int32_t* sizes, int32_t n,
+                         int32_t radar_maps_size, float* out, int32_t map_size, void* stream);
+
 /* sizes of the descriptor structs, so a binding can assert its mirror layout */
 int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights */
 

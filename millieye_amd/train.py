@@ -1,9 +1,9 @@
 """Stage-3 training harness: the loop of ``module3_our_dataset/train.py``.
 
 The reference's loop lives under ``if __name__ == "__main__"`` (train.py:24-272); here it is a function
-so that a caller (or :func:`main`, which mirrors the script's command line) can drive it with any
-iterable of ``(paths, imgs, targets, radar_boxes, radar_maps)`` batches - the input producer
-(``utils/datasets.MyDataset``) is the caller's.  What is kept, line by line:
+so that a caller (or :func:`main`, which mirrors the script's command line and feeds it from
+``millieye_amd/utils/datasets.MyDataset``) can drive it with any iterable of
+``(paths, imgs, targets, radar_boxes, radar_maps)`` batches.  What is kept, line by line:
 
 * ``load_pretrained_module2`` - the stage-2 -> stage-3 tensor hand-over by *position* (train.py:113-141): the
   tensors of the stage-2 checkpoint whose names are in ``NAMES_M2`` are collected in the checkpoint's own order
@@ -155,11 +155,10 @@ def build_parser():
 
 
 def main(argv=None):
-    """``python -m millieye_amd.train`` - needs the caller's ``utils.datasets.MyDataset`` on ``sys.path`` (as the
-    reference script does, train.py:2,150)."""
+    """``python -m millieye_amd.train`` - the reference script's command line (train.py:24-165)."""
     from .my_models import Network, define_yolo, init_yolo
+    from .utils.datasets import MyDataset
     from .utils.utils import load_classes, weights_init_normal
-    from utils.datasets import MyDataset  # the caller's input producer
 
     opt = build_parser().parse_args(argv)
     class_names = load_classes(opt.classes_path)

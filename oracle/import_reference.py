@@ -33,12 +33,14 @@ def _stub(name, **attrs):
 def install_stubs():
     from oracle import tv_ops
 
+    sys.dont_write_bytecode = True  # the reference tree is read-only for us: no __pycache__ droppings next to its sources
+
     if "torchvision" not in sys.modules:
         boxes = _stub("torchvision.ops.boxes", batched_nms=tv_ops.batched_nms, nms=tv_ops.nms)
         ops = _stub("torchvision.ops", ps_roi_align=tv_ops.ps_roi_align, roi_align=tv_ops.roi_align, boxes=boxes,
                     nms=tv_ops.nms, batched_nms=tv_ops.batched_nms)
 
-        class _ToTensor:  # only needed when utils.datasets is imported
+        class _ToTensor:  # torchvision.transforms.ToTensor for the two inputs utils/datasets.py feeds it
             def __call__(self, pic):
                 import numpy as np
                 import torch
@@ -46,7 +48,8 @@ def install_stubs():
                 arr = np.asarray(pic)
                 if arr.ndim == 2:
                     arr = arr[:, :, None]
-                return torch.from_numpy(arr.transpose(2, 0, 1).copy()).float().div(255)
+                t = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+                return t.float().div(255) if arr.dtype == np.uint8 else t  # only byte images are scaled
 
         transforms = _stub("torchvision.transforms", ToTensor=_ToTensor)
         _stub("torchvision.datasets")
@@ -83,4 +86,5 @@ def import_module3(chdir=True):
     ns.models = importlib.import_module("yolov3.models")
     ns.my_models = importlib.import_module("my_models")
     ns.root = root
+    ns.load_datasets = lambda: importlib.import_module("utils.datasets")  # needs PIL + matplotlib (both present)
     return ns

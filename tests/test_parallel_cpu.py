@@ -50,7 +50,8 @@ def _worker(rank, world, port, q):
     x = torch.arange(12, dtype=torch.float32).view(2, 6) + rank
     model[1](model[0](x)).sum().backward() if rank == 0 else model[0](x).sum().backward()  # rank 1: layer 1 has no grad
     nbytes = par.allreduce_gradients(model.parameters())
-    res = {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+    res = {k: (None if p.grad is None else p.grad.numpy().copy()) for k, p in model.named_parameters()}  # by value:
+    # a tensor would travel as a shared-memory handle that dies with this process
     q.put((rank, nbytes, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -85,4 +86,4 @@ def test_allreduce_gradients_gloo_world2():
             if not p.requires_grad or p.grad is None:
                 assert res[k] is None  # frozen, or no gradient on any rank
             else:
-                assert torch.allclose(res[k], p.grad, atol=1e-6), (rank, k)
+                assert torch.allclose(torch.from_numpy(res[k]), p.grad, atol=1e-6), (rank, k)
