@@ -331,6 +331,14 @@ int me_image_pad_resize_u8_f32(const uint8_t* src, int32_t h, int32_t w, float* 
 int me_radar_heatmap_f32(const double* points, const int32_t* offsets, const int32_t* sizes, int32_t n,
                          int32_t radar_maps_size, float* out, int32_t map_size, void* stream);
 
+/* ---- evaluation tail -----------------------------------------------------------------
+ * get_batch_statistics (module3_our_dataset/utils/utils.py:185-236) for one batch, on the output rows of
+ * Network.forward as they are: rows [m,cols] = (image_i, x1,y1,x2,y2, ..., class_pred last), targets [q,6] =
+ * (image_i, class, x1,y1,x2,y2) already in pixels (test_fusion.py:95-96).  tp [m] <- 1.0 where the reference's greedy
+ * scan marks a true positive, else 0.0 (rows of images >= n_images are left untouched).  One wave per image. */
+int me_batch_statistics_f32(const float* rows, int32_t m, int32_t cols, const float* targets, int32_t q,
+                            int32_t n_images, float iou_threshold, float* tp, void* stream);
+
 /* sizes of the descriptor structs, so a binding can assert its mirror layout */
 int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights */
 

@@ -103,6 +103,8 @@ SIGNATURES = {
     "me_last_error": (C.c_char_p, []),
     "me_device_query": (C.c_int, [C.POINTER(C.c_int32)] * 3),
     "me_sizeof": (C.c_int32, [C.c_int32]),
+    "me_batch_statistics_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                          C.c_void_p, C.c_void_p]),
     "me_image_pad_resize_u8_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "me_radar_heatmap_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_void_p]),

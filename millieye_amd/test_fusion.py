@@ -21,7 +21,7 @@ try:
 except Exception:  # pragma: no cover
     tqdm = None
 
-__all__ = ["mode_selection", "evaluate", "regroup_outputs"]
+__all__ = ["mode_selection", "evaluate", "regroup_outputs", "batch_statistics_device"]
 
 
 def mode_selection(mode, img, paths):
@@ -47,8 +47,34 @@ def regroup_outputs(outputs, batch_size):
     return grouped
 
 
+def batch_statistics_device(outputs, targets, batch_size, iou_threshold):
+    """``get_batch_statistics(regroup_outputs(outputs), targets, iou_threshold)`` with the greedy matching done by
+    ``me_batch_statistics_f32`` on the device rows: same list of
+    ``[true_positives, pred_scores, pred_labels]`` per image that has detections, one device->host copy per batch
+    instead of a python loop per detection.  ``outputs`` [m,8] CUDA, ``targets`` [q,6] xyxy in pixels (any device)."""
+    from . import hip
+
+    m = outputs.shape[0]
+    if m == 0:
+        return []
+    rows = outputs.contiguous()
+    tg = targets.to(device=rows.device, dtype=torch.float32).contiguous()
+    tp = torch.zeros(m, device=rows.device, dtype=torch.float32)
+    hip.check(hip.lib().me_batch_statistics_f32(rows.data_ptr(), m, rows.shape[1], tg.data_ptr() if len(tg) else None,
+                                                len(tg), batch_size, float(iou_threshold), tp.data_ptr(),
+                                                hip.stream_ptr()), "me_batch_statistics_f32")
+    host = torch.cat((rows, tp[:, None]), 1).cpu().numpy()
+    idx = host[:, 0].astype(np.int32)
+    metrics = []
+    for i in range(batch_size):
+        sel = host[idx == i]
+        if len(sel):
+            metrics.append([sel[:, -1].astype(np.float64), sel[:, 5], sel[:, -2]])
+    return metrics
+
+
 def evaluate(model, mode, model_mode, illumination, iou_thresh, nms_thresh, img_size, batch_size, test_list,
-             dataloader=None, dataset_folder="../data/our_dataset", num_workers=4):
+             dataloader=None, dataset_folder="../data/our_dataset", num_workers=4, device_statistics=True):
     model.eval()
     if dataloader is None:
         from .utils.datasets import MyDataset
@@ -69,13 +95,21 @@ def evaluate(model, mode, model_mode, illumination, iou_thresh, nms_thresh, img_
             radar_boxes = radar_boxes.to(device)
             mode_now = mode_selection(model_mode, imgs, paths)
             outputs = model(imgs, radar_maps, radar_boxes, mode_now)
-            outputs_reshape = regroup_outputs(outputs, len(imgs))
-            for image_pred in outputs_reshape:
-                box_stat["after"].append(len(image_pred) if image_pred is not None else 0)
+            on_device = device_statistics and outputs.is_cuda
+            if on_device:
+                counts = torch.bincount(outputs[:, 0].to(torch.int64), minlength=len(imgs))[:len(imgs)].tolist()
+                box_stat["after"] += [int(c) for c in counts]
+            else:
+                outputs_reshape = regroup_outputs(outputs, len(imgs))
+                for image_pred in outputs_reshape:
+                    box_stat["after"].append(len(image_pred) if image_pred is not None else 0)
         labels += targets[:, 1].tolist()
         targets[:, 2:] = xywh2xyxy(targets[:, 2:])
         targets[:, 2:] *= img_size
-        sample_metrics += get_batch_statistics(outputs_reshape, targets, iou_threshold=iou_thresh)
+        if on_device:
+            sample_metrics += batch_statistics_device(outputs, targets, len(imgs), iou_thresh)
+        else:
+            sample_metrics += get_batch_statistics(outputs_reshape, targets, iou_threshold=iou_thresh)
 
     if sample_metrics == []:
         true_positives, pred_scores, pred_labels, labels = np.array([0]), np.array([1]), np.array([1]), np.array([1])

@@ -122,3 +122,45 @@ def test_evaluate_end_to_end_matches_reference(hip_lib):
             ref = g[k + f"rows{i}"]
             assert r.shape == ref.shape, (model_mode, i, r.shape, ref.shape)
             assert np.all(np.abs(r - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref))), (model_mode, i, np.abs(r - ref).max())
+
+
+def test_batch_statistics_kernel_vs_host(hip_lib):
+    """me_batch_statistics_f32 against the host get_batch_statistics (itself pinned bit-for-bit to the reference,
+    tests/golden/metrics_synth.npz): random detections around the targets, exact IoU ties, duplicate boxes, labels
+    absent from the targets, images without targets / without detections, early exit once all targets are taken."""
+    from millieye_amd import synth
+    from millieye_amd.test_fusion import batch_statistics_device, regroup_outputs
+    from millieye_amd.utils.utils import get_batch_statistics
+    n_img, q, m = 6, 23, 400
+    t_xy = synth.uniform("bs/txy", (q, 2), 20, 300)
+    t_wh = synth.uniform("bs/twh", (q, 2), 20, 120)
+    t_img = np.floor(synth.uniform("bs/ti", (q, 1), 0, 4))          # images 4, 5 have no targets
+    t_lab = np.floor(synth.uniform("bs/tl", (q, 1), 0, 2))
+    targets = np.concatenate([t_img, t_lab, t_xy, t_xy + t_wh], 1).astype(np.float32)
+    targets[7, 2:] = targets[6, 2:]                                 # duplicate target box (tie -> first index)
+    targets[7, 0] = targets[6, 0]
+    pick = np.floor(synth.uniform("bs/pick", (m,), 0, q)).astype(int)
+    jitter = synth.uniform("bs/jit", (m, 4), -12, 12)
+    boxes = targets[pick, 2:] + jitter
+    boxes[:40] = targets[pick[:40], 2:]                             # exact copies: IoU 1.0, ties between duplicates
+    img = targets[pick, 0].copy()
+    img[350:] = np.floor(synth.uniform("bs/oi", (50,), 3, 6))       # detections on images 3 (no dets otherwise), 4, 5
+    p = synth.uniform("bs/p", (m,), 0.01, 0.99)
+    lab = np.floor(synth.uniform("bs/l", (m,), 0, 3))               # label 2 never occurs among the targets
+    order = np.argsort(-p, kind="stable")
+    rows = np.concatenate([img[:, None], boxes, p[:, None], p[:, None] * 0.5, lab[:, None]], 1).astype(np.float32)[order]
+    out = torch.from_numpy(rows).cuda()
+    tg = torch.from_numpy(targets)
+    for thr in (0.5, 0.3, 0.9):
+        got = batch_statistics_device(out, tg, n_img, thr)
+        ref = get_batch_statistics(regroup_outputs(out, n_img), tg, iou_threshold=thr)
+        assert len(got) == len(ref) and len(ref) >= 4
+        n_tp = 0
+        for (tp_g, sc_g, lb_g), (tp_r, sc_r, lb_r) in zip(got, ref):
+            assert np.array_equal(tp_g, np.asarray(tp_r)), thr
+            assert np.array_equal(sc_g, np.asarray(sc_r)) and np.array_equal(lb_g, np.asarray(lb_r))
+            n_tp += int(tp_g.sum())
+        assert n_tp > 5
+    assert batch_statistics_device(out[:0], tg, n_img, 0.5) == []
+    none = batch_statistics_device(out, tg[:0], n_img, 0.5)         # no targets at all: every TP is 0
+    assert sum(int(x[0].sum()) for x in none) == 0 and len(none) == len(ref)
