@@ -251,6 +251,19 @@ typedef struct me_heads_desc {
 } me_heads_desc;
 int me_roi_heads_f32(const me_heads_desc* d, void* stream);
 
+/* Stage 2 (module2_mixed/my_models.py:299-364) heads for every box of every class: PS-RoIAlign (7x7, 490 -> 10 maps) on
+ * img_map, refinement_head((490,256,class_num+1)) (net0 LeakyReLU, net1 -> regress [cap,4], net2 sigmoid -> refine
+ * [cap,class_num+1]), ensemble_head((2,32,32*(class_num+1),2)) on (refine, (obj_conf, class scores)) with the LeakyReLU
+ * after fc2 and the softmax, mask [cap] = masks[:,1]; out_rows [cap,8] = (image_i, box_regress(x1,y1,x2,y2), mask,
+ * class_conf, class_pred), keep = mask > refine_threshold, sort_key = mask.  boxes [cap, box_cols >= 8+class_num] rows
+ * (image_i, x1,y1,x2,y2, obj, cls_conf, cls_pred, class scores...), *n_boxes of them valid (device scalar).
+ * Weights: w0t [490,256] (transposed), b0, w1 [4,256], b1, w2 [class_num+1,256], b2, e1w [32,2], e1b, e2w
+ * [2,32*(class_num+1)], e2b of me_heads_weights; the radar fields are ignored. */
+int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t fh, int32_t fw, float spatial_scale,
+                    const float* boxes, const int32_t* n_boxes, int32_t boxes_cap, int32_t box_cols, int32_t class_num,
+                    const me_heads_weights* w, float refine_threshold, float* regress_out, float* refine_out,
+                    float* mask_out, float* out_rows, uint8_t* keep, float* sort_key, void* stream);
+
 /* scalar tail of the heads for `k` RoIs from a saved `small` [k,16] block (training forward; identical
  * arithmetic to the fused inference tail).  d->wts.rscale/rshift must hold the radar_net BatchNorm as an
  * affine on rconv (batch statistics in train mode); reads d->img_boxes / n_img / radar_boxes, writes

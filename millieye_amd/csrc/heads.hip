@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void gather_class_boxes_kernel(const float* d
     for (int k0 = 0; k0 < cnt; k0 += 1024) {
       const int k = k0 + t;
       const float* d = det + ((long long)img * max_det + (k < cnt ? k : 0)) * width;
-      const bool take = (k < cnt) && (d[6] == (float)class_idx);
+      const bool take = (k < cnt) && (class_idx < 0 || d[6] == (float)class_idx);  // class_idx < 0: every class (module 2)
       const unsigned long long m = __ballot(take);
       const int before = __popcll(m & ((1ull << lane) - 1ull));
       if (lane == 0) s_wave[wv] = __popcll(m);
@@ -332,6 +332,100 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
 }
 
 
+// ---- module 2 (stage 2): PS-RoIAlign + refinement_head + ensemble_head over ALL classes -------------------------
+// Reference module2_mixed/my_models.py:299-364: boxes [K, 8 + C] (every class, C = 12), refinement_head((490, 256, C+1))
+// = net0 (490->256, LeakyReLU; Dropout is identity in eval), net1 (256->4), net2 (256->C+1, sigmoid);
+// ensemble_head((2, 32, 32*(C+1), 2)): stack(refinement_vector, yolo_vector) -> fc1 (2->32, leaky) per class ->
+// flatten -> fc2 (32*(C+1) -> 2, **leaky**) -> softmax; masks[:,1] is the new confidence; box_regress on the kept rows.
+constexpr int M2_MAXC = 16;  // C + 1 <= 16
+
+struct M2Desc {
+  const float* img_map; long long img_pitch; int n, fh, fw; float spatial_scale;
+  const float* boxes; const int* n_boxes; int box_cols, ncls1;  // ncls1 = C + 1
+  const float *w0t, *b0, *w1, *b1, *w2, *b2, *e1w, *e1b, *e2w, *e2b;
+  float thr;
+  float *regress_out, *refine_out, *mask_out, *out_rows, *sort_key; unsigned char* keep;
+};
+
+__global__ __launch_bounds__(256) void m2_heads_kernel(M2Desc d) {
+  __shared__ float s_feat[RPB][FEAT];
+  __shared__ float s_hid[RPB][HID];
+  __shared__ float s_small[RPB][4 + M2_MAXC];  // 0-3 reg, 4.. class logits
+  __shared__ float s_roi[RPB][5];
+  const int t = threadIdx.x;
+  const int total = *d.n_boxes;
+  const int k0 = blockIdx.x * RPB;
+  if (k0 >= total) return;
+  const int nr = (total - k0 < RPB) ? total - k0 : RPB;
+  if (t < RPB * 5) {
+    const int r = t / 5, c = t % 5;
+    s_roi[r][c] = (r < nr) ? d.boxes[(long long)(k0 + r) * d.box_cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int idx = t; idx < nr * FEAT; idx += 256) {
+    const int r = idx / FEAT, f = idx % FEAT;
+    const int pw = f % P, ph = (f / P) % P;
+    s_feat[r][f] = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_roi[r], d.spatial_scale, f, ph, pw);
+  }
+  __syncthreads();
+  {
+    float acc[RPB];
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) acc[r] = 0.f;
+    for (int k = 0; k < FEAT; ++k) {
+      const float w = d.w0t[k * HID + t];
+#pragma unroll
+      for (int r = 0; r < RPB; ++r) acc[r] = fmaf(w, s_feat[r][k], acc[r]);
+    }
+    const float b = d.b0[t];
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) s_hid[r][t] = leaky(acc[r] + b);
+  }
+  __syncthreads();
+  {
+    const int r = t >> 5, j = t & 31;  // 32 lanes per RoI, 4 + ncls1 <= 20 dot products over the hidden vector
+    if (r < nr && j < 4 + d.ncls1) {
+      const float* wrow = (j < 4) ? d.w1 + j * HID : d.w2 + (j - 4) * HID;
+      float acc = 0.f;
+      for (int k = 0; k < HID; ++k) acc = fmaf(wrow[k], s_hid[r][k], acc);
+      s_small[r][j] = acc + ((j < 4) ? d.b1[j] : d.b2[j - 4]);
+    }
+  }
+  __syncthreads();
+  if (t < nr) {
+    const int k = k0 + t, nc = d.ncls1;
+    const float* sm = s_small[t];
+    const float* bx = d.boxes + (long long)k * d.box_cols;
+    float o0 = d.e2b[0], o1 = d.e2b[1];
+    for (int c = 0; c < nc; ++c) {
+      const float rv = sigmoidf(sm[4 + c]);
+      const float yv = (c == 0) ? bx[5] : bx[8 + (c - 1)];  // yolo_vector = (obj_conf, class scores)
+      d.refine_out[(long long)k * nc + c] = rv;
+      for (int u = 0; u < 32; ++u) {
+        const float h = leaky(d.e1w[2 * u] * rv + d.e1w[2 * u + 1] * yv + d.e1b[u]);
+        o0 += d.e2w[c * 32 + u] * h;
+        o1 += d.e2w[nc * 32 + c * 32 + u] * h;
+      }
+    }
+    o0 = leaky(o0);
+    o1 = leaky(o1);
+    const float m = fmaxf(o0, o1);
+    const float e0 = expf(o0 - m), e1 = expf(o1 - m);
+    const float p = e1 / (e0 + e1);  // masks[:, 1]
+    for (int c = 0; c < 4; ++c) d.regress_out[4ll * k + c] = sm[c];
+    d.mask_out[k] = p;
+    d.keep[k] = (p > d.thr) ? 1 : 0;
+    d.sort_key[k] = p;
+    const float x1 = bx[1], y1 = bx[2], x2 = bx[3], y2 = bx[4];
+    const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2, bw = x2 - x1, bh = y2 - y1;
+    const float nx = sm[0] * bw + cx, ny = sm[1] * bh + cy;
+    const float nw = expf(sm[2]) * bw, nh = expf(sm[3]) * bh;
+    float* o = d.out_rows + 8ll * k;
+    o[0] = bx[0]; o[1] = nx - nw / 2; o[2] = ny - nh / 2; o[3] = nx + nw / 2; o[4] = ny + nh / 2;
+    o[5] = p; o[6] = bx[6]; o[7] = bx[7];
+  }
+}
+
 // ---- training: stand-alone tail, loss terms, tail backward -----------------------------------------
 __global__ __launch_bounds__(256) void heads_tail_kernel(me_heads_desc d, const float* small, int k) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -450,10 +544,30 @@ int me_gather_class_boxes_f32(const float* det, const int32_t* count, int32_t n,
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ME_REQUIRE(det && count && boxes && total, ME_E_NULLPTR, "me_gather_class_boxes_f32: null pointer");
   ME_REQUIRE(n > 0 && max_det > 0 && num_classes >= 1 && class_num >= 0 && class_num <= num_classes, ME_E_BADARG,
-             "me_gather_class_boxes_f32: bad dimensions");
+             "me_gather_class_boxes_f32: bad dimensions");  // class_idx < 0 gathers every class
   hipLaunchKernelGGL(gather_class_boxes_kernel, dim3(1), dim3(1024), 0, stream, det, count, n, max_det, num_classes,
                      class_idx, class_num, boxes, total);
   return me::check_launch("gather_class_boxes_kernel");
+}
+
+int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t fh, int32_t fw, float spatial_scale,
+                    const float* boxes, const int32_t* n_boxes, int32_t boxes_cap, int32_t box_cols, int32_t class_num,
+                    const me_heads_weights* w, float refine_threshold, float* regress_out, float* refine_out,
+                    float* mask_out, float* out_rows, uint8_t* keep, float* sort_key, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (boxes_cap == 0) return 0;
+  ME_REQUIRE(img_map && boxes && n_boxes && w && regress_out && refine_out && mask_out && out_rows && keep && sort_key,
+             ME_E_NULLPTR, "me_m2_heads_f32: null pointer");
+  ME_REQUIRE(class_num >= 1 && class_num + 1 <= M2_MAXC && box_cols >= 8 + class_num, ME_E_BADARG,
+             "me_m2_heads_f32: class_num %d / box_cols %d", class_num, box_cols);
+  ME_REQUIRE(w->w0t && w->b0 && w->w1 && w->b1 && w->w2 && w->b2 && w->e1w && w->e1b && w->e2w && w->e2b, ME_E_NULLPTR,
+             "me_m2_heads_f32: null weight pointer");
+  M2Desc d{img_map, img_pitch, n, fh, fw, spatial_scale, boxes, n_boxes, box_cols, class_num + 1,
+           w->w0t, w->b0, w->w1, w->b1, w->w2, w->b2, w->e1w, w->e1b, w->e2w, w->e2b, refine_threshold,
+           regress_out, refine_out, mask_out, out_rows, sort_key, keep};
+  const int blocks = (boxes_cap + RPB - 1) / RPB;
+  hipLaunchKernelGGL(m2_heads_kernel, dim3(blocks), dim3(256), 0, stream, d);
+  return me::check_launch("m2_heads_kernel");
 }
 
 int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {

@@ -184,8 +184,9 @@ def fill_network_(net, tag, trained_like=True, **trained_kwargs):
     fill_darknet_(net.base_detector, tag + "/det")
     if trained_like:
         trained_like_(net.base_detector, tag + "/det/trained", **trained_kwargs)
-    for name in ("img_cnn_layers", "radar_cnn_layers", "refinement_head", "ensemble_head"):
-        fill_state_dict(getattr(net, name), f"{tag}/{name}")
+    for name in ("img_cnn_layers", "radar_cnn_layers", "fcn_layers", "refinement_head", "ensemble_head"):
+        if hasattr(net, name):  # stage 3 has img_/radar_cnn_layers, stage 2 (module2_mixed) fcn_layers
+            fill_state_dict(getattr(net, name), f"{tag}/{name}")
     return net
 
 

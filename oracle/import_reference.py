@@ -88,3 +88,27 @@ def import_module3(chdir=True):
     ns.root = root
     ns.load_datasets = lambda: importlib.import_module("utils.datasets")  # needs PIL + matplotlib (both present)
     return ns
+
+
+def import_module2(chdir=True):
+    """The stage-2 tree (``module2_mixed``): ``models``, ``utils``, ``parse_config``, ``my_models``.  Same top-level
+    module names as module 3 - use a fresh interpreter (tests/golden/make_golden.py --module2)."""
+    if not reference_available():
+        raise RuntimeError("/root/reference is not present (GPU box?) - fixtures are committed under tests/golden")
+    install_stubs()
+    root = os.path.join(REFERENCE_ROOT, "module2_mixed")
+    for name in ("utils", "utils.utils", "utils.parse_config", "yolov3", "yolov3.models", "my_models"):
+        mod = sys.modules.get(name)
+        if mod is not None and not getattr(mod, "__file__", "").startswith(root):
+            raise RuntimeError(f"top-level module name {name!r} already imported from {mod.__file__}")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    if chdir:
+        os.chdir(tempfile.mkdtemp(prefix="millieye_ref_m2_"))
+    ns = types.SimpleNamespace()
+    ns.parse_config = importlib.import_module("utils.parse_config")
+    ns.utils = importlib.import_module("utils.utils")
+    ns.models = importlib.import_module("yolov3.models")
+    ns.my_models = importlib.import_module("my_models")
+    ns.root = root
+    return ns
