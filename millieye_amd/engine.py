@@ -539,7 +539,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune.json")
+    return os.path.join(base, "millieye_amd", "conv_tune_v3.json")  # bump with every kernel generation
 
 
 def _tune_load():
