@@ -568,7 +568,8 @@ __device__ __forceinline__ void dma_stage(const unsigned (&v)[LPW], u32x4 ra, u3
 #undef ME_DMA_TAIL
 }
 
-template <int BM, int BN, int WR, int WC, int MINW = 1>
+// BABL (ablation, tuning only): 1 = every DMA lane is out of range (zero fill, no L2 / HBM traffic at all).
+template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p) {
   constexpr int NW = WR * WC;  // waves per workgroup (4 or 8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
       const int co_local = row - BM;
       if (n0 + co_local < p.cout) v_base[j] = (unsigned)co_local * (unsigned)p.ktot * 4u + 16u * q;
     }
-    v_cur[j] = v_base[j];
+    v_cur[j] = BABL == 1 ? kOobOffset : v_base[j];
   }
 
   const int sid = blockIdx.y;
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
   unsigned a_off = 0, b_off = 0;  // scalar byte offsets of the next stage to issue
   auto enter_tap = [&]() {        // VALU work only here: once per filter tap
 #pragma unroll
-    for (int j = 0; j < LA; ++j) v_cur[j] = ((v_pad[j] >> tap) & 1u) ? kOobOffset : v_base[j];
+    for (int j = 0; j < LA; ++j) v_cur[j] = (BABL == 1 || ((v_pad[j] >> tap) & 1u)) ? kOobOffset : v_base[j];
     a_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 4);
     b_off = (unsigned)tap * (unsigned)p.cin * 4u;
   };
@@ -939,6 +940,7 @@ const TileCfg kExtraTiles[] = {  // forced ids only (engine autotuner, tools/con
     {54, 128, 32, 16, 7, 1, 0.75f},  {55, 128, 128, 32, 2, 1, 1.0f}, {31, 128, 128, 16, 3, 1, 1.0f},
     {11, 128, 128, 16, 3, 1, 1.0f},  {12, 128, 128, 16, 3, 1, 1.0f}, {13, 128, 128, 16, 3, 1, 1.0f},
     {61, 128, 128, 16, 3, 1, 1.0f},  {65, 256, 128, 16, 2, 2, 1.0f},
+    {81, 128, 128, 16, 3, 1, 1.0f},  {82, 128, 64, 16, 4, 1, 0.9f},  {83, 64, 64, 16, 8, 1, 0.85f}, {85, 256, 128, 16, 2, 2, 1.0f},
 };
 constexpr int kMaxSplit = 16;
 
@@ -1085,7 +1087,7 @@ bool buf_addressable(const ConvP& p) {
   return a_max < (1ll << 31) && b_max < (1ll << 31) && (long long)p.x_pitch * 4 < (1ll << 31);
 }
 
-template <int BM, int BN, int WR, int WC, int MINW = 1>
+template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0>
 int launch_buf(ConvP& p, hipStream_t stream) {
   if (!buf_addressable<BM>(p)) return launch_dma<BM, BN, WR, WC, 1, MINW>(p, stream);
   constexpr int BK = 16;
@@ -1099,7 +1101,7 @@ int launch_buf(ConvP& p, hipStream_t stream) {
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
   const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
-  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW>;
+  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW, BABL>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1223,6 +1225,10 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
     case 24: return launch_dma<128, 32, 4, 1, 1>(p, stream);
     case 25: return launch_dma<256, 128, 4, 2, 1, 4>(p, stream);
     case 6: return launch_dma<256, 128, 4, 2, 1, 1>(p, stream);      // 8 waves, registers unconstrained
+    case 81: return launch_buf<128, 128, 2, 2, 1, 1>(p, stream);  // ablation: no memory traffic (all lanes out of range)
+    case 82: return launch_buf<128, 64, 2, 2, 1, 1>(p, stream);
+    case 83: return launch_buf<64, 64, 2, 2, 1, 1>(p, stream);
+    case 85: return launch_buf<256, 128, 4, 2, 4, 1>(p, stream);
     case 61: return launch_dma<128, 128, 2, 2, 1, 1, 1>(p, stream);  // ablation: DMA sources = zero block
     case 65: return launch_dma<256, 128, 4, 2, 1, 4, 1>(p, stream);
     case 51: return launch_igemm<128, 128, 16, 2, 2>(p, stream);  // register-staged, double-buffered LDS

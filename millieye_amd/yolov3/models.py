@@ -242,6 +242,8 @@ class Darknet(nn.Module):
         ``loss`` is the summed YOLO loss of every scale (reference :261-267).  The loss is a VALUE: the
         detector backward is not built (no reference script trains the detector)."""
         plan, yolo_outputs = self._run(x, keep_raw=targets is not None)
+        if getattr(plan, "graph", None) is not None:
+            yolo_outputs = yolo_outputs.clone()  # graph replays write a static buffer: the caller gets its own tensor
         if plan.tap is not None:
             # fresh tensor per call like the reference's ``x.detach()`` of a fresh activation;
             # memory stays channels-last (NHWC), shape is the reference's [N,256,S/16,S/16]
