@@ -99,6 +99,105 @@ def conv_roofline(model, x, steps):
     return achieved, total_ms * 1e3 / launches, launches, total_flops / launches, per_layer
 
 
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TF = 157.3
+
+
+def stage_roofline(model, net, x, step, rois, reps=5):
+    """Achieved fraction of the bounding roofline per stage of one step (north_star: "achieved-fraction-of-roofline
+    per stage"), from HIP events recorded in sequence inside real steps.  Detector stages come from per-launch
+    events over the engine's launch list; the post-detector stages from the marks Network.forward sets."""
+    from millieye_amd import hip
+
+    engine = model.engine
+    plan = engine.plan_for(x)
+    lib = hip.lib()
+    stream = hip.stream_ptr()
+    descs = {m: d for m, d in plan.conv_descs}
+    n, size = x.shape[0], x.shape[-1]
+    acc = {}
+
+    def add(name, ms, **work):
+        e = acc.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0))
+        e["ms"] += ms
+        for k, v in work.items():
+            e[k] += v
+
+    engine.run(x)
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        evs = []
+        for fn, args, _k, name in plan.launches:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn(*args, stream)
+            b.record()
+            evs.append((name, fn, a, b))
+        torch.cuda.synchronize()
+        for name, fn, a, b in evs:
+            ms = a.elapsed_time(b)
+            if fn is lib.me_conv2d_f32:
+                d = descs[int(name[4:])]
+                if d.cin <= 4:
+                    add("stem conv (cin 3, direct)", ms, bytes=4.0 * n * (d.cin * d.h * d.w + d.cout * d.ho * d.wo))
+                else:
+                    add("MFMA convs (3x3 / 1x1 + BN + leaky + shortcut/upsample/route epilogues)", ms,
+                        flops=float(lib.me_conv2d_flops(d)))
+            elif fn is lib.me_yolo_decode_f32:
+                rows_c = plan.rows * (5 + (plan.num_classes or 0))
+                add("YOLO decode", ms, bytes=0.0)  # bytes added once below (three launches share the output tensor)
+            else:
+                add("pool / copy", ms)
+    if "YOLO decode" in acc:
+        acc["YOLO decode"]["bytes"] = reps * 2.0 * 4.0 * n * plan.rows * (5 + (plan.num_classes or 0))
+    if net is not None:
+        marks = []
+        net._stage_cb = lambda name: marks.append((name, _ev()))
+        for _ in range(reps):
+            marks.clear()
+            step()
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                ms = e0.elapsed_time(e1)
+                if n1 == "nms":
+                    add("NMS (prep + greedy select + emit)", ms, bytes=4.0 * n * plan.rows * (5 + (plan.num_classes or 0)))
+                elif n1 == "proposals":
+                    add("proposal assembly", ms)
+                elif n1 == "score_maps":
+                    add("score maps (1x1 256->490 + radar CNN)", ms, flops=n * (0.170e9 + 0.128e9) * (size / 416.0) ** 2)
+                elif n1 == "roi_heads":
+                    add("RoI pooling + refinement / ensemble heads", ms, flops=rois * 0.27e6,
+                        bytes=rois * (2 * 490 * 4 * 4.0) + (rois / 8.0) * 490 * 256 * 4.0)
+                elif n1 == "output":
+                    add("compaction + sort of output rows", ms)
+        net._stage_cb = None
+    out = []
+    for name, e in acc.items():
+        ms = e["ms"] / reps
+        row = {"stage": name, "ms": round(ms, 4)}
+        if e["flops"] and name.startswith("MFMA"):
+            tf = e["flops"] / reps / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4))
+        elif e["bytes"]:
+            gbs = e["bytes"] / reps / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4))
+            if e["flops"]:
+                row["gflops"] = round(e["flops"] / reps / (ms * 1e-3) / 1e9, 1)
+        elif e["flops"]:
+            tf = e["flops"] / reps / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", achieved=round(tf, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4))
+        else:
+            row.update(bound="latency")
+        out.append(row)
+    return out
+
+
+def _ev():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
 def conv_traffic(batch):
     """HBM bytes per conv launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, two separate
     passes over this same command; tools/pmc_traffic.py -> profiles/conv_traffic.json).  PMC counters cannot
@@ -325,6 +424,9 @@ def main():
             out["config"]["grad_bucket_bytes"] = int(last.get("bucket_bytes", 0))
             out["config"]["loss_last_step"] = round(float(last["loss"]), 5)
             out["config"]["workload"] = out["config"]["workload"].replace("inference", "training (heads), inference (detector)")
+        if args.workload != "train":
+            rois = out["config"].get("rois_last_step", 0)
+            out["stages"] = stage_roofline(model, net, x, step, rois)
         if os.environ.get("BENCH_LAYERS"):
             for mod, flops, ms in per_layer:
                 print(f"[layer] conv{mod}: {flops / 1e9:.3f} GF {ms * 1e3:.1f} us {flops / ms / 1e9:.1f} TF/s",

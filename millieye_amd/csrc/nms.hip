@@ -24,6 +24,7 @@ namespace {
 
 constexpr int SEL_THREADS = 1024;
 constexpr int MAX_ROWS = 32768;  // 32 candidates per thread
+constexpr int LDS_CANDS = 4096;  // candidates per image kept in LDS by nms_select (96 KiB)
 
 struct NmsWs {
   float4* raw;               // [n][cap] raw xyxy
@@ -122,15 +123,31 @@ __global__ __launch_bounds__(256) void nms_prep_boxes_kernel(const float* boxes,
 }
 
 // ---- select -----------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFull), s, 64);
-    const unsigned hi = __shfl_xor((unsigned)(v >> 32), s, 64);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    v = o > v ? o : v;
+// 64-lane unsigned max through the DPP network (row shifts + row broadcasts, gfx9 family): ~12 VALU ops instead of six
+// ds_bpermute round trips (~120 cycles each) per 32-bit word - the argmax is on the critical path of every greedy step.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define ME_DPP_MAX(ctrl, row_mask)                                                                      \
+  {                                                                                                     \
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xf, false);    \
+    v = o > v ? o : v;                                                                                  \
   }
-  return v;
+  ME_DPP_MAX(0x111, 0xf)  // row_shr:1
+  ME_DPP_MAX(0x112, 0xf)  // row_shr:2
+  ME_DPP_MAX(0x114, 0xf)  // row_shr:4
+  ME_DPP_MAX(0x118, 0xf)  // row_shr:8   -> lane 15 of every 16-lane row holds the row maximum
+  ME_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  ME_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave maximum
+#undef ME_DPP_MAX
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// keys are (sortable score << 32) | ~row: maximum of the high words first, then of the low words among its holders
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32);
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned lo = (hi == mh) ? (unsigned)(v & 0xFFFFFFFFull) : 0u;
+  const unsigned ml = wave_max_u32(lo);
+  return ((unsigned long long)mh << 32) | ml;
 }
 
 // torchvision nms_cpu_kernel IoU test, literal operation order (std::max(a,b) = a < b ? b : a).
@@ -172,13 +189,30 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     return;
   }
   const long long base = (long long)img * w.cap;
+  // Only as many waves as the candidate count deserves take part (surplus waves exit before the first barrier;
+  // s_barrier only counts live waves).  Up to 2048 candidates every thread owns <= 2 of them and the greedy loop
+  // runs in "register mode" (below); beyond that the generic loop with up to 32 candidates per thread is used.
+  const bool reg_mode = cnt <= 2 * SEL_THREADS;
+  int T = SEL_THREADS;
+  if (reg_mode) {
+    T = ((cnt + 1) / 2 + 63) & ~63;
+    if (T < 64) T = 64;
+  }
+  if (t >= T) return;
+  const int nwaves = T >> 6;
+  // up to LDS_CANDS candidates live in LDS (offset box + key, 24 B each): every greedy step re-reads the alive ones,
+  // and from global memory that is two dependent ~1 us round trips per step - 200 steps = the whole kernel time
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  float4* s_box = reinterpret_cast<float4*>(dyn_lds);
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(dyn_lds + (size_t)LDS_CANDS * 16);
+  const bool in_lds = cnt <= LDS_CANDS;
 
   // ---- offsets: boxes + label * (boxes.max() + 1)  (batched_nms) --------------------------
   float maxc = 0.f;
   if (use_offsets) {
     float m = -INFINITY;
     int nan = 0;
-    for (int j = t; j < cnt; j += SEL_THREADS) {
+    for (int j = t; j < cnt; j += T) {
       const float4 b = w.raw[base + j];
       nan |= (b.x != b.x) | (b.y != b.y) | (b.z != b.z) | (b.w != b.w);
       m = fmaxf(m, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
@@ -196,7 +230,7 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     if (t == 0) {
       float mm = s_redf[0];
       int nn = s_redi[0];
-      for (int k = 1; k < SEL_THREADS / 64; ++k) {
+      for (int k = 1; k < nwaves; ++k) {
         mm = fmaxf(mm, s_redf[k]);
         nn |= s_redi[k];
       }
@@ -205,21 +239,110 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     __syncthreads();
     maxc = s_maxc;
   }
+  if (reg_mode) {
+    // ---- register mode: box / area / key of this thread's <= 2 candidates stay in VGPRs; one barrier per greedy
+    // step: each wave publishes its best (key, box) into a parity-toggled LDS slot, after the barrier everybody
+    // picks the workgroup winner from the <= 16 slots.  ~500 cycles per kept box instead of ~5000.
+    __shared__ unsigned long long s_k2[2][SEL_THREADS / 64];
+    __shared__ float4 s_b2[2][SEL_THREADS / 64];
+    const float mp1 = maxc + 1.f;
+    float4 cb[2];
+    float ca[2];
+    unsigned long long ck[2];
+    int cj[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = t + c * T;
+      cj[c] = j;
+      ck[c] = 0ull;
+      cb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ca[c] = 0.f;
+      if (j < cnt) {
+        float4 bb = w.raw[base + j];
+        if (use_offsets) {
+          const float o = w.label[base + j] * mp1;
+          bb.x = bb.x + o; bb.y = bb.y + o; bb.z = bb.z + o; bb.w = bb.w + o;
+        }
+        cb[c] = bb;
+        ca[c] = box_area(bb);
+        ck[c] = w.key[base + j];  // never 0: the low word is 0xFFFFFFFF - row (make_key)
+      }
+    }
+    int* s_keep = reinterpret_cast<int*>(dyn_lds);  // <= 2048 winners; register mode does not use s_box / s_key
+    int kept = 0;
+    int par = 0;
+    float4 wbox = make_float4(0.f, 0.f, 0.f, 0.f);
+    float warea = 0.f;
+    bool have_winner = false;
+    while (true) {
+      unsigned long long best = 0ull;
+      int best_c = 0;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (ck[c] == 0ull) continue;  // dead or absent
+        if (have_winner && iou_exceeds(wbox, warea, cb[c], ca[c], iou_thresh)) {
+          ck[c] = 0ull;
+          continue;
+        }
+        if (ck[c] > best) {
+          best = ck[c];
+          best_c = c;
+        }
+      }
+      const unsigned long long wg = wave_max_u64(best);
+      if (best == wg && wg != 0ull) {  // unique owner inside the wave (keys embed the row)
+        s_k2[par][wv] = wg;
+        s_b2[par][wv] = cb[best_c];
+      } else if (wg == 0ull && lane == 0) {
+        s_k2[par][wv] = 0ull;
+      }
+      __syncthreads();
+      unsigned long long g = s_k2[par][0];
+      int gw = 0;
+      for (int q = 1; q < nwaves; ++q) {
+        const unsigned long long v = s_k2[par][q];
+        if (v > g) {
+          g = v;
+          gw = q;
+        }
+      }
+      if (g == 0ull) break;  // nothing alive (uniform)
+      wbox = s_b2[par][gw];
+      warea = box_area(wbox);
+      have_winner = true;
+      if (best == g) {  // the owner retires its candidate and records the winner
+        s_keep[kept] = cj[best_c];  // LDS, flushed once at the end: a global store here would be waited for by
+        ck[best_c] = 0ull;          // every following __syncthreads (vmcnt(0)) - 1 us per greedy step
+      }
+      ++kept;
+      par ^= 1;
+      if (kept >= max_det) break;
+    }
+    __syncthreads();
+    for (int q = t; q < kept; q += T) w.keep_slot[base + q] = s_keep[q];
+    if (t == 0) out_count[img] = kept;
+    return;
+  }
   unsigned alive = 0;
   {
     const float mp1 = maxc + 1.f;
     int i = 0;
-    for (int j = t; j < cnt; j += SEL_THREADS, ++i) {
+    for (int j = t; j < cnt; j += T, ++i) {
       float4 b = w.raw[base + j];
       if (use_offsets) {
         const float o = w.label[base + j] * mp1;
         b.x = b.x + o; b.y = b.y + o; b.z = b.z + o; b.w = b.w + o;
       }
-      w.off[base + j] = b;
+      if (in_lds) {
+        s_box[j] = b;
+        s_key[j] = w.key[base + j];
+      } else {
+        w.off[base + j] = b;
+      }
       alive |= (1u << i);
     }
   }
-  // each thread only ever re-reads the w.off entries it wrote itself -> no barrier needed
+  // each thread only ever re-reads the entries it wrote itself -> no barrier needed
 
   int kept = 0;
   bool have_winner = false;
@@ -233,15 +356,15 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
       while (bits) {
         const int i = __ffs(bits) - 1;
         bits &= bits - 1;
-        const int j = t + i * SEL_THREADS;
+        const int j = t + i * T;
         if (have_winner) {
-          const float4 b = w.off[base + j];
+          const float4 b = in_lds ? s_box[j] : w.off[base + j];
           if (iou_exceeds(wbox, warea, b, box_area(b), iou_thresh)) {
             alive &= ~(1u << i);
             continue;
           }
         }
-        const unsigned long long k = w.key[base + j];
+        const unsigned long long k = in_lds ? s_key[j] : w.key[base + j];
         if (k > best) {
           best = k;
           best_i = i;
@@ -252,13 +375,12 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     if (lane == 0) s_red[wv] = g;
     __syncthreads();
     g = s_red[0];
-#pragma unroll
-    for (int k = 1; k < SEL_THREADS / 64; ++k) g = s_red[k] > g ? s_red[k] : g;
+    for (int k = 1; k < nwaves; ++k) g = s_red[k] > g ? s_red[k] : g;
     if (g == 0ull) break;  // nothing alive (uniform)
     if (best == g) {       // unique owner: keys embed the row index
-      const int j = t + best_i * SEL_THREADS;
+      const int j = t + best_i * T;
       alive &= ~(1u << best_i);
-      const float4 b = w.off[base + j];
+      const float4 b = in_lds ? s_box[j] : w.off[base + j];
       s_wbox = b;
       s_warea = box_area(b);
       w.keep_slot[base + kept] = j;
@@ -271,6 +393,14 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     if (kept >= max_det) break;
   }
   if (t == 0) out_count[img] = kept;
+}
+
+constexpr size_t kSelectLds = (size_t)LDS_CANDS * 24;
+
+inline hipError_t select_lds_attr() {  // > 64 KiB of dynamic LDS needs the opt-in, once per process
+  static hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_select_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelectLds);
+  return rc;
 }
 
 // ---- emit -------------------------------------------------------------------------------------
@@ -333,7 +463,8 @@ int me_nms_batched_f32(const me_nms_desc* d, void* stream_) {
   int rc = me::check_launch("nms_prep_kernel");
   if (rc) return rc;
   const int max_det = d->max_det < d->rows ? d->max_det : d->rows;
-  hipLaunchKernelGGL(nms_select_kernel, dim3(d->n), dim3(SEL_THREADS), 0, stream, w, 1, d->iou_thresh, max_det,
+  ME_HIP(select_lds_attr());
+  hipLaunchKernelGGL(nms_select_kernel, dim3(d->n), dim3(SEL_THREADS), kSelectLds, stream, w, 1, d->iou_thresh, max_det,
                      d->count);
   rc = me::check_launch("nms_select_kernel");
   if (rc) return rc;
@@ -358,7 +489,8 @@ int me_nms_boxes_f32(const float* boxes, const float* scores, const float* label
   hipLaunchKernelGGL(nms_prep_boxes_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, boxes, scores, labels, m, w);
   int rc = me::check_launch("nms_prep_boxes_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, w, labels ? 1 : 0, iou_thresh, m,
+  ME_HIP(select_lds_attr());
+  hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_THREADS), kSelectLds, stream, w, labels ? 1 : 0, iou_thresh, m,
                      keep_count);
   rc = me::check_launch("nms_select_kernel");
   if (rc) return rc;

@@ -321,9 +321,13 @@ class Network(nn.Module):
         f32 = dict(device=dev, dtype=torch.float32)
 
         # ---- candidate boxes from the base detector (reference :454-473), all on device
+        mark = getattr(self, "_stage_cb", None) or (lambda _name: None)  # bench.py: per-stage HIP events
+        mark("start")
         plan, yolo_out = self.base_detector._run(images)
+        mark("detector")
         det, cnt = hip.nms_batched(yolo_out, float(self.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
                                    writeback_xyxy=False)
+        mark("nms")
         num_classes = yolo_out.shape[2] - 5
         cols = 8 + self.class_num
         cap_img = n * _DETECTIONS_PER_IMG
@@ -333,6 +337,7 @@ class Network(nn.Module):
         hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
                                                 int(self.class_idx), int(self.class_num), img_boxes.data_ptr(),
                                                 n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
+        mark("proposals")
         if model_mode == 1:  # yolo only
             return img_boxes[: int(n_img_dev.item()), :8]
         if model_mode == 2:  # radar only: permanent, like the reference (quirk q3)
@@ -360,6 +365,7 @@ class Network(nn.Module):
         self._conv(t1.data_ptr(), 32, False, n, mh, mw, 32, packs["r2"], 3, 1, hip.ACT_LEAKY, t2)
         self._conv(t2.data_ptr(), 64, False, n, mh, mw, 64, packs["r3"], 3, 1, hip.ACT_LEAKY, t3)
         self._conv(t3.data_ptr(), 128, False, n, mh, mw, 128, packs["r4"], 1, 0, hip.ACT_SIGMOID, radar_score_map)
+        mark("score_maps")
         if (mh, mw) != (fh, fw):
             # the reference hands both maps to RoI ops with the same spatial_scale; a size mismatch is
             # legal there (demo feeds 32x32, quirk q15) - the pooling kernel takes per-map sizes
@@ -393,11 +399,13 @@ class Network(nn.Module):
         d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
         d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
         hip.check(lib.me_roi_heads_f32(C.byref(d), hip.stream_ptr()), "me_roi_heads_f32")
+        mark("roi_heads")
         self.refinement_head.count += 1
 
         # ---- keep positives, order by confidence (reference :517-539); the one host sync
         idx = torch.nonzero(keep, as_tuple=False).flatten()
         order = torch.sort(key[idx], descending=True, stable=True).indices
         output = rows[idx[order]]
+        mark("output")
         self._last = dict(regress=regress, refine=refine, mask1=mask1, n_img=n_img_dev, img_boxes=img_boxes)
         return output

@@ -41,7 +41,7 @@ def _pred(tag, n, rows, nc, frac_pass=0.3, size=416.0):
 
 
 @pytest.mark.parametrize("n,rows,nc,thr", [(2, 300, 12, 0.2), (3, 2535, 12, 0.01), (1, 10647, 80, 0.5),
-                                            (2, 64, 1, 0.0), (1, 5000, 3, 0.05)])
+                                            (2, 64, 1, 0.0), (1, 5000, 3, 0.05), (1, 20000, 2, 0.0)])  # 1 / 4 / 16 waves per image
 def test_nms_matches_oracle_bitexact(hip_lib, n, rows, nc, thr):
     from millieye_amd import hip
     pred = _pred(f"nms{n}{rows}", n, rows, nc)
