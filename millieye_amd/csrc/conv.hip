@@ -499,6 +499,53 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_dma_f32(ConvP p
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stem, second version (cin == 3, cout a multiple of CT): one thread = one output pixel x CT output channels.
+// The weights are wave-uniform, so hipcc fetches them with scalar loads and feeds them to the FMAs as SGPR operands -
+// no LDS at all (conv_smallcin_f32 re-reads its weights from LDS for every pixel: 54 ds_read_b128 per thread, the LDS
+// port was the limiter at 2.7 TB/s of output).  A wave reads 64 consecutive pixels of the NCHW planes (256 B per load)
+// and stores 64 x CT consecutive floats (NHWC rows of adjacent pixels are adjacent).  HBM-bound: in + out bytes.
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void conv_stem3_f32(ConvP p) {
+  constexpr int K = 27;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int co0 = blockIdx.y * CT;
+  if (m >= p.M) return;
+  const int hw = p.ho * p.wo;
+  const int nimg = m / hw;
+  const int rem = m - nimg * hw;
+  const int oy = rem / p.wo, ox = rem - oy * p.wo;
+  float xin[K];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+      const bool ok = ((unsigned)iy < (unsigned)p.h) && ((unsigned)ix < (unsigned)p.w);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+        if (ok)
+          v = p.x_nchw ? p.x[(((long long)nimg * 3 + c) * p.h + iy) * p.w + ix]
+                       : p.x[((long long)(nimg * p.h + iy) * p.w + ix) * p.x_pitch + c];
+        xin[(ky * 3 + kx) * 3 + c] = v;
+      }
+    }
+  const float* __restrict__ wg = p.wgt + (long long)co0 * K;  // [cout][ky][kx][cin], uniform -> s_load
+  float acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) a = fmaf(xin[k], wg[j * K + k], a);  // same k order as conv_smallcin_f32
+    acc[j] = apply_act(a * p.scale[co0 + j] + p.shift[co0 + j], p.act);
+  }
+  float* yrow = p.y + (long long)m * p.y_pitch + co0;
+#pragma unroll
+  for (int j = 0; j < CT; j += 4) *reinterpret_cast<float4*>(yrow + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // implicit-GEMM MFMA kernel, buffer-addressed LDS-DMA edition (production).  Same tiling, LDS image,
 // swizzle and 3-stage pipeline as conv_igemm_dma_f32, but the stage loop carries (almost) no VALU / SALU
 // work: on gfx950 every non-MFMA instruction issued on a SIMD costs matrix-pipe time (measured with
@@ -1179,6 +1226,17 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
                "me_conv2d_f32: small-cin kernel has no residual/upsample epilogue");
     ME_REQUIRE(d->x_nchw || d->x_pitch >= d->cin, ME_E_BADARG, "me_conv2d_f32: x_pitch < cin");
     ME_REQUIRE(me::aligned16(d->y), ME_E_ALIGN, "me_conv2d_f32: y not 16-byte aligned");
+    if (d->cin == 3 && (d->y_pitch & 3) == 0 && d->tile != 91) {  // tile 91 forces the first version (A/B)
+      const unsigned mb = (unsigned)((p.M + 255) / 256);
+      if (d->cout % 32 == 0) {
+        hipLaunchKernelGGL(conv_stem3_f32<32>, dim3(mb, d->cout / 32), dim3(256), 0, stream, p);
+        return me::check_launch("conv_stem3_f32");
+      }
+      if (d->cout % 16 == 0) {
+        hipLaunchKernelGGL(conv_stem3_f32<16>, dim3(mb, d->cout / 16), dim3(256), 0, stream, p);
+        return me::check_launch("conv_stem3_f32");
+      }
+    }
     const long long threads = (long long)p.M * (((p.cout + 7) & ~7) >> 3);
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     if (d->cin == 3)
