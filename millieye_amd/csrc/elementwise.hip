@@ -135,18 +135,19 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* x, long 
 // ---- YOLO decode -------------------------------------------------------------------------------
 // one thread per output element (n, a, pixel, k): reads and writes are both contiguous in k.
 __global__ __launch_bounds__(kThreads) void yolo_decode_kernel(me_yolo_desc d) {
-  const int per = d.num_classes + 5;
-  const int gg = d.g * d.g;
-  const long long total = (long long)d.n * d.num_anchors * gg * per;
-  for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * kThreads) {
-    const int k = (int)(idx % per);
-    long long t = idx / per;
-    const int pix = (int)(t % gg);
-    t /= gg;
-    const int a = (int)(t % d.num_anchors);
-    const int nimg = (int)(t / d.num_anchors);
-    const float v = d.x[((long long)nimg * gg + pix) * d.x_pitch + a * per + k];
+  // blockIdx.y = (image, anchor); blockIdx.x strides over that anchor's g*g*(5+C) elements: one 32-bit division per
+  // element (the flat 64-bit index needed three), reads and writes contiguous in k
+  const unsigned per = d.num_classes + 5;
+  const unsigned gg = d.g * d.g;
+  const unsigned a = blockIdx.y % d.num_anchors, nimg = blockIdx.y / d.num_anchors;
+  const unsigned total = gg * per;
+  const float* xin = d.x + (long long)nimg * gg * d.x_pitch + a * per;
+  float* out = d.out + ((long long)nimg * d.rows_total + d.row_offset + (long long)a * gg) * per;
+  const float aw = d.anchors[2 * a], ah = d.anchors[2 * a + 1];
+  for (unsigned idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += gridDim.x * kThreads) {
+    const unsigned pix = idx / per;
+    const unsigned k = idx - pix * per;
+    const float v = xin[(long long)pix * d.x_pitch + k];
     float o;
     if (k < 2) {
       const float s = 1.f / (1.f + expf(-v));
@@ -154,11 +155,11 @@ __global__ __launch_bounds__(kThreads) void yolo_decode_kernel(me_yolo_desc d) {
       o = (s + g) * d.stride;
     } else if (k < 4) {
       // reference order: exp(t) * (anchor / stride), then * stride (yolov3/models.py:126,162-163,168)
-      o = (expf(v) * d.anchors[2 * a + (k - 2)]) * d.stride;  // anchors are pre-divided by stride
+      o = (expf(v) * (k == 2 ? aw : ah)) * d.stride;  // anchors are pre-divided by stride
     } else {
       o = 1.f / (1.f + expf(-v));
     }
-    d.out[((long long)nimg * d.rows_total + d.row_offset + a * gg + pix) * per + k] = o;
+    out[idx] = o;
   }
 }
 
@@ -259,8 +260,13 @@ int me_yolo_decode_f32(const me_yolo_desc* d, void* stream_) {
   ME_REQUIRE(d->row_offset >= 0 && d->row_offset + d->num_anchors * d->g * d->g <= d->rows_total, ME_E_BADARG,
              "me_yolo_decode_f32: rows out of range");
   ME_REQUIRE(d->stride > 0.f, ME_E_BADARG, "me_yolo_decode_f32: stride must be positive");
-  const long long work = (long long)d->n * d->num_anchors * d->g * d->g * (d->num_classes + 5);
-  hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(work)), dim3(kThreads), 0, stream, *d);
+  const long long per_anchor = (long long)d->g * d->g * (d->num_classes + 5);
+  ME_REQUIRE(per_anchor < (1ll << 31) && (long long)d->n * d->num_anchors < 65536, ME_E_TOOBIG,
+             "me_yolo_decode_f32: grid too large");
+  long long bx = (per_anchor + kThreads - 1) / kThreads;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)bx, (unsigned)(d->n * d->num_anchors)), dim3(kThreads), 0, stream,
+                     *d);
   return me::check_launch("yolo_decode_kernel");
 }
 

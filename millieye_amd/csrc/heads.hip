@@ -150,31 +150,34 @@ __global__ __launch_bounds__(1024) void gather_class_boxes_kernel(const float* d
   const int width = 7 + num_classes, cols = 8 + class_num;
   if (t == 0) s_base = 0;
   __syncthreads();
-  for (int img = 0; img < n; ++img) {
-    const int cnt = count[img];
-    for (int k0 = 0; k0 < cnt; k0 += 1024) {
-      const int k = k0 + t;
-      const float* d = det + ((long long)img * max_det + (k < cnt ? k : 0)) * width;
-      const bool take = (k < cnt) && (class_idx < 0 || d[6] == (float)class_idx);  // class_idx < 0: every class (module 2)
-      const unsigned long long m = __ballot(take);
-      const int before = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) s_wave[wv] = __popcll(m);
-      __syncthreads();
-      int woff = 0, all = 0;
-      for (int q = 0; q < 16; ++q) {
-        if (q < wv) woff += s_wave[q];
-        all += s_wave[q];
-      }
-      const int base = s_base;
-      if (take) {
-        float* o = boxes + (long long)(base + woff + before) * cols;
-        o[0] = (float)img;
-        for (int c = 0; c < 7 + class_num; ++c) o[1 + c] = d[c];
-      }
-      __syncthreads();
-      if (t == 0) s_base = base + all;
-      __syncthreads();
+  // flat scan over the n * max_det slots, 1024 at a time (image-major order is the slot order): a slot is taken if it
+  // is below its image's count and passes the class test; ballot + prefix counts keep the order
+  const int slots = n * max_det;
+  for (int k0 = 0; k0 < slots; k0 += 1024) {
+    const int sidx = k0 + t;
+    const int img = sidx < slots ? sidx / max_det : 0;
+    const int k = sidx - img * max_det;
+    const bool in_range = sidx < slots && k < count[img];
+    const float* d = det + ((long long)img * max_det + (in_range ? k : 0)) * width;
+    const bool take = in_range && (class_idx < 0 || d[6] == (float)class_idx);  // class_idx < 0: every class (module 2)
+    const unsigned long long m = __ballot(take);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int woff = 0, all = 0;
+    for (int q = 0; q < 16; ++q) {
+      if (q < wv) woff += s_wave[q];
+      all += s_wave[q];
     }
+    const int base = s_base;
+    if (take) {
+      float* o = boxes + (long long)(base + woff + before) * cols;
+      o[0] = (float)img;
+      for (int c = 0; c < 7 + class_num; ++c) o[1 + c] = d[c];
+    }
+    __syncthreads();
+    if (t == 0) s_base = base + all;
+    __syncthreads();
   }
   if (t == 0) *total = s_base;
 }
