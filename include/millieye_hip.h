@@ -307,6 +307,31 @@ int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld
                         const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
                         int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* workspace,
                         void* stream);
+/* ---- detector backward (Darknet.forward(x, targets) -> loss.backward(); reference yolov3/models.py:181-267 under
+ * autograd, BatchNorm in eval mode = a per-channel affine) ---------------------------------------------------------
+ * me_affine_act_bwd_f32: conv block y = act(scale*c + shift) with the stored output y [rows,channels] and dy:
+ *   dc = dy * act'(y) * scale (scale NULL = 1), dshift[c] = sum dy*act'(y) (= d beta, or d bias when there is no BN),
+ *   dgamma[c] = sum dy*act'(y) * xhat with xhat = (act^-1(y) - beta) / gamma (gamma/beta/dgamma NULL when no BN).
+ *   act: linear or leaky.  workspace: me_bn_workspace_bytes(channels).  Fixed-order reductions.
+ * me_upsample2_bwd_f32: dx [n,h,w,c] += 2x2 block sums of dy [n,2h,2w,c] (nearest x2, models.py:82-92).
+ * me_maxpool_bwd_f32: dx += dy routed to the first maximum of each window (MaxPool2d / ZeroPad2d+MaxPool2d, :43-49).
+ * me_yolo_loss_bwd_f32: d(loss)/d(raw map) of one YOLOLayer (:196-214) from the build_targets tensors
+ *   (obj / noobj masks [N,A,G,G] u8; tx,ty,tw,th,tconf [N,A,G,G]; tcls [N,A,G,G,C]), n_obj / n_noobj = mask counts,
+ *   grad_scale = upstream gradient of the scalar loss; raw / draw are NHWC [N,G,G,A*(5+C)] with a pitch. */
+int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
+                          const float* scale, const float* gamma, const float* beta, int32_t act, float* dc, int64_t lddc,
+                          float* dshift, float* dgamma, void* workspace, void* stream);
+int me_upsample2_bwd_f32(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n, int32_t h, int32_t w,
+                         int32_t c, void* stream);
+int me_maxpool_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n,
+                       int32_t h, int32_t w, int32_t c, int32_t size, int32_t stride, int32_t pad, int32_t zero_ext,
+                       void* stream);
+int me_yolo_loss_bwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                         const uint8_t* obj_mask, const uint8_t* noobj_mask, const float* tx, const float* ty,
+                         const float* tw, const float* th, const float* tcls, const float* tconf, float n_obj,
+                         float n_noobj, float obj_scale, float noobj_scale, float grad_scale, float* draw,
+                         int64_t dpitch, void* stream);
+
 /* dx = dy * act'(y) from the activation output y (sigmoid / leaky) */
 int me_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx, int64_t lddx, int64_t rows,
                    int32_t channels, int32_t act, void* stream);

@@ -356,6 +356,174 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// detector backward building blocks (Darknet.forward(x, targets) -> loss.backward(), eval-mode BatchNorm)
+// ---------------------------------------------------------------------------------------------
+// conv block y = act(scale * c + shift), c = conv(x, W), (scale, shift) = folded BN(eval) or (1, bias):
+// g = dy * act'(y); dc = g * scale; per channel s0 = sum g (= dbeta / dbias), s1 = sum g * xhat (= dgamma) with
+// xhat = (z - beta) / gamma recovered from the stored output (z = act^-1(y): LeakyReLU is invertible).
+__global__ __launch_bounds__(256) void affine_bwd_partial_kernel(const float* __restrict__ Y, long long ldy,
+                                                                 const float* __restrict__ G, long long ldg, int rows,
+                                                                 int C, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int act, float* p0,
+                                                                 float* p1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  if (c >= C) return;
+  const int per = (rows + BN_CHUNKS - 1) / BN_CHUNKS;
+  const int r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float inv_ga = (gamma && ga != 0.f) ? 1.f / ga : 0.f;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    const float y = Y[(long long)r * ldy + c];
+    float g = G[(long long)r * ldg + c];
+    float z = y;
+    if (act == ME_ACT_LEAKY) {
+      g = y > 0.f ? g : 0.1f * g;
+      z = y > 0.f ? y : y * 10.f;
+    }
+    s0 += g;
+    s1 += (double)g * ((z - be) * inv_ga);
+  }
+  p0[(long long)chunk * C + c] = (float)s0;
+  p1[(long long)chunk * C + c] = (float)s1;
+}
+
+__global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __restrict__ Y, long long ldy,
+                                                               const float* __restrict__ G, long long ldg,
+                                                               long long rows, int C, const float* __restrict__ scale,
+                                                               int act, float* DC, long long lddc, const float* p0,
+                                                               const float* p1, float* dshift, float* dgamma) {
+  const long long total = rows * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    const float y = Y[r * ldy + c];
+    float g = G[r * ldg + c];
+    if (act == ME_ACT_LEAKY) g = y > 0.f ? g : 0.1f * g;
+    DC[r * lddc + c] = scale ? g * scale[c] : g;
+    if (r == 0) {
+      if (dshift) dshift[c] = p0[c];
+      if (dgamma) dgamma[c] = p1[c];
+    }
+  }
+}
+
+// nearest x2 upsample backward: dx[n,y,x,c] += sum of the 2x2 block of dy
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ DY, long long lddy, float* DX,
+                                                            long long lddx, int n, int h, int w, int c) {
+  const long long total = (long long)n * h * w * c;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cc = (int)(idx % c);
+    long long pix = idx / c;
+    const int x = (int)(pix % w);
+    pix /= w;
+    const int y = (int)(pix % h);
+    const int nimg = (int)(pix / h);
+    const long long o = ((long long)(nimg * 2 * h + 2 * y) * (2 * w) + 2 * x);
+    const float v = (DY[o * lddy + cc] + DY[(o + 1) * lddy + cc]) + (DY[(o + 2 * w) * lddy + cc] + DY[(o + 2 * w + 1) * lddy + cc]);
+    DX[((long long)(nimg * h + y) * w + x) * lddx + cc] += v;
+  }
+}
+
+// max-pool backward (size k, stride s, zero_ext = the darknet ZeroPad2d((0,1,0,1)) before a stride-1 pool): the
+// gradient of every output goes to the FIRST maximal input of its window (aten max_pool2d picks the first in
+// row-major order); a padded zero that wins receives nothing.  One thread per INPUT element gathers from the <= k*k
+// windows that cover it (no atomics, deterministic).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ X, long long ldx,
+                                                          const float* __restrict__ DY, long long lddy, float* DX,
+                                                          long long lddx, int n, int h, int w, int c, int k, int s, int pad,
+                                                          int zero_ext, int ho, int wo) {
+  const long long total = (long long)n * h * w * c;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cc = (int)(idx % c);
+    long long pix = idx / c;
+    const int ix = (int)(pix % w);
+    pix /= w;
+    const int iy = (int)(pix % h);
+    const int nimg = (int)(pix / h);
+    float acc = 0.f;
+    for (int oy = 0; oy < ho; ++oy) {
+      const int y0 = oy * s - pad;
+      if (iy < y0 || iy >= y0 + k) continue;
+      for (int ox = 0; ox < wo; ++ox) {
+        const int x0 = ox * s - pad;
+        if (ix < x0 || ix >= x0 + k) continue;
+        // argmax of the window, first maximum in (row, col) order; out-of-range cells: -inf (pad) or 0 (zero_ext)
+        float best = -INFINITY;
+        int by = -1, bx = -1;
+        for (int a = 0; a < k; ++a)
+          for (int b = 0; b < k; ++b) {
+            const int yy = y0 + a, xx = x0 + b;
+            float v;
+            if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w)
+              v = X[((long long)(nimg * h + yy) * w + xx) * ldx + cc];
+            else if (zero_ext && yy <= h && xx <= w && yy >= 0 && xx >= 0)
+              v = 0.f;
+            else
+              continue;
+            if (v > best) {
+              best = v;
+              by = yy;
+              bx = xx;
+            }
+          }
+        if (by == iy && bx == ix) acc += DY[((long long)(nimg * ho + oy) * wo + ox) * lddy + cc];
+      }
+    }
+    DX[((long long)(nimg * h + iy) * w + ix) * lddx + cc] += acc;
+  }
+}
+
+// gradient of the YOLO loss (yolov3/models.py:196-214) w.r.t. the raw detection map [N,G,G,A*(5+C)] (NHWC, pitch):
+// loss = mse(x) + mse(y) + mse(w) + mse(h) (means over the n_obj object cells) + obj_scale * bce(conf | obj) +
+// noobj_scale * bce(conf | noobj) (means over n_obj / n_noobj) + bce(cls | obj) (mean over n_obj * C).
+// masks / targets are the [N,A,G,G] tensors build_targets returns (tcls [N,A,G,G,C]).
+__global__ __launch_bounds__(256) void yolo_loss_bwd_kernel(const float* __restrict__ raw, long long pitch, int n, int g,
+                                                            int na, int nc, const unsigned char* __restrict__ obj,
+                                                            const unsigned char* __restrict__ noobj,
+                                                            const float* __restrict__ tx, const float* __restrict__ ty,
+                                                            const float* __restrict__ tw, const float* __restrict__ th,
+                                                            const float* __restrict__ tcls, const float* __restrict__ tconf,
+                                                            float n_obj, float n_noobj, float obj_scale, float noobj_scale,
+                                                            float gscale, float* draw, long long dpitch) {
+  const int per = nc + 5;
+  const long long total = (long long)n * na * g * g * per;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int k = (int)(idx % per);
+    long long t = idx / per;
+    const int gx = (int)(t % g);
+    t /= g;
+    const int gy = (int)(t % g);
+    t /= g;
+    const int a = (int)(t % na);
+    const int nimg = (int)(t / na);
+    const long long cell = (((long long)nimg * na + a) * g + gy) * g + gx;           // [N,A,G,G]
+    const long long at = ((long long)(nimg * g + gy) * g + gx);
+    const float r = raw[at * pitch + a * per + k];
+    const bool is_obj = obj[cell] != 0, is_noobj = noobj[cell] != 0;
+    float d = 0.f;
+    if (k < 2) {
+      if (is_obj) {
+        const float sg = 1.f / (1.f + expf(-r));
+        d = 2.f * (sg - (k == 0 ? tx[cell] : ty[cell])) / n_obj * sg * (1.f - sg);
+      }
+    } else if (k < 4) {
+      if (is_obj) d = 2.f * (r - (k == 2 ? tw[cell] : th[cell])) / n_obj;
+    } else if (k == 4) {
+      const float sg = 1.f / (1.f + expf(-r));
+      if (is_obj) d += obj_scale * (sg - tconf[cell]) / n_obj;
+      if (is_noobj) d += noobj_scale * (sg - tconf[cell]) / n_noobj;
+    } else if (is_obj) {
+      const float sg = 1.f / (1.f + expf(-r));
+      d = (sg - tcls[cell * nc + (k - 5)]) / (n_obj * (float)nc);
+    }
+    draw[at * dpitch + a * per + k] = d * gscale;
+  }
+}
+
 inline unsigned grid1d(long long work) {
   long long b = (work + 255) / 256;
   if (b > 8192) b = 8192;
@@ -436,6 +604,64 @@ int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld
                      (long long)ldx, dy, (long long)lddy, rows, channels, save_mean, save_rstd, gamma, beta, act, p0,
                      p1, dgamma, dbeta, dx, (long long)lddx);
   return me::check_launch("bn_train_bwd");
+}
+
+int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
+                          const float* scale, const float* gamma, const float* beta, int32_t act, float* dc, int64_t lddc,
+                          float* dshift, float* dgamma, void* workspace, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(y && dy && dc && workspace, ME_E_NULLPTR, "me_affine_act_bwd_f32: null pointer");
+  ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_affine_act_bwd_f32: bad dimensions");
+  ME_REQUIRE(act == ME_ACT_LINEAR || act == ME_ACT_LEAKY, ME_E_BADARG, "me_affine_act_bwd_f32: activation %d", act);
+  float* p0 = reinterpret_cast<float*>(workspace);
+  float* p1 = p0 + (long long)BN_CHUNKS * channels;
+  const unsigned cb = (channels + 255) / 256;
+  hipLaunchKernelGGL(affine_bwd_partial_kernel, dim3(cb, BN_CHUNKS), dim3(256), 0, stream, y, (long long)ldy, dy,
+                     (long long)lddy, rows, channels, gamma, beta, act, p0, p1);
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, channels);
+  hipLaunchKernelGGL(affine_bwd_apply_kernel, dim3(grid1d((long long)rows * channels)), dim3(256), 0, stream, y,
+                     (long long)ldy, dy, (long long)lddy, (long long)rows, channels, scale, act, dc, (long long)lddc, p0, p1,
+                     dshift, dgamma);
+  return me::check_launch("affine_act_bwd");
+}
+
+int me_upsample2_bwd_f32(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n, int32_t h, int32_t w,
+                         int32_t c, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(dy && dx, ME_E_NULLPTR, "me_upsample2_bwd_f32: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, ME_E_BADARG, "me_upsample2_bwd_f32: bad dimensions");
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid1d((long long)n * h * w * c)), dim3(256), 0, stream, dy,
+                     (long long)lddy, dx, (long long)lddx, n, h, w, c);
+  return me::check_launch("upsample2_bwd_kernel");
+}
+
+int me_maxpool_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n,
+                       int32_t h, int32_t w, int32_t c, int32_t size, int32_t stride, int32_t pad, int32_t zero_ext,
+                       void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(x && dy && dx, ME_E_NULLPTR, "me_maxpool_bwd_f32: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && size >= 1 && stride >= 1, ME_E_BADARG, "me_maxpool_bwd_f32: bad dimensions");
+  const int ext = zero_ext ? 1 : 0;
+  const int ho = (h + ext + 2 * pad - size) / stride + 1, wo = (w + ext + 2 * pad - size) / stride + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid1d((long long)n * h * w * c)), dim3(256), 0, stream, x, (long long)ldx,
+                     dy, (long long)lddy, dx, (long long)lddx, n, h, w, c, size, stride, pad, zero_ext, ho, wo);
+  return me::check_launch("maxpool_bwd_kernel");
+}
+
+int me_yolo_loss_bwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                         const uint8_t* obj_mask, const uint8_t* noobj_mask, const float* tx, const float* ty,
+                         const float* tw, const float* th, const float* tcls, const float* tconf, float n_obj,
+                         float n_noobj, float obj_scale, float noobj_scale, float grad_scale, float* draw,
+                         int64_t dpitch, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(raw && obj_mask && noobj_mask && tx && ty && tw && th && tcls && tconf && draw, ME_E_NULLPTR,
+             "me_yolo_loss_bwd_f32: null pointer");
+  ME_REQUIRE(n > 0 && g > 0 && num_anchors > 0 && num_classes > 0, ME_E_BADARG, "me_yolo_loss_bwd_f32: bad dimensions");
+  const long long work = (long long)n * num_anchors * g * g * (num_classes + 5);
+  hipLaunchKernelGGL(yolo_loss_bwd_kernel, dim3(grid1d(work)), dim3(256), 0, stream, raw, (long long)pitch, n, g,
+                     num_anchors, num_classes, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf, n_obj, n_noobj,
+                     obj_scale, noobj_scale, grad_scale, draw, (long long)dpitch);
+  return me::check_launch("yolo_loss_bwd_kernel");
 }
 
 int me_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx, int64_t lddx, int64_t rows,

@@ -1,0 +1,266 @@
+"""Detector forward + backward for ``Darknet.forward(x, targets)`` under autograd.
+
+Reference: ``module3_our_dataset/yolov3/models.py:181-267`` - with ``targets`` the module loop returns the summed YOLO
+loss of every scale and torch autograd differentiates the whole backbone.  No reference script trains the detector
+(``train.py:170`` keeps ``base_detector.eval()`` and Network detaches its outputs), so BatchNorm runs in **eval** mode here
+too: a per-channel affine ``scale * conv + shift`` whose ``weight`` / ``bias`` still receive gradients, exactly like
+``F.batch_norm(training=False)`` does.  Train-mode (batch-statistics) BatchNorm inside the detector raises.
+
+The graph is static, so forward and backward are explicit launch sequences over ``libmillieye_hip`` and autograd sees
+one :class:`torch.autograd.Function` whose inputs are the detector parameters:
+
+forward   every module output is kept (NHWC): ``me_conv2d_f32`` (folded BN + LeakyReLU epilogue), ``me_maxpool_f32``,
+          ``me_upsample_f32``, ``me_add_f32`` (shortcut), ``me_copy_f32`` (route concat); the YOLO loss value and the
+          ``build_targets`` masks come from ``YOLOLayer.loss_from_raw`` (index bookkeeping, as in the reference).
+backward  ``me_yolo_loss_bwd_f32`` seeds the raw detection maps; modules are walked in reverse:
+          ``me_affine_act_bwd_f32`` (activation + BN-affine backward, d gamma / d beta / d bias),
+          ``me_conv_wgrad_f32`` (weight gradient), the data gradient as ``me_conv2d_f32`` on the 180-degree rotated,
+          transposed weights (stride 2: on the zero-interleaved gradient; the 255 / 51-channel detection convs:
+          ``me_gemm_f32``), ``me_upsample2_bwd_f32``, ``me_maxpool_bwd_f32``, ``me_add_f32`` for fan-out accumulation.
+
+Correctness first: the weight-gradient kernel is the simple tiled one of the stage-3 heads; an MFMA wgrad is future work.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _resolve(v, i):
+    v = int(v)
+    return i + v if v < 0 else v
+
+
+def _add_into(dst, src_ptr, src_pitch, pixels, c, dst_off=0):
+    """dst[..., dst_off:dst_off+c] += src (pitched)."""
+    lib = hip.lib()
+    dp = dst.data_ptr() + 4 * dst_off
+    hip.check(lib.me_add_f32(dp, dst.shape[-1], src_ptr, src_pitch, dp, dst.shape[-1], pixels, c, hip.stream_ptr()),
+              "me_add_f32")
+
+
+class _State:
+    pass
+
+
+class DetectorTrainer:
+    def __init__(self, model):
+        self.m = model
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            raise hip.MeError("Darknet training forward needs a 4-D CUDA float32 tensor; there is no CPU fallback")
+        m, lib = self.m, hip.lib()
+        eng = m.engine
+        x = x.contiguous()
+        eng.refresh_weights(x.device)  # raises for train-mode BatchNorm
+        defs = m.module_defs
+        outs, raws = [], {}
+        for i, d in enumerate(defs):
+            t = d["type"]
+            if t == "convolutional":
+                cw = eng._conv_weights(i)
+                k, s = int(d["size"]), int(d["stride"])
+                act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
+                src = x if i == 0 else outs[i - 1]
+                y = hip.conv2d(src, cw.wgt, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0))
+            elif t == "maxpool":
+                k, s = int(d["size"]), int(d["stride"])
+                y = hip.maxpool(outs[i - 1], k, s, zero_ext=(k == 2 and s == 1))
+            elif t == "upsample":
+                y = hip.upsample(outs[i - 1], int(d["stride"]))
+            elif t == "shortcut":
+                a, b = outs[i - 1], outs[_resolve(d["from"], i)]
+                y = torch.empty_like(a)
+                hip.check(lib.me_add_f32(a.data_ptr(), a.shape[-1], b.data_ptr(), b.shape[-1], y.data_ptr(), y.shape[-1],
+                                         a.numel() // a.shape[-1], a.shape[-1], hip.stream_ptr()), "me_add_f32")
+            elif t == "route":
+                parts = [outs[_resolve(v, i)] for v in d["layers"].split(",")]
+                if len(parts) == 1:
+                    y = parts[0]
+                else:
+                    ct = sum(p.shape[-1] for p in parts)
+                    y = torch.empty(parts[0].shape[:3] + (ct,), device=x.device, dtype=torch.float32)
+                    off = 0
+                    for p in parts:
+                        hip.check(lib.me_copy_f32(p.data_ptr(), p.shape[-1], y.data_ptr() + 4 * off, ct,
+                                                  p.numel() // p.shape[-1], p.shape[-1], hip.stream_ptr()), "me_copy_f32")
+                        off += p.shape[-1]
+            elif t == "yolo":
+                raws[i] = outs[i - 1]
+                y = None
+            else:
+                raise ValueError(f"unsupported cfg block [{t}] at module {i}")
+            outs.append(y)
+        st = _State()
+        st.x, st.outs, st.raws = x, outs, raws
+        return st
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, st, draws):
+        """``draws``: {yolo module index: d loss / d raw map [N,G,G,A*(5+C)]}.  Returns {parameter name: gradient}."""
+        m, lib = self.m, hip.lib()
+        eng = m.engine
+        defs, outs, x = m.module_defs, st.outs, st.x
+        dev = x.device
+        L = len(defs)
+        dout = [None] * L
+        grads = {}
+        stream = hip.stream_ptr
+
+        def grad_buf(i):
+            if dout[i] is None:
+                dout[i] = torch.zeros_like(outs[i])
+            return dout[i]
+
+        x_nhwc = None
+        for i in reversed(range(L)):
+            d = defs[i]
+            t = d["type"]
+            if t == "yolo":
+                g = draws[i]
+                _add_into(grad_buf(i - 1), g.data_ptr(), g.shape[-1], g.numel() // g.shape[-1], g.shape[-1])
+                continue
+            dy = dout[i]
+            if dy is None:
+                continue
+            if t == "convolutional":
+                seq = m.module_list[i]
+                conv = seq[0]
+                bn = seq[1] if len(seq) > 1 and isinstance(seq[1], torch.nn.BatchNorm2d) else None
+                cw = eng._conv_weights(i)
+                k, s = int(d["size"]), int(d["stride"])
+                pad = (k - 1) // 2
+                act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
+                y = outs[i]
+                n, ho, wo, cout = y.shape
+                rows = n * ho * wo
+                dc = torch.empty_like(y)
+                dshift = torch.empty(cout, device=dev)
+                dgamma = torch.empty(cout, device=dev) if bn is not None else None
+                ws = torch.empty(lib.me_bn_workspace_bytes(cout), dtype=torch.uint8, device=dev)
+                gam = bn.weight.detach().to(dev, torch.float32).contiguous() if bn is not None else None
+                bet = bn.bias.detach().to(dev, torch.float32).contiguous() if bn is not None else None
+                hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
+                                                    cw.scale.data_ptr() if bn is not None else None, _ptr(gam), _ptr(bet),
+                                                    act, dc.data_ptr(), cout, dshift.data_ptr(), _ptr(dgamma),
+                                                    ws.data_ptr(), stream()), "me_affine_act_bwd_f32")
+                if bn is not None:
+                    grads[f"module_list.{i}.batch_norm_{i}.weight"] = dgamma
+                    grads[f"module_list.{i}.batch_norm_{i}.bias"] = dshift
+                else:
+                    grads[f"module_list.{i}.conv_{i}.bias"] = dshift
+                # weight gradient
+                if i == 0:
+                    if x_nhwc is None:
+                        x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+                    xin = x_nhwc
+                else:
+                    xin = outs[i - 1]
+                _, h, w, cin = xin.shape
+                dw = torch.empty((cout, k, k, cin), device=dev, dtype=torch.float32)
+                hip.check(lib.me_conv_wgrad_f32(xin.data_ptr(), cin, dc.data_ptr(), cout, dw.data_ptr(), n, h, w, cin, cout,
+                                                k, s, pad, stream()), "me_conv_wgrad_f32")
+                grads[f"module_list.{i}.conv_{i}.weight"] = dw.permute(0, 3, 1, 2).contiguous()
+                if i == 0:
+                    continue
+                # data gradient
+                if cout % 4 != 0:
+                    if k != 1 or s != 1:
+                        raise NotImplementedError(f"conv {i}: data gradient for cout={cout} (not a multiple of 4) needs k=1")
+                    dx = torch.empty((n, h, w, cin), device=dev, dtype=torch.float32)
+                    hip.check(lib.me_gemm_f32(0, 0, rows, cin, cout, 1.0, dc.data_ptr(), cout, cw.wgt.data_ptr(), cin, 0.0,
+                                              dx.data_ptr(), cin, stream()), "me_gemm_f32")
+                else:
+                    wt = cw.wgt.flip(1, 2).permute(3, 1, 2, 0).contiguous()  # [cin][k][k][cout], rotated 180 degrees
+                    ones = torch.ones(cin, device=dev)
+                    zeros = torch.zeros(cin, device=dev)
+                    if s == 1:
+                        dx = hip.conv2d(dc, wt, ones, zeros, k, 1, k - 1 - pad, hip.ACT_LINEAR)
+                    else:
+                        # transposed convolution = stride-1 correlation over the zero-interleaved gradient
+                        pp = k - 1 - pad
+                        z = torch.zeros((n, h + k - 1, w + k - 1, cout), device=dev, dtype=torch.float32)
+                        z[:, pp:pp + s * ho:s, pp:pp + s * wo:s, :] = dc
+                        dx = hip.conv2d(z, wt, ones, zeros, k, 1, 0, hip.ACT_LINEAR)
+                _add_into(grad_buf(i - 1), dx.data_ptr(), cin, n * h * w, cin)
+            elif t == "shortcut":
+                c = dy.shape[-1]
+                px = dy.numel() // c
+                _add_into(grad_buf(i - 1), dy.data_ptr(), c, px, c)
+                _add_into(grad_buf(_resolve(d["from"], i)), dy.data_ptr(), c, px, c)
+            elif t == "route":
+                srcs = [_resolve(v, i) for v in d["layers"].split(",")]
+                if len(srcs) == 1:
+                    c = dy.shape[-1]
+                    _add_into(grad_buf(srcs[0]), dy.data_ptr(), c, dy.numel() // c, c)
+                else:
+                    ct, off = dy.shape[-1], 0
+                    for sidx in srcs:
+                        c = outs[sidx].shape[-1]
+                        _add_into(grad_buf(sidx), dy.data_ptr() + 4 * off, ct, dy.numel() // ct, c)
+                        off += c
+            elif t == "upsample":
+                if int(d["stride"]) != 2:
+                    raise NotImplementedError("upsample backward: stride 2 only")
+                n, h, w, c = outs[i - 1].shape
+                hip.check(lib.me_upsample2_bwd_f32(dy.data_ptr(), c, grad_buf(i - 1).data_ptr(), c, n, h, w, c, stream()),
+                          "me_upsample2_bwd_f32")
+            elif t == "maxpool":
+                k, s = int(d["size"]), int(d["stride"])
+                zero_ext = 1 if (k == 2 and s == 1) else 0
+                xin = outs[i - 1]
+                n, h, w, c = xin.shape
+                hip.check(lib.me_maxpool_bwd_f32(xin.data_ptr(), c, dy.data_ptr(), c, grad_buf(i - 1).data_ptr(), c, n, h, w,
+                                                 c, k, s, 0 if zero_ext else (k - 1) // 2, zero_ext, stream()),
+                          "me_maxpool_bwd_f32")
+            dout[i] = None  # free as we go
+        return grads
+
+
+class _DarknetLoss(torch.autograd.Function):
+    """loss = Darknet.forward(x, targets)[0] with the detector parameters as differentiable inputs."""
+
+    @staticmethod
+    def forward(ctx, model, x, targets, names, *params):
+        trainer = DetectorTrainer(model)
+        st = trainer.forward(x)
+        loss = 0
+        seeds = {}
+        for layer, (idx, raw) in zip(model.yolo_layers, sorted(st.raws.items())):
+            layer.img_dim = x.shape[2]
+            value, bt = layer.loss_from_raw(raw, targets, return_targets=True)
+            loss = loss + value
+            seeds[idx] = bt
+        ctx.trainer, ctx.st, ctx.seeds, ctx.names = trainer, st, seeds, names
+        ctx.model = model
+        return loss.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        model, st, lib = ctx.model, ctx.st, hip.lib()
+        gscale = float(grad_loss)
+        draws = {}
+        for layer, (idx, raw) in zip(model.yolo_layers, sorted(st.raws.items())):
+            bt = ctx.seeds[idx]
+            n, g, _, ch = raw.shape
+            draw = torch.empty_like(raw)
+            hip.check(lib.me_yolo_loss_bwd_f32(raw.data_ptr(), ch, n, g, layer.num_anchors, layer.num_classes,
+                                               bt["obj"].data_ptr(), bt["noobj"].data_ptr(), bt["tx"].data_ptr(),
+                                               bt["ty"].data_ptr(), bt["tw"].data_ptr(), bt["th"].data_ptr(),
+                                               bt["tcls"].data_ptr(), bt["tconf"].data_ptr(), float(bt["n_obj"]),
+                                               float(bt["n_noobj"]), float(layer.obj_scale), float(layer.noobj_scale),
+                                               gscale, draw.data_ptr(), ch, hip.stream_ptr()), "me_yolo_loss_bwd_f32")
+            draws[idx] = draw
+        grads = ctx.trainer.backward(st, draws)
+        out = []
+        for name, needs in zip(ctx.names, ctx.needs_input_grad[4:]):
+            g = grads.get(name) if needs else None
+            out.append(g)
+        return (None, None, None, None) + tuple(out)

@@ -82,7 +82,7 @@ class YOLOLayer(nn.Module):
             return output, 0
         return output, self.loss_from_raw(nhwc, targets)
 
-    def loss_from_raw(self, raw_nhwc, targets):
+    def loss_from_raw(self, raw_nhwc, targets, return_targets=False):
         """YOLO loss + metrics of this scale (reference :181-232) from the raw detection map
         ``raw_nhwc`` [N, G, G, A*(5+C)] (any strides) and ``targets`` [m,6] = (image_i, class, cx, cy, w, h)
         normalised to [0,1].  Device-side torch ops (anchor matching is index bookkeeping,
@@ -135,6 +135,13 @@ class YOLOLayer(nn.Module):
                 "conf_obj": to_cpu(pred_conf[obj_mask].mean()).item(),
                 "conf_noobj": to_cpu(pred_conf[noobj_mask].mean()).item(), "grid_size": g,
             }
+        if return_targets:  # what me_yolo_loss_bwd_f32 needs (detector backward, millieye_amd/detector_train.py)
+            f = dict(device=dev, dtype=torch.float32)
+            bt = dict(obj=obj_mask.to(torch.uint8).contiguous(), noobj=noobj_mask.to(torch.uint8).contiguous(),
+                      tx=tx.to(**f).contiguous(), ty=ty.to(**f).contiguous(), tw=tw.to(**f).contiguous(),
+                      th=th.to(**f).contiguous(), tcls=tcls.to(**f).contiguous(), tconf=tconf.to(**f).contiguous(),
+                      n_obj=int(obj_mask.sum()), n_noobj=int(noobj_mask.sum()))
+            return total_loss, bt
         return total_loss
 
 
@@ -241,6 +248,8 @@ class Darknet(nn.Module):
         """``(featuremap, yolo_outputs)``, or with ``targets`` ``(loss, featuremap, yolo_outputs)`` where
         ``loss`` is the summed YOLO loss of every scale (reference :261-267).  The loss is a VALUE: the
         detector backward is not built (no reference script trains the detector)."""
+        if targets is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(x, targets)
         plan, yolo_outputs = self._run(x, keep_raw=targets is not None)
         if getattr(plan, "graph", None) is not None:
             yolo_outputs = yolo_outputs.clone()  # graph replays write a static buffer: the caller gets its own tensor
@@ -258,6 +267,23 @@ class Darknet(nn.Module):
                 loss = loss + layer.loss_from_raw(raw, targets)
             return loss, self.featuremap, yolo_outputs
         return self.featuremap, yolo_outputs
+
+    def _forward_train(self, x, targets):
+        """``(loss, featuremap, yolo_outputs)`` with a differentiable loss (reference :181-267 under autograd): every
+        module output is kept and ``loss.backward()`` runs the HIP backward of millieye_amd/detector_train.py.  The
+        decoded ``yolo_outputs`` / ``featuremap`` come from the regular inference engine on the same weights."""
+        from ..detector_train import _DarknetLoss
+        with torch.no_grad():
+            plan, yolo_outputs = self._run(x)
+            if getattr(plan, "graph", None) is not None:
+                yolo_outputs = yolo_outputs.clone()
+            if plan.tap is not None:
+                self.featuremap = plan.tap.clone()
+        if not hasattr(self, "featuremap"):
+            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+        named = [(k, p) for k, p in self.named_parameters()]
+        loss = _DarknetLoss.apply(self, x, targets, [k for k, _ in named], *[p for _, p in named])
+        return loss, self.featuremap, yolo_outputs
 
     # -- darknet .weights I/O (reference :269-352) ---------------------------------------------
     def _conv_blocks(self, stop=None):

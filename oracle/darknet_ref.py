@@ -112,3 +112,91 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
             outs.append(x)
     res = (feat, torch.cat(yolo, 1))
     return res + (outs,) if return_layers else res
+
+
+# ---------------------------------------------------------------------------------------------------
+# detector training step: Darknet.forward(x, targets) -> loss.backward() (models.py:181-267 under autograd, BatchNorm
+# in eval mode as every reference script keeps it).  Pinned by tests/golden/yololoss_*.npz (loss + every gradient).
+# ---------------------------------------------------------------------------------------------------
+def _wh_iou(wh1, wh2):
+    """bbox_wh_iou (utils/utils.py:239-245)."""
+    wh2 = wh2.t()
+    inter = torch.min(wh1[0], wh2[0]) * torch.min(wh1[1], wh2[1])
+    return inter / ((wh1[0] * wh1[1] + 1e-16) + wh2[0] * wh2[1] - inter)
+
+
+def yolo_loss(raw, anchors, num_classes, img_dim, targets, ignore_thres=0.5, obj_scale=1, noobj_scale=100):
+    """Loss of one YOLOLayer (models.py:132-214) from its raw input map ``raw`` [N, A*(5+C), G, G] (NCHW)."""
+    n, g, na = raw.shape[0], raw.shape[2], len(anchors)
+    pred = raw.view(n, na, num_classes + 5, g, g).permute(0, 1, 3, 4, 2).contiguous()
+    x, y = torch.sigmoid(pred[..., 0]), torch.sigmoid(pred[..., 1])
+    w, h = pred[..., 2], pred[..., 3]
+    conf, cls = torch.sigmoid(pred[..., 4]), torch.sigmoid(pred[..., 5:])
+    stride = img_dim / g
+    sa = torch.tensor([(aw / stride, ah / stride) for aw, ah in anchors], dtype=torch.float32)
+    # build_targets (utils/utils.py:381-440): index bookkeeping, no gradient
+    with torch.no_grad():
+        obj = torch.zeros(n, na, g, g, dtype=torch.bool)
+        noobj = torch.ones(n, na, g, g, dtype=torch.bool)
+        tx, ty, tw, th = (torch.zeros(n, na, g, g) for _ in range(4))
+        tcls = torch.zeros(n, na, g, g, num_classes)
+        tb = targets[:, 2:6] * g
+        gxy, gwh = tb[:, :2], tb[:, 2:]
+        ious = torch.stack([_wh_iou(a, gwh) for a in sa])
+        best_n = ious.max(0)[1]
+        b, labels = targets[:, :2].long().t()
+        gi, gj = gxy.long().t()
+        obj[b, best_n, gj, gi] = True
+        noobj[b, best_n, gj, gi] = False
+        for k, a_ious in enumerate(ious.t()):
+            noobj[b[k], a_ious > ignore_thres, gj[k], gi[k]] = False
+        tx[b, best_n, gj, gi] = gxy[:, 0] - gxy[:, 0].floor()
+        ty[b, best_n, gj, gi] = gxy[:, 1] - gxy[:, 1].floor()
+        tw[b, best_n, gj, gi] = torch.log(gwh[:, 0] / sa[best_n][:, 0] + 1e-16)
+        th[b, best_n, gj, gi] = torch.log(gwh[:, 1] / sa[best_n][:, 1] + 1e-16)
+        tcls[b, best_n, gj, gi, labels] = 1
+        tconf = obj.float()
+    mse, bce = F.mse_loss, F.binary_cross_entropy
+    loss = (mse(x[obj], tx[obj]) + mse(y[obj], ty[obj]) + mse(w[obj], tw[obj]) + mse(h[obj], th[obj])
+            + obj_scale * bce(conf[obj], tconf[obj]) + noobj_scale * bce(conf[noobj], tconf[noobj])
+            + bce(cls[obj], tcls[obj]))
+    return loss
+
+
+def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list."):
+    """Summed YOLO loss of every scale + its gradient w.r.t. every detector parameter (eval-mode BatchNorm).
+    Returns ``(loss, {name: grad})``; ``state_dict`` is not modified."""
+    blocks = parse_cfg_text(cfg_text)[1:]
+    img_dim = x.shape[2]
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in state_dict.items()
+         if v.dtype == torch.float32 and "running_" not in k}
+    outs = []
+    loss = 0
+    for i, b in enumerate(blocks):
+        kind = b["type"]
+        if kind == "convolutional":
+            k = int(b["size"])
+            x = F.conv2d(x, P[f"{prefix}{i}.conv_{i}.weight"], P.get(f"{prefix}{i}.conv_{i}.bias"), stride=int(b["stride"]),
+                         padding=(k - 1) // 2)
+            if int(b["batch_normalize"]):
+                p = f"{prefix}{i}.batch_norm_{i}."
+                x = F.batch_norm(x, state_dict[p + "running_mean"], state_dict[p + "running_var"], P[p + "weight"],
+                                 P[p + "bias"], False, 0.9, 1e-5)
+            if b["activation"] == "leaky":
+                x = F.leaky_relu(x, 0.1)
+        elif kind == "maxpool":
+            k, s = int(b["size"]), int(b["stride"])
+            if k == 2 and s == 1:
+                x = F.pad(x, (0, 1, 0, 1), value=0.0)
+            x = F.max_pool2d(x, k, s, (k - 1) // 2)
+        elif kind == "upsample":
+            x = F.interpolate(x, scale_factor=int(b["stride"]), mode="nearest")
+        elif kind == "route":
+            x = torch.cat([outs[int(l)] for l in b["layers"].split(",")], 1)
+        elif kind == "shortcut":
+            x = outs[-1] + outs[int(b["from"])]
+        elif kind == "yolo":
+            loss = loss + yolo_loss(x, _anchors_of(b), int(b["classes"]), img_dim, targets)
+        outs.append(x)
+    loss.backward()
+    return loss.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()}

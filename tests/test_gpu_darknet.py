@@ -64,7 +64,7 @@ def test_cpu_input_is_rejected_loudly(hip_lib):
 
 def test_yolo_loss_value_vs_reference_golden(hip_lib):
     """Darknet.forward(x, targets) -> (loss, featuremap, yolo_outputs): loss value and per-scale metrics
-    against the reference's own numbers (row a6; the value only - the detector backward is not built)."""
+    against the reference's own numbers (row a6), on the no-grad path."""
     import os
     import numpy as np
     from millieye_amd import synth
@@ -73,10 +73,80 @@ def test_yolo_loss_value_vs_reference_golden(hip_lib):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     model = ph.make_darknet(cfg, tag=name).cuda()
     x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s))).cuda()
-    loss, fm, yolo = model(x, torch.from_numpy(g["targets"]))
+    with torch.no_grad():
+        loss, fm, yolo = model(x, torch.from_numpy(g["targets"]))
     assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
     for i, yl in enumerate(model.yolo_layers):
         for k, v in yl.metrics.items():
             ref = float(g[f"m{i}/{k}"])
             assert abs(float(v) - ref) <= 1e-3 * max(1.0, abs(ref)), (i, k, v, ref)
     assert tuple(fm.shape) == (n, 256, s // 16, s // 16) and yolo.shape[0] == n
+
+
+def _grad_check(got, ref, name, tol=2e-3):
+    """|got - ref| <= tol * max|ref| elementwise (gradients span orders of magnitude inside one tensor)."""
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{name}: max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_detector_backward_vs_oracle_and_reference_golden(hip_lib):
+    """Darknet.forward(x, targets) under autograd + loss.backward() on the HIP path (millieye_amd/detector_train.py):
+    the loss and the gradient of EVERY detector parameter (conv weights, BN gamma / beta in eval mode, detection
+    biases) against the oracle's CPU autograd and against the reference's own autograd run (golden norms + samples).
+    tiny-12: conv / maxpool / zero-pad maxpool / upsample / route concat; tolerance 2e-3 of each tensor's max."""
+    import os
+    import numpy as np
+    from millieye_amd import cfgs, synth
+    from oracle import darknet_ref
+    from tests.golden.make_golden import YOLO_LOSS_CASE
+    name, cfg, n, s = YOLO_LOSS_CASE
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    cpu_model = ph.make_darknet(cfg, tag=name)
+    targets = torch.from_numpy(g["targets"])
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    ref_loss, ref_grads = darknet_ref.darknet_train_step(cfgs.KNOWN[cfg](), cpu_model.state_dict(), x, targets)
+    model = ph.make_darknet(cfg, tag=name).cuda()
+    loss, fm, yolo = model(x.cuda(), targets)
+    assert loss.requires_grad and tuple(fm.shape) == (n, 256, s // 16, s // 16)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    (2.0 * loss).backward()  # upstream gradient 2: must scale every gradient
+    seen = 0
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        got = p.grad.cpu() / 2.0
+        _grad_check(got, ref_grads[k], k)
+        gn = float(g["gnorm/" + k])
+        assert abs(float(got.double().norm()) - gn) <= 2e-3 * max(gn, 1e-6), k
+        samp = got.flatten()[::max(1, got.numel() // 64)].numpy()
+        assert np.all(np.abs(samp - g["gsamp/" + k]) <= 2e-3 * max(float(np.abs(g["gsamp/" + k]).max()), 1e-6)), k
+        seen += 1
+    assert seen == 37
+    # frozen parameters get no gradient; an optimizer step works on the rest
+    model.zero_grad()
+    model.module_list[0][0].weight.requires_grad = False
+    loss2, _, _ = model(x.cuda(), targets)
+    loss2.backward()
+    assert model.module_list[0][0].weight.grad is None and model.module_list[2][0].weight.grad is not None
+    torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4).step()
+    with torch.no_grad():
+        loss3, _, _ = model(x.cuda(), targets)
+    assert float(loss3) < float(loss2)
+
+
+def test_detector_backward_darknet53_vs_oracle(hip_lib):
+    """Darknet-53 (stride-2 convs, 23 shortcuts, 3 scales, two upsample + route concats) at 64 px: every parameter
+    gradient against the oracle's CPU autograd."""
+    from millieye_amd import cfgs, synth
+    from oracle import darknet_ref
+    name, n, s = "d53bwd", 1, 64
+    cpu_model = ph.make_darknet("yolov3", tag=name)
+    targets = torch.tensor([[0, 3, 0.30, 0.40, 0.20, 0.30], [0, 17, 0.70, 0.60, 0.50, 0.40], [0, 60, 0.52, 0.48, 0.10, 0.15]])
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    ref_loss, ref_grads = darknet_ref.darknet_train_step(cfgs.KNOWN["yolov3"](), cpu_model.state_dict(), x, targets)
+    model = ph.make_darknet("yolov3", tag=name).cuda()
+    loss, _fm, _yo = model(x.cuda(), targets)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
+    loss.backward()
+    for k, p in model.named_parameters():
+        _grad_check(p.grad.cpu(), ref_grads[k], k, tol=5e-3)

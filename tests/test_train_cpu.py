@@ -70,3 +70,26 @@ def test_vectorised_iou_labels_equal_the_reference_loop():
     assert (l0 > 0.7).sum() >= 10 and (l0 == 0).sum() > 0
     e, _ = iou_labels_vectorized(b[:0], t)
     assert e.shape == (0, 1)
+
+
+def test_oracle_detector_training_step_matches_reference():
+    """oracle/darknet_ref.darknet_train_step (loss + gradient of every detector parameter, eval-mode BatchNorm) against
+    the reference's own autograd run (tests/golden/yololoss_tiny12_s96_n2.npz)."""
+    from oracle import darknet_ref
+    from tests.golden.make_golden import YOLO_LOSS_CASE
+    from tests.parity_helpers import make_darknet
+    name, cfg, n, s = YOLO_LOSS_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    model = make_darknet(cfg, name)
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    loss, grads = darknet_ref.darknet_train_step(cfgs.KNOWN[cfg](), model.state_dict(), x, torch.from_numpy(g["targets"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    checked = 0
+    for key in g.files:
+        if key.startswith("gnorm/"):
+            k = key[6:]
+            gr = grads[k]
+            assert abs(float(gr.double().norm()) - float(g[key])) <= 1e-4 * max(1e-6, float(g[key])), k
+            assert np.allclose(gr.flatten()[::max(1, gr.numel() // 64)].numpy(), g["gsamp/" + k], rtol=1e-4, atol=1e-6), k
+            checked += 1
+    assert checked == 37
