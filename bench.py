@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--cfg", default="yolov3")
-    ap.add_argument("--workload", default="full", choices=["detector", "full", "train"])
+    ap.add_argument("--workload", default="full", choices=["detector", "full", "train", "detector_train"])
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed clock ramp-up before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
@@ -281,7 +281,31 @@ def main():
     frames_cpu = torch.from_numpy(synth.uniform(f"bench/frames/{rank}", (batch, 3, args.size, args.size)))
     x = frames_cpu.to(dev)
     radar = None
-    if args.workload == "detector":
+    if args.workload == "detector_train":
+        # detector fine-tuning step (row a6): Darknet.forward(x, targets) under autograd -> loss.backward() (HIP backward,
+        # eval-mode BatchNorm) -> SUM all-reduce of the full 61.9 M-parameter gradient bucket (247.8 MB) -> SGD step
+        from millieye_amd import parallel as par
+        model = Darknet(cfg_path).eval()
+        synth.fill_darknet_(model, "bench/" + args.cfg)
+        synth.trained_like_(model, "bench/" + args.cfg + "/trained")
+        state_cpu = {}
+        model = model.to(dev)
+        net = None
+        last = {}
+        det_targets = torch.tensor([[i, (3 * i) % 80, 0.3 + 0.04 * (i % 8), 0.4 + 0.03 * (i % 5), 0.2, 0.3]
+                                    for i in range(batch)], dtype=torch.float32)
+        det_params = [p for p in model.parameters()]
+        det_opt = torch.optim.SGD(det_params, lr=1e-5)
+
+        def step():
+            loss, _fm, yo = model(x, det_targets)
+            loss.backward()
+            last["bucket_bytes"] = par.allreduce_gradients(det_params)
+            det_opt.step()
+            det_opt.zero_grad(set_to_none=True)
+            last["loss"] = loss.detach()
+            return yo
+    elif args.workload == "detector":
         model = Darknet(cfg_path).eval()
         synth.fill_darknet_(model, "bench/" + args.cfg)
         synth.trained_like_(model, "bench/" + args.cfg + "/trained")
@@ -388,6 +412,8 @@ def main():
                             + ("Darknet.forward -> featuremap + yolo_outputs" if args.workload == "detector" else
                                "full milliEye: Darknet.forward -> NMS -> Network.forward mode 0 (R-CNN head + radar "
                                "fusion, 2 radar boxes/frame) -> output rows" if args.workload == "full" else
+                               "Darknet.forward(x, targets) -> loss.backward() -> all-reduce -> SGD"
+                               if args.workload == "detector_train" else
                                "stage-3 training step: frozen detector + NMS + train-mode heads + focal/BCE loss + "
                                "backward + SUM all-reduce of the flat gradient bucket + Adam step")
                             + ", synthetic frames U[0,1), deterministic trained-like weights",
@@ -412,7 +438,7 @@ def main():
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),
             },
         }
-        if not args.no_cpu_baseline and world == 1 and args.workload != "train":
+        if not args.no_cpu_baseline and world == 1 and args.workload not in ("train", "detector_train"):
             from millieye_amd.engine import pick_tap_module
             out["cpu_baseline"] = cpu_baseline(args, frames_cpu, state_cpu, cfgs.KNOWN[args.cfg](),
                                                pick_tap_module(model.module_defs), args.cpu_seconds, radar)
@@ -420,11 +446,17 @@ def main():
             out["config"]["output_rows_last_step"] = int(last["out"].shape[0])
             out["config"]["rois_last_step"] = int(getattr(net, "_last", {}).get("n_img", torch.zeros(1)).sum().item()) \
                 + batch * 2 if args.workload == "full" else int(net._last_train["k"])
+        if args.workload == "detector_train":
+            out["config"]["grad_bucket_bytes"] = int(last.get("bucket_bytes", 0))
+            out["config"]["loss_last_step"] = round(float(last["loss"]), 5)
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "fp32 inference", "fp32 detector training step (forward + HIP backward of every layer, eval-mode BN, "
+                "full-gradient all-reduce, SGD)")
         if args.workload == "train":
             out["config"]["grad_bucket_bytes"] = int(last.get("bucket_bytes", 0))
             out["config"]["loss_last_step"] = round(float(last["loss"]), 5)
             out["config"]["workload"] = out["config"]["workload"].replace("inference", "training (heads), inference (detector)")
-        if args.workload != "train":
+        if args.workload in ("full", "detector"):
             rois = out["config"].get("rois_last_step", 0)
             out["stages"] = stage_roofline(model, net, x, step, rois)
         if os.environ.get("BENCH_LAYERS"):

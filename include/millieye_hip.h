@@ -312,12 +312,13 @@ int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld
  * me_affine_act_bwd_f32: conv block y = act(scale*c + shift) with the stored output y [rows,channels] and dy:
  *   dc = dy * act'(y) * scale (scale NULL = 1), dshift[c] = sum dy*act'(y) (= d beta, or d bias when there is no BN),
  *   dgamma[c] = sum dy*act'(y) * xhat with xhat = (act^-1(y) - beta) / gamma (gamma/beta/dgamma NULL when no BN).
- *   act: linear or leaky.  workspace: me_bn_workspace_bytes(channels).  Fixed-order reductions.
+ *   act: linear or leaky.  workspace: me_affine_bwd_workspace_bytes(rows, channels).  Fixed-order reductions.
  * me_upsample2_bwd_f32: dx [n,h,w,c] += 2x2 block sums of dy [n,2h,2w,c] (nearest x2, models.py:82-92).
  * me_maxpool_bwd_f32: dx += dy routed to the first maximum of each window (MaxPool2d / ZeroPad2d+MaxPool2d, :43-49).
  * me_yolo_loss_bwd_f32: d(loss)/d(raw map) of one YOLOLayer (:196-214) from the build_targets tensors
  *   (obj / noobj masks [N,A,G,G] u8; tx,ty,tw,th,tconf [N,A,G,G]; tcls [N,A,G,G,C]), n_obj / n_noobj = mask counts,
  *   grad_scale = upstream gradient of the scalar loss; raw / draw are NHWC [N,G,G,A*(5+C)] with a pitch. */
+int64_t me_affine_bwd_workspace_bytes(int32_t rows, int32_t channels);
 int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
                           const float* scale, const float* gamma, const float* beta, int32_t act, float* dc, int64_t lddc,
                           float* dshift, float* dgamma, void* workspace, void* stream);
@@ -340,6 +341,13 @@ int me_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, f
 int me_conv_wgrad_f32(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n,
                       int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
                       void* stream);
+/* the same weight gradient on the matrix pipe (v_mfma_f32_32x32x2_f32, reduction over the output pixels split into
+ * slices whose slabs are added in a fixed order: deterministic).  workspace: me_conv_wgrad_workspace_bytes(n, ho, wo,
+ * cin, cout, ksize) bytes (0 = no slicing needed); without it the kernel runs unsliced (correct, slower). */
+int64_t me_conv_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize);
+int me_conv_wgrad_mfma_f32(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n,
+                           int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 /* RoI pooling backward: grad_out [k,c_out,7,7] scattered (atomicAdd) into the zero-filled NHWC grad_map */
 int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
                          int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch, void* stream);

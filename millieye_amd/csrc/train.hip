@@ -289,6 +289,109 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv weight gradient on the matrix pipe.  Per filter tap this is a GEMM whose reduction runs over the output
+// pixels: dW_tap[co][ci] = sum_p dY[p][co] * X[p (+) tap][ci].  Both operands are "K-major" in memory (channels
+// contiguous, pixels strided), so LDS holds [pixel][channel] tiles and every v_mfma_f32_32x32x2_f32 takes one
+// ds_read_b32 per operand (lane i, k-half kk reads row 2t+kk, column i; the column is XOR-ed with 32*(row&1) so the
+// two rows of a k-step hit different banks).  One workgroup = 64 co x 64 ci of one tap over a slice of the pixels
+// (blockIdx.z = tap * splits + split); 4 waves, each a 32x32 accumulator.  Global loads of stage s+1 are issued into
+// registers before the MFMAs of stage s (two LDS buffers, one barrier per stage).  Slices write slabs
+// [split][cout][k*k][cin] that conv_wgrad_reduce_kernel adds in split order (deterministic).
+// ---------------------------------------------------------------------------------------------
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const float* __restrict__ X, long long xp,
+                                                              const float* __restrict__ DY, long long dyp, float* OUT,
+                                                              int n, int h, int w, int cin, int cout, int ks, int stride,
+                                                              int pad, int ho, int wo, int splits, int px_per_split) {
+  __shared__ __attribute__((aligned(16))) float Ys[2][16][64];
+  __shared__ __attribute__((aligned(16))) float Xs[2][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tap = blockIdx.z / splits, split = blockIdx.z - tap * splits;
+  const int ky = tap / ks, kx = tap - ky * ks;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+  const int P = n * ho * wo;
+  const int p_begin = split * px_per_split;
+  const int p_end = (p_begin + px_per_split < P) ? p_begin + px_per_split : P;
+  const int hw = ho * wo;
+  // loader role: pixel row pp of the stage, 4 consecutive channels cc
+  const int pp = tid >> 4, cc = (tid & 15) * 4;
+  const int sw_cc = cc ^ ((pp & 1) << 5);  // swizzled LDS column
+
+  float4 ry = make_float4(0.f, 0.f, 0.f, 0.f), rx = ry;
+  auto fetch = [&](int p0) {
+    const int p = p0 + pp;
+    ry = make_float4(0.f, 0.f, 0.f, 0.f);
+    rx = ry;
+    if (p < p_end) {
+      const float* yrow = DY + (long long)p * dyp + co0 + cc;
+      const int nimg = p / hw;
+      const int rem = p - nimg * hw;
+      const int oy = rem / wo, ox = rem - oy * wo;
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+      const float* xrow = X + ((long long)(nimg * h + iy) * w + ix) * xp + ci0 + cc;
+      if (VEC) {
+        if (co0 + cc < cout) ry = *reinterpret_cast<const float4*>(yrow);
+        if (inb && ci0 + cc < cin) rx = *reinterpret_cast<const float4*>(xrow);
+      } else {
+        if (co0 + cc + 0 < cout) ry.x = yrow[0];
+        if (co0 + cc + 1 < cout) ry.y = yrow[1];
+        if (co0 + cc + 2 < cout) ry.z = yrow[2];
+        if (co0 + cc + 3 < cout) ry.w = yrow[3];
+        if (inb) {
+          if (ci0 + cc + 0 < cin) rx.x = xrow[0];
+          if (ci0 + cc + 1 < cin) rx.y = xrow[1];
+          if (ci0 + cc + 2 < cin) rx.z = xrow[2];
+          if (ci0 + cc + 3 < cin) rx.w = xrow[3];
+        }
+      }
+    }
+  };
+
+  wg_f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int i32 = lane & 31, kk = lane >> 5;
+  const int a_col = (wr * 32 + i32) ^ (kk << 5), b_col = (wc * 32 + i32) ^ (kk << 5);
+
+  fetch(p_begin);
+  int buf = 0;
+  for (int p0 = p_begin; p0 < p_end; p0 += 16) {
+    *reinterpret_cast<float4*>(&Ys[buf][pp][sw_cc]) = ry;
+    *reinterpret_cast<float4*>(&Xs[buf][pp][sw_cc]) = rx;
+    __syncthreads();
+    if (p0 + 16 < p_end) fetch(p0 + 16);  // in flight while the matrix pipe works
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float a = Ys[buf][2 * t + kk][a_col];
+      const float b = Xs[buf][2 * t + kk][b_col];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+  // C layout of the 32x32 MFMA: lane (column i32 = ci, row group kk), element e -> row (e&3) + 8*(e>>2) + 4*kk = co
+  float* out = OUT + (long long)split * cout * ks * ks * cin;
+  const int ci = ci0 + wc * 32 + i32;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int co = co0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+    if (co < cout && ci < cin) out[((long long)co * ks * ks + tap) * cin + ci] = acc[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* DW, long long count,
+                                                                int splits) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    float v = slabs[i];
+    for (int k = 1; k < splits; ++k) v += slabs[(long long)k * count + i];
+    DW[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RoI pooling backward (torchvision roi_align / ps_roi_align backward semantics, oracle/tv_ops.c):
 // every sample scatters grad * w / count to its four bilinear corners with atomicAdd.
 // grad_map is NHWC [n,h,w,c] (pitch), zero-filled by the caller.
@@ -363,32 +466,54 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const float* __restrict__ 
 // conv block y = act(scale * c + shift), c = conv(x, W), (scale, shift) = folded BN(eval) or (1, bias):
 // g = dy * act'(y); dc = g * scale; per channel s0 = sum g (= dbeta / dbias), s1 = sum g * xhat (= dgamma) with
 // xhat = (z - beta) / gamma recovered from the stored output (z = act^-1(y): LeakyReLU is invertible).
+// grid (ceil(C / 64), chunks): a block owns 64 channels x one row chunk; its 256 threads are 64 channels x 4 row lanes
+// (a wave reads 64 consecutive channels of one row), the four lanes of a channel are combined through LDS.
 __global__ __launch_bounds__(256) void affine_bwd_partial_kernel(const float* __restrict__ Y, long long ldy,
                                                                  const float* __restrict__ G, long long ldg, int rows,
                                                                  int C, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int act, float* p0,
-                                                                 float* p1) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+                                                                 float* p1, int chunks) {
+  __shared__ double s0s[4][64], s1s[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int chunk = blockIdx.y;
-  if (c >= C) return;
-  const int per = (rows + BN_CHUNKS - 1) / BN_CHUNKS;
+  const int per = (rows + chunks - 1) / chunks;
   const int r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
-  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-  const float inv_ga = (gamma && ga != 0.f) ? 1.f / ga : 0.f;
   double s0 = 0.0, s1 = 0.0;
-  for (int r = r0; r < r1; ++r) {
-    const float y = Y[(long long)r * ldy + c];
-    float g = G[(long long)r * ldg + c];
-    float z = y;
-    if (act == ME_ACT_LEAKY) {
-      g = y > 0.f ? g : 0.1f * g;
-      z = y > 0.f ? y : y * 10.f;
+  if (c < C) {
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float inv_ga = (gamma && ga != 0.f) ? 1.f / ga : 0.f;
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float y = Y[(long long)r * ldy + c];
+      float g = G[(long long)r * ldg + c];
+      float z = y;
+      if (act == ME_ACT_LEAKY) {
+        g = y > 0.f ? g : 0.1f * g;
+        z = y > 0.f ? y : y * 10.f;
+      }
+      s0 += g;
+      s1 += (double)g * ((z - be) * inv_ga);
     }
-    s0 += g;
-    s1 += (double)g * ((z - be) * inv_ga);
   }
-  p0[(long long)chunk * C + c] = (float)s0;
-  p1[(long long)chunk * C + c] = (float)s1;
+  s0s[rl][cl] = s0;
+  s1s[rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    p0[(long long)chunk * C + c] = (float)(((s0s[0][cl] + s0s[1][cl]) + s0s[2][cl]) + s0s[3][cl]);
+    p1[(long long)chunk * C + c] = (float)(((s1s[0][cl] + s1s[1][cl]) + s1s[2][cl]) + s1s[3][cl]);
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(float* p0, float* p1, int C, int chunks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s0 += p0[(long long)k * C + c];
+    s1 += p1[(long long)k * C + c];
+  }
+  p0[c] = (float)s0;
+  p1[c] = (float)s1;
 }
 
 __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __restrict__ Y, long long ldy,
@@ -606,6 +731,17 @@ int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld
   return me::check_launch("bn_train_bwd");
 }
 
+static int affine_chunks(int rows) {
+  int c = rows / 256;
+  if (c < 1) c = 1;
+  if (c > 1024) c = 1024;
+  return c;
+}
+
+int64_t me_affine_bwd_workspace_bytes(int32_t rows, int32_t channels) {
+  return (int64_t)2 * affine_chunks(rows) * channels * (int64_t)sizeof(float);
+}
+
 int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
                           const float* scale, const float* gamma, const float* beta, int32_t act, float* dc, int64_t lddc,
                           float* dshift, float* dgamma, void* workspace, void* stream_) {
@@ -613,12 +749,12 @@ int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t 
   ME_REQUIRE(y && dy && dc && workspace, ME_E_NULLPTR, "me_affine_act_bwd_f32: null pointer");
   ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_affine_act_bwd_f32: bad dimensions");
   ME_REQUIRE(act == ME_ACT_LINEAR || act == ME_ACT_LEAKY, ME_E_BADARG, "me_affine_act_bwd_f32: activation %d", act);
+  const int chunks = affine_chunks(rows);
   float* p0 = reinterpret_cast<float*>(workspace);
-  float* p1 = p0 + (long long)BN_CHUNKS * channels;
-  const unsigned cb = (channels + 255) / 256;
-  hipLaunchKernelGGL(affine_bwd_partial_kernel, dim3(cb, BN_CHUNKS), dim3(256), 0, stream, y, (long long)ldy, dy,
-                     (long long)lddy, rows, channels, gamma, beta, act, p0, p1);
-  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, channels);
+  float* p1 = p0 + (long long)chunks * channels;
+  hipLaunchKernelGGL(affine_bwd_partial_kernel, dim3((channels + 63) / 64, chunks), dim3(256), 0, stream, y, (long long)ldy,
+                     dy, (long long)lddy, rows, channels, gamma, beta, act, p0, p1, chunks);
+  hipLaunchKernelGGL(affine_bwd_reduce_kernel, dim3((channels + 255) / 256), dim3(256), 0, stream, p0, p1, channels, chunks);
   hipLaunchKernelGGL(affine_bwd_apply_kernel, dim3(grid1d((long long)rows * channels)), dim3(256), 0, stream, y,
                      (long long)ldy, dy, (long long)lddy, (long long)rows, channels, scale, act, dc, (long long)lddc, p0, p1,
                      dshift, dgamma);
@@ -687,6 +823,55 @@ int me_conv_wgrad_f32(const float* x, int64_t x_pitch, const float* dy, int64_t 
   hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy, (long long)dy_pitch, dw,
                      n, h, w, cin, cout, ksize, stride, pad, ho, wo);
   return me::check_launch("conv_wgrad_kernel");
+}
+
+// pixel slices so that the grid has ~2048 workgroups; each slice a multiple of 16 pixels
+static int wgrad_splits(long long P, int cin, int cout, int ks) {
+  const long long tiles = (long long)((cin + 63) / 64) * ((cout + 63) / 64) * ks * ks;
+  long long s = (2048 + tiles - 1) / tiles;
+  const long long max_s = (P + 63) / 64;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+int64_t me_conv_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize) {
+  const int s = wgrad_splits((long long)n * ho * wo, cin, cout, ksize);
+  return s > 1 ? (int64_t)s * cout * ksize * ksize * cin * (int64_t)sizeof(float) : 0;
+}
+
+int me_conv_wgrad_mfma_f32(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n,
+                           int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
+                           void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(x && dy && dw, ME_E_NULLPTR, "me_conv_wgrad_mfma_f32: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0,
+             ME_E_BADARG, "me_conv_wgrad_mfma_f32: bad dimensions");
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+  const long long P = (long long)n * ho * wo;
+  ME_REQUIRE(P < (1ll << 31), ME_E_TOOBIG, "me_conv_wgrad_mfma_f32: too many output pixels");
+  int splits = wgrad_splits(P, cin, cout, ksize);
+  const long long count = (long long)cout * ksize * ksize * cin;
+  if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * count * (int64_t)sizeof(float))) splits = 1;
+  int per = (int)((P + splits - 1) / splits);
+  per = (per + 15) & ~15;
+  ME_REQUIRE((long long)ksize * ksize * splits < 65536, ME_E_TOOBIG, "me_conv_wgrad_mfma_f32: grid too large");
+  float* out = splits > 1 ? reinterpret_cast<float*>(workspace) : dw;
+  const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (x_pitch % 4 == 0) && (dy_pitch % 4 == 0) && me::aligned16(x) &&
+                   me::aligned16(dy);
+  dim3 grid((cin + 63) / 64, (cout + 63) / 64, ksize * ksize * splits);
+  if (vec)
+    hipLaunchKernelGGL(conv_wgrad_mfma_kernel<true>, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,
+                       (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per);
+  else
+    hipLaunchKernelGGL(conv_wgrad_mfma_kernel<false>, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,
+                       (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per);
+  int rc = me::check_launch("conv_wgrad_mfma_kernel");
+  if (rc || splits == 1) return rc;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid1d(count)), dim3(256), 0, stream,
+                     reinterpret_cast<const float*>(workspace), dw, count, splits);
+  return me::check_launch("conv_wgrad_reduce_kernel");
 }
 
 static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w, int32_t c,

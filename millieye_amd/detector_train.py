@@ -14,11 +14,10 @@ forward   every module output is kept (NHWC): ``me_conv2d_f32`` (folded BN + Lea
           ``build_targets`` masks come from ``YOLOLayer.loss_from_raw`` (index bookkeeping, as in the reference).
 backward  ``me_yolo_loss_bwd_f32`` seeds the raw detection maps; modules are walked in reverse:
           ``me_affine_act_bwd_f32`` (activation + BN-affine backward, d gamma / d beta / d bias),
-          ``me_conv_wgrad_f32`` (weight gradient), the data gradient as ``me_conv2d_f32`` on the 180-degree rotated,
+          ``me_conv_wgrad_mfma_f32`` (weight gradient on the matrix pipe), the data gradient as ``me_conv2d_f32`` on the 180-degree rotated,
           transposed weights (stride 2: on the zero-interleaved gradient; the 255 / 51-channel detection convs:
           ``me_gemm_f32``), ``me_upsample2_bwd_f32``, ``me_maxpool_bwd_f32``, ``me_add_f32`` for fan-out accumulation.
 
-Correctness first: the weight-gradient kernel is the simple tiled one of the stage-3 heads; an MFMA wgrad is future work.
 """
 import ctypes as C
 
@@ -144,7 +143,7 @@ class DetectorTrainer:
                 dc = torch.empty_like(y)
                 dshift = torch.empty(cout, device=dev)
                 dgamma = torch.empty(cout, device=dev) if bn is not None else None
-                ws = torch.empty(lib.me_bn_workspace_bytes(cout), dtype=torch.uint8, device=dev)
+                ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
                 gam = bn.weight.detach().to(dev, torch.float32).contiguous() if bn is not None else None
                 bet = bn.bias.detach().to(dev, torch.float32).contiguous() if bn is not None else None
                 hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
@@ -164,9 +163,7 @@ class DetectorTrainer:
                 else:
                     xin = outs[i - 1]
                 _, h, w, cin = xin.shape
-                dw = torch.empty((cout, k, k, cin), device=dev, dtype=torch.float32)
-                hip.check(lib.me_conv_wgrad_f32(xin.data_ptr(), cin, dc.data_ptr(), cout, dw.data_ptr(), n, h, w, cin, cout,
-                                                k, s, pad, stream()), "me_conv_wgrad_f32")
+                dw = hip.conv_wgrad(xin, dc, k, s, pad)  # MFMA weight gradient
                 grads[f"module_list.{i}.conv_{i}.weight"] = dw.permute(0, 3, 1, 2).contiguous()
                 if i == 0:
                     continue

@@ -144,6 +144,7 @@ SIGNATURES = {
     "me_bn_train_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "me_affine_bwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "me_affine_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
@@ -157,6 +158,9 @@ SIGNATURES = {
                                  C.c_int32, C.c_int32, C.c_void_p]),
     "me_conv_wgrad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "me_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int32] * 6),
+    "me_conv_wgrad_mfma_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
+                               + [C.c_void_p, C.c_int64, C.c_void_p]),
     "me_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "me_ps_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -412,3 +416,21 @@ def roi_align(map_nhwc, rois, pooled=7, spatial_scale=1.0 / 16):
 def ps_roi_align(map_nhwc, rois, pooled=7, spatial_scale=1.0 / 16):
     """torchvision.ops.ps_roi_align(sampling_ratio=-1) on an NHWC map -> [K,C/49,7,7]."""
     return _roi("me_ps_roi_align_f32", map_nhwc, rois, pooled, spatial_scale, True)
+
+
+def conv_wgrad(x_nhwc, dy_nhwc, ksize, stride, pad):
+    """dW [cout, k, k, cin] (the packed layout of me_conv2d_f32) of y = conv(x, W) given dy, on the matrix pipe
+    (me_conv_wgrad_mfma_f32; slices of the pixel reduction go through a workspace and are added in a fixed order)."""
+    _require_cuda_f32(x_nhwc, "x")
+    _require_cuda_f32(dy_nhwc, "dy")
+    n, h, w, cin = x_nhwc.shape
+    _, ho, wo, cout = dy_nhwc.shape
+    dw = torch.empty((cout, ksize, ksize, cin), device=x_nhwc.device, dtype=torch.float32)
+    need = lib().me_conv_wgrad_workspace_bytes(n, ho, wo, cin, cout, ksize)
+    ws_ptr, keep = (None, None)
+    if need > 0:
+        ws_ptr, keep = _workspace(need, x_nhwc.device, slot="wgrad")
+    check(lib().me_conv_wgrad_mfma_f32(x_nhwc.data_ptr(), x_nhwc.stride(2), dy_nhwc.data_ptr(), dy_nhwc.stride(2),
+                                       dw.data_ptr(), n, h, w, cin, cout, ksize, stride, pad, ws_ptr, need, stream_ptr()),
+          "me_conv_wgrad_mfma_f32")
+    return dw

@@ -95,6 +95,28 @@ def test_conv_wgrad_and_dgrad(hip_lib, cin, cout, k):
         assert _rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-4
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,k,s", [(2, 10, 12, 32, 64, 3, 1), (3, 13, 13, 64, 255, 1, 1), (2, 16, 16, 3, 32, 3, 1),
+                                                (2, 20, 20, 32, 64, 3, 2), (1, 7, 7, 10, 10, 7, 1), (4, 26, 26, 128, 256, 3, 1),
+                                                (1, 5, 9, 48, 20, 3, 1)])
+def test_conv_wgrad_mfma(hip_lib, n, h, w, cin, cout, k, s):
+    """me_conv_wgrad_mfma_f32 (matrix-pipe weight gradient, sliced pixel reduction + ordered slab sum) against torch
+    CPU autograd: stride 2, ragged / unaligned channel counts (cin 3, cout 255), 1x1 and 7x7 (pad 0), many slices."""
+    from millieye_amd import hip
+    pad = 0 if k == 7 else (k - 1) // 2
+    tag = f"wm{n}{h}{cin}{cout}{k}{s}"
+    x = _t(tag + "x", (n, cin, h, w))
+    wt = _t(tag + "w", (cout, cin, k, k), -0.2, 0.2).requires_grad_(True)
+    y = F.conv2d(x, wt, None, s, pad)
+    dy = _t(tag + "dy", tuple(y.shape))
+    y.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dw = hip.conv_wgrad(xd, dyd, k, s, pad)
+    dw2 = hip.conv_wgrad(xd, dyd, k, s, pad)
+    assert torch.equal(dw, dw2), "the sliced reduction must be deterministic"
+    assert _rel(dw.permute(0, 3, 1, 2), wt.grad) < 1e-4
+
+
 def test_roi_backward_vs_oracle(hip_lib):
     from millieye_amd import hip
     from oracle import tv_ops
