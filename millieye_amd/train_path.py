@@ -34,6 +34,16 @@ def _ptr(t):
 
 
 def _gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, alpha=1.0, beta=0.0):
+    if ta and not tb and alpha == 1.0 and beta == 0.0 and ldc == n and k >= 64:
+        # C[m,n] = A^T B with A [k,m], B [k,n]: the weight gradient of a 1x1 convolution over k "pixels" -> matrix pipe
+        lib = hip.lib()
+        need = lib.me_conv_wgrad_workspace_bytes(1, k, 1, n, m, 1)
+        ws_ptr, _keep = (None, None)
+        if need > 0:
+            ws_ptr, _keep = hip._workspace(need, c.device, slot="wgrad")
+        hip.check(lib.me_conv_wgrad_mfma_f32(_ptr(b), ldb, _ptr(a), lda, _ptr(c), 1, k, 1, n, m, 1, 1, 0, ws_ptr, need,
+                                             hip.stream_ptr()), "me_conv_wgrad_mfma_f32")
+        return
     hip.check(hip.lib().me_gemm_f32(int(ta), int(tb), m, n, k, alpha, _ptr(a), lda, _ptr(b), ldb, beta, _ptr(c), ldc,
                                     hip.stream_ptr()), "me_gemm_f32")
 
@@ -85,9 +95,16 @@ def _conv(x, x_pitch, n, h, w, cin, wgt, scale, shift, k, pad, act, out):
 
 
 def _wgrad(x, x_pitch, dy, dy_pitch, n, h, w, cin, cout, k, pad):
+    """Weight gradient on the matrix pipe (me_conv_wgrad_mfma_f32); returns OIHW like the parameter."""
     dw = _f32(x.device, cout, k, k, cin)
-    hip.check(hip.lib().me_conv_wgrad_f32(_ptr(x), x_pitch, _ptr(dy), dy_pitch, _ptr(dw), n, h, w, cin, cout, k, 1,
-                                          pad, hip.stream_ptr()), "me_conv_wgrad_f32")
+    lib = hip.lib()
+    ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+    need = lib.me_conv_wgrad_workspace_bytes(n, ho, wo, cin, cout, k)
+    ws_ptr, _keep = (None, None)
+    if need > 0:
+        ws_ptr, _keep = hip._workspace(need, x.device, slot="wgrad")
+    hip.check(lib.me_conv_wgrad_mfma_f32(_ptr(x), x_pitch, _ptr(dy), dy_pitch, _ptr(dw), n, h, w, cin, cout, k, 1, pad,
+                                         ws_ptr, need, hip.stream_ptr()), "me_conv_wgrad_mfma_f32")
     return dw.permute(0, 3, 1, 2).contiguous()  # OHWI -> OIHW (the parameter's layout)
 
 
