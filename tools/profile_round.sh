@@ -13,6 +13,7 @@ export MILLIEYE_TUNE_CACHE=/tmp/tune_$TAG.json     # first bench run tunes; the 
 python bench.py > $OUT/${TAG}_bench_full_b32.json 2> $OUT/bench_full.err
 python bench.py --workload detector --no-cpu-baseline > $OUT/${TAG}_bench_detector_b8.json 2>> $OUT/bench_full.err
 python bench.py --workload train --no-cpu-baseline > $OUT/${TAG}_bench_train_b8.json 2>> $OUT/bench_full.err
+python bench.py --workload detector_train --no-cpu-baseline > $OUT/${TAG}_bench_detector_train_b8.json 2>> $OUT/bench_full.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d /tmp/pf_$TAG -o full -- python $R/bench.py --no-cpu-baseline > /tmp/pf.log 2>&1
 python $R/tools/prof_summary.py /tmp/pf_$TAG/full_results.db | head -40 > $OUT/${TAG}_bench_full_b32_kernel_stats.txt
