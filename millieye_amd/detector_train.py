@@ -2,9 +2,10 @@
 
 Reference: ``module3_our_dataset/yolov3/models.py:181-267`` - with ``targets`` the module loop returns the summed YOLO
 loss of every scale and torch autograd differentiates the whole backbone.  No reference script trains the detector
-(``train.py:170`` keeps ``base_detector.eval()`` and Network detaches its outputs), so BatchNorm runs in **eval** mode here
-too: a per-channel affine ``scale * conv + shift`` whose ``weight`` / ``bias`` still receive gradients, exactly like
-``F.batch_norm(training=False)`` does.  Train-mode (batch-statistics) BatchNorm inside the detector raises.
+(``train.py:170`` keeps ``base_detector.eval()`` and Network detaches its outputs).  Both BatchNorm modes are covered, per
+layer: **eval** = a per-channel affine ``scale * conv + shift`` whose ``weight`` / ``bias`` still receive gradients, exactly
+like ``F.batch_norm(training=False)``; **train** = batch statistics (``me_bn_train_fwd_f32`` / ``me_bn_train_bwd_f32``) with
+the running statistics updated by the module's momentum (0.9 in this model, models.py:38).
 
 The graph is static, so forward and backward are explicit launch sequences over ``libmillieye_hip`` and autograd sees
 one :class:`torch.autograd.Function` whose inputs are the detector parameters:
@@ -56,19 +57,35 @@ class DetectorTrainer:
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             raise hip.MeError("Darknet training forward needs a 4-D CUDA float32 tensor; there is no CPU fallback")
         m, lib = self.m, hip.lib()
+        from .train_path import _bn_fwd
         eng = m.engine
         x = x.contiguous()
-        eng.refresh_weights(x.device)  # raises for train-mode BatchNorm
         defs = m.module_defs
-        outs, raws = [], {}
+        outs, raws, bn_state = [], {}, {}
+        ws_t = torch.empty(int(lib.me_bn_workspace_bytes(2048)) + 256, dtype=torch.uint8, device=x.device)
+        ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256
         for i, d in enumerate(defs):
             t = d["type"]
             if t == "convolutional":
                 cw = eng._conv_weights(i)
+                cw.refresh(x.device)
                 k, s = int(d["size"]), int(d["stride"])
                 act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
                 src = x if i == 0 else outs[i - 1]
-                y = hip.conv2d(src, cw.wgt, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0))
+                seq = m.module_list[i]
+                bn = seq[1] if len(seq) > 1 and isinstance(seq[1], torch.nn.BatchNorm2d) else None
+                if bn is not None and bn.training:  # batch statistics: plain convolution, then BN(train) + activation
+                    cout = cw.wgt.shape[0]
+                    if cout > 2048:
+                        raise hip.MeError("train-mode BatchNorm: more than 2048 channels")
+                    ones, zeros = torch.ones(cout, device=x.device), torch.zeros(cout, device=x.device)
+                    c_raw = hip.conv2d(src, cw.wgt, ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, x_nchw=(i == 0))
+                    y = torch.empty_like(c_raw)
+                    rows = c_raw.numel() // cout
+                    st_bn = _bn_fwd(c_raw, cout, rows, cout, bn, act, y, cout, ws)
+                    bn_state[i] = (c_raw, st_bn)
+                else:
+                    y = hip.conv2d(src, cw.wgt, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0))
             elif t == "maxpool":
                 k, s = int(d["size"]), int(d["stride"])
                 y = hip.maxpool(outs[i - 1], k, s, zero_ext=(k == 2 and s == 1))
@@ -98,7 +115,7 @@ class DetectorTrainer:
                 raise ValueError(f"unsupported cfg block [{t}] at module {i}")
             outs.append(y)
         st = _State()
-        st.x, st.outs, st.raws = x, outs, raws
+        st.x, st.outs, st.raws, st.bn_state = x, outs, raws, bn_state
         return st
 
     # ------------------------------------------------------------------------------------------ backward
@@ -141,15 +158,22 @@ class DetectorTrainer:
                 n, ho, wo, cout = y.shape
                 rows = n * ho * wo
                 dc = torch.empty_like(y)
-                dshift = torch.empty(cout, device=dev)
-                dgamma = torch.empty(cout, device=dev) if bn is not None else None
-                ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
-                gam = bn.weight.detach().to(dev, torch.float32).contiguous() if bn is not None else None
-                bet = bn.bias.detach().to(dev, torch.float32).contiguous() if bn is not None else None
-                hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
-                                                    cw.scale.data_ptr() if bn is not None else None, _ptr(gam), _ptr(bet),
-                                                    act, dc.data_ptr(), cout, dshift.data_ptr(), _ptr(dgamma),
-                                                    ws.data_ptr(), stream()), "me_affine_act_bwd_f32")
+                if i in st.bn_state:  # train-mode BatchNorm: gradient through the batch statistics
+                    from .train_path import _bn_bwd
+                    c_raw, st_bn = st.bn_state[i]
+                    ws = torch.empty(int(lib.me_bn_workspace_bytes(cout)) + 256, dtype=torch.uint8, device=dev)
+                    dgamma, dshift = _bn_bwd(c_raw, cout, dy, cout, rows, cout, bn, st_bn, act, dc, cout,
+                                             ws.data_ptr() + (-ws.data_ptr()) % 256)
+                else:
+                    dshift = torch.empty(cout, device=dev)
+                    dgamma = torch.empty(cout, device=dev) if bn is not None else None
+                    ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
+                    gam = bn.weight.detach().to(dev, torch.float32).contiguous() if bn is not None else None
+                    bet = bn.bias.detach().to(dev, torch.float32).contiguous() if bn is not None else None
+                    hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
+                                                        cw.scale.data_ptr() if bn is not None else None, _ptr(gam),
+                                                        _ptr(bet), act, dc.data_ptr(), cout, dshift.data_ptr(),
+                                                        _ptr(dgamma), ws.data_ptr(), stream()), "me_affine_act_bwd_f32")
                 if bn is not None:
                     grads[f"module_list.{i}.batch_norm_{i}.weight"] = dgamma
                     grads[f"module_list.{i}.batch_norm_{i}.bias"] = dshift
@@ -237,6 +261,7 @@ class _DarknetLoss(torch.autograd.Function):
             seeds[idx] = bt
         ctx.trainer, ctx.st, ctx.seeds, ctx.names = trainer, st, seeds, names
         ctx.model = model
+        model._train_state = st  # Darknet._forward_train reads the decoded rows / feature tap from it
         return loss.detach().clone()
 
     @staticmethod

@@ -271,18 +271,25 @@ class Darknet(nn.Module):
     def _forward_train(self, x, targets):
         """``(loss, featuremap, yolo_outputs)`` with a differentiable loss (reference :181-267 under autograd): every
         module output is kept and ``loss.backward()`` runs the HIP backward of millieye_amd/detector_train.py.  The
-        decoded ``yolo_outputs`` / ``featuremap`` come from the regular inference engine on the same weights."""
+        decoded ``yolo_outputs`` / ``featuremap`` are taken from that same forward."""
+        from .. import hip
         from ..detector_train import _DarknetLoss
-        with torch.no_grad():
-            plan, yolo_outputs = self._run(x)
-            if getattr(plan, "graph", None) is not None:
-                yolo_outputs = yolo_outputs.clone()
-            if plan.tap is not None:
-                self.featuremap = plan.tap.clone()
-        if not hasattr(self, "featuremap"):
-            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         named = [(k, p) for k, p in self.named_parameters()]
         loss = _DarknetLoss.apply(self, x, targets, [k for k, _ in named], *[p for _, p in named])
+        st = self.__dict__.pop("_train_state")
+        with torch.no_grad():  # decoded rows + feature tap straight from the training forward (works for both BN modes)
+            rows_total = sum(l.num_anchors * r.shape[1] * r.shape[2] for l, (_i, r) in zip(self.yolo_layers, sorted(st.raws.items())))
+            yolo_outputs, off = None, 0
+            for layer, (_idx, raw) in zip(self.yolo_layers, sorted(st.raws.items())):
+                yolo_outputs = hip.yolo_decode(raw, layer.anchors, layer.num_classes, x.shape[2], out=yolo_outputs,
+                                               rows_total=rows_total, row_offset=off)
+                off += layer.num_anchors * raw.shape[1] * raw.shape[2]
+                layer.grid_size, layer.stride = raw.shape[1], x.shape[2] / raw.shape[1]
+            tap = self.engine.tap_module
+            if tap is not None and tap < len(st.outs) and st.outs[tap] is not None:
+                self.featuremap = hip.nhwc_to_nchw(st.outs[tap])
+        if not hasattr(self, "featuremap"):
+            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         return loss, self.featuremap, yolo_outputs
 
     # -- darknet .weights I/O (reference :269-352) ---------------------------------------------

@@ -163,13 +163,16 @@ def yolo_loss(raw, anchors, num_classes, img_dim, targets, ignore_thres=0.5, obj
     return loss
 
 
-def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list."):
-    """Summed YOLO loss of every scale + its gradient w.r.t. every detector parameter (eval-mode BatchNorm).
-    Returns ``(loss, {name: grad})``; ``state_dict`` is not modified."""
+def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list.", training=False):
+    """Summed YOLO loss of every scale + its gradient w.r.t. every detector parameter.  ``training`` selects the
+    BatchNorm mode (False: running statistics, what every reference script uses; True: batch statistics, momentum 0.9).
+    Returns ``(loss, {name: grad})`` and, with ``training``, ``{name: updated running statistic}`` as a third item;
+    ``state_dict`` is not modified."""
     blocks = parse_cfg_text(cfg_text)[1:]
     img_dim = x.shape[2]
     P = {k: v.detach().clone().requires_grad_(True) for k, v in state_dict.items()
          if v.dtype == torch.float32 and "running_" not in k}
+    B = {k: v.detach().clone() for k, v in state_dict.items() if "running_" in k}
     outs = []
     loss = 0
     for i, b in enumerate(blocks):
@@ -180,8 +183,8 @@ def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list."):
                          padding=(k - 1) // 2)
             if int(b["batch_normalize"]):
                 p = f"{prefix}{i}.batch_norm_{i}."
-                x = F.batch_norm(x, state_dict[p + "running_mean"], state_dict[p + "running_var"], P[p + "weight"],
-                                 P[p + "bias"], False, 0.9, 1e-5)
+                x = F.batch_norm(x, B[p + "running_mean"], B[p + "running_var"], P[p + "weight"], P[p + "bias"], training,
+                                 0.9, 1e-5)
             if b["activation"] == "leaky":
                 x = F.leaky_relu(x, 0.1)
         elif kind == "maxpool":
@@ -199,4 +202,5 @@ def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list."):
             loss = loss + yolo_loss(x, _anchors_of(b), int(b["classes"]), img_dim, targets)
         outs.append(x)
     loss.backward()
-    return loss.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()}
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()}
+    return (loss.detach(), grads, B) if training else (loss.detach(), grads)

@@ -131,7 +131,7 @@ def test_detector_backward_vs_oracle_and_reference_golden(hip_lib):
     torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4).step()
     with torch.no_grad():
         loss3, _, _ = model(x.cuda(), targets)
-    assert float(loss3) < float(loss2)
+    assert float(loss3) < float(loss2.detach())
 
 
 def test_detector_backward_darknet53_vs_oracle(hip_lib):
@@ -150,3 +150,35 @@ def test_detector_backward_darknet53_vs_oracle(hip_lib):
     loss.backward()
     for k, p in model.named_parameters():
         _grad_check(p.grad.cpu(), ref_grads[k], k, tol=5e-3)
+
+
+def test_detector_backward_train_mode_batchnorm(hip_lib):
+    """model.train(): batch-statistics BatchNorm in every conv block (me_bn_train_fwd/bwd_f32), running statistics
+    updated with momentum 0.9 - loss, every gradient and every running statistic against the reference's own run
+    (yololoss_tiny12_s96_n2_bntrain.npz) and the oracle."""
+    import os
+    import numpy as np
+    from millieye_amd import cfgs, synth
+    from oracle import darknet_ref
+    from tests.golden.make_golden import YOLO_LOSS_CASE
+    name, cfg, n, s = YOLO_LOSS_CASE
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_bntrain.npz"))
+    cpu_model = ph.make_darknet(cfg, tag=name)
+    targets = torch.from_numpy(g["targets"])
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    ref_loss, ref_grads, ref_bufs = darknet_ref.darknet_train_step(cfgs.KNOWN[cfg](), cpu_model.state_dict(), x, targets,
+                                                                  training=True)
+    model = ph.make_darknet(cfg, tag=name).cuda().train()
+    loss, fm, yolo = model(x.cuda(), targets)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    assert tuple(fm.shape) == (n, 256, s // 16, s // 16) and yolo.shape == (n, 3 * (3 * 3 + 6 * 6), 17)
+    loss.backward()
+    for k, p in model.named_parameters():
+        _grad_check(p.grad.cpu(), ref_grads[k], k, tol=5e-3)
+        gn = float(g["gnorm/" + k])
+        assert abs(float(p.grad.double().norm()) - gn) <= 5e-3 * max(gn, 1e-6), k
+    sd = model.state_dict()
+    for key in g.files:
+        if key.startswith("buf/"):
+            assert np.allclose(sd[key[4:]].cpu().numpy(), g[key], rtol=1e-3, atol=1e-4), key
+    assert int(sd["module_list.0.batch_norm_0.num_batches_tracked"]) == 1

@@ -93,3 +93,24 @@ def test_oracle_detector_training_step_matches_reference():
             assert np.allclose(gr.flatten()[::max(1, gr.numel() // 64)].numpy(), g["gsamp/" + k], rtol=1e-4, atol=1e-6), k
             checked += 1
     assert checked == 37
+
+
+def test_oracle_detector_training_step_train_mode_bn_matches_reference():
+    """Same with the detector in train() mode: batch-statistics BatchNorm (momentum 0.9), loss, gradients and the
+    updated running statistics against the reference's own run (yololoss_tiny12_s96_n2_bntrain.npz)."""
+    from oracle import darknet_ref
+    from tests.golden.make_golden import YOLO_LOSS_CASE
+    from tests.parity_helpers import make_darknet
+    name, cfg, n, s = YOLO_LOSS_CASE
+    g = np.load(os.path.join(GOLD, name + "_bntrain.npz"))
+    model = make_darknet(cfg, name)
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    loss, grads, bufs = darknet_ref.darknet_train_step(cfgs.KNOWN[cfg](), model.state_dict(), x,
+                                                       torch.from_numpy(g["targets"]), training=True)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    for key in g.files:
+        if key.startswith("gnorm/"):
+            k = key[6:]
+            assert abs(float(grads[k].double().norm()) - float(g[key])) <= 2e-4 * max(1e-6, float(g[key])), k
+        elif key.startswith("buf/"):
+            assert np.allclose(bufs[key[4:]].numpy(), g[key], rtol=1e-5, atol=1e-6), key
