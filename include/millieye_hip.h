@@ -264,6 +264,22 @@ int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t 
                     const me_heads_weights* w, float refine_threshold, float* regress_out, float* refine_out,
                     float* mask_out, float* out_rows, uint8_t* keep, float* sort_key, void* stream);
 
+/* ---- stage-2 training building blocks (module2_mixed/my_models.py:96-164 heads, :366-459 objective) ------------------
+ * me_linear_f32: y [rows,out] = act(x [rows,in] . w[out,in]^T + bias) (nn.Linear + Linear / LeakyReLU / Sigmoid).
+ * me_mask_scale_f32: y = mask ? x * scale : 0 (nn.Dropout(0.5) in train mode, forward and backward; the mask is drawn
+ *   by the caller with torch's CPU generator, like the reference's run).
+ * me_m2_loss_f32: per-RoI terms [k,5] = (focal on softmax(o), confidence BCE, category BCE, SmoothL1 xy, SmoothL1 wh) and
+ *   the gradients d_o [k,2], d_refine [k,c1], d_regress [k,4] of
+ *   focal + (conf + category)/lambda0 + (xy + wh)/lambda1, times grad_scale; pos / sample are the IoU-positive and the
+ *   sampled rows, class_label [k,c1-1] and target_location [k,4] come from the host-side labelling. */
+int me_linear_f32(const float* x, int64_t ldx, int64_t rows, int32_t in_features, const float* w, const float* bias,
+                  int32_t out_features, int32_t act, float* y, int64_t ldy, void* stream);
+int me_mask_scale_f32(const float* x, const uint8_t* mask, float scale, int64_t count, float* y, void* stream);
+int me_m2_loss_f32(const float* o, const float* refine, int32_t c1, const float* regress, const float* boxes,
+                   int32_t box_cols, const float* target_location, const float* class_label, const uint8_t* pos,
+                   const uint8_t* sample, int32_t k, float alpha, float lambda0, float lambda1, float grad_scale,
+                   float* terms, float* d_o, float* d_refine, float* d_regress, void* stream);
+
 /* scalar tail of the heads for `k` RoIs from a saved `small` [k,16] block (training forward; identical
  * arithmetic to the fused inference tail).  d->wts.rscale/rshift must hold the radar_net BatchNorm as an
  * affine on rconv (batch statistics in train mode); reads d->img_boxes / n_img / radar_boxes, writes

@@ -1,0 +1,163 @@
+// Stage-2 (module2_mixed) training building blocks: small dense layers of the refinement / ensemble heads and the
+// stage-2 objective.  Reference: module2_mixed/my_models.py:96-164 (heads), :366-459 (losses).  Everything here is tiny
+// next to the detector (K <= 200 * N RoIs): one thread per output element, fixed-order sums (bit-reproducible).
+#include <math.h>
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+inline unsigned grid_for(long long work) {
+  long long b = (work + 255) / 256;
+  if (b > 65535) b = 65535;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == ME_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+  if (act == ME_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+
+// y[r][o] = act(sum_i x[r][i] * w[o][i] + b[o])  (nn.Linear + activation)
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, long long ldx, long long rows, int in_f,
+                                                     const float* __restrict__ W, const float* __restrict__ B, int out_f,
+                                                     int act, float* Y, long long ldy) {
+  const long long total = rows * out_f;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int o = (int)(idx % out_f);
+    const long long r = idx / out_f;
+    const float* x = X + r * ldx;
+    const float* w = W + (long long)o * in_f;
+    float acc = 0.f;
+    for (int i = 0; i < in_f; ++i) acc = fmaf(x[i], w[i], acc);
+    Y[r * ldy + o] = act_fwd(acc + (B ? B[o] : 0.f), act);
+  }
+}
+
+// y = x * mask * scale  (nn.Dropout in training mode and its backward)
+__global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict__ X, const unsigned char* __restrict__ M,
+                                                         float scale, long long count, float* Y) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
+    Y[i] = M[i] ? X[i] * scale : 0.f;
+}
+
+// Per-RoI terms of the stage-2 loss and their gradients (my_models.py:411-456).
+//   o [K,2]       ensemble fc2 output (after its LeakyReLU); masks = softmax(o)
+//   refine [K,C1] refinement_vector (sigmoid outputs), regress [K,4]
+//   roi = boxes[:, 1:5]; target_location [K,4]; class_label [K,C1-1] (built on the host, with the reference's row quirk)
+//   pos / sample [K] u8
+// terms [K,5] = (focal, conf_bce, category_bce, smooth_l1_xy, smooth_l1_wh) - unscaled sums per RoI;
+// d_o [K,2], d_refine [K,C1], d_regress [K,4] = gradients of
+//   loss = focal + (conf + category) / lambda0 + (xy + wh) / lambda1   times gscale.
+__global__ __launch_bounds__(256) void m2_loss_kernel(const float* __restrict__ O, const float* __restrict__ R, int c1,
+                                                      const float* __restrict__ REG, const float* __restrict__ boxes,
+                                                      int box_cols, const float* __restrict__ tloc,
+                                                      const float* __restrict__ clabel, const unsigned char* __restrict__ pos,
+                                                      const unsigned char* __restrict__ sample, int k, float alpha,
+                                                      float lambda0, float lambda1, float gscale, float* terms, float* d_o,
+                                                      float* d_r, float* d_reg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const bool is_pos = pos[i] != 0, in_s = sample[i] != 0;
+  float t_focal = 0.f, t_conf = 0.f, t_cat = 0.f, t_xy = 0.f, t_wh = 0.f;
+  float go0 = 0.f, go1 = 0.f;
+  for (int c = 0; c < c1; ++c) d_r[(long long)i * c1 + c] = 0.f;
+  for (int c = 0; c < 4; ++c) d_reg[4ll * i + c] = 0.f;
+  if (in_s) {
+    // softmax over the two logits
+    const float o0 = O[2ll * i], o1 = O[2ll * i + 1];
+    const float m = fmaxf(o0, o1);
+    const float e0 = expf(o0 - m), e1 = expf(o1 - m);
+    const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+    const float p = is_pos ? p1 : p0;
+    const float a = is_pos ? alpha : 1.f - alpha;
+    const float lp = logf(p);
+    t_focal = -a * ((1.f - p) * (1.f - p)) * lp;
+    const float dp = -a * (-2.f * (1.f - p) * lp + (1.f - p) * (1.f - p) / p);  // d focal / d p
+    // p = softmax component c*: dp/do_j = p (delta - p_j)
+    if (is_pos) {
+      go1 = dp * p1 * (1.f - p1);
+      go0 = dp * (-p1 * p0);
+    } else {
+      go0 = dp * p0 * (1.f - p0);
+      go1 = dp * (-p0 * p1);
+    }
+    // confidence BCE (sum) on refinement_vector[:, 0]
+    const float r0 = R[(long long)i * c1];
+    const float y = is_pos ? 1.f : 0.f;
+    t_conf = -(y * fmaxf(logf(r0), -100.f) + (1.f - y) * fmaxf(logf(1.f - r0), -100.f));
+    d_r[(long long)i * c1] = gscale * ((r0 - y) / fmaxf(r0 * (1.f - r0), 1e-12f)) / lambda0;
+  }
+  if (is_pos) {
+    for (int c = 1; c < c1; ++c) {
+      const float r = R[(long long)i * c1 + c], y = clabel[(long long)i * (c1 - 1) + (c - 1)];
+      t_cat += -(y * fmaxf(logf(r), -100.f) + (1.f - y) * fmaxf(logf(1.f - r), -100.f));
+      d_r[(long long)i * c1 + c] = gscale * ((r - y) / fmaxf(r * (1.f - r), 1e-12f)) / lambda0;
+    }
+    // box regression targets (regression_loss, :264-279) and SmoothL1(sum, beta 1) against regress_param
+    const float* b = boxes + (long long)i * box_cols;
+    const float x = (b[1] + b[3]) / 2, yy = (b[2] + b[4]) / 2, w = b[3] - b[1], h = b[4] - b[2];
+    const float* t = tloc + 4ll * i;
+    const float xt = (t[0] + t[2]) / 2, yt = (t[1] + t[3]) / 2, wt = t[2] - t[0], ht = t[3] - t[1];
+    float tgt[4];
+    tgt[0] = (xt - x) / (w + 1e-16f);
+    tgt[1] = (yt - yy) / (h + 1e-16f);
+    tgt[2] = logf(wt / w + 1e-16f);
+    tgt[3] = logf(ht / h + 1e-16f);
+    for (int c = 0; c < 4; ++c) {
+      const float d = tgt[c] - REG[4ll * i + c];
+      const float ad = fabsf(d);
+      const float l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+      if (c < 2) t_xy += l; else t_wh += l;
+      const float dl = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);   // d l / d d; d = target - pred
+      d_reg[4ll * i + c] = gscale * (-dl) / lambda1;
+    }
+  }
+  terms[5ll * i + 0] = t_focal; terms[5ll * i + 1] = t_conf; terms[5ll * i + 2] = t_cat;
+  terms[5ll * i + 3] = t_xy; terms[5ll * i + 4] = t_wh;
+  d_o[2ll * i] = gscale * go0;
+  d_o[2ll * i + 1] = gscale * go1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int me_linear_f32(const float* x, int64_t ldx, int64_t rows, int32_t in_features, const float* w, const float* bias,
+                  int32_t out_features, int32_t act, float* y, int64_t ldy, void* stream) {
+  if (rows == 0) return 0;
+  ME_REQUIRE(x && w && y, ME_E_NULLPTR, "me_linear_f32: null pointer");
+  ME_REQUIRE(rows > 0 && in_features > 0 && out_features > 0 && ldx >= in_features && ldy >= out_features, ME_E_BADARG,
+             "me_linear_f32: bad dimensions");
+  ME_REQUIRE(act >= 0 && act <= 2, ME_E_BADARG, "me_linear_f32: unknown activation %d", act);
+  hipLaunchKernelGGL(linear_kernel, dim3(grid_for((long long)rows * out_features)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y, (long long)ldy);
+  return me::check_launch("linear_kernel");
+}
+
+int me_mask_scale_f32(const float* x, const uint8_t* mask, float scale, int64_t count, float* y, void* stream) {
+  if (count == 0) return 0;
+  ME_REQUIRE(x && mask && y, ME_E_NULLPTR, "me_mask_scale_f32: null pointer");
+  hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, mask, scale,
+                     (long long)count, y);
+  return me::check_launch("mask_scale_kernel");
+}
+
+int me_m2_loss_f32(const float* o, const float* refine, int32_t c1, const float* regress, const float* boxes,
+                   int32_t box_cols, const float* target_location, const float* class_label, const uint8_t* pos,
+                   const uint8_t* sample, int32_t k, float alpha, float lambda0, float lambda1, float grad_scale,
+                   float* terms, float* d_o, float* d_refine, float* d_regress, void* stream) {
+  if (k == 0) return 0;
+  ME_REQUIRE(o && refine && regress && boxes && target_location && class_label && pos && sample && terms && d_o &&
+                 d_refine && d_regress, ME_E_NULLPTR, "me_m2_loss_f32: null pointer");
+  ME_REQUIRE(k > 0 && c1 >= 2 && box_cols >= 5, ME_E_BADARG, "me_m2_loss_f32: bad dimensions");
+  hipLaunchKernelGGL(m2_loss_kernel, dim3((k + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, refine, c1, regress, boxes,
+                     box_cols, target_location, class_label, pos, sample, k, alpha, lambda0, lambda1, grad_scale, terms, d_o,
+                     d_refine, d_regress);
+  return me::check_launch("m2_loss_kernel");
+}
+
+}  // extern "C"

@@ -127,6 +127,12 @@ SIGNATURES = {
     "me_gather_class_boxes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "me_roi_heads_f32": (C.c_int, [C.POINTER(HeadsDesc), C.c_void_p]),
+    "me_linear_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_mask_scale_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
+    "me_m2_loss_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "me_m2_heads_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(HeadsWeights), C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

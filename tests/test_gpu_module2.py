@@ -40,3 +40,56 @@ def test_module2_forward_vs_oracle_and_reference(hip_lib, name, cfg, n, s, conf)
     # a higher refine_threshold drops rows, like masks[:, 1] > thr (:349)
     net.refine_threshold = float(np.median(g["output"][:, 5]))
     assert 0 < net(x.cuda()).shape[0] < out.shape[0]
+
+
+def test_module2_training_step_vs_oracle_and_reference(hip_lib):
+    """Network.forward(images, targets) -> (output, loss, metric), loss.backward() on the HIP path
+    (millieye_amd/module2/train_path.py) against the oracle's CPU autograd and the real module-2 reference's training step
+    (train_m2_tiny12_s160_n2.npz): loss, output rows, all 14 head gradients, BatchNorm running statistics.  The Dropout
+    mask and the negative sampling are reproduced by seeding torch / random exactly like the reference run."""
+    import random
+    from millieye_amd.module2.my_models import Network, define_yolo
+    from oracle import network_m2_ref
+    from tests.golden.make_golden import M2_TRAIN_CASE, m2_train_fill_
+    name, cfg, n, s, conf, seed = M2_TRAIN_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    targets = torch.from_numpy(g["targets"])
+    cpu_net = m2_train_fill_(Network(define_yolo(cfg_path(cfg)), conf), name)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    ref = network_m2_ref.network_m2_train_step(cfgs.KNOWN[cfg](), cpu_net.state_dict(), x, targets.clone(), conf_thresh=conf)
+    net = m2_train_fill_(Network(define_yolo(cfg_path(cfg)), conf), name)
+    net = net.to(net.device).train()
+    net.base_detector.eval()
+    random.seed(seed)
+    torch.manual_seed(seed)
+    tg = targets.clone()
+    output, loss, metric = net(x.cuda(), tg)
+    assert output.device.type == "cpu" and int(metric["true"]) == int(g["n_pos"]) == ref["n_pos"] > 0
+    assert int(metric["total"]) == int(g["total"])
+    assert not torch.equal(tg, targets), "targets are converted in place like the reference does (:369-370)"
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])), (float(loss.detach()), float(g["loss"]))
+    assert_close(output, torch.from_numpy(g["output"]), 1e-3, "output rows vs reference")
+    loss.backward()
+    seen = 0
+    for k, p in net.named_parameters():
+        if k.startswith("base_detector."):
+            assert p.grad is None
+            continue
+        gr, rg = p.grad.cpu(), ref["grads"][k]
+        if k == "fcn_layers.net.conv_0.bias":
+            # a bias in front of a train-mode BatchNorm has a mathematically zero gradient: both sides hold rounding noise
+            assert float(gr.abs().max()) <= 1e-5 and float(rg.abs().max()) <= 1e-5
+            seen += 1
+            continue
+        scale = max(float(rg.abs().max()), 1e-6)
+        assert float((gr - rg).abs().max()) <= 2e-3 * scale, (k, float((gr - rg).abs().max()), scale)
+        gn = float(g["gnorm/" + k])
+        assert abs(float(gr.double().norm()) - gn) <= 2e-3 * max(gn, 1e-6), k
+        seen += 1
+    assert seen == 14
+    sd = net.state_dict()
+    for key in g.files:
+        if key.startswith("buf/"):
+            assert np.allclose(sd[key[4:]].cpu().numpy(), g[key], rtol=1e-3, atol=1e-5), key
