@@ -35,7 +35,7 @@ def test_tiny(hip_lib, name, n, s):
     _run(name, n, s)
 
 
-@pytest.mark.parametrize("n,s", [(2, 64), (1, 416), (2, 160)])
+@pytest.mark.parametrize("n,s", [(2, 64), (1, 416), (2, 160), (1, 608)])  # 608: BASELINE configs[4] size, R = 22743 rows
 def test_darknet53(hip_lib, n, s):
     _run("yolov3", n, s)
 
