@@ -302,6 +302,42 @@ class Network(nn.Module):
         hip.check(hip.lib().me_conv2d_f32(C.byref(d), hip.stream_ptr()), "me_conv2d_f32")
         return out
 
+    def _side_stream(self, dev):
+        st = self.__dict__.get("_side")
+        if st is None or st.device != dev:
+            st = torch.cuda.Stream(device=dev)
+            object.__setattr__(self, "_side", st)
+        return st
+
+    def _score_maps(self, plan, maps, n, dev):
+        """roi_score_map [n,fh,fw,490] (cnn_layers_1 on the feature tap) and radar_score_map [n,h,w,10 (pitch 12)]
+        (cnn_layers_3 on the radar maps) on the current stream; returns (roi_score_map, radar_score_map, fh, fw)."""
+        f32 = dict(device=dev, dtype=torch.float32)
+        packs = self._get_packs()
+        for key in ("img", "r1", "r2", "r3", "r4"):
+            packs[key].refresh(dev)
+        fh, fw, fc = plan.tap_shape
+        roi_score_map = torch.empty((n, fh, fw, 490), **f32)
+        self._conv(plan.tap_ptr, plan.tap_pitch, False, n, fh, fw, fc, packs["img"], 1, 0, hip.ACT_LEAKY, roi_score_map)
+        maps = maps.contiguous()
+        if not (maps.is_cuda and maps.dtype == torch.float32):
+            raise hip.MeError("radar maps must be CUDA float32 [N,3,h,w]")
+        mh, mw = maps.shape[2], maps.shape[3]
+        t1 = torch.empty((n, mh, mw, 32), **f32)
+        t2 = torch.empty((n, mh, mw, 64), **f32)
+        t3 = torch.empty((n, mh, mw, 128), **f32)
+        radar_score_map = torch.empty((n, mh, mw, 12), **f32)  # 10 channels, pitch 12
+        self._conv(maps.data_ptr(), 3, True, n, mh, mw, 3, packs["r1"], 3, 1, hip.ACT_LEAKY, t1)
+        self._conv(t1.data_ptr(), 32, False, n, mh, mw, 32, packs["r2"], 3, 1, hip.ACT_LEAKY, t2)
+        self._conv(t2.data_ptr(), 64, False, n, mh, mw, 64, packs["r3"], 3, 1, hip.ACT_LEAKY, t3)
+        self._conv(t3.data_ptr(), 128, False, n, mh, mw, 128, packs["r4"], 1, 0, hip.ACT_SIGMOID, radar_score_map)
+        if (mh, mw) != (fh, fw):
+            # the reference hands both maps to RoI ops with the same spatial_scale; a size mismatch is
+            # legal there (demo feeds 32x32, quirk q15) - the pooling kernel takes per-map sizes
+            raise NotImplementedError("radar map size != feature map size (demo-only configuration, quirk q15)")
+        self._keep_side = (t1, t2, t3, maps)  # alive until the next forward: the side stream may still read them
+        return roi_score_map, radar_score_map, fh, fw
+
     # ---------------------------------------------------------------------------------- forward
     def forward(self, images, maps, radar_boxes_location, model_mode=0, targets=None):
         """See the reference docstring (my_models.py:434-450).  Returns ``output [m, 8]`` rows
@@ -321,10 +357,21 @@ class Network(nn.Module):
         f32 = dict(device=dev, dtype=torch.float32)
 
         # ---- candidate boxes from the base detector (reference :454-473), all on device
-        mark = getattr(self, "_stage_cb", None) or (lambda _name: None)  # bench.py: per-stage HIP events
+        cb = getattr(self, "_stage_cb", None)
+        mark = cb or (lambda _name: None)  # bench.py: per-stage HIP events
         mark("start")
         plan, yolo_out = self.base_detector._run(images)
         mark("detector")
+        # The score maps (reference :486-487) only need the feature tap, NMS only the decoded rows: NMS keeps 32
+        # workgroups busy for ~0.3 ms, so the score-map convolutions run beside it on a second stream (mode 0 / 2 / 3).
+        overlap = cb is None and model_mode != 1 and plan.tap is not None
+        maps_job = None
+        if overlap:
+            self._check_eval()
+            side = self._side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                maps_job = self._score_maps(plan, maps, n, dev)
         det, cnt = hip.nms_batched(yolo_out, float(self.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
                                    writeback_xyxy=False)
         mark("nms")
@@ -344,32 +391,16 @@ class Network(nn.Module):
             self.refine_threshold_img = 1
 
         # ---- score maps (reference :486-487)
-        self._check_eval()
-        if plan.tap is None:
-            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+        if maps_job is None:
+            self._check_eval()
+            if plan.tap is None:
+                raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+            maps_job = self._score_maps(plan, maps, n, dev)
+        else:
+            torch.cuda.current_stream(dev).wait_stream(self._side_stream(dev))
+        roi_score_map, radar_score_map, fh, fw = maps_job
         packs = self._get_packs()
-        for key in ("img", "r1", "r2", "r3", "r4"):
-            packs[key].refresh(dev)
-        fh, fw, fc = plan.tap_shape
-        roi_score_map = torch.empty((n, fh, fw, 490), **f32)
-        self._conv(plan.tap_ptr, plan.tap_pitch, False, n, fh, fw, fc, packs["img"], 1, 0, hip.ACT_LEAKY, roi_score_map)
-        maps = maps.contiguous()
-        if not (maps.is_cuda and maps.dtype == torch.float32):
-            raise hip.MeError("radar maps must be CUDA float32 [N,3,h,w]")
-        mh, mw = maps.shape[2], maps.shape[3]
-        t1 = torch.empty((n, mh, mw, 32), **f32)
-        t2 = torch.empty((n, mh, mw, 64), **f32)
-        t3 = torch.empty((n, mh, mw, 128), **f32)
-        radar_score_map = torch.empty((n, mh, mw, 12), **f32)  # 10 channels, pitch 12
-        self._conv(maps.data_ptr(), 3, True, n, mh, mw, 3, packs["r1"], 3, 1, hip.ACT_LEAKY, t1)
-        self._conv(t1.data_ptr(), 32, False, n, mh, mw, 32, packs["r2"], 3, 1, hip.ACT_LEAKY, t2)
-        self._conv(t2.data_ptr(), 64, False, n, mh, mw, 64, packs["r3"], 3, 1, hip.ACT_LEAKY, t3)
-        self._conv(t3.data_ptr(), 128, False, n, mh, mw, 128, packs["r4"], 1, 0, hip.ACT_SIGMOID, radar_score_map)
         mark("score_maps")
-        if (mh, mw) != (fh, fw):
-            # the reference hands both maps to RoI ops with the same spatial_scale; a size mismatch is
-            # legal there (demo feeds 32x32, quirk q15) - the pooling kernel takes per-map sizes
-            raise NotImplementedError("radar map size != feature map size (demo-only configuration, quirk q15)")
 
         # ---- RoIs: image proposals then radar proposals (reference :490-492)
         if len(radar_boxes_location) > 0:
