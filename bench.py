@@ -355,7 +355,7 @@ def main():
             net.train()
             net.base_detector.eval()
             heads = head_parameters(net)
-            opt = torch.optim.Adam(heads, lr=5e-4)
+            opt = torch.optim.Adam(heads, lr=5e-4, fused=True)
 
             def step():  # noqa: F811
                 loss, out_rows, _metric, _att = net(x, maps_d, boxes_d.clone(), targets.clone())

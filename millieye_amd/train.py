@@ -69,7 +69,10 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
     device = getattr(model, "device", torch.device("cuda"))
     os.makedirs(checkpoint_dir, exist_ok=True)
     if optimizer is None:
-        optimizer = torch.optim.Adam(model.parameters(), lr=5e-4)
+        # same update rule as the reference's Adam(lr=5e-4); the fused implementation is one launch instead of a dozen
+        # multi-tensor launches + 2 host reads per parameter
+        params = list(model.parameters())
+        optimizer = torch.optim.Adam(params, lr=5e-4, fused=all(p.is_cuda for p in params))
     distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
     rank = torch.distributed.get_rank() if distributed else 0
     history = dict(losses=[], steps=[], checkpoints=[], evaluations=[])

@@ -136,13 +136,31 @@ def iou_labels_vectorized(boxes, targets):
     return iou_labels, target_location
 
 
+def _head_named(net):
+    """(names, parameters) of everything outside the detector, cached on the module: walking named_parameters() of a
+    107-module Darknet costs ~1 ms, and the training step asks several times.  The cache follows the Parameter objects
+    (re-assigning a parameter re-walks)."""
+    cache = net.__dict__.get("_head_cache")
+    if cache is not None and all(a is b for a, b in zip(cache[2], (net._parameters, net._modules))):
+        ids = cache[3]
+        if len(ids) == len(cache[1]) and all(id(p) == i for p, i in zip(cache[1], ids)):
+            return cache[0], cache[1]
+    names, params = [], []
+    for name, p in net.named_parameters():
+        if not name.startswith("base_detector."):
+            names.append(name)
+            params.append(p)
+    object.__setattr__(net, "_head_cache", (names, params, (net._parameters, net._modules), [id(p) for p in params]))
+    return names, params
+
+
 def head_parameters(net):
     """Fixed order of every non-detector parameter (the autograd inputs of the training step)."""
-    return [p for name, p in net.named_parameters() if not name.startswith("base_detector.")]
+    return list(_head_named(net)[1])
 
 
 def _head_names(net):
-    return [name for name, _ in net.named_parameters() if not name.startswith("base_detector.")]
+    return list(_head_named(net)[0])
 
 
 class _StageThree(torch.autograd.Function):

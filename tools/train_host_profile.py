@@ -1,0 +1,44 @@
+"""Where does the host time of a stage-3 training step go?  (tools; GPU box)  python tools/train_host_profile.py"""
+import cProfile, os, pstats, random, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g; g.build()
+from millieye_amd import cfgs, synth, parallel as par
+from millieye_amd.my_models import Network
+from millieye_amd.train_path import head_parameters
+from millieye_amd.yolov3.models import Darknet
+batch = 8
+net = Network(Darknet(cfgs.write_cfg("yolov3", "/tmp/thp_cfg")), 0.2).eval()
+synth.fill_network_(net, "bench/yolov3", cls0_bias=3.0, cls_bias=-4.0)
+net = net.cuda()
+x = torch.from_numpy(synth.uniform("bench/frames/0", (batch, 3, 416, 416))).cuda()
+maps_np, boxes_np = synth.radar_inputs("bench/radar/0", batch, 26, boxes_per_image=2)
+maps_d, boxes_d = torch.from_numpy(maps_np).cuda(), torch.from_numpy(boxes_np).cuda()
+with torch.no_grad():
+    det = net(x, maps_d, boxes_d.clone(), 1).cpu()
+tg = []
+for i in range(batch):
+    rows_i = det[det[:, 0] == i]
+    for j in (0, 3):
+        if j < len(rows_i):
+            b = rows_i[j, 1:5] / 416
+            tg.append([i, 0, float((b[0] + b[2]) / 2), float((b[1] + b[3]) / 2), float(b[2] - b[0]) * 1.05, float(b[3] - b[1]) * 0.95])
+targets = torch.tensor(tg, dtype=torch.float32).reshape(-1, 6)
+net.train(); net.base_detector.eval()
+heads = head_parameters(net)
+opt = torch.optim.Adam(heads, lr=5e-4, fused=True)
+random.seed(1)
+def step():
+    loss, out_rows, _m, _a = net(x, maps_d, boxes_d.clone(), targets.clone())
+    loss.backward()
+    par.allreduce_gradients(heads)
+    opt.step(); opt.zero_grad(set_to_none=True)
+for _ in range(5): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): step()
+torch.cuda.synchronize()
+print("ms/step", (time.perf_counter() - t0) / 20 * 1e3)
+pr = cProfile.Profile(); pr.enable()
+for _ in range(20): step()
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
