@@ -170,37 +170,53 @@ class MyDataset(Dataset):
         pad = _pad_amounts(h, w)
         padded_h, padded_w = h + pad[2] + pad[3], w + pad[0] + pad[1]
 
-        targets = None
-        if os.path.exists(label_path):  # (class, cx, cy, w, h) relative to the unpadded image, float64 like np.loadtxt
-            boxes = torch.from_numpy(np.loadtxt(label_path).reshape(-1, 5))
-            x1 = (boxes[:, 1] - boxes[:, 3] / 2) * w + pad[0]
-            y1 = (boxes[:, 2] - boxes[:, 4] / 2) * h + pad[2]
-            x2 = (boxes[:, 1] + boxes[:, 3] / 2) * w + pad[1]
-            y2 = (boxes[:, 2] + boxes[:, 4] / 2) * h + pad[3]
-            boxes[:, 1] = ((x1 + x2) / 2) / padded_w
-            boxes[:, 2] = ((y1 + y2) / 2) / padded_h
-            boxes[:, 3] *= w / padded_w
-            boxes[:, 4] *= h / padded_h
-            targets = torch.zeros((len(boxes), 6))
-            targets[:, 1:] = boxes
-
-        with open(box_path, "rb") as handle:
-            radar_box = torch.from_numpy(pickle.load(handle))  # [r,4] xyxy in pixels of the unpadded image
-        radar_box_output = None
-        if len(radar_box) > 0:
-            radar_box[:, 0] += pad[0]
-            radar_box[:, 2] += pad[1]
-            radar_box[:, 1] += pad[2]
-            radar_box[:, 3] += pad[3]
-            radar_box = torch.clamp(radar_box / padded_h, 0, 1)
-            radar_box = radar_box[torch.logical_and(radar_box[:, 0] < radar_box[:, 2], radar_box[:, 1] < radar_box[:, 3])]
-            if len(radar_box) > 0:
-                radar_box_output = torch.zeros((len(radar_box), 5))
-                radar_box_output[:, 1:] = radar_box
+        targets = self._load_targets(label_path, (h, w), pad, (padded_h, padded_w))
+        radar_box_output = self._load_radar_boxes(box_path, pad, padded_h)
 
         with open(point_path, "rb") as handle:
             points = np.asarray(pickle.load(handle), dtype=np.float64).reshape(-1, 4)  # (u, v, depth, velocity) rows
         return img_path, frame, targets, radar_box_output, (points, (w, h))
+
+    @staticmethod
+    def _load_targets(label_path, hw, pad, padded_hw):
+        """YOLO label file (class, cx, cy, w, h relative to the *unpadded* frame) -> ``[k,6]`` rows
+        ``(0, class, cx, cy, w, h)`` relative to the padded square, or ``None`` without a file.  float64 arithmetic in
+        the reference's order (datasets.py:224-245): corners in pixels, shift by the padding, centre back to [0,1]."""
+        if not os.path.exists(label_path):
+            return None
+        h, w = hw
+        padded_h, padded_w = padded_hw
+        lab = torch.from_numpy(np.loadtxt(label_path).reshape(-1, 5))
+        half_w, half_h = lab[:, 3] / 2, lab[:, 4] / 2
+        left = (lab[:, 1] - half_w) * w + pad[0]
+        right = (lab[:, 1] + half_w) * w + pad[1]
+        top = (lab[:, 2] - half_h) * h + pad[2]
+        bottom = (lab[:, 2] + half_h) * h + pad[3]
+        out = torch.zeros((len(lab), 6))
+        out[:, 1] = lab[:, 0]
+        out[:, 2] = ((left + right) / 2) / padded_w
+        out[:, 3] = ((top + bottom) / 2) / padded_h
+        out[:, 4] = lab[:, 3] * (w / padded_w)
+        out[:, 5] = lab[:, 4] * (h / padded_h)
+        return out
+
+    @staticmethod
+    def _load_radar_boxes(box_path, pad, padded_side):
+        """Radar proposals: pickled ``[r,4]`` xyxy pixels of the unpadded frame -> ``[r',5]`` rows ``(0, x1,y1,x2,y2)`` in
+        [0,1] of the padded square (clamped, empty boxes dropped), or ``None`` (datasets.py:250-264)."""
+        with open(box_path, "rb") as handle:
+            rb = torch.from_numpy(pickle.load(handle))
+        if len(rb) == 0:
+            return None
+        shift = torch.tensor([pad[0], pad[2], pad[1], pad[3]], dtype=rb.dtype)
+        rb += shift  # in place on the unpickled array, like the reference's column-wise +=
+        rb = torch.clamp(rb / padded_side, 0, 1)
+        rb = rb[(rb[:, 0] < rb[:, 2]) & (rb[:, 1] < rb[:, 3])]
+        if len(rb) == 0:
+            return None
+        out = torch.zeros((len(rb), 5))
+        out[:, 1:] = rb
+        return out
 
     def collate_fn(self, batch):
         paths, frames, targets, radar_boxes, radar_points = list(zip(*batch))

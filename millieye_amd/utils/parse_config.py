@@ -12,39 +12,35 @@ __all__ = ["parse_model_config", "parse_data_config"]
 
 
 def _significant_lines(text):
-    for raw in text.split("\n"):
-        line = raw.strip()
-        if not line or line.startswith("#"):
-            continue
-        yield line
+    """Stripped lines that are neither blank nor ``#`` comments."""
+    return [ln for ln in (raw.strip() for raw in text.split("\n")) if ln and ln[0] != "#"]
 
 
 def parse_model_config(path):
     """cfg file -> list of dicts, first entry is the ``[net]`` hyper-parameter block."""
     with open(path, "r") as fh:
-        text = fh.read()
+        lines = _significant_lines(fh.read())
     blocks = []
-    for line in _significant_lines(text):
-        if line.startswith("["):
-            block = {"type": line[1:-1].rstrip()}
-            if block["type"] == "convolutional":
-                block["batch_normalize"] = 0  # int on purpose: falsy default, see reference :14-15
-            blocks.append(block)
-            continue
-        key, value = line.split("=")  # exactly one '=' per line, like the reference
-        blocks[-1][key.rstrip()] = value.strip()
+    for line in lines:
+        if line[0] == "[":
+            kind = line[1:-1].rstrip()
+            # ``batch_normalize`` gets an *int* 0 default (falsy) while parsed values stay strings, reference :14-15
+            blocks.append({"type": kind, "batch_normalize": 0} if kind == "convolutional" else {"type": kind})
+        else:
+            key, value = line.split("=")  # exactly one '=' per line, like the reference
+            blocks[-1][key.rstrip()] = value.strip()
     return blocks
 
 
 def parse_data_config(path):
     """``key=value`` data file -> dict (space separated values become lists)."""
-    options = {"gpus": "0,1,2,3", "num_workers": "10"}
+    options = dict(gpus="0,1,2,3", num_workers="10")
     with open(path, "r") as fh:
-        for raw in fh.readlines():
-            line = raw.strip()
-            if line == "" or line.startswith("#"):
-                continue
-            key, value = line.split("=")
-            parts = value.split(" ")
-            options[key.strip()] = parts if len(parts) > 1 else value
+        entries = [raw.strip() for raw in fh.readlines()]
+    for entry in entries:
+        if entry == "" or entry.startswith("#"):
+            continue
+        key, value = entry.split("=")
+        pieces = value.split(" ")
+        options[key.strip()] = value if len(pieces) == 1 else pieces
     return options

@@ -71,38 +71,31 @@ def weights_init_normal(m):
 
 
 def rescale_boxes(boxes, current_dim, original_shape):
-    """Undo pad-to-square + resize (reference :41-56); mutates and returns ``boxes``."""
-    orig_h, orig_w = original_shape
+    """Undo pad-to-square + resize (reference :41-56); mutates and returns ``boxes`` (xyxy in the square frame ->
+    xyxy in the original ``(h, w)`` frame).  Per axis: ``((v - pad // 2) / unpadded) * original``."""
+    orig = {"y": original_shape[0], "x": original_shape[1]}
     ratio = current_dim / max(original_shape)
-    pad_x = max(orig_h - orig_w, 0) * ratio
-    pad_y = max(orig_w - orig_h, 0) * ratio
-    unpad_h = current_dim - pad_y
-    unpad_w = current_dim - pad_x
-    boxes[:, 0] = ((boxes[:, 0] - pad_x // 2) / unpad_w) * orig_w
-    boxes[:, 1] = ((boxes[:, 1] - pad_y // 2) / unpad_h) * orig_h
-    boxes[:, 2] = ((boxes[:, 2] - pad_x // 2) / unpad_w) * orig_w
-    boxes[:, 3] = ((boxes[:, 3] - pad_y // 2) / unpad_h) * orig_h
+    pad = {"x": max(orig["y"] - orig["x"], 0) * ratio, "y": max(orig["x"] - orig["y"], 0) * ratio}
+    for col, axis in ((0, "x"), (1, "y"), (2, "x"), (3, "y")):
+        unpadded = current_dim - pad[axis]
+        boxes[:, col] = ((boxes[:, col] - pad[axis] // 2) / unpadded) * orig[axis]
     return boxes
 
 
+def _stack_last(parts, like):
+    return torch.stack(parts, -1) if isinstance(like, torch.Tensor) else np.stack(parts, -1)
+
+
 def xyxy2xywh(x):
-    """[x1,y1,x2,y2] -> [cx,cy,w,h] (torch or numpy), reference :59-66."""
-    y = torch.zeros_like(x) if isinstance(x, torch.Tensor) else np.zeros_like(x)
-    y[..., 0] = (x[..., 0] + x[..., 2]) / 2
-    y[..., 1] = (x[..., 1] + x[..., 3]) / 2
-    y[..., 2] = x[..., 2] - x[..., 0]
-    y[..., 3] = x[..., 3] - x[..., 1]
-    return y
+    """corners -> centre / size, reference :59-66 (torch or numpy input; a new array of the same dtype)."""
+    left, top, right, bottom = x[..., 0], x[..., 1], x[..., 2], x[..., 3]
+    return _stack_last(((left + right) / 2, (top + bottom) / 2, right - left, bottom - top), x)
 
 
 def xywh2xyxy(x):
-    """[cx,cy,w,h] -> [x1,y1,x2,y2], reference :68-74 (half extents computed as ``w / 2``)."""
-    y = torch.empty_like(x)
-    y[..., 0] = x[..., 0] - x[..., 2] / 2
-    y[..., 1] = x[..., 1] - x[..., 3] / 2
-    y[..., 2] = x[..., 0] + x[..., 2] / 2
-    y[..., 3] = x[..., 1] + x[..., 3] / 2
-    return y
+    """centre / size -> corners, reference :68-74 (half extents computed as ``w / 2``)."""
+    cx, cy, half_w, half_h = x[..., 0], x[..., 1], x[..., 2] / 2, x[..., 3] / 2
+    return _stack_last((cx - half_w, cy - half_h, cx + half_w, cy + half_h), x)
 
 
 # --------------------------------------------------------------------------------------
@@ -170,33 +163,32 @@ def ap_per_class(tp, conf, pred_cls, target_cls):
 
 
 def bbox_wh_iou(wh1, wh2):
-    """IoU of anchor shape ``wh1`` with target shapes ``wh2[n,2]`` (reference :239-245)."""
-    wh2 = wh2.t()
-    w1, h1 = wh1[0], wh1[1]
-    w2, h2 = wh2[0], wh2[1]
-    inter_area = torch.min(w1, w2) * torch.min(h1, h2)
-    union_area = (w1 * h1 + 1e-16) + w2 * h2 - inter_area
-    return inter_area / union_area
+    """IoU of one anchor shape ``wh1`` with target shapes ``wh2[n,2]``, both centred on the same point (reference
+    :239-245): ``min(w) * min(h) / ((w1*h1 + 1e-16) + w2*h2 - inter)``."""
+    anchor_w, anchor_h = wh1[0], wh1[1]
+    tgt_w, tgt_h = wh2[:, 0], wh2[:, 1]
+    overlap = torch.min(anchor_w, tgt_w) * torch.min(anchor_h, tgt_h)
+    return overlap / ((anchor_w * anchor_h + 1e-16) + tgt_w * tgt_h - overlap)
+
+
+def _as_corners(box, x1y1x2y2):
+    if x1y1x2y2:
+        return box[:, 0], box[:, 1], box[:, 2], box[:, 3]
+    half_w, half_h = box[:, 2] / 2, box[:, 3] / 2
+    return box[:, 0] - half_w, box[:, 1] - half_h, box[:, 0] + half_w, box[:, 1] + half_h
 
 
 def bbox_iou(box1, box2, x1y1x2y2=True):
-    """IoU with the reference's **+1 pixel** convention (reference :248-278)."""
-    if not x1y1x2y2:
-        b1_x1, b1_x2 = box1[:, 0] - box1[:, 2] / 2, box1[:, 0] + box1[:, 2] / 2
-        b1_y1, b1_y2 = box1[:, 1] - box1[:, 3] / 2, box1[:, 1] + box1[:, 3] / 2
-        b2_x1, b2_x2 = box2[:, 0] - box2[:, 2] / 2, box2[:, 0] + box2[:, 2] / 2
-        b2_y1, b2_y2 = box2[:, 1] - box2[:, 3] / 2, box2[:, 1] + box2[:, 3] / 2
-    else:
-        b1_x1, b1_y1, b1_x2, b1_y2 = box1[:, 0], box1[:, 1], box1[:, 2], box1[:, 3]
-        b2_x1, b2_y1, b2_x2, b2_y2 = box2[:, 0], box2[:, 1], box2[:, 2], box2[:, 3]
-    ix1 = torch.max(b1_x1, b2_x1)
-    iy1 = torch.max(b1_y1, b2_y1)
-    ix2 = torch.min(b1_x2, b2_x2)
-    iy2 = torch.min(b1_y2, b2_y2)
-    inter_area = torch.clamp(ix2 - ix1 + 1, min=0) * torch.clamp(iy2 - iy1 + 1, min=0)
-    b1_area = (b1_x2 - b1_x1 + 1) * (b1_y2 - b1_y1 + 1)
-    b2_area = (b2_x2 - b2_x1 + 1) * (b2_y2 - b2_y1 + 1)
-    return inter_area / (b1_area + b2_area - inter_area + 1e-16)
+    """IoU with the reference's **+1 pixel** convention (reference :248-278): widths / heights are ``hi - lo + 1``
+    for the intersection and for both areas; ``box1`` [1,4] or [n,4] broadcasts against ``box2`` [n,4]."""
+    l1, t1, r1, b1 = _as_corners(box1, x1y1x2y2)
+    l2, t2, r2, b2 = _as_corners(box2, x1y1x2y2)
+    span_x = torch.clamp(torch.min(r1, r2) - torch.max(l1, l2) + 1, min=0)
+    span_y = torch.clamp(torch.min(b1, b2) - torch.max(t1, t2) + 1, min=0)
+    shared = span_x * span_y
+    area1 = (r1 - l1 + 1) * (b1 - t1 + 1)
+    area2 = (r2 - l2 + 1) * (b2 - t2 + 1)
+    return shared / (area1 + area2 - shared + 1e-16)
 
 
 def get_batch_statistics(outputs, targets, iou_threshold):
@@ -300,41 +292,37 @@ def build_targets(pred_boxes, pred_cls, target, anchors, ignore_thres):
 
     Returns ``(iou_scores, class_mask, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf)``."""
     dev = pred_boxes.device
-    nB, nA, nG = pred_boxes.size(0), pred_boxes.size(1), pred_boxes.size(2)
-    nC = pred_cls.size(-1)
+    n_img, n_anchor, grid = pred_boxes.shape[0], pred_boxes.shape[1], pred_boxes.shape[2]
+    cells = (n_img, n_anchor, grid, grid)
+    f32 = dict(dtype=torch.float32, device=dev)
+    obj_mask = torch.zeros(cells, dtype=torch.uint8, device=dev)
+    noobj_mask = torch.ones(cells, dtype=torch.uint8, device=dev)
+    class_mask, iou_scores = torch.zeros(cells, **f32), torch.zeros(cells, **f32)
+    tx, ty, tw, th = (torch.zeros(cells, **f32) for _ in range(4))
+    tcls = torch.zeros(cells + (pred_cls.shape[-1],), **f32)
 
-    def zeros(*shape, dtype=torch.float32):
-        return torch.zeros(*shape, dtype=dtype, device=dev)
+    # targets in grid units; the anchor whose *shape* fits a target best owns it (position does not matter here)
+    target_boxes = target[:, 2:6] * grid
+    centre, extent = target_boxes[:, :2], target_boxes[:, 2:]
+    shape_iou = torch.stack([bbox_wh_iou(anchor, extent) for anchor in anchors])  # [n_anchor, n_target]
+    best_n = shape_iou.max(0)[1]
+    image_of, label_of = target[:, 0].long(), target[:, 1].long()
+    gi, gj = centre[:, 0].long(), centre[:, 1].long()
+    owner = (image_of, best_n, gj, gi)
 
-    obj_mask = zeros(nB, nA, nG, nG, dtype=torch.uint8)
-    noobj_mask = torch.ones(nB, nA, nG, nG, dtype=torch.uint8, device=dev)
-    class_mask = zeros(nB, nA, nG, nG)
-    iou_scores = zeros(nB, nA, nG, nG)
-    tx, ty, tw, th = (zeros(nB, nA, nG, nG) for _ in range(4))
-    tcls = zeros(nB, nA, nG, nG, nC)
+    obj_mask[owner] = 1
+    noobj_mask[owner] = 0
+    for t_idx in range(shape_iou.shape[1]):  # other anchors that fit well are neither object nor background
+        noobj_mask[image_of[t_idx], shape_iou[:, t_idx] > ignore_thres, gj[t_idx], gi[t_idx]] = 0
 
-    target_boxes = target[:, 2:6] * nG
-    gxy = target_boxes[:, :2]
-    gwh = target_boxes[:, 2:]
-    ious = torch.stack([bbox_wh_iou(anchor, gwh) for anchor in anchors])
-    _, best_n = ious.max(0)
-    b, target_labels = target[:, :2].long().t()
-    gx, gy = gxy.t()
-    gw, gh = gwh.t()
-    gi, gj = gxy.long().t()
-
-    obj_mask[b, best_n, gj, gi] = 1
-    noobj_mask[b, best_n, gj, gi] = 0
-    for k, anchor_ious in enumerate(ious.t()):
-        noobj_mask[b[k], anchor_ious > ignore_thres, gj[k], gi[k]] = 0
-
-    tx[b, best_n, gj, gi] = gx - gx.floor()
-    ty[b, best_n, gj, gi] = gy - gy.floor()
-    tw[b, best_n, gj, gi] = torch.log(gw / anchors[best_n][:, 0] + 1e-16)
-    th[b, best_n, gj, gi] = torch.log(gh / anchors[best_n][:, 1] + 1e-16)
-    tcls[b, best_n, gj, gi, target_labels] = 1
-    class_mask[b, best_n, gj, gi] = (pred_cls[b, best_n, gj, gi].argmax(-1) == target_labels).float()
-    iou_scores[b, best_n, gj, gi] = bbox_iou(pred_boxes[b, best_n, gj, gi], target_boxes, x1y1x2y2=False)
+    tx[owner] = centre[:, 0] - centre[:, 0].floor()
+    ty[owner] = centre[:, 1] - centre[:, 1].floor()
+    own_anchor = anchors[best_n]
+    tw[owner] = torch.log(extent[:, 0] / own_anchor[:, 0] + 1e-16)
+    th[owner] = torch.log(extent[:, 1] / own_anchor[:, 1] + 1e-16)
+    tcls[owner + (label_of,)] = 1
+    class_mask[owner] = (pred_cls[owner].argmax(-1) == label_of).float()
+    iou_scores[owner] = bbox_iou(pred_boxes[owner], target_boxes, x1y1x2y2=False)
 
     tconf = obj_mask.float()
     return iou_scores, class_mask, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf
