@@ -74,7 +74,6 @@ struct HeatP {
 
 __global__ __launch_bounds__(256) void radar_heatmap_kernel(HeatP p) {
   __shared__ float maps[3][HM_MAX * HM_MAX];  // [c][y * bw + x], already float32 (ToTensor().float())
-  __shared__ int pbin[256];
   const int f = blockIdx.x;
   const int img_w = p.sizes[2 * f], img_h = p.sizes[2 * f + 1];
   const int r0 = p.offsets[f], npts = p.offsets[f + 1] - r0;
@@ -109,7 +108,6 @@ __global__ __launch_bounds__(256) void radar_heatmap_kernel(HeatP p) {
     maps[1][b] = (float)c1;
     maps[2][b] = (float)c2;
   }
-  (void)pbin;
   __syncthreads();
   // pad_to_square (zeros) + bilinear, align_corners=True (aten upsample_bilinear2d, float32 arithmetic)
   const int P = bh > bw ? bh : bw;

@@ -20,8 +20,6 @@ backward  ``me_yolo_loss_bwd_f32`` seeds the raw detection maps; modules are wal
           ``me_gemm_f32``), ``me_upsample2_bwd_f32``, ``me_maxpool_bwd_f32``, ``me_add_f32`` for fan-out accumulation.
 
 """
-import ctypes as C
-
 import torch
 
 from . import hip

@@ -14,7 +14,6 @@ forward   frozen detector -> NMS -> all-class proposals (as in inference); ``me_
 backward  ``me_act_bwd_f32`` + ``me_gemm_f32`` / MFMA weight gradient / ``me_colsum_f32`` per Linear, the Dropout mask again,
           ``me_ps_roi_align_bwd_f32``, ``me_bn_train_bwd_f32``, 1x1-conv weight gradient.
 """
-import ctypes as C
 import random
 
 import numpy as np
@@ -22,7 +21,7 @@ import torch
 
 from .. import hip
 from ..my_models import _DETECTIONS_PER_IMG, _NMS_THRESH
-from ..train_path import _BnState, _bn_bwd, _bn_fwd, _colsum, _conv, _f32, _gemm, _ptr, iou_labels_vectorized
+from ..train_path import _bn_bwd, _bn_fwd, _colsum, _conv, _f32, _gemm, _ptr, iou_labels_vectorized
 from ..utils.utils import xywh2xyxy
 
 LEAKY, SIGMOID, LINEAR = hip.ACT_LEAKY, hip.ACT_SIGMOID, hip.ACT_LINEAR

@@ -23,7 +23,6 @@ import numpy as np
 import torch
 
 from . import hip
-from .engine import ConvWeights
 
 _EPS = 1e-5
 _MOM = 0.1

@@ -61,7 +61,7 @@ def network_m2_train_step(cfg_text, sd, images, targets, conf_thresh=0.2, class_
 
     import numpy as np
 
-    from .network_ref import bbox_iou_plus1, obtain_iou_labels, xywh2xyxy, xyxy2xywh
+    from .network_ref import obtain_iou_labels, xywh2xyxy, xyxy2xywh
 
     det_sd = {k[len("base_detector."):]: v for k, v in sd.items() if k.startswith("base_detector.")}
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()

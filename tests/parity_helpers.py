@@ -3,7 +3,6 @@ the comparison conventions (tolerances are written where they are used)."""
 import os
 import tempfile
 
-import numpy as np
 import torch
 
 from millieye_amd import cfgs, synth

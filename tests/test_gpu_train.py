@@ -2,7 +2,6 @@
 CPU autograd / the oracle's torchvision backward, then the whole step (loss, every parameter gradient,
 BatchNorm running statistics, optimizer step) against oracle/network_ref.network_train_step and the
 reference's own golden numbers (tests/golden/train_*.npz).  Tolerance 1e-3 relative to the tensor's scale."""
-import ctypes as C
 import os
 import random
 

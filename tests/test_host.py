@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from millieye_amd import cfgs, synth
+from millieye_amd import synth
 from tests import parity_helpers as ph
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

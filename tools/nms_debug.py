@@ -1,4 +1,4 @@
-import os, sys, time, torch
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g; g.build()
 from millieye_amd import cfgs, synth, hip
