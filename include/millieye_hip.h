@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 1
+#define ME_ABI_VERSION 2
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -223,7 +223,9 @@ typedef struct me_heads_desc {
   const float* img_map;
   const float* radar_map;
   int64_t img_pitch, radar_pitch;
-  int32_t n, fh, fw;
+  int32_t n, fh, fw;           /* batch, size of img_map */
+  int32_t rh, rw;              /* size of radar_map (equal to fh, fw in training / evaluation; 32 x 32 in the
+                                  reference's demos, run_sp.py:199-204 - same spatial_scale, quirk q15) */
   float spatial_scale;         /* 1/16 */
   const float* img_boxes;      /* [n_img_cap, box_cols] */
   const int32_t* n_img;        /* device scalar */

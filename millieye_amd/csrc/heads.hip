@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
     } else {
       const int g = f - FEAT;
       const int pw = g % P, ph = (g / P) % P, c = g / PP;
-      v = roi_sample(d.radar_map, d.radar_pitch, d.fh, d.fw, s_roi[r], d.spatial_scale, c, ph, pw);
+      v = roi_sample(d.radar_map, d.radar_pitch, d.rh, d.rw, s_roi[r], d.spatial_scale, c, ph, pw);
     }
     s_feat[r][f] = v;
   }
@@ -584,7 +584,8 @@ int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
   ME_REQUIRE(w.w0t && w.b0 && w.w1 && w.b1 && w.w2 && w.b2 && w.rw && w.rscale && w.rshift && w.rw2 && w.rb2 &&
                  w.e1w && w.e1b && w.e2w && w.e2b,
              ME_E_NULLPTR, "me_roi_heads_f32: null weight pointer");
-  ME_REQUIRE(d->n > 0 && d->fh > 0 && d->fw > 0 && d->n_img_cap >= 0 && d->n_radar >= 0 && d->box_cols >= 9,
+  ME_REQUIRE(d->n > 0 && d->fh > 0 && d->fw > 0 && d->rh > 0 && d->rw > 0 && d->n_img_cap >= 0 && d->n_radar >= 0 &&
+                 d->box_cols >= 9,
              ME_E_BADARG, "me_roi_heads_f32: bad dimensions");
   ME_REQUIRE(d->img_pitch >= FEAT && d->radar_pitch >= C_OUT, ME_E_BADARG, "me_roi_heads_f32: map pitch too small");
   const bool train = d->save_small || d->save_feat_img || d->save_feat_rad || d->save_hidden;

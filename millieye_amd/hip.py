@@ -79,7 +79,7 @@ class HeadsDesc(C.Structure):
     _fields_ = [
         ("img_map", C.c_void_p), ("radar_map", C.c_void_p),
         ("img_pitch", C.c_int64), ("radar_pitch", C.c_int64),
-        ("n", C.c_int32), ("fh", C.c_int32), ("fw", C.c_int32),
+        ("n", C.c_int32), ("fh", C.c_int32), ("fw", C.c_int32), ("rh", C.c_int32), ("rw", C.c_int32),
         ("spatial_scale", C.c_float),
         ("img_boxes", C.c_void_p), ("n_img", C.c_void_p),
         ("n_img_cap", C.c_int32), ("box_cols", C.c_int32),
@@ -202,8 +202,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 1:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 1")
+    if lib_.me_abi_version() != 2:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 2")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "

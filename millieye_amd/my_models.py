@@ -311,7 +311,7 @@ class Network(nn.Module):
 
     def _score_maps(self, plan, maps, n, dev):
         """roi_score_map [n,fh,fw,490] (cnn_layers_1 on the feature tap) and radar_score_map [n,h,w,10 (pitch 12)]
-        (cnn_layers_3 on the radar maps) on the current stream; returns (roi_score_map, radar_score_map, fh, fw)."""
+        (cnn_layers_3 on the radar maps) on the current stream; returns (roi_score_map, radar_score_map, fh, fw, mh, mw)."""
         f32 = dict(device=dev, dtype=torch.float32)
         packs = self._get_packs()
         for key in ("img", "r1", "r2", "r3", "r4"):
@@ -331,12 +331,10 @@ class Network(nn.Module):
         self._conv(t1.data_ptr(), 32, False, n, mh, mw, 32, packs["r2"], 3, 1, hip.ACT_LEAKY, t2)
         self._conv(t2.data_ptr(), 64, False, n, mh, mw, 64, packs["r3"], 3, 1, hip.ACT_LEAKY, t3)
         self._conv(t3.data_ptr(), 128, False, n, mh, mw, 128, packs["r4"], 1, 0, hip.ACT_SIGMOID, radar_score_map)
-        if (mh, mw) != (fh, fw):
-            # the reference hands both maps to RoI ops with the same spatial_scale; a size mismatch is
-            # legal there (demo feeds 32x32, quirk q15) - the pooling kernel takes per-map sizes
-            raise NotImplementedError("radar map size != feature map size (demo-only configuration, quirk q15)")
+        # the reference hands both maps to the RoI ops with the same spatial_scale; a radar map of another size (the
+        # demos feed the raw 32 x 32 map, quirk q15) is legal there: the pooling kernel takes per-map sizes
         self._keep_side = (t1, t2, t3, maps)  # alive until the next forward: the side stream may still read them
-        return roi_score_map, radar_score_map, fh, fw
+        return roi_score_map, radar_score_map, fh, fw, mh, mw
 
     # ---------------------------------------------------------------------------------- forward
     def forward(self, images, maps, radar_boxes_location, model_mode=0, targets=None):
@@ -398,7 +396,7 @@ class Network(nn.Module):
             maps_job = self._score_maps(plan, maps, n, dev)
         else:
             torch.cuda.current_stream(dev).wait_stream(self._side_stream(dev))
-        roi_score_map, radar_score_map, fh, fw = maps_job
+        roi_score_map, radar_score_map, fh, fw, rh_, rw_ = maps_job
         packs = self._get_packs()
         mark("score_maps")
 
@@ -420,6 +418,7 @@ class Network(nn.Module):
         d.img_map, d.radar_map = roi_score_map.data_ptr(), radar_score_map.data_ptr()
         d.img_pitch, d.radar_pitch = 490, 12
         d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16
+        d.rh, d.rw = rh_, rw_
         d.img_boxes, d.n_img, d.n_img_cap, d.box_cols = img_boxes.data_ptr(), n_img_dev.data_ptr(), cap_img, cols
         d.radar_boxes, d.n_radar = (rb.data_ptr() if n_radar else None), n_radar
         d.thr_img, d.thr_radar = float(self.refine_threshold_img), float(self.refine_threshold_radar)

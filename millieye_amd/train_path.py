@@ -278,6 +278,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
         d = hip.HeadsDesc()
         d.img_map, d.radar_map, d.img_pitch, d.radar_pitch = a1.data_ptr(), r4.data_ptr(), 490, 10
         d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16
+        d.rh, d.rw = mh, mw
         d.img_boxes, d.n_img, d.n_img_cap, d.box_cols = img_boxes.data_ptr(), n_img_dev.data_ptr(), n_img, cols
         d.radar_boxes, d.n_radar = (rb.data_ptr() if n_radar else None), n_radar
         d.thr_img, d.thr_radar = float(net.refine_threshold_img), float(net.refine_threshold_radar)

@@ -120,3 +120,20 @@ def test_train_py_call_form_is_recognised(hip_lib):
     x, maps, rboxes = _inputs("callform", 1, 96)
     with pytest.raises(NotImplementedError):  # recognised as the training call (tail not built yet), not a crash
         net(x.cuda(), maps.cuda(), rboxes.cuda(), torch.zeros((1, 6)))
+
+
+def test_demo_radar_map_size_quirk(hip_lib):
+    """run_sp.py / run_mp.py feed the raw 32x32 radar map with a 416 image (feature map 26x26) and the same
+    spatial_scale (quirk q15): the radar branch pools from a map of its own size.  Here 12x12 radar maps with a
+    160 px image (10x10 features), against the oracle."""
+    from oracle import network_ref
+    name, cfg, n, s, conf = "q15", "yolov3-tiny-12", 2, 160, 0.2
+    net = _build(name, cfg, conf).eval()
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    maps, rboxes = synth.radar_inputs(name + "/radar", n, 12)
+    maps, rboxes = torch.from_numpy(maps), torch.from_numpy(rboxes)
+    ref = network_ref.network_forward(cfgs.KNOWN[cfg](), net.state_dict(), x, maps, rboxes, 0, conf)
+    net = net.to(net.device)
+    out = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+    _cmp_rows(out.cpu(), ref, "mode 0 with 12x12 radar maps on a 10x10 feature map")
+    assert ref.shape[0] > 4
