@@ -137,3 +137,16 @@ def test_demo_radar_map_size_quirk(hip_lib):
     out = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
     _cmp_rows(out.cpu(), ref, "mode 0 with 12x12 radar maps on a 10x10 feature map")
     assert ref.shape[0] > 4
+
+
+def test_network_forward_is_repeatable(hip_lib):
+    """Same inputs, same rows - bit for bit - across runs (the score maps run on a second stream beside NMS; split-K sums
+    are ordered; nothing in the inference path uses atomics)."""
+    name, cfg, n, s, conf = NETWORK_CASES[0]
+    net = _build(name, cfg, conf).eval()
+    net = net.to(net.device)
+    x, maps, rboxes = _inputs(name, n, s)
+    first = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).clone()
+    for _ in range(20):
+        again = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+        assert torch.equal(first, again)
