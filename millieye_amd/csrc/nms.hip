@@ -25,6 +25,7 @@ namespace {
 constexpr int SEL_THREADS = 1024;
 constexpr int MAX_ROWS = 32768;  // 32 candidates per thread
 constexpr int LDS_CANDS = 4096;  // candidates per image kept in LDS by nms_select (96 KiB)
+constexpr int MAT_CANDS = 768;   // ... up to this many are resolved through a suppression bit matrix in LDS (108 KiB)
 
 struct NmsWs {
   float4* raw;               // [n][cap] raw xyxy
@@ -192,9 +193,12 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
   // Only as many waves as the candidate count deserves take part (surplus waves exit before the first barrier;
   // s_barrier only counts live waves).  Up to 2048 candidates every thread owns <= 2 of them and the greedy loop
   // runs in "register mode" (below); beyond that the generic loop with up to 32 candidates per thread is used.
-  const bool reg_mode = cnt <= 2 * SEL_THREADS;
+  const bool mat_mode = cnt <= MAT_CANDS;
+  const bool reg_mode = !mat_mode && cnt <= 2 * SEL_THREADS;
   int T = SEL_THREADS;
-  if (reg_mode) {
+  if (mat_mode) {
+    T = cnt > 128 ? SEL_THREADS : ((cnt + 63) & ~63);  // the N^2 / 2 IoU tests of the bit matrix want every lane
+  } else if (reg_mode) {
     T = ((cnt + 1) / 2 + 63) & ~63;
     if (T < 64) T = 64;
   }
@@ -238,6 +242,86 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     }
     __syncthreads();
     maxc = s_maxc;
+  }
+  if (mat_mode) {
+    // ---- matrix mode (the common case: a few hundred candidates).  Sort by key (rank = number of larger keys),
+    // build the upper-triangular suppression bit matrix of the sorted boxes in parallel, then one wave walks it:
+    // the next winner is the first clear bit of the "removed" words, and taking it ORs its matrix row in.  The greedy
+    // chain of <= max_det dependent steps costs ~30 scalar-ish instructions each instead of a workgroup-wide argmax.
+    unsigned long long* mkey = reinterpret_cast<unsigned long long*>(dyn_lds);                       // [MAT]
+    float4* mbox = reinterpret_cast<float4*>(dyn_lds + MAT_CANDS * 8);                                // [MAT] unsorted
+    float4* sbox = reinterpret_cast<float4*>(dyn_lds + MAT_CANDS * 24);                               // [MAT] sorted
+    int* sslot = reinterpret_cast<int*>(dyn_lds + MAT_CANDS * 40);                                    // [MAT]
+    int* skeep = reinterpret_cast<int*>(dyn_lds + MAT_CANDS * 44);                                    // [MAT]
+    unsigned long long* mrow = reinterpret_cast<unsigned long long*>(dyn_lds + MAT_CANDS * 48);       // [MAT][W]
+    const int W = (cnt + 63) >> 6;
+    const float mp1 = maxc + 1.f;
+    if (t < cnt) {
+      float4 bb = w.raw[base + t];
+      if (use_offsets) {
+        const float o = w.label[base + t] * mp1;
+        bb.x = bb.x + o; bb.y = bb.y + o; bb.z = bb.z + o; bb.w = bb.w + o;
+      }
+      mbox[t] = bb;
+      mkey[t] = w.key[base + t];
+    }
+    __syncthreads();
+    if (t < cnt) {
+      const unsigned long long mine = mkey[t];
+      int rank = 0;
+      for (int i = 0; i < cnt; ++i) rank += (mkey[i] > mine) ? 1 : 0;  // keys are unique (they embed the row)
+      sbox[rank] = mbox[t];
+      sslot[rank] = t;
+    }
+    __syncthreads();
+    for (int idx = t; idx < cnt * W; idx += T) {
+      const int i = idx / W, wd = idx - i * W;
+      unsigned long long bits = 0ull;
+      if (wd >= (i >> 6)) {
+        const float4 bi = sbox[i];
+        const float ai = box_area(bi);
+        const int j0 = wd << 6;
+        for (int b = 0; b < 64; ++b) {
+          const int j = j0 + b;
+          if (j > i && j < cnt) {
+            const float4 bj = sbox[j];
+            if (iou_exceeds(bi, ai, bj, box_area(bj), iou_thresh)) bits |= 1ull << b;
+          }
+        }
+      }
+      mrow[(size_t)i * W + wd] = bits;
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    // wave 0: lane l holds removed-word l (W <= 12)
+    unsigned rem_lo = 0u, rem_hi = 0u;
+    int kept = 0, i = 0;
+    while (i < cnt && kept < max_det) {
+      const int wd = i >> 6;
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)rem_lo, wd);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)rem_hi, wd);
+      unsigned long long avail = ~(((unsigned long long)hi << 32) | lo);
+      avail &= ~0ull << (i & 63);
+      const int last = cnt - (wd << 6);
+      if (last < 64) avail &= (1ull << last) - 1ull;
+      if (avail == 0ull) {
+        i = (wd + 1) << 6;
+        continue;
+      }
+      i = (wd << 6) + __builtin_ctzll(avail);
+      if (lane == 0) skeep[kept] = sslot[i];
+      ++kept;
+      if (lane < W) {
+        const unsigned long long row = mrow[(size_t)i * W + lane];
+        rem_lo |= (unsigned)row;
+        rem_hi |= (unsigned)(row >> 32);
+      }
+      ++i;
+    }
+    __syncthreads();  // (only wave 0 is alive) skeep written by lane 0 is read by every lane below
+    for (int q = lane; q < kept; q += 64) w.keep_slot[base + q] = skeep[q];
+    if (lane == 0) out_count[img] = kept;
+    return;
   }
   if (reg_mode) {
     // ---- register mode: box / area / key of this thread's <= 2 candidates stay in VGPRs; one barrier per greedy
@@ -395,7 +479,7 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
   if (t == 0) out_count[img] = kept;
 }
 
-constexpr size_t kSelectLds = (size_t)LDS_CANDS * 24;
+constexpr size_t kSelectLds = 112 * 1024;  // max(LDS_CANDS * 24, matrix mode: keys + boxes + sorted copies + 768 x 12 x 8 B bits)
 
 inline hipError_t select_lds_attr() {  // > 64 KiB of dynamic LDS needs the opt-in, once per process
   static hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_select_kernel),
