@@ -1089,6 +1089,7 @@ int launch_igemm(ConvP& p, hipStream_t stream) {
 
 template <int BM, int BN, int WR, int WC, int DPRIO = 0, int MINW = 1, int DABL = 0>
 int launch_dma(ConvP& p, hipStream_t stream) {
+  ME_REQUIRE(p.ks * p.ks <= 32, ME_E_BADARG, "conv_igemm_dma_f32: filters larger than 5x5 need the register-staged tiles (51-55)");
   constexpr int BK = 16;
   p.cs = (p.cin + BK - 1) / BK;
   p.stages = p.ks * p.ks * p.cs;
@@ -1136,6 +1137,12 @@ bool buf_addressable(const ConvP& p) {
 
 template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0>
 int launch_buf(ConvP& p, hipStream_t stream) {
+  if (p.ks * p.ks > 32) {  // the DMA kernels keep a 32-bit "tap is padding" mask per lane: larger filters (6x6, 7x7)
+    if constexpr (WR * WC == 4)  // go through the register-staged kernel, which tests bounds per stage
+      return launch_igemm<BM, BN, 16, WR, WC>(p, stream);
+    else
+      return launch_igemm<128, 128, 16, 2, 2>(p, stream);
+  }
   if (!buf_addressable<BM>(p)) return launch_dma<BM, BN, WR, WC, 1, MINW>(p, stream);
   constexpr int BK = 16;
   p.cs = (p.cin + BK - 1) / BK;

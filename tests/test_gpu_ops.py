@@ -1,6 +1,7 @@
 """-m gpu: per-kernel parity of the detector ops, through the C ABI, against stock torch CPU
 fp32 ops (the same library calls the reference's CPU path makes).  Tolerance: 1e-3
 (allclose(rtol=atol=1e-3), BASELINE.json north_star); observed errors are ~1e-6."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -186,3 +187,26 @@ def test_yolo_decode(hip_lib, g, nc, img):
     ref = darknet_ref.yolo_decode(x, anchors, nc, img)
     got = hip.yolo_decode(x.permute(0, 2, 3, 1).contiguous().cuda(), anchors, nc, img).cpu()
     assert_close(got, ref, 1e-5, "yolo decode")
+
+
+def test_conv_random_shapes(hip_lib):
+    """Seeded sweep of odd shapes through the automatic plan (and the buffer-addressed kernel where it applies):
+    filters 1/3/5/7 (7x7 has more taps than the DMA kernels' 32-bit padding mask: register-staged fallback), strides 1-3,
+    pads 0-3, h != w, h or w = 1, channel counts around the 16 / 64 boundaries, every activation."""
+    from millieye_amd import hip
+    rng = np.random.RandomState(20260928)
+    done = 0
+    for case in range(60):
+        k = int(rng.choice([1, 3, 3, 5, 7]))
+        s = int(rng.choice([1, 1, 2, 3]))
+        pad = (k - 1) // 2   # the wrapper mirrors darknet: pad = (k - 1) // 2
+        cin = int(rng.choice([8, 12, 16, 24, 32, 48, 64, 80]))  # cin <= 4 is the stem kernel (3x3 only, fails loudly otherwise)
+        cout = int(rng.choice([1, 5, 16, 33, 64, 96, 130]))
+        h, w = int(rng.randint(1, 23)), int(rng.randint(1, 23))
+        if (h + 2 * pad - k) < 0 or (w + 2 * pad - k) < 0:
+            continue
+        n = int(rng.randint(1, 4))
+        _conv_case(hip, f"rnd{case}", n, h, w, cin, cout, k, s, int(rng.randint(0, 3)), residual=bool(rng.randint(0, 2)),
+                   split_k=int(rng.choice([0, 0, 2, 3])))
+        done += 1
+    assert done >= 45
