@@ -150,3 +150,23 @@ def test_network_forward_is_repeatable(hip_lib):
     for _ in range(20):
         again = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
         assert torch.equal(first, again)
+
+
+def test_no_rois_at_all(hip_lib):
+    """Nothing passes the confidence threshold and there is no radar proposal: the reference's empty [0,8] result (its
+    torch ops run on empty tensors), for modes 0 and 1, and with radar proposals only."""
+    from oracle import network_ref
+    name, cfg, n, s, conf = "empty", "yolov3-tiny-12", 2, 96, 2.0   # sigmoid outputs never reach 2.0
+    net = _build(name, cfg, conf).eval()
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    maps, rboxes = synth.radar_inputs(name + "/radar", n, s // 16)
+    maps, rboxes = torch.from_numpy(maps), torch.from_numpy(rboxes)
+    sd = net.state_dict()
+    net = net.to(net.device)
+    for mode in (0, 1):
+        out = net(x.cuda(), maps.cuda(), torch.zeros((0, 5)).cuda(), mode)
+        assert tuple(out.shape) == (0, 8)
+    out = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)      # radar proposals only
+    ref = network_ref.network_forward(cfgs.KNOWN[cfg](), sd, x, maps, rboxes, 0, conf)
+    _cmp_rows(out.cpu(), ref, "radar-only RoIs")
+    assert out.shape[0] == ref.shape[0] > 0
