@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 2
+#define ME_ABI_VERSION 3
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -403,8 +403,46 @@ int me_radar_heatmap_f32(const double* points, const int32_t* offsets, const int
 int me_batch_statistics_f32(const float* rows, int32_t m, int32_t cols, const float* targets, int32_t q,
                             int32_t n_images, float iou_threshold, float* tp, void* stream);
 
+/* ---- 16-bit storage mode (BASELINE configs[2] / [4]: "bf16 inference") -------------------------------------------
+ * The same conv block as me_conv2d_f32 (models.py:22-41) with bfloat16 activations and weights and fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16.  Opt-in; the fp32 entry points stay the default and the ones the 1e-3 parity bar is quoted on.
+ *   x    bf16 NHWC (pitches in elements, %% 8);   stem only (cin == 3): float32 NCHW (x_nchw = 1) or NHWC
+ *   wgt  bf16 [cout][k][k][cin], cin %% 32 == 0;  stem: float32 [cout][3][3][3]
+ *   res  same type as y (or NULL);  y bf16, or float32 when y_f32 != 0 (the detection convs that feed me_yolo_decode_f32)
+ * Rounding points: weights once on the host, every stored activation once (RNE, after activation + residual). */
+typedef struct me_conv16_desc {
+  const void* x;
+  const void* wgt;
+  const float* scale;
+  const float* shift;
+  const void* res;
+  void* y;
+  int64_t x_pitch, res_pitch, y_pitch;
+  int32_t n, h, w, cin;
+  int32_t cout, ksize, stride, pad;
+  int32_t ho, wo;
+  int32_t act;
+  int32_t upsample;
+  int32_t x_nchw;
+  int32_t y_f32;
+  int32_t tile;    /* 0 = auto; 1..4 = 128x128 / 128x64 / 64x64 / 256x128; 11..14 = single sub-stage variants */
+  int32_t split_k; /* as me_conv_desc */
+  void* workspace;
+  int64_t workspace_bytes;
+} me_conv16_desc;
+int me_conv2d_bf16(const me_conv16_desc* d, void* stream);
+int64_t me_conv2d_bf16_workspace_bytes(const me_conv16_desc* d);
+/* bf16 NHWC twins of me_maxpool_f32 / me_upsample_f32 / me_add_f32 / me_copy_f32 (channels and pitches %% 8) */
+int me_maxpool_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                    int32_t size, int32_t stride, int32_t pad, int32_t zero_ext, int32_t ho, int32_t wo, void* stream);
+int me_upsample_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                     int32_t factor, void* stream);
+int me_add_bf16(const void* a, int64_t a_pitch, const void* b, int64_t b_pitch, void* y, int64_t y_pitch, int64_t pixels,
+                int32_t c, void* stream);
+int me_copy_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int64_t pixels, int32_t c, void* stream);
+
 /* sizes of the descriptor structs, so a binding can assert its mirror layout */
-int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights */
+int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights, 6 conv16 */
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,7 @@ int32_t me_sizeof(int32_t which) {
     case 3: return (int32_t)sizeof(me_nms_desc);
     case 4: return (int32_t)sizeof(me_heads_desc);
     case 5: return (int32_t)sizeof(me_heads_weights);
+    case 6: return (int32_t)sizeof(me_conv16_desc);
     default: return -1;
   }
 }

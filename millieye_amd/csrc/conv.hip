@@ -17,6 +17,7 @@
 // Replaces the nn.Conv2d + BatchNorm2d + LeakyReLU blocks of
 // module3_our_dataset/yolov3/models.py:22-41 (see include/millieye_hip.h).
 #include "common.h"
+#include "dma.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -562,58 +563,7 @@ __global__ __launch_bounds__(256) void conv_stem3_f32(ConvP p) {
 //   * M0 is saved / restored once per stage around all of the wave's DMAs.
 // Needs cin % 16 == 0 (no per-chunk channel predicate); other shapes use conv_igemm_dma_f32.
 // ---------------------------------------------------------------------------------------------
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOobOffset = 0x80000000u;
-
-__device__ __forceinline__ u32x4 make_rsrc(const void* base) {
-  const unsigned long long b = (unsigned long long)base;
-  u32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
-  r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);  // stride 0 (raw buffer)
-  r.z = kOobOffset;                                                      // num_records (bytes)
-  r.w = 0x00020000u;                                                     // gfx9 raw-buffer dword 3
-  return r;
-}
-
-// All of one wave's DMAs of one stage in a single asm block (M0 saved / restored once).  LA A-type loads
-// (descriptor ra, scalar offset sa) are followed by LPW - LA B-type loads (rb, sb); LDS destinations advance by STEP.
-template <int LPW, int LA, int STEP>
-__device__ __forceinline__ void dma_stage(const unsigned (&v)[LPW], u32x4 ra, u32x4 rb, unsigned sa, unsigned sb,
-                                          unsigned dst) {
-  unsigned keep;
-  static_assert(LPW >= 2 && LPW <= 4 && LA >= 1 && LA <= 2, "unsupported DMA shape");
-#define ME_DMA_HEAD "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
-#define ME_DMA_NEXT "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\t"
-#define ME_DMA_A(i) "buffer_load_dwordx4 %[v" #i "], %[ra], %[sa] offen lds\n\t"
-#define ME_DMA_B(i) "buffer_load_dwordx4 %[v" #i "], %[rb], %[sb] offen lds\n\t"
-#define ME_DMA_TAIL "s_mov_b32 m0, %[k]"
-  if constexpr (LPW == 4 && LA == 2) {
-    asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_A(1) ME_DMA_NEXT ME_DMA_B(2) ME_DMA_NEXT ME_DMA_B(3) ME_DMA_TAIL
-                 : [k] "=&s"(keep)
-                 : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
-                   [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3])
-                 : "memory", "scc");
-  } else if constexpr (LPW == 3 && LA == 2) {
-    asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_A(1) ME_DMA_NEXT ME_DMA_B(2) ME_DMA_TAIL
-                 : [k] "=&s"(keep)
-                 : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
-                   [v1] "v"(v[1]), [v2] "v"(v[2])
-                 : "memory", "scc");
-  } else if constexpr (LPW == 2 && LA == 1) {
-    asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_B(1) ME_DMA_TAIL
-                 : [k] "=&s"(keep)
-                 : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
-                   [v1] "v"(v[1])
-                 : "memory", "scc");
-  } else {
-    static_assert(LPW == 0, "add the (LPW, LA) combination");
-  }
-#undef ME_DMA_HEAD
-#undef ME_DMA_NEXT
-#undef ME_DMA_A
-#undef ME_DMA_B
-#undef ME_DMA_TAIL
-}
+using namespace me_dma;
 
 // BABL (ablation, tuning only): 1 = every DMA lane is out of range (zero fill, no L2 / HBM traffic at all).
 template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0>

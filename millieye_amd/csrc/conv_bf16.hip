@@ -1,0 +1,701 @@
+// conv_bf16.hip - the detector's conv blocks with 16-bit storage (bf16 activations and weights, fp32 accumulate) for
+// gfx950: BASELINE configs[2] / [4] ("bf16 inference").  Opt-in (MILLIEYE_DTYPE=bf16 / Darknet.compute_dtype); the
+// fp32 path of conv.hip stays the default and the one the 1e-3 parity bar is quoted on.
+//
+//   conv_igemm_buf_bf16 : the buffer-addressed LDS-DMA implicit GEMM of conv.hip on v_mfma_f32_32x32x16_bf16
+//                         (2.5 PFLOP/s dense peak, 16x the fp32 matrix rate).  A stage is KSUB sub-stages of
+//                         (BM + BN) rows x 32 channels (64-byte rows - the same 1 KiB-per-DMA LDS image and XOR
+//                         swizzle as the fp32 kernel); one ds_read_b128 is one MFMA operand (8 bf16 per lane).
+//                         Epilogue: fp32 affine (folded BN / bias) + LeakyReLU + residual, one RNE rounding to bf16
+//                         (v_cvt_pk_bf16_f32) or fp32 output for the detection convs that feed the YOLO decode.
+//   conv_stem3_bf16     : the cin = 3 stem on the VALU (fp32 frames in, fp32 weights, bf16 NHWC out).
+//   maxpool / upsample / add / copy on bf16 NHWC (16 bytes = 8 channels per lane).
+//
+// Rounding points (what oracle/darknet_ref.py's storage="bf16" mode restates): weights once (host, RNE), every
+// stored activation once (after activation + residual), nothing else; accumulation and the affine are fp32.
+#include <math.h>
+#include <type_traits>
+#include "common.h"
+#include "dma.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+using namespace me_dma;
+
+struct Conv16P {
+  const unsigned short* x;
+  const unsigned short* wgt;
+  const float* scale;
+  const float* shift;
+  const void* res;
+  void* y;
+  long long x_pitch, res_pitch, y_pitch;  // elements
+  int n, h, w, cin, cout, ks, stride, pad, ho, wo, act, ups, y_f32, x_nchw;
+  int M;       // n*ho*wo
+  int ktot;    // ks*ks*cin
+  int cs;      // stages per filter tap = cin / (32*KSUB)
+  int stages;  // ks*ks*cs
+  int tiles_m, tiles_n;
+  float* partial;  // split-K slabs [splitk][M][cout] (raw fp32 accumulators), or nullptr
+  int splitk, sps;
+};
+
+__device__ __forceinline__ float act16(float v, int act) {
+  if (act == ME_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+  if (act == ME_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+__device__ __forceinline__ unsigned short to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ float from_bf16(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// one output element through the fused epilogue tail: residual, rounding, (replicated) store
+__device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float v, int hw) {
+  if (p.res) {
+    v += p.y_f32 ? reinterpret_cast<const float*>(p.res)[(long long)m * p.res_pitch + co]
+                 : from_bf16(reinterpret_cast<const unsigned short*>(p.res)[(long long)m * p.res_pitch + co]);
+  }
+  if (p.ups == 1) {
+    const long long o = (long long)m * p.y_pitch + co;
+    if (p.y_f32)
+      reinterpret_cast<float*>(p.y)[o] = v;
+    else
+      reinterpret_cast<unsigned short*>(p.y)[o] = to_bf16(v);
+    return;
+  }
+  const int nimg = m / hw;
+  const int rem = m - nimg * hw;
+  const int oy = rem / p.wo, ox = rem - oy * p.wo;
+  const int W2 = p.wo * 2;
+  const long long base = ((long long)nimg * (p.ho * 2) + 2 * oy) * W2 + 2 * ox;
+  const long long o[4] = {base * p.y_pitch + co, (base + 1) * p.y_pitch + co, (base + W2) * p.y_pitch + co,
+                          (base + W2 + 1) * p.y_pitch + co};
+  if (p.y_f32) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<float*>(p.y)[o[k]] = v;
+  } else {
+    const unsigned short b = to_bf16(v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<unsigned short*>(p.y)[o[k]] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit GEMM on the bf16 matrix cores.  M = n*ho*wo output pixels, N = cout, K = ks*ks*cin.
+// Needs cin % (32*KSUB) == 0 (the planner pads the one odd tensor of the tiny cfgs, engine.py).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16P p) {
+  constexpr int NW = WR * WC;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  constexpr int NST = 3;
+  constexpr int TM = BM / WR, TN = BN / WC;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int GA = BM / 16, G = (BM + BN) / 16;  // 16-row groups (1 KiB each): A first, then B
+  constexpr int LPW = (G + NW - 1) / NW;            // DMA instructions per wave per sub-stage
+  constexpr int LA = GA / NW;                       // ... of which A-type
+  constexpr unsigned SUB_B = LPW * NW * 1024u;      // bytes per sub-stage image (incl. dummy groups)
+  constexpr unsigned STAGE_B = SUB_B * KSUB;
+  static_assert(GA % NW == 0, "A groups must split evenly over the waves");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int r32 = lane & 31, hh = lane >> 5;
+
+  int tile_m, tile_n;
+  {  // XCD-aware: consecutive tiles of one XCD share weight rows / neighbouring pixels in that XCD's L2
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_n = wg % p.tiles_n;
+    tile_m = wg / p.tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int hw = p.ho * p.wo;
+
+  const int img0 = m0 / hw;
+  const long long img_elems = (long long)p.h * p.w * p.x_pitch;
+  const long long bias_elems = ((long long)p.pad * p.w + p.pad) * p.x_pitch;
+  const u32x4 rsrc_a = make_rsrc(p.x + (long long)img0 * img_elems - bias_elems);
+  const u32x4 rsrc_b = make_rsrc(p.wgt + (long long)n0 * p.ktot);
+
+  const int lrow = lane >> 2;
+  unsigned v_base[LPW], v_pad[LA], v_cur[LPW];
+#pragma unroll
+  for (int j = 0; j < LPW; ++j) {
+    const int g = wave + NW * j;
+    const int row = g * 16 + lrow;
+    const int q = (lane & 3) ^ ((row >> 2) & 3);  // source 16-byte chunk (8 channels) for this LDS slot
+    v_base[j] = kOobOffset;
+    if (j < LA) {
+      unsigned padmask = 0xFFFFFFFFu;
+      const int m = m0 + row;
+      if (m < p.M) {
+        const int nimg = m / hw;
+        const int rem = m - nimg * hw;
+        const int oy = rem / p.wo, ox = rem - oy * p.wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        unsigned ok = 0;
+        for (int ky = 0; ky < p.ks; ++ky)
+          for (int kx = 0; kx < p.ks; ++kx)
+            if ((unsigned)(iy0 + ky) < (unsigned)p.h && (unsigned)(ix0 + kx) < (unsigned)p.w)
+              ok |= 1u << (ky * p.ks + kx);
+        padmask = ~ok;
+        const long long e = (long long)(nimg - img0) * img_elems + ((long long)iy0 * p.w + ix0) * p.x_pitch + bias_elems;
+        v_base[j] = (unsigned)(e * 2) + 16u * q;
+      }
+      v_pad[j] = padmask;
+    } else if (g < G) {
+      const int co_local = row - BM;
+      if (n0 + co_local < p.cout) v_base[j] = (unsigned)co_local * (unsigned)p.ktot * 2u + 16u * q;
+    }
+    v_cur[j] = v_base[j];
+  }
+
+  const int sid = blockIdx.y;
+  const int s_begin = sid * p.sps;
+  const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
+  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;
+  int ky = tap / p.ks, kx = tap - ky * p.ks;
+  unsigned a_off = 0, b_off = 0;
+  auto enter_tap = [&]() {
+#pragma unroll
+    for (int j = 0; j < LA; ++j) v_cur[j] = ((v_pad[j] >> tap) & 1u) ? kOobOffset : v_base[j];
+    a_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 2);
+    b_off = (unsigned)tap * (unsigned)p.cin * 2u;
+  };
+  enter_tap();
+  a_off += (unsigned)cc * (64u * KSUB);
+  b_off += (unsigned)cc * (64u * KSUB);
+
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+  auto issue_stage = [&](unsigned lds_dst) {
+#pragma unroll
+    for (int u = 0; u < KSUB; ++u)
+      dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off + 64u * u, b_off + 64u * u, lds_dst + u * SUB_B);
+    a_off += 64u * KSUB;
+    b_off += 64u * KSUB;
+    if (++cc == p.cs) {
+      cc = 0;
+      ++tap;
+      if (++kx == p.ks) {
+        kx = 0;
+        ++ky;
+      }
+      enter_tap();
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nstages = s_end - s_begin;
+  issue_stage(wave_lds);
+  if (nstages > 1) issue_stage(wave_lds + STAGE_B);
+
+  // lane's operand = 8 consecutive channels (one 16-byte chunk) of row r32: chunk 2*kstep + hh, XOR-swizzled
+  const int sw = (r32 >> 2) & 3;
+  const unsigned char* a_frag = smem16 + (wr * TM + r32) * 64;
+  const unsigned char* b_frag = smem16 + (BM + wc * TN + r32) * 64;
+  const int offk[2] = {((0 + hh) ^ sw) * 16, ((2 + hh) ^ sw) * 16};
+
+  auto compute_stage = [&](const unsigned char* Ab, const unsigned char* Bb) {
+    bf16x8 af[KSUB][2][MT], bf[KSUB][2][NT];
+#pragma unroll
+    for (int u = 0; u < KSUB; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          af[u][ks][i] = *reinterpret_cast<const bf16x8*>(Ab + u * SUB_B + i * 32 * 64 + offk[ks]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          bf[u][ks][j] = *reinterpret_cast<const bf16x8*>(Bb + u * SUB_B + j * 32 * 64 + offk[ks]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KSUB; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u][ks][i], bf[u][ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  auto step = [&](auto slot_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW * KSUB) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_stage(wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+    compute_stage(a_frag + SLOT * STAGE_B, b_frag + SLOT * STAGE_B);
+  };
+  int s = 0;
+  for (; s + 3 <= nstages - 2; s += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  int slot = 0;
+  for (; s < nstages; ++s) {
+    if (s + 1 < nstages)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW * KSUB) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 2 < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);
+    compute_stage(a_frag + slot * STAGE_B, b_frag + slot * STAGE_B);
+    slot = slot == NST - 1 ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: lane r32 = output channel, accumulator element e = pixel row --------------------
+  if (p.splitk > 1) {
+    float* slab = p.partial + (long long)sid * p.M * p.cout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = n0 + wc * TN + j * 32 + r32;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (co < p.cout && m < p.M) slab[(long long)m * p.cout + co] = acc[i][j][e];
+        }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + wc * TN + j * 32 + r32;
+    const bool co_ok = co < p.cout;
+    const float sc = co_ok ? p.scale[co] : 0.f;
+    const float sh = co_ok ? p.shift[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (!co_ok || m >= p.M) continue;
+        store_out(p, m, co, act16(acc[i][j][e] * sc + sh, p.act), hw);
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_splitk_reduce_bf16(Conv16P p) {
+  const long long total = (long long)p.M * p.cout;
+  const int hw = p.ho * p.wo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int co = (int)(idx % p.cout);
+    const int m = (int)(idx / p.cout);
+    float a = p.partial[idx];
+    for (int k = 1; k < p.splitk; ++k) a += p.partial[(long long)k * total + idx];
+    store_out(p, m, co, act16(a * p.scale[co] + p.shift[co], p.act), hw);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem (cin == 3): fp32 frames (NCHW as the caller hands them, or NHWC) and fp32 weights in, bf16 NHWC out.
+// Same arithmetic and k order as conv_stem3_f32 (conv.hip); one thread = one pixel x CT output channels.
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void conv_stem3_bf16(Conv16P p) {
+  constexpr int K = 27;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int co0 = blockIdx.y * CT;
+  if (m >= p.M) return;
+  const int hw = p.ho * p.wo;
+  const int nimg = m / hw;
+  const int rem = m - nimg * hw;
+  const int oy = rem / p.wo, ox = rem - oy * p.wo;
+  const float* xf = reinterpret_cast<const float*>(p.x);
+  float xin[K];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+      const bool ok = ((unsigned)iy < (unsigned)p.h) && ((unsigned)ix < (unsigned)p.w);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+        if (ok)
+          v = p.x_nchw ? xf[(((long long)nimg * 3 + c) * p.h + iy) * p.w + ix]
+                       : xf[((long long)(nimg * p.h + iy) * p.w + ix) * p.x_pitch + c];
+        xin[(ky * 3 + kx) * 3 + c] = v;
+      }
+    }
+  const float* __restrict__ wg = reinterpret_cast<const float*>(p.wgt) + (long long)co0 * K;  // uniform -> s_load
+  unsigned packed[CT / 2];
+#pragma unroll
+  for (int j = 0; j < CT; j += 2) {
+    float v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) a = fmaf(xin[k], wg[(j + t) * K + k], a);
+      v[t] = act16(a * p.scale[co0 + j + t] + p.shift[co0 + j + t], p.act);
+    }
+    packed[j / 2] = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+  }
+  unsigned short* yrow = reinterpret_cast<unsigned short*>(p.y) + (long long)m * p.y_pitch + co0;
+#pragma unroll
+  for (int j = 0; j < CT / 2; j += 4)
+    *reinterpret_cast<uint4*>(yrow + 2 * j) = make_uint4(packed[j], packed[j + 1], packed[j + 2], packed[j + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// HBM-bound NHWC helpers on bf16: 8 channels (16 bytes) per lane, channel-fastest
+// ---------------------------------------------------------------------------------------------
+constexpr int kThreads = 256;
+inline unsigned grid_for(long long work) {
+  long long b = (work + kThreads - 1) / kThreads;
+  const long long cap = 256ll * 32;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+struct Pool16P {
+  const unsigned short* x;
+  unsigned short* y;
+  long long x_pitch, y_pitch;
+  int n, h, w, c, size, stride, pad, zero_ext, ho, wo;
+};
+
+__device__ __forceinline__ unsigned max_pair(unsigned a, unsigned b) {  // two packed bf16, fmaxf semantics per half
+  const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
+  const float hi = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
+  return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(kThreads) void maxpool_bf16_kernel(Pool16P d) {
+  const int cv = d.c / 8;
+  const long long total = (long long)d.n * d.ho * d.wo * cv;
+  const unsigned ninf = 0xff80ff80u;  // (-inf, -inf)
+  for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kThreads) {
+    const int c = (int)(idx % cv) * 8;
+    long long pix = idx / cv;
+    const int ox = (int)(pix % d.wo);
+    pix /= d.wo;
+    const int oy = (int)(pix % d.ho);
+    const int nimg = (int)(pix / d.ho);
+    uint4 best = make_uint4(ninf, ninf, ninf, ninf);
+    for (int ky = 0; ky < d.size; ++ky) {
+      const int iy = oy * d.stride - d.pad + ky;
+      for (int kx = 0; kx < d.size; ++kx) {
+        const int ix = ox * d.stride - d.pad + kx;
+        if ((unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w) {
+          const uint4 t = *reinterpret_cast<const uint4*>(d.x + ((long long)(nimg * d.h + iy) * d.w + ix) * d.x_pitch + c);
+          best.x = max_pair(best.x, t.x);
+          best.y = max_pair(best.y, t.y);
+          best.z = max_pair(best.z, t.z);
+          best.w = max_pair(best.w, t.w);
+        } else if (d.zero_ext && iy >= 0 && ix >= 0 && iy <= d.h && ix <= d.w) {
+          best.x = max_pair(best.x, 0u);  // ZeroPad2d((0,1,0,1)): zeros take part in the max (quirk q16)
+          best.y = max_pair(best.y, 0u);
+          best.z = max_pair(best.z, 0u);
+          best.w = max_pair(best.w, 0u);
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(d.y + ((long long)(nimg * d.ho + oy) * d.wo + ox) * d.y_pitch + c) = best;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void upsample_bf16_kernel(const unsigned short* x, long long xp, unsigned short* y,
+                                                                 long long yp, int n, int h, int w, int c, int f) {
+  const int cv = c / 8;
+  const int ho = h * f, wo = w * f;
+  const long long total = (long long)n * ho * wo * cv;
+  for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kThreads) {
+    const int cc = (int)(idx % cv) * 8;
+    long long pix = idx / cv;
+    const int ox = (int)(pix % wo);
+    pix /= wo;
+    const int oy = (int)(pix % ho);
+    const int nimg = (int)(pix / ho);
+    *reinterpret_cast<uint4*>(y + ((long long)(nimg * ho + oy) * wo + ox) * yp + cc) =
+        *reinterpret_cast<const uint4*>(x + ((long long)(nimg * h + oy / f) * w + ox / f) * xp + cc);
+  }
+}
+
+__device__ __forceinline__ unsigned add_pair(unsigned a, unsigned b) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  return (unsigned)to_bf16(lo) | ((unsigned)to_bf16(hi) << 16);
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(kThreads) void addcopy_bf16_kernel(const unsigned short* a, long long ap,
+                                                                const unsigned short* b, long long bp, unsigned short* y,
+                                                                long long yp, long long pixels, int c) {
+  const int cv = c / 8;
+  const long long total = pixels * cv;
+  for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kThreads) {
+    const int cc = (int)(idx % cv) * 8;
+    const long long pix = idx / cv;
+    uint4 u = *reinterpret_cast<const uint4*>(a + pix * ap + cc);
+    if (ADD) {
+      const uint4 t = *reinterpret_cast<const uint4*>(b + pix * bp + cc);
+      u.x = add_pair(u.x, t.x);
+      u.y = add_pair(u.y, t.y);
+      u.z = add_pair(u.z, t.z);
+      u.w = add_pair(u.w, t.w);
+    }
+    *reinterpret_cast<uint4*>(y + pix * yp + cc) = u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxSplit16 = 16;
+
+bool addressable16(const Conv16P& p, int bm) {
+  const long long hw = (long long)p.ho * p.wo;
+  const long long span_imgs = (bm - 1) / hw + 2;
+  const long long img_bytes = (long long)p.h * p.w * p.x_pitch * 2;
+  const long long tap_bytes = ((long long)p.ks * p.w + p.ks) * p.x_pitch * 2 + (long long)p.cin * 2;
+  const long long a_max = span_imgs * img_bytes + 2 * tap_bytes;
+  const long long b_max = 256ll * p.ktot * 2 + (long long)p.ktot * 2;
+  return a_max < (1ll << 31) && b_max < (1ll << 31);
+}
+
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1>
+int launch16(Conv16P& p, hipStream_t stream) {
+  ME_REQUIRE(addressable16(p, BM), ME_E_TOOBIG,
+             "me_conv2d_bf16: one tile's input window exceeds the 2 GiB buffer-descriptor range");
+  p.cs = p.cin / (32 * KSUB);
+  p.stages = p.ks * p.ks * p.cs;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.cout + BN - 1) / BN;
+  if (p.splitk > p.stages) p.splitk = p.stages;
+  p.sps = (p.stages + p.splitk - 1) / p.splitk;
+  while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;
+  constexpr int NW = WR * WC;
+  constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
+  const size_t lds = (size_t)3 * KSUB * LPW * NW * 1024;
+  auto kern = conv_igemm_buf_bf16<BM, BN, WR, WC, KSUB, MINW>;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      attr_set = true;
+    }
+  }
+  const long long blocks = (long long)p.tiles_m * p.tiles_n;
+  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_bf16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(64 * NW), lds, stream, p);
+  int rc = me::check_launch("conv_igemm_buf_bf16");
+  if (rc || p.splitk == 1) return rc;
+  long long rb = ((long long)p.M * p.cout + 255) / 256;
+  if (rb > 256 * 16) rb = 256 * 16;
+  hipLaunchKernelGGL(conv_splitk_reduce_bf16, dim3((unsigned)rb), dim3(256), 0, stream, p);
+  return me::check_launch("conv_splitk_reduce_bf16");
+}
+
+int fill16(const me_conv16_desc* d, Conv16P& p) {
+  ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_bf16: null descriptor");
+  ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
+             "me_conv2d_bf16: non-positive dimension");
+  ME_REQUIRE(d->ksize >= 1 && d->stride >= 1 && d->pad >= 0, ME_E_BADARG, "me_conv2d_bf16: bad ksize/stride/pad");
+  const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1;
+  const int wo = (d->w + 2 * d->pad - d->ksize) / d->stride + 1;
+  ME_REQUIRE(ho == d->ho && wo == d->wo, ME_E_BADARG, "me_conv2d_bf16: ho/wo (%d,%d) != derived (%d,%d)", d->ho, d->wo,
+             ho, wo);
+  ME_REQUIRE((long long)d->n * d->ho * d->wo < (1ll << 31), ME_E_TOOBIG, "me_conv2d_bf16: too many output pixels");
+  p.x = reinterpret_cast<const unsigned short*>(d->x);
+  p.wgt = reinterpret_cast<const unsigned short*>(d->wgt);
+  p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
+  p.x_pitch = d->x_pitch; p.res_pitch = d->res_pitch; p.y_pitch = d->y_pitch;
+  p.n = d->n; p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout; p.ks = d->ksize;
+  p.stride = d->stride; p.pad = d->pad; p.ho = d->ho; p.wo = d->wo; p.act = d->act; p.ups = d->upsample;
+  p.y_f32 = d->y_f32; p.x_nchw = d->x_nchw;
+  p.M = d->n * d->ho * d->wo;
+  p.ktot = d->ksize * d->ksize * d->cin;
+  p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
+  p.partial = nullptr;
+  p.splitk = 1;
+  p.sps = 0;
+  return 0;
+}
+
+// default (tile, split) when the caller does not force one: the engine's autotuner measures the candidates; this is
+// the cold-start guess - the largest tile that still gives every CU >= 2 workgroups, split-K below that.
+void plan16(const Conv16P& p, int max_split, int* tile, int* split) {
+  static const int bm[] = {0, 128, 128, 64, 256}, bn[] = {0, 128, 64, 64, 128};
+  int best = 3;
+  for (int t : {4, 1, 2, 3}) {
+    const long long blocks = (long long)((p.M + bm[t] - 1) / bm[t]) * ((p.cout + bn[t] - 1) / bn[t]);
+    if (blocks >= 512) {
+      best = t;
+      break;
+    }
+  }
+  const long long blocks = (long long)((p.M + bm[best] - 1) / bm[best]) * ((p.cout + bn[best] - 1) / bn[best]);
+  int s = 1;
+  const int stages = p.ks * p.ks * (p.cin / 32);
+  while (s < max_split && blocks * s < 512 && stages / (s * 2) >= 8) s *= 2;
+  *tile = best;
+  *split = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t me_conv2d_bf16_workspace_bytes(const me_conv16_desc* d) {
+  Conv16P p;
+  if (!d || fill16(d, p) != 0 || d->cin <= 4) return 0;
+  int tile, split;
+  plan16(p, d->split_k > 0 ? d->split_k : kMaxSplit16, &tile, &split);
+  if (d->split_k > 0) split = d->split_k;
+  return split > 1 ? (int64_t)split * p.M * p.cout * (int64_t)sizeof(float) : 0;
+}
+
+int me_conv2d_bf16(const me_conv16_desc* d, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  Conv16P p;
+  int rc = fill16(d, p);
+  if (rc) return rc;
+  ME_REQUIRE(d->x && d->wgt && d->scale && d->shift && d->y, ME_E_NULLPTR, "me_conv2d_bf16: null tensor pointer");
+  ME_REQUIRE(d->upsample == 1 || d->upsample == 2, ME_E_BADARG, "me_conv2d_bf16: upsample must be 1 or 2");
+  ME_REQUIRE(d->act >= 0 && d->act <= 2, ME_E_BADARG, "me_conv2d_bf16: unknown activation %d", d->act);
+  ME_REQUIRE(d->y_pitch >= d->cout, ME_E_BADARG, "me_conv2d_bf16: y_pitch < cout");
+
+  if (d->cin <= 4) {  // stem: fp32 frames + fp32 weights -> bf16
+    ME_REQUIRE(d->cin == 3 && d->ksize == 3, ME_E_BADARG, "me_conv2d_bf16: the stem kernel needs cin 3, ksize 3");
+    ME_REQUIRE(d->cout % 16 == 0 && d->y_pitch % 8 == 0 && !d->y_f32, ME_E_BADARG,
+               "me_conv2d_bf16: stem needs cout %% 16 == 0, y_pitch %% 8 == 0, bf16 output");
+    ME_REQUIRE(d->res == nullptr && d->upsample == 1, ME_E_BADARG, "me_conv2d_bf16: stem has no residual/upsample epilogue");
+    ME_REQUIRE(d->x_nchw || d->x_pitch >= d->cin, ME_E_BADARG, "me_conv2d_bf16: x_pitch < cin");
+    ME_REQUIRE(me::aligned16(d->y), ME_E_ALIGN, "me_conv2d_bf16: y not 16-byte aligned");
+    const unsigned mb = (unsigned)((p.M + 255) / 256);
+    if (d->cout % 32 == 0)
+      hipLaunchKernelGGL(conv_stem3_bf16<32>, dim3(mb, d->cout / 32), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL(conv_stem3_bf16<16>, dim3(mb, d->cout / 16), dim3(256), 0, stream, p);
+    return me::check_launch("conv_stem3_bf16");
+  }
+
+  ME_REQUIRE(!d->x_nchw, ME_E_BADARG, "me_conv2d_bf16: NCHW input only for the stem");
+  ME_REQUIRE(d->cin % 32 == 0, ME_E_BADARG, "me_conv2d_bf16: cin %% 32 != 0 (cin=%d): pad the channels", d->cin);
+  ME_REQUIRE(d->x_pitch >= d->cin && d->x_pitch % 8 == 0, ME_E_ALIGN, "me_conv2d_bf16: x_pitch must be >= cin, %% 8");
+  ME_REQUIRE(me::aligned16(d->x) && me::aligned16(d->wgt), ME_E_ALIGN, "me_conv2d_bf16: x / wgt not 16-byte aligned");
+  ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_bf16: res_pitch < cout");
+  ME_REQUIRE(d->split_k >= 0 && d->split_k <= 64, ME_E_BADARG, "me_conv2d_bf16: split_k out of range");
+  ME_REQUIRE(d->ksize * d->ksize <= 32, ME_E_TOOBIG, "me_conv2d_bf16: filters with more than 32 taps are not supported");
+
+  const long long slab = (long long)p.M * p.cout * (long long)sizeof(float);
+  int max_split = 1;
+  if (d->workspace && d->workspace_bytes >= 2 * slab) {
+    const long long fit = d->workspace_bytes / slab;
+    max_split = fit < kMaxSplit16 ? (int)fit : kMaxSplit16;
+  }
+  int tile = d->tile, split = 1;
+  if (tile == 0 || d->split_k == 0) {
+    int t0, s0;
+    plan16(p, max_split, &t0, &s0);
+    if (tile == 0) tile = t0;
+    split = s0;
+  }
+  if (d->split_k > 0) {
+    ME_REQUIRE(d->split_k == 1 || (d->workspace && d->workspace_bytes >= d->split_k * slab), ME_E_BADARG,
+               "me_conv2d_bf16: split_k=%d needs a workspace of %lld bytes", d->split_k, d->split_k * slab);
+    split = d->split_k;
+  }
+  p.splitk = split;
+  p.partial = reinterpret_cast<float*>(d->workspace);
+  const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows
+  switch (tile) {
+    case 1: return k2 ? launch16<128, 128, 2, 2, 2>(p, stream) : launch16<128, 128, 2, 2, 1>(p, stream);
+    case 2: return k2 ? launch16<128, 64, 2, 2, 2>(p, stream) : launch16<128, 64, 2, 2, 1>(p, stream);
+    case 3: return k2 ? launch16<64, 64, 2, 2, 2>(p, stream) : launch16<64, 64, 2, 2, 1>(p, stream);
+    case 4: return k2 ? launch16<256, 128, 4, 2, 2, 2>(p, stream) : launch16<256, 128, 4, 2, 1, 2>(p, stream);
+    // forced ids (tuning): single sub-stage variants
+    case 11: return launch16<128, 128, 2, 2, 1>(p, stream);
+    case 12: return launch16<128, 64, 2, 2, 1>(p, stream);
+    case 13: return launch16<64, 64, 2, 2, 1>(p, stream);
+    case 14: return launch16<256, 128, 4, 2, 1, 2>(p, stream);
+    default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_bf16: unknown tile id %d", tile);
+  }
+  return 0;
+}
+
+int me_maxpool_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                    int32_t size, int32_t stride, int32_t pad, int32_t zero_ext, int32_t ho, int32_t wo, void* stream) {
+  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_maxpool_bf16: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && size >= 1 && stride >= 1 && pad >= 0, ME_E_BADARG,
+             "me_maxpool_bf16: bad dimensions");
+  ME_REQUIRE(c % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0 && x_pitch >= c && y_pitch >= c, ME_E_ALIGN,
+             "me_maxpool_bf16: channels and pitches must be multiples of 8");
+  ME_REQUIRE(me::aligned16(x) && me::aligned16(y), ME_E_ALIGN, "me_maxpool_bf16: pointers not 16-byte aligned");
+  const int eh = (h + (zero_ext ? 1 : 0) + 2 * pad - size) / stride + 1, ew = (w + (zero_ext ? 1 : 0) + 2 * pad - size) / stride + 1;
+  ME_REQUIRE(eh == ho && ew == wo, ME_E_BADARG, "me_maxpool_bf16: ho/wo (%d,%d) != derived (%d,%d)", ho, wo, eh, ew);
+  Pool16P d{reinterpret_cast<const unsigned short*>(x), reinterpret_cast<unsigned short*>(y), x_pitch, y_pitch, n, h, w, c,
+            size, stride, pad, zero_ext, ho, wo};
+  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(grid_for((long long)n * ho * wo * (c / 8))), dim3(kThreads), 0,
+                     reinterpret_cast<hipStream_t>(stream), d);
+  return me::check_launch("maxpool_bf16_kernel");
+}
+
+int me_upsample_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                     int32_t factor, void* stream) {
+  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_upsample_bf16: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, ME_E_BADARG, "me_upsample_bf16: bad dimensions");
+  ME_REQUIRE(c % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0 && me::aligned16(x) && me::aligned16(y), ME_E_ALIGN,
+             "me_upsample_bf16: channels / pitches %% 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL(upsample_bf16_kernel, dim3(grid_for((long long)n * h * factor * w * factor * (c / 8))), dim3(kThreads),
+                     0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(x), x_pitch,
+                     reinterpret_cast<unsigned short*>(y), y_pitch, n, h, w, c, factor);
+  return me::check_launch("upsample_bf16_kernel");
+}
+
+int me_add_bf16(const void* a, int64_t a_pitch, const void* b, int64_t b_pitch, void* y, int64_t y_pitch, int64_t pixels,
+                int32_t c, void* stream) {
+  ME_REQUIRE(a && b && y, ME_E_NULLPTR, "me_add_bf16: null pointer");
+  ME_REQUIRE(pixels > 0 && c > 0, ME_E_BADARG, "me_add_bf16: bad dimensions");
+  ME_REQUIRE(c % 8 == 0 && a_pitch % 8 == 0 && b_pitch % 8 == 0 && y_pitch % 8 == 0 && me::aligned16(a) &&
+                 me::aligned16(b) && me::aligned16(y),
+             ME_E_ALIGN, "me_add_bf16: channels / pitches %% 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL((addcopy_bf16_kernel<true>), dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(a), a_pitch,
+                     reinterpret_cast<const unsigned short*>(b), b_pitch, reinterpret_cast<unsigned short*>(y), y_pitch,
+                     pixels, c);
+  return me::check_launch("addcopy_bf16_kernel");
+}
+
+int me_copy_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int64_t pixels, int32_t c, void* stream) {
+  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_copy_bf16: null pointer");
+  ME_REQUIRE(pixels > 0 && c > 0, ME_E_BADARG, "me_copy_bf16: bad dimensions");
+  ME_REQUIRE(c % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0 && me::aligned16(x) && me::aligned16(y), ME_E_ALIGN,
+             "me_copy_bf16: channels / pitches %% 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL((addcopy_bf16_kernel<false>), dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(x), x_pitch,
+                     reinterpret_cast<const unsigned short*>(x), x_pitch, reinterpret_cast<unsigned short*>(y), y_pitch,
+                     pixels, c);
+  return me::check_launch("addcopy_bf16_kernel");
+}
+
+}  // extern "C"

@@ -39,6 +39,21 @@ class ConvDesc(C.Structure):
     ]
 
 
+class Conv16Desc(C.Structure):
+    """me_conv16_desc: the bf16-storage twin of ConvDesc (adds ``y_f32``)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("wgt", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("res", C.c_void_p), ("y", C.c_void_p),
+        ("x_pitch", C.c_int64), ("res_pitch", C.c_int64), ("y_pitch", C.c_int64),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32),
+        ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32),
+        ("act", C.c_int32), ("upsample", C.c_int32), ("x_nchw", C.c_int32), ("y_f32", C.c_int32),
+        ("tile", C.c_int32), ("split_k", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+    ]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p),
@@ -95,7 +110,7 @@ class HeadsDesc(C.Structure):
     ]
 
 
-_STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights}
+_STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights, 6: Conv16Desc}
 
 # name -> (restype, argtypes); every symbol include/millieye_hip.h declares
 SIGNATURES = {
@@ -111,6 +126,14 @@ SIGNATURES = {
     "me_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "me_conv2d_flops": (C.c_int64, [C.POINTER(ConvDesc)]),
     "me_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "me_conv2d_bf16": (C.c_int, [C.POINTER(Conv16Desc), C.c_void_p]),
+    "me_conv2d_bf16_workspace_bytes": (C.c_int64, [C.POINTER(Conv16Desc)]),
+    "me_maxpool_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 10 + [C.c_void_p]),
+    "me_upsample_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_void_p]),
+    "me_add_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                              C.c_int32, C.c_void_p]),
+    "me_copy_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "me_maxpool_f32": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p]),
     "me_upsample_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
@@ -202,8 +225,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 2:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 2")
+    if lib_.me_abi_version() != 3:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 3")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
@@ -288,6 +311,90 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
         ws_ptr, keep = _workspace(need, x_nhwc.device, slot="conv")
         d.workspace, d.workspace_bytes = ws_ptr, need
     check(lib().me_conv2d_f32(C.byref(d), stream_ptr()), "me_conv2d_f32")
+    return out
+
+
+def conv2d_bf16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
+                x_nchw=False, y_f32=False, tile=0, split_k=0):
+    """bf16-storage twin of :func:`conv2d`.  ``x``: bf16 NHWC [N,H,W,Cin] (or a channel slice), or - stem, Cin == 3 -
+    float32 NCHW / NHWC; ``wgt_packed``: bf16 [Cout,k,k,Cin] (float32 for the stem); ``residual``: the output's dtype.
+    Returns bf16 NHWC (float32 when ``y_f32``)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        raise MeError("x must be a CUDA tensor")
+    if x_nchw:
+        n, cin, h, w = x.shape
+    else:
+        n, h, w, cin = x.shape
+    want = torch.float32 if cin <= 4 else torch.bfloat16
+    if x.dtype != want or wgt_packed.dtype != want:
+        raise MeError(f"me_conv2d_bf16: x / wgt must be {want} for cin={cin} (got {x.dtype} / {wgt_packed.dtype})")
+    cout = wgt_packed.shape[0]
+    ho = (h + 2 * pad - ksize) // stride + 1
+    wo = (w + 2 * pad - ksize) // stride + 1
+    odt = torch.float32 if y_f32 else torch.bfloat16
+    if out is None:
+        out = torch.empty((n, ho * upsample, wo * upsample, cout), device=x.device, dtype=odt)
+    if out.dtype != odt or (residual is not None and residual.dtype != odt):
+        raise MeError("me_conv2d_bf16: out / residual dtype does not match y_f32")
+    d = Conv16Desc()
+    d.x, d.wgt, d.scale, d.shift = x.data_ptr(), wgt_packed.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    d.res = residual.data_ptr() if residual is not None else None
+    d.y = out.data_ptr()
+    d.x_pitch = cin
+    if not x_nchw and not x.is_contiguous():
+        pitch = x.stride(2)
+        if x.stride() != (h * w * pitch, w * pitch, pitch, 1):
+            raise MeError("x must be NHWC-contiguous or a channel slice of an NHWC-contiguous tensor")
+        d.x_pitch = pitch
+    d.res_pitch = residual.shape[-1] if residual is not None else 0
+    d.y_pitch = out.shape[-1]
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+    d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, stride, pad, ho, wo
+    d.act, d.upsample, d.x_nchw, d.y_f32, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, 1 if y_f32 else 0, \
+        tile, split_k
+    need = lib().me_conv2d_bf16_workspace_bytes(C.byref(d))
+    keep = None
+    if need > 0:
+        ws_ptr, keep = _workspace(need, x.device, slot="conv")
+        d.workspace, d.workspace_bytes = ws_ptr, need
+    check(lib().me_conv2d_bf16(C.byref(d), stream_ptr()), "me_conv2d_bf16")
+    return out
+
+
+def _require_cuda_bf16(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise MeError(f"{name} must be a contiguous CUDA bfloat16 tensor")
+
+
+def maxpool_bf16(x_nhwc, size, stride, zero_ext=False):
+    _require_cuda_bf16(x_nhwc, "x")
+    n, h, w, c = x_nhwc.shape
+    pad = 0 if zero_ext else (size - 1) // 2
+    ext = 1 if zero_ext else 0
+    ho = (h + ext + 2 * pad - size) // stride + 1
+    wo = (w + ext + 2 * pad - size) // stride + 1
+    out = torch.empty((n, ho, wo, c), device=x_nhwc.device, dtype=torch.bfloat16)
+    check(lib().me_maxpool_bf16(x_nhwc.data_ptr(), c, out.data_ptr(), c, n, h, w, c, size, stride, pad, ext, ho, wo,
+                                stream_ptr()), "me_maxpool_bf16")
+    return out
+
+
+def upsample_bf16(x_nhwc, factor):
+    _require_cuda_bf16(x_nhwc, "x")
+    n, h, w, c = x_nhwc.shape
+    out = torch.empty((n, h * factor, w * factor, c), device=x_nhwc.device, dtype=torch.bfloat16)
+    check(lib().me_upsample_bf16(x_nhwc.data_ptr(), c, out.data_ptr(), c, n, h, w, c, factor, stream_ptr()),
+          "me_upsample_bf16")
+    return out
+
+
+def add_bf16(a, b):
+    _require_cuda_bf16(a, "a")
+    _require_cuda_bf16(b, "b")
+    c = a.shape[-1]
+    out = torch.empty_like(a)
+    check(lib().me_add_bf16(a.data_ptr(), c, b.data_ptr(), c, out.data_ptr(), c, a.numel() // c, c, stream_ptr()),
+          "me_add_bf16")
     return out
 
 

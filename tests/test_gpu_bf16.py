@@ -1,0 +1,128 @@
+"""bf16-storage mode (BASELINE configs[2] / [4]) through the C ABI: ``me_conv2d_bf16`` and the bf16 NHWC helpers against
+torch CPU fp32 ops applied to the same bf16-rounded operands.
+
+Parity bar for this mode (written here): with identical bf16 inputs and weights the fp32-output form
+(``y_f32``) must match the fp32 CPU convolution to 1e-3 (only the accumulation order differs); the bf16-output form must
+equal the RNE rounding of that fp32 result except where the two fp32 values straddle a rounding boundary - there the
+difference is one bf16 ulp (<= 2^-7 relative; + 1e-5 absolute where a sum cancels to ~0) - and such elements must stay
+below 0.5 % of the tensor.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _ref(x_bf, w_bf, scale, shift, k, s, pad, act, res=None, ups=1):
+    y = F.conv2d(x_bf.float().permute(0, 3, 1, 2), w_bf.float(), stride=s, padding=pad)
+    y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if act == 1:
+        y = torch.where(y > 0, y, 0.1 * y)
+    y = y.permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + res.float()
+    if ups == 2:
+        y = y.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    return y.contiguous()
+
+
+def _check_bf16(got_bf, ref_f32, what):
+    got = got_bf.float().cpu()
+    want = ref_f32.to(torch.bfloat16).float()
+    diff = (got - want).abs()
+    # one bf16 ulp is at most 2^-7 relative; 1e-5 absolute covers sums that cancel to ~0 (fp32 accumulation order)
+    ulp = torch.maximum(want.abs(), ref_f32.abs()) * 2.0 ** -7 + 1e-5
+    assert bool((diff <= ulp).all()), f"{what}: max {float((diff / ulp).max()):.2f} bf16 ulp"
+    frac = float((diff > 0).float().mean())
+    assert frac < 5e-3, f"{what}: {frac:.4%} of the elements differ from the rounded fp32 result"
+
+
+CASES = [
+    # name, n, h, w, cin, cout, k, s, act, res, ups
+    ("3x3 residual", 2, 26, 26, 64, 128, 3, 1, 1, True, 1),
+    ("3x3 stride 2", 2, 52, 52, 64, 128, 3, 2, 1, False, 1),
+    ("1x1 cin32", 3, 20, 20, 32, 64, 1, 1, 1, False, 1),
+    ("1x1 upsample", 2, 13, 13, 256, 128, 1, 1, 1, False, 2),
+    ("3x3 ragged", 1, 13, 13, 96, 72, 3, 1, 0, False, 1),
+    ("3x3 wide", 1, 13, 13, 512, 320, 3, 1, 1, True, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16_tiles(hip_lib, case):
+    from millieye_amd import hip
+    name, n, h, w, cin, cout, k, s, act, with_res, ups = case
+    g = torch.Generator().manual_seed(len(name) * 7 + cin)
+    x = _bf(torch.randn((n, h, w, cin), generator=g))
+    wgt = _bf(torch.randn((cout, cin, k, k), generator=g) / (k * k * cin) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    pad = (k - 1) // 2
+    ho = (h + 2 * pad - k) // s + 1
+    res = _bf(torch.randn((n, ho, ho, cout), generator=g)) if with_res else None
+    ref = _ref(x, wgt, scale, shift, k, s, pad, act, res, ups)
+    packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+    xs, sc, sh = x.cuda(), scale.cuda(), shift.cuda()
+    rs = res.cuda() if res is not None else None
+    tiles = (1, 2, 3, 4, 11, 12, 13, 14) if cin % 64 == 0 else (1, 2, 3, 4)
+    for tile in tiles:
+        for split in (1, 2, 3):
+            if split > k * k * (cin // 64 if cin % 64 == 0 and tile < 10 else cin // 32):
+                continue
+            y = hip.conv2d_bf16(xs, packed, sc, sh, k, s, pad, act, residual=rs, upsample=ups, tile=tile, split_k=split)
+            _check_bf16(y, ref, f"{name} tile {tile} split {split}")
+    # fp32 output form (detection convs): accumulation order is the only difference from the CPU convolution
+    rs32 = res.float().cuda() if res is not None else None
+    y32 = hip.conv2d_bf16(xs, packed, sc, sh, k, s, pad, act, residual=rs32, upsample=ups, y_f32=True)
+    ref32 = _ref(x, wgt, scale, shift, k, s, pad, act, res, ups)
+    err = (y32.cpu() - ref32).abs()
+    assert bool((err <= 1e-3 * torch.clamp(ref32.abs(), min=1.0)).all()), f"{name} fp32 out: {float(err.max())}"
+
+
+def test_conv_bf16_detection_and_slices(hip_lib):
+    """cout = 255 (ragged weight rows -> zero-filled by the buffer range check), fp32 output, input given as a channel
+    slice of a wider NHWC buffer ([route]), output written into a slice (pitched)."""
+    from millieye_amd import hip
+    g = torch.Generator().manual_seed(5)
+    n, h, cin, cout = 2, 13, 128, 255
+    wide = _bf(torch.randn((n, h, h, 320), generator=g))
+    x = wide[..., 64:64 + cin]
+    wgt = _bf(torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5)
+    scale, shift = torch.ones(cout), torch.randn(cout, generator=g)
+    ref = _ref(x.contiguous(), wgt, scale, shift, 1, 1, 0, 0)
+    packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+    y = hip.conv2d_bf16(wide.cuda()[..., 64:64 + cin], packed, scale.cuda(), shift.cuda(), 1, 1, 0, 0, y_f32=True)
+    err = (y.cpu() - ref).abs()
+    assert bool((err <= 1e-3 * torch.clamp(ref.abs(), min=1.0)).all()), float(err.max())
+
+
+def test_stem_and_helpers_bf16(hip_lib):
+    from millieye_amd import hip
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand((2, 3, 40, 40), generator=g)
+    for cout in (16, 32, 64):
+        w = torch.randn((cout, 3, 3, 3), generator=g) * 0.2
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+        ref = F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        ref = torch.where(ref > 0, ref, 0.1 * ref).permute(0, 2, 3, 1).contiguous()
+        y = hip.conv2d_bf16(x.cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), scale.cuda(), shift.cuda(), 3, 1, 1, 1,
+                            x_nchw=True)
+        _check_bf16(y, ref, f"stem cout {cout}")
+    a = _bf(torch.randn((2, 13, 13, 64), generator=g))
+    b = _bf(torch.randn((2, 13, 13, 64), generator=g))
+    ac, bc = a.cuda(), b.cuda()
+    # pools are exact on bf16 values
+    ref = F.max_pool2d(a.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(hip.maxpool_bf16(ac, 2, 2).float().cpu(), ref)
+    padded = F.pad(a.float().permute(0, 3, 1, 2), (0, 1, 0, 1))
+    ref = F.max_pool2d(padded, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(hip.maxpool_bf16(ac, 2, 1, zero_ext=True).float().cpu(), ref)
+    ref = a.float().repeat_interleave(2, 1).repeat_interleave(2, 2)
+    assert torch.equal(hip.upsample_bf16(ac, 2).float().cpu(), ref)
+    ref = (a.float() + b.float()).to(torch.bfloat16)
+    assert torch.equal(hip.add_bf16(ac, bc).cpu(), ref)
