@@ -26,6 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -38,6 +39,9 @@ def parse():
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--cfg", default="yolov3")
     ap.add_argument("--workload", default="full", choices=["detector", "full", "train", "detector_train"])
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="storage of the detector activations / weights: f32 (default, the parity mode) or bf16 "
+                         "(BASELINE configs[2]/[4]: bf16 operands, fp32 accumulate; inference workloads only)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed clock ramp-up before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
@@ -66,7 +70,7 @@ def conv_roofline(model, x, steps):
     algorithmic flops per launch)."""
     from millieye_amd import hip
 
-    engine = model.engine
+    engine = model.engine_for(model.compute_dtype)
     plan = engine.plan_for(x)
     stream = hip.stream_ptr()
     engine.run(x)  # patches the input / output pointers of the plan
@@ -76,7 +80,7 @@ def conv_roofline(model, x, steps):
     timed = {}  # module -> list of (start, end) events; launches stay IN SEQUENCE (real cache state)
     for _ in range(steps):
         for fn, args, _k, name in plan.launches:
-            mfma_conv = fn is lib.me_conv2d_f32 and descs[int(name[4:])].cin > 4
+            mfma_conv = (fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_bf16) and descs[int(name[4:])].cin > 4
             if mfma_conv:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -90,13 +94,17 @@ def conv_roofline(model, x, steps):
     per_layer = []
     for mod, evs in timed.items():
         ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-        flops = lib.me_conv2d_flops(descs[mod])
+        flops = _conv_flops(descs[mod])
         per_layer.append((mod, flops, ms))
         total_ms += ms
         total_flops += flops
         launches += 1
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     return achieved, total_ms * 1e3 / launches, launches, total_flops / launches, per_layer
+
+
+def _conv_flops(d):
+    return 2 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * d.cin
 
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
@@ -109,12 +117,14 @@ def stage_roofline(model, net, x, step, rois, reps=5):
     events over the engine's launch list; the post-detector stages from the marks Network.forward sets."""
     from millieye_amd import hip
 
-    engine = model.engine
+    engine = model.engine_for(model.compute_dtype)
     plan = engine.plan_for(x)
     lib = hip.lib()
     stream = hip.stream_ptr()
     descs = {m: d for m, d in plan.conv_descs}
     n, size = x.shape[0], x.shape[-1]
+    bf16 = model.compute_dtype == "bf16"
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TF
     acc = {}
 
     def add(name, ms, **work):
@@ -136,13 +146,14 @@ def stage_roofline(model, net, x, step, rois, reps=5):
         torch.cuda.synchronize()
         for name, fn, a, b in evs:
             ms = a.elapsed_time(b)
-            if fn is lib.me_conv2d_f32:
+            if fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_bf16:
                 d = descs[int(name[4:])]
                 if d.cin <= 4:
-                    add("stem conv (cin 3, direct)", ms, bytes=4.0 * n * (d.cin * d.h * d.w + d.cout * d.ho * d.wo))
+                    add("stem conv (cin 3, direct)", ms,
+                        bytes=n * (4.0 * d.cin * d.h * d.w + (2.0 if bf16 else 4.0) * d.cout * d.ho * d.wo))
                 else:
                     add("MFMA convs (3x3 / 1x1 + BN + leaky + shortcut/upsample/route epilogues)", ms,
-                        flops=float(lib.me_conv2d_flops(d)))
+                        flops=float(_conv_flops(d)))
             elif fn is lib.me_yolo_decode_f32:
                 rows_c = plan.rows * (5 + (plan.num_classes or 0))
                 add("YOLO decode", ms, bytes=0.0)  # bytes added once below (three launches share the output tensor)
@@ -177,7 +188,7 @@ def stage_roofline(model, net, x, step, rois, reps=5):
         row = {"stage": name, "ms": round(ms, 4)}
         if e["flops"] and name.startswith("MFMA"):
             tf = e["flops"] / reps / (ms * 1e-3) / 1e12
-            row.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4))
+            row.update(bound="mfma", achieved=round(tf, 2), peak=mfma_peak, unit="TFLOP/s", frac=round(tf / mfma_peak, 4))
         elif e["bytes"]:
             gbs = e["bytes"] / reps / (ms * 1e-3) / 1e9
             row.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4))
@@ -368,6 +379,10 @@ def main():
 
     # untimed pre-warm: the GPU needs a few hundred ms of sustained load to reach its steady clocks (the first
     # ~100 ms run ~15 % slower, measured with tools/conv_bench.py); serving throughput is the steady state
+    if args.dtype != "f32":
+        if args.workload not in ("full", "detector"):
+            raise SystemExit("--dtype bf16 is an inference mode (workloads: full, detector)")
+        model.compute_dtype = args.dtype
     t_pre = time.perf_counter() + args.prewarm_seconds
     while time.perf_counter() < t_pre:
         step()
@@ -392,7 +407,9 @@ def main():
 
     if rank == 0:
         frames = batch * world * args.steps
-        plan = model.engine.plan_for(x)
+        plan = model.engine_for(model.compute_dtype).plan_for(x)
+        bf16 = args.dtype == "bf16"
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         ach, avg_us, launches, flops_per_launch, per_layer = conv_roofline(model, x, max(3, min(args.steps, 10)))
         out = {
             "metric": "frames/sec YOLOv3-416+fusion @batch32, 1/2/4/8 MI355X; mAP@0.5 vs ref",
@@ -405,10 +422,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{args.cfg}.cfg {args.size}x{args.size} fp32 inference, batch={batch} per GPU, "
+                "workload": f"{args.cfg}.cfg {args.size}x{args.size} "
+                            + ("bf16-storage (bf16 operands, fp32 accumulate)" if bf16 else "fp32")
+                            + f" inference, batch={batch} per GPU, "
                             + ("Darknet.forward -> featuremap + yolo_outputs" if args.workload == "detector" else
                                "full milliEye: Darknet.forward -> NMS -> Network.forward mode 0 (R-CNN head + radar "
                                "fusion, 2 radar boxes/frame) -> output rows" if args.workload == "full" else
@@ -423,16 +442,17 @@ def main():
                 "img_size": args.size,
                 "parallelism": f"frames sharded over {world} GPU(s), no collective",
                 "conv_gflop_per_frame": round(plan.conv_flops / batch / 1e9, 3),
-                "arena_mb": round(plan.arena_floats * 4 / 2 ** 20, 1),
+                "arena_mb": round(plan.arena_bytes / 2 ** 20, 1),
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_igemm_buf_f32 (v_mfma_f32_32x32x2_f32 implicit-GEMM conv, all 3x3 / 1x1 layers)",
+                "kernel": ("conv_igemm_buf_bf16 (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv, all 3x3 / 1x1 layers)" if bf16
+                           else "conv_igemm_buf_f32 (v_mfma_f32_32x32x2_f32 implicit-GEMM conv, all 3x3 / 1x1 layers)"),
                 "achieved": round(ach, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": conv_traffic(batch),
+                "frac": round(ach / peak, 4),
+                "traffic": None if bf16 else conv_traffic(batch),
                 "launches_per_step": launches,
                 "avg_launch_us": round(avg_us, 2),
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),

@@ -26,7 +26,8 @@ from . import hip
 
 __all__ = ["DarknetEngine", "ConvWeights", "pick_tap_module"]
 
-_ALIGN = 64  # floats (256 bytes)
+_ALIGN = 256  # bytes
+_DTYPES = ("f32", "bf16")
 
 
 def _resolve(idx, current):
@@ -65,8 +66,11 @@ class ConvWeights:
     checkpoint compatibility); this object re-packs them in place
     whenever their version counters or storage change, so descriptor pointers stay valid."""
 
-    def __init__(self, conv, bn=None):
+    def __init__(self, conv, bn=None, dtype="f32", cin_pad=0, cout_pad=0):
+        """``dtype="bf16"``: weights stored as bfloat16 (one RNE rounding; the cin <= 4 stem keeps fp32 - it runs on the
+        VALU).  ``cin_pad`` / ``cout_pad``: zero-extend the channel dimensions (bf16 MFMA kernel: cin % 32 == 0)."""
         self.conv, self.bn = conv, bn
+        self.dtype, self.cin_pad, self.cout_pad = dtype, cin_pad, cout_pad
         self.wgt = self.scale = self.shift = None
         self._stamp = None
 
@@ -105,7 +109,19 @@ class ConvWeights:
                 else:
                     shift = torch.zeros(cout, dtype=torch.float64, device=device)
             scale, shift = scale.to(torch.float32), shift.to(torch.float32)
-            realloc = self.wgt is None or self.wgt.device != device or self.wgt.shape != packed.shape
+            cin = packed.shape[3]
+            if self.cin_pad > cin:
+                packed = torch.nn.functional.pad(packed, (0, self.cin_pad - cin))
+            if self.cout_pad > cout:  # padded output channels: weight 0, scale 0, shift 0 -> exactly 0 after any activation
+                extra = self.cout_pad - cout
+                packed = torch.nn.functional.pad(packed, (0, 0, 0, 0, 0, 0, 0, extra))
+                scale = torch.nn.functional.pad(scale, (0, extra))
+                shift = torch.nn.functional.pad(shift, (0, extra))
+            if self.dtype == "bf16" and cin > 4:
+                packed = packed.to(torch.bfloat16)
+            packed = packed.contiguous()
+            realloc = (self.wgt is None or self.wgt.device != device or self.wgt.shape != packed.shape
+                       or self.wgt.dtype != packed.dtype)
             if realloc:
                 self.wgt, self.scale, self.shift = packed, scale.contiguous(), shift.contiguous()
             else:  # keep the pointers the plans hold
@@ -117,10 +133,13 @@ class ConvWeights:
 
 
 class _Tensor:
-    __slots__ = ("h", "w", "c", "parent", "chan_off", "producers", "readers", "offset", "pinned", "external")
+    __slots__ = ("h", "w", "c", "parent", "chan_off", "producers", "readers", "offset", "pinned", "external", "esize",
+                 "padded")
 
-    def __init__(self, h, w, c):
+    def __init__(self, h, w, c, esize=4):
         self.h, self.w, self.c = h, w, c
+        self.esize = esize    # bytes per element (4 = float32, 2 = bfloat16)
+        self.padded = 0       # zero channels appended behind the logical ones (bf16 mode, tiny cfgs' 16-channel stem)
         self.parent = None
         self.chan_off = 0
         self.producers = []
@@ -144,21 +163,30 @@ class _Plan:
 class DarknetEngine:
     """Compiled execution of a :class:`millieye_amd.yolov3.models.Darknet` module tree."""
 
-    def __init__(self, model):
+    def __init__(self, model, dtype="f32"):
+        """``dtype``: storage of the activations and MFMA-conv weights between layers - ``"f32"`` (default; the mode the
+        1e-3 parity bar is quoted on) or ``"bf16"`` (BASELINE configs[2]/[4]: bf16 operands, fp32 accumulation and
+        epilogue, fp32 detection maps into the YOLO decode; inference only)."""
+        if dtype not in _DTYPES:
+            raise ValueError(f"unknown engine dtype {dtype!r} (expected one of {_DTYPES})")
         self.model = model
+        self.dtype = dtype
         self._plans = {}
         self._weights = {}
         self.tap_module = pick_tap_module(model.module_defs)
 
     # ---------------------------------------------------------------------------------- weights
-    def _conv_weights(self, i):
+    def _conv_weights(self, i, cin_pad=0, cout_pad=0):
         cw = self._weights.get(i)
         if cw is None:
             seq = self.model.module_list[i]
             conv = seq[0]
             bn = seq[1] if isinstance(seq[1] if len(seq) > 1 else None, torch.nn.BatchNorm2d) else None
-            cw = ConvWeights(conv, bn)
+            cw = ConvWeights(conv, bn, self.dtype, cin_pad, cout_pad)
             self._weights[i] = cw
+        elif (cin_pad, cout_pad) != (0, 0) and (cw.cin_pad, cw.cout_pad) != (cin_pad, cout_pad):
+            cw.cin_pad, cw.cout_pad = cin_pad, cout_pad
+            cw._stamp = None
         return cw
 
     def refresh_weights(self, device):
@@ -224,13 +252,20 @@ class DarknetEngine:
         tap = self.tap_module
 
         tensors = []
+        bf16 = self.dtype == "bf16"
+        if bf16 and keep_raw:
+            raise NotImplementedError("the bf16 storage mode is inference only (the YOLO loss / backward run in fp32)")
+        act_esize = 2 if bf16 else 4
 
-        def new_tensor(hh, ww, cc):
-            t = _Tensor(hh, ww, cc)
+        def new_tensor(hh, ww, cc, esize=None):
+            t = _Tensor(hh, ww, cc, act_esize if esize is None else esize)
             tensors.append(t)
             return t
 
-        t_in = new_tensor(h, w, hyper_c)
+        def feeds_yolo_only(idx):
+            return bool(readers[idx]) and all(defs[r]["type"] == "yolo" for r in readers[idx])
+
+        t_in = new_tensor(h, w, hyper_c, 4)
         t_in.external = True
         out = [None] * L  # layer index -> _Tensor
         ops = []  # dicts
@@ -250,15 +285,24 @@ class DarknetEngine:
                 ho = (x.h + 2 * pad - k) // s + 1
                 wo = (x.w + 2 * pad - k) // s + 1
                 act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
-                op = dict(kind="conv", module=i, x=x, res=None, k=k, s=s, pad=pad, act=act, ups=1, ho=ho, wo=wo)
+                op = dict(kind="conv", module=i, x=x, res=None, k=k, s=s, pad=pad, act=act, ups=1, ho=ho, wo=wo,
+                          cout=cout)
+                y_esize, y_c = act_esize, cout
+                if bf16:
+                    if x.esize != (4 if x.external else 2):
+                        raise RuntimeError(f"module {i}: a convolution reads an fp32 detection map in bf16 mode")
+                    if feeds_yolo_only(i):
+                        y_esize = 4   # raw detection maps stay fp32 for the YOLO decode
+                    elif cout % 32:
+                        y_c = -(-cout // 32) * 32  # the next MFMA conv needs cin % 32 == 0: zero channels behind the real ones
                 nxt = defs[i + 1] if i + 1 < L else None
                 only_next = readers[i] == [i + 1] and i != tap
                 if (nxt is not None and nxt["type"] == "shortcut" and only_next and x.c > 4
                         and srcs[i + 1][0] == i and out[srcs[i + 1][1]] is not None
                         and srcs[i + 1][1] != i):
                     res = out[srcs[i + 1][1]]
-                    if (res.h, res.w, res.c) == (ho, wo, cout):
-                        y = new_tensor(ho, wo, cout)
+                    if (res.h, res.w, res.c) == (ho, wo, cout) and y_c == cout and y_esize == res.esize:
+                        y = new_tensor(ho, wo, cout, y_esize)
                         op["res"] = res
                         op["y"] = y
                         op["covers"] = (i, i + 1)
@@ -268,8 +312,8 @@ class DarknetEngine:
                         i += 2
                         continue
                 if (nxt is not None and nxt["type"] == "upsample" and int(nxt["stride"]) == 2 and only_next
-                        and x.c > 4):
-                    y = new_tensor(ho * 2, wo * 2, cout)
+                        and x.c > 4 and y_c == cout):
+                    y = new_tensor(ho * 2, wo * 2, cout, y_esize)
                     op["ups"] = 2
                     op["y"] = y
                     op["covers"] = (i, i + 1)
@@ -278,7 +322,8 @@ class DarknetEngine:
                     ops.append(op)
                     i += 2
                     continue
-                y = new_tensor(ho, wo, cout)
+                y = new_tensor(ho, wo, y_c, y_esize)
+                y.padded = y_c - cout
                 op["y"] = y
                 op["covers"] = (i,)
                 out[i] = y
@@ -291,18 +336,22 @@ class DarknetEngine:
                 ext = 1 if zero_ext else 0
                 ho = (x.h + ext + 2 * pad - k) // s + 1
                 wo = (x.w + ext + 2 * pad - k) // s + 1
-                y = new_tensor(ho, wo, x.c)
+                y = new_tensor(ho, wo, x.c, x.esize)
+                y.padded = x.padded
                 ops.append(dict(kind="pool", module=i, x=x, y=y, k=k, s=s, pad=pad, zero_ext=ext, ho=ho, wo=wo))
                 out[i] = y
             elif t == "upsample":
                 x = out[i - 1]
                 f = int(d["stride"])
-                y = new_tensor(x.h * f, x.w * f, x.c)
+                y = new_tensor(x.h * f, x.w * f, x.c, x.esize)
+                y.padded = x.padded
                 ops.append(dict(kind="upsample", module=i, x=x, y=y, f=f))
                 out[i] = y
             elif t == "shortcut":
                 a, b = out[srcs[i][0]], out[srcs[i][1]]
-                y = new_tensor(a.h, a.w, a.c)
+                if a.esize != b.esize or a.padded or b.padded:
+                    raise NotImplementedError(f"shortcut {i}: mixed storage types / padded channels")
+                y = new_tensor(a.h, a.w, a.c, a.esize)
                 ops.append(dict(kind="add", module=i, a=a, b=b, y=y))
                 out[i] = y
             elif t == "route":
@@ -312,7 +361,9 @@ class DarknetEngine:
                 if len(parts) == 1:
                     out[i] = parts[0]
                 else:
-                    cat = new_tensor(parts[0].h, parts[0].w, sum(p.c for p in parts))
+                    if any(p.padded or p.esize != parts[0].esize for p in parts):
+                        raise NotImplementedError(f"route {i}: mixed storage types / padded channels")
+                    cat = new_tensor(parts[0].h, parts[0].w, sum(p.c for p in parts), parts[0].esize)
                     off = 0
                     for p in parts:
                         if (p.h, p.w) != (cat.h, cat.w):
@@ -320,7 +371,7 @@ class DarknetEngine:
                         if p.parent is None and not p.external and p is not cat and not _in_family(cat, p):
                             p.parent, p.chan_off = cat, off
                         else:  # already part of another concat: materialise a copy
-                            piece = new_tensor(p.h, p.w, p.c)
+                            piece = new_tensor(p.h, p.w, p.c, p.esize)
                             piece.parent, piece.chan_off = cat, off
                             ops.append(dict(kind="copy", module=i, x=p, y=piece))
                         off += p.c
@@ -333,6 +384,8 @@ class DarknetEngine:
                 na, nc = yl.num_anchors, yl.num_classes
                 if x.c != na * (nc + 5):
                     raise ValueError(f"yolo {i}: {x.c} channels != {na}*({nc}+5)")
+                if x.esize != 4:
+                    raise RuntimeError(f"yolo {i}: the detection map is shared with another reader (bf16 mode)")
                 ops.append(dict(kind="yolo", module=i, x=x, layer=yl, g=x.h, row_offset=sum(yolo_rows)))
                 yolo_rows.append(na * x.h * x.h)
                 out[i] = None  # decoded rows are never routed
@@ -376,7 +429,7 @@ class DarknetEngine:
             if pin:
                 last = len(ops)
             last = max(last, first)
-            size = -(-(n * tt.h * tt.w * tt.c) // _ALIGN) * _ALIGN
+            size = -(-(n * tt.h * tt.w * tt.c * tt.esize) // _ALIGN) * _ALIGN  # bytes
             roots.append((first, last, size, tt))
         roots.sort(key=lambda r: (r[0], -r[2]))
         placed = []  # (offset, size, first, last)
@@ -394,15 +447,27 @@ class DarknetEngine:
 
         plan = _Plan()
         plan.n, plan.h, plan.w = n, h, w
-        plan.arena = torch.empty(max(total, _ALIGN), dtype=torch.float32, device=device)
-        plan.arena_floats = total
+        plan.arena = torch.empty(max(total, _ALIGN), dtype=torch.uint8, device=device)
+        if plan.arena.data_ptr() % _ALIGN:
+            raise RuntimeError("the caching allocator returned an arena that is not 256-byte aligned")
+        plan.arena_bytes = total
+        plan.dtype = self.dtype
         plan.rows = sum(yolo_rows)
         plan.num_classes = None
         base = plan.arena.data_ptr()
 
         def view(tt):
             root, coff = tt.root()
-            return base + 4 * (root.offset + coff), root.c
+            return base + root.offset + tt.esize * coff, root.c
+
+        def typed_view(tt, nchw):
+            """torch view of an arena tensor ([n,h,w,c], or the NCHW permutation of it) - API boundary only"""
+            root, coff = tt.root()
+            flat = plan.arena.view(torch.bfloat16 if tt.esize == 2 else torch.float32)
+            pitch, off = root.c, root.offset // tt.esize + coff
+            if nchw:
+                return torch.as_strided(flat, (n, tt.c, tt.h, tt.w), (tt.h * tt.w * pitch, 1, tt.w * pitch, pitch), off)
+            return torch.as_strided(flat, (n, tt.h, tt.w, tt.c), (tt.h * tt.w * pitch, tt.w * pitch, pitch, 1), off)
 
         lib = hip.lib()
         launches = []
@@ -414,9 +479,11 @@ class DarknetEngine:
         for op in ops:
             kind = op["kind"]
             if kind == "conv":
-                cw = self._conv_weights(op["module"])
                 x, y = op["x"], op["y"]
-                dsc = hip.ConvDesc()
+                cw = self._conv_weights(op["module"], x.c if x.padded else 0, y.c if y.padded else 0)
+                if cw.refresh(device) == "realloc" and self._plans:
+                    self._plans.clear()
+                dsc = hip.Conv16Desc() if bf16 else hip.ConvDesc()
                 if x.external:
                     dsc.x, dsc.x_pitch, dsc.x_nchw = None, x.c, 1
                     plan.input_descs.append(dsc)
@@ -433,9 +500,19 @@ class DarknetEngine:
                 dsc.cout, dsc.ksize, dsc.stride, dsc.pad = cw.wgt.shape[0], op["k"], op["s"], op["pad"]
                 dsc.ho, dsc.wo, dsc.act, dsc.upsample, dsc.tile = op["ho"], op["wo"], op["act"], op["ups"], 0
                 dsc.split_k, dsc.workspace, dsc.workspace_bytes = 0, None, 0
-                launches.append((lib.me_conv2d_f32, (C.byref(dsc),), dsc, f"conv{op['module']}"))
+                if bf16:
+                    dsc.y_f32 = 1 if y.esize == 4 else 0
+                launches.append((lib.me_conv2d_bf16 if bf16 else lib.me_conv2d_f32, (C.byref(dsc),), dsc,
+                                 f"conv{op['module']}"))
                 plan.conv_descs.append((op["module"], dsc))
-                flops += 2 * n * op["ho"] * op["wo"] * dsc.cout * op["k"] * op["k"] * x.c
+                flops += 2 * n * op["ho"] * op["wo"] * op["cout"] * op["k"] * op["k"] * (x.c - x.padded)
+            elif kind == "pool" and bf16:
+                x, y = op["x"], op["y"]
+                (xp, xpitch), (yp, ypitch) = view(x), view(y)
+                launches.append((lib.me_maxpool_bf16,
+                                 (xp, xpitch, yp, ypitch, n, x.h, x.w, x.c, op["k"], op["s"],
+                                  0 if op["zero_ext"] else op["pad"], op["zero_ext"], op["ho"], op["wo"]), None,
+                                 f"pool{op['module']}"))
             elif kind == "pool":
                 x, y = op["x"], op["y"]
                 dsc = hip.PoolDesc()
@@ -449,17 +526,20 @@ class DarknetEngine:
             elif kind == "upsample":
                 x, y = op["x"], op["y"]
                 (xp, xpitch), (yp, ypitch) = view(x), view(y)
-                launches.append((lib.me_upsample_f32, (xp, xpitch, yp, ypitch, n, x.h, x.w, x.c, op["f"]), None,
+                launches.append((lib.me_upsample_bf16 if x.esize == 2 else lib.me_upsample_f32,
+                                 (xp, xpitch, yp, ypitch, n, x.h, x.w, x.c, op["f"]), None,
                                  f"upsample{op['module']}"))
             elif kind == "add":
                 a, b, y = op["a"], op["b"], op["y"]
                 (ap, apitch), (bp, bpitch), (yp, ypitch) = view(a), view(b), view(y)
-                launches.append((lib.me_add_f32, (ap, apitch, bp, bpitch, yp, ypitch, n * a.h * a.w, a.c), None,
+                launches.append((lib.me_add_bf16 if a.esize == 2 else lib.me_add_f32,
+                                 (ap, apitch, bp, bpitch, yp, ypitch, n * a.h * a.w, a.c), None,
                                  f"add{op['module']}"))
             elif kind == "copy":
                 x, y = op["x"], op["y"]
                 (xp, xpitch), (yp, ypitch) = view(x), view(y)
-                launches.append((lib.me_copy_f32, (xp, xpitch, yp, ypitch, n * x.h * x.w, x.c), None,
+                launches.append((lib.me_copy_bf16 if x.esize == 2 else lib.me_copy_f32,
+                                 (xp, xpitch, yp, ypitch, n * x.h * x.w, x.c), None,
                                  f"copy{op['module']}"))
             elif kind == "yolo":
                 x, yl = op["x"], op["layer"]
@@ -475,36 +555,32 @@ class DarknetEngine:
                     dsc.anchors[2 * k + 1] = ah / stride
                 plan.num_classes = yl.num_classes
                 plan.yolo_descs.append(dsc)
-                xroot, xoff = x.root()
-                plan.yolo_raw.append(torch.as_strided(
-                    plan.arena, (n, x.h, x.w, x.c), (x.h * x.w * xroot.c, x.w * xroot.c, xroot.c, 1),
-                    xroot.offset + xoff))
+                plan.yolo_raw.append(typed_view(x, nchw=False))
                 launches.append((lib.me_yolo_decode_f32, (C.byref(dsc),), dsc, f"yolo{op['module']}"))
                 # side effects the reference's YOLOLayer.forward has (models.py:135-156)
                 yl.img_dim = h
                 yl.grid_size = op["g"]
                 yl.stride = stride
         # shared scratch for the deterministic split-K slabs (launches are serial on one stream)
-        need = max([lib.me_conv2d_workspace_bytes(C.byref(d)) for _m, d in plan.conv_descs] + [0])
+        ws_fn = lib.me_conv2d_bf16_workspace_bytes if bf16 else lib.me_conv2d_workspace_bytes
+        need = max([ws_fn(C.byref(d)) for _m, d in plan.conv_descs] + [0])
         plan.conv_ws = None
         plan.graph = None
         if need > 0:
             plan.conv_ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
             ws_ptr = plan.conv_ws.data_ptr() + (-plan.conv_ws.data_ptr()) % 256
             for _m, d in plan.conv_descs:
-                if lib.me_conv2d_workspace_bytes(C.byref(d)) > 0:
+                if ws_fn(C.byref(d)) > 0:
                     d.workspace, d.workspace_bytes = ws_ptr, need
         plan.launches = launches
         plan.conv_flops = flops
         if _autotune_enabled():
             _autotune(plan, lib)
         if tap_tensor is not None:
-            root, coff = tap_tensor.root()
-            pitch = root.c
-            plan.tap = torch.as_strided(
-                plan.arena, (n, tap_tensor.c, tap_tensor.h, tap_tensor.w),
-                (tap_tensor.h * tap_tensor.w * pitch, 1, tap_tensor.w * pitch, pitch), root.offset + coff)
-            plan.tap_ptr, plan.tap_pitch = base + 4 * (root.offset + coff), pitch
+            # NCHW view of the feature tap in its storage type (bf16 mode: callers that need fp32 convert at the API
+            # boundary - Darknet.forward; Network.forward hands the bf16 tap straight to the score-map conv)
+            plan.tap = typed_view(tap_tensor, nchw=True)
+            plan.tap_ptr, plan.tap_pitch = view(tap_tensor)
             plan.tap_shape = (tap_tensor.h, tap_tensor.w, tap_tensor.c)
         else:
             plan.tap = None
@@ -594,6 +670,9 @@ _TUNE_CACHE = {}
 _TUNE_FILE_LOADED = [False]
 _TUNE_TILES = (1, 2, 3, 4, 5)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
+_TUNE_TILES_BF16 = (1, 2, 3, 4, 11, 12, 13, 14)  # 1x = one 32-channel sub-stage per pipeline stage (more workgroups / CU)
+_TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
+                     11: (128, 128), 12: (128, 64), 13: (64, 64), 14: (256, 128)}
 
 
 def _autotune_enabled():
@@ -648,11 +727,15 @@ def _autotune(plan, lib):
 
     stream = hip.stream_ptr()
     _tune_load()
+    bf16 = plan.dtype == "bf16"
+    conv_fn = lib.me_conv2d_bf16 if bf16 else lib.me_conv2d_f32
     todo = []
     for _m, d in plan.conv_descs:
         if d.cin <= 4:
             continue
         key = (d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.upsample, int(bool(d.res)))
+        if bf16:
+            key += (16 + d.y_f32,)
         hit = _TUNE_CACHE.get(key)
         if hit is not None:
             d.tile, d.split_k = hit
@@ -687,7 +770,7 @@ def _autotune(plan, lib):
 
     def run(d, reps):
         for _ in range(reps):
-            rc = lib.me_conv2d_f32(C.byref(d), stream)
+            rc = conv_fn(C.byref(d), stream)
             if rc != 0:
                 return False
         return True
@@ -703,8 +786,13 @@ def _autotune(plan, lib):
         slab = d.n * d.ho * d.wo * d.cout * 4
         stages = d.ksize * d.ksize * ((d.cin + 15) // 16)
         best = (float("inf"), 0, 1)
-        for tile in _TUNE_TILES:
-            bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128)}[tile]
+        tiles = _TUNE_TILES
+        if bf16:
+            stages = d.ksize * d.ksize * (d.cin // 32)
+            tiles = _TUNE_TILES_BF16 if d.cin % 64 == 0 else _TUNE_TILES_BF16[:4]
+        for tile in tiles:
+            bm, bn = _TILE_SHAPES_BF16[tile] if bf16 else \
+                {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128)}[tile]
             tiles = -(-d.n * d.ho * d.wo // bm) * -(-d.cout // bn)
             for split in _TUNE_SPLITS:
                 if split > 1 and (split * slab > ws_bytes or tiles * split > 4096 or split > stages):

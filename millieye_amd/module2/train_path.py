@@ -80,7 +80,7 @@ def forward_train(net, images, targets):
     c1 = net.class_num + 1
 
     with torch.no_grad():
-        plan, yolo_out = net.base_detector._run(images)
+        plan, yolo_out = net.base_detector.engine.run(images)  # training: always the fp32 engine
         det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG, writeback_xyxy=False)
         num_classes = yolo_out.shape[2] - 5
         cols, cap = 8 + net.class_num, n * _DETECTIONS_PER_IMG

@@ -196,7 +196,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
 
     # ---- frozen detector, NMS, proposal assembly (no grad) -------------------------------------------
     with torch.no_grad():
-        plan, yolo_out = net.base_detector._run(images)
+        plan, yolo_out = net.base_detector.engine.run(images)  # training: always the fp32 engine
         det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
                                    writeback_xyxy=False)
         num_classes = yolo_out.shape[2] - 5

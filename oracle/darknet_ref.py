@@ -70,13 +70,46 @@ def _anchors_of(block):
     return [pairs[int(m)] for m in block["mask"].split(",")]
 
 
-def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list.", return_layers=False):
+def _readers(blocks):
+    """module index -> indices of the modules that read its output"""
+    readers = [[] for _ in blocks]
+    for i, b in enumerate(blocks):
+        if b["type"] == "route":
+            srcs = [int(l) for l in b["layers"].split(",")]
+        elif b["type"] == "shortcut":
+            srcs = [-1, int(b["from"])]
+        else:
+            srcs = [-1]
+        for s in srcs:
+            j = i + s if s < 0 else s
+            if j >= 0:
+                readers[j].append(i)
+    return readers
+
+
+def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list.", return_layers=False, storage="f32"):
     """Evaluate the detector.  ``state_dict`` keys: ``{prefix}{i}.conv_{i}.weight`` etc.
-    Returns ``(featuremap or None, yolo_outputs [N,R,5+C])`` (+ per-module outputs on request)."""
+    Returns ``(featuremap or None, yolo_outputs [N,R,5+C])`` (+ per-module outputs on request).
+
+    ``storage="bf16"`` restates the build's 16-bit storage mode (BASELINE configs[2]/[4]; no reference counterpart - the
+    reference is fp32 only, so this mode is pinned to nothing but the fp32 path it approximates): same fp32 library ops,
+    with one round-to-nearest-even to bfloat16 at every point where millieye_amd/csrc/conv_bf16.hip stores 16-bit data -
+    the weights of every convolution with more than 4 input channels, and every activation written to memory, i.e. after
+    conv+BN+LeakyReLU (and after the [shortcut] add when that convolution feeds only the shortcut - the add is then part of
+    the same kernel and sees the unrounded value).  Detection convolutions (read only by a [yolo] block) stay fp32."""
     blocks = parse_cfg_text(cfg_text)[1:]
     img_dim = x.shape[2]
     outs, yolo = [], []
     feat = None
+    bf16 = storage == "bf16"
+    if storage not in ("f32", "bf16"):
+        raise ValueError(storage)
+    readers = _readers(blocks)
+
+    def q(t):
+        return t.to(torch.bfloat16).to(torch.float32) if bf16 else t
+
+    pending = None  # unrounded output of a conv fused with the following shortcut
     with torch.no_grad():
         for i, b in enumerate(blocks):
             kind = b["type"]
@@ -84,6 +117,8 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
                 k = int(b["size"])
                 w = state_dict[f"{prefix}{i}.conv_{i}.weight"]
                 bias = state_dict.get(f"{prefix}{i}.conv_{i}.bias")
+                if bf16 and w.shape[1] > 4:
+                    w = q(w)
                 x = F.conv2d(x, w, bias, stride=int(b["stride"]), padding=(k - 1) // 2)
                 if int(b["batch_normalize"]):
                     p = f"{prefix}{i}.batch_norm_{i}."
@@ -91,6 +126,14 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
                                      state_dict[p + "weight"], state_dict[p + "bias"], False, 0.9, 1e-5)
                 if b["activation"] == "leaky":
                     x = F.leaky_relu(x, 0.1)
+                if bf16:
+                    nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+                    fused = (nxt is not None and nxt["type"] == "shortcut" and readers[i] == [i + 1] and i != tap_module
+                             and w.shape[1] > 4 and i + 1 + int(nxt["from"]) != i)
+                    if fused:
+                        pending = x
+                    if not all(blocks[r]["type"] == "yolo" for r in readers[i]) or not readers[i]:
+                        x = q(x)
                 if i == tap_module:
                     feat = x
             elif kind == "maxpool":
@@ -103,7 +146,8 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
             elif kind == "route":
                 x = torch.cat([outs[int(l)] for l in b["layers"].split(",")], 1)
             elif kind == "shortcut":
-                x = outs[-1] + outs[int(b["from"])]
+                x = q((outs[-1] if pending is None else pending) + outs[int(b["from"])])
+                pending = None
             elif kind == "yolo":
                 x = yolo_decode(x, _anchors_of(b), int(b["classes"]), img_dim)
                 yolo.append(x)
