@@ -15,6 +15,7 @@
 // stored activation once (after activation + residual), nothing else; accumulation and the affine are fp32.
 #include <math.h>
 #include <type_traits>
+#include <utility>
 #include "common.h"
 #include "dma.h"
 
@@ -40,6 +41,7 @@ struct Conv16P {
   int tiles_m, tiles_n;
   float* partial;  // split-K slabs [splitk][M][cout] (raw fp32 accumulators), or nullptr
   int splitk, sps;
+  int vec_epi;     // 16-byte epilogue allowed (bf16 out, no upsample, leaky / linear, pitches % 8, 16-byte aligned)
 };
 
 __device__ __forceinline__ float act16(float v, int act) {
@@ -49,6 +51,11 @@ __device__ __forceinline__ float act16(float v, int act) {
 }
 __device__ __forceinline__ unsigned short to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 __device__ __forceinline__ float from_bf16(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+template <class F, int... J>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, J...>) {
+  (f(std::integral_constant<int, J>{}), ...);
+}
 
 // one output element through the fused epilogue tail: residual, rounding, (replicated) store
 __device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float v, int hw) {
@@ -85,11 +92,13 @@ __device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float
 // implicit GEMM on the bf16 matrix cores.  M = n*ho*wo output pixels, N = cout, K = ks*ks*cin.
 // Needs cin % (32*KSUB) == 0 (the planner pads the one odd tensor of the tiny cfgs, engine.py).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1>
+// ABL (tuning only, wrong results): 1 = every DMA lane out of range (zero fill: no L2 / HBM traffic), 2 = no MFMAs,
+// 3 = no DMA instructions at all.
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int NST = 3>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16P p) {
   constexpr int NW = WR * WC;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  constexpr int NST = 3;
+  static_assert(NST == 3, "the unrolled stage loop assumes 3 slots");
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int MT = TM / 32, NT = TN / 32;
   constexpr int GA = BM / 16, G = (BM + BN) / 16;  // 16-row groups (1 KiB each): A first, then B
@@ -129,13 +138,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
 
   const int lrow = lane >> 2;
   unsigned v_base[LPW], v_pad[LA], v_cur[LPW];
-#pragma unroll
-  for (int j = 0; j < LPW; ++j) {
+  auto setup_lane = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     const int g = wave + NW * j;
     const int row = g * 16 + lrow;
     const int q = (lane & 3) ^ ((row >> 2) & 3);  // source 16-byte chunk (8 channels) for this LDS slot
     v_base[j] = kOobOffset;
-    if (j < LA) {
+    if constexpr (j < LA) {
       unsigned padmask = 0xFFFFFFFFu;
       const int m = m0 + row;
       if (m < p.M) {
@@ -157,8 +166,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
       const int co_local = row - BM;
       if (n0 + co_local < p.cout) v_base[j] = (unsigned)co_local * (unsigned)p.ktot * 2u + 16u * q;
     }
-    v_cur[j] = v_base[j];
-  }
+    v_cur[j] = ABL == 1 ? kOobOffset : v_base[j];
+  };
+  static_for(setup_lane, std::make_integer_sequence<int, LPW>{});  // forced expansion: the arrays must stay in VGPRs
 
   const int sid = blockIdx.y;
   const int s_begin = sid * p.sps;
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
   unsigned a_off = 0, b_off = 0;
   auto enter_tap = [&]() {
 #pragma unroll
-    for (int j = 0; j < LA; ++j) v_cur[j] = ((v_pad[j] >> tap) & 1u) ? kOobOffset : v_base[j];
+    for (int j = 0; j < LA; ++j) v_cur[j] = (ABL == 1 || ((v_pad[j] >> tap) & 1u)) ? kOobOffset : v_base[j];
     a_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 2);
     b_off = (unsigned)tap * (unsigned)p.cin * 2u;
   };
@@ -178,9 +188,22 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
 
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
   auto issue_stage = [&](unsigned lds_dst) {
+    if (ABL == 3) return;  // ablation: no DMA at all (LDS reads + MFMAs + barriers only)
 #pragma unroll
-    for (int u = 0; u < KSUB; ++u)
-      dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off + 64u * u, b_off + 64u * u, lds_dst + u * SUB_B);
+    for (int u = 0; u < KSUB; ++u) {
+      if constexpr (LPW <= 4 && LA <= 2) {
+        dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off + 64u * u, b_off + 64u * u, lds_dst + u * SUB_B);
+      } else {  // large tiles: A groups, then B groups, at most 4 loads per asm block
+        constexpr int LB = LPW - LA;
+        static_assert(LA <= 8 && LB <= 8, "at most 8 groups per operand per wave");
+        dma_same<(LA < 4 ? LA : 4), NW * 1024, 0>(v_cur, rsrc_a, a_off + 64u * u, lds_dst + u * SUB_B);
+        if constexpr (LA > 4)
+          dma_same<LA - 4, NW * 1024, 4>(v_cur, rsrc_a, a_off + 64u * u, lds_dst + u * SUB_B + 4u * NW * 1024u);
+        dma_same<(LB < 4 ? LB : 4), NW * 1024, LA>(v_cur, rsrc_b, b_off + 64u * u, lds_dst + u * SUB_B + LA * NW * 1024u);
+        if constexpr (LB > 4)
+          dma_same<LB - 4, NW * 1024, LA + 4>(v_cur, rsrc_b, b_off + 64u * u, lds_dst + u * SUB_B + (LA + 4u) * NW * 1024u);
+      }
+    }
     a_off += 64u * KSUB;
     b_off += 64u * KSUB;
     if (++cc == p.cs) {
@@ -234,7 +257,8 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u][ks][i], bf[u][ks][j], acc[i][j], 0, 0, 0);
+            if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u][ks][i], bf[u][ks][j], acc[i][j], 0, 0, 0);
+            else acc[i][j][0] += (float)af[u][ks][i][0] + (float)bf[u][ks][j][0];
   };
 
   auto step = [&](auto slot_c) {
@@ -267,34 +291,120 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
   // ---- epilogue: lane r32 = output channel, accumulator element e = pixel row --------------------
   if (p.splitk > 1) {
     float* slab = p.partial + (long long)sid * p.M * p.cout;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    auto slab_out = [&](auto ic, auto jc) {
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
       const int co = n0 + wc * TN + j * 32 + r32;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (co < p.cout && m < p.M) slab[(long long)m * p.cout + co] = acc[i][j][e];
-        }
-    }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int co = n0 + wc * TN + j * 32 + r32;
-    const bool co_ok = co < p.cout;
-    const float sc = co_ok ? p.scale[co] : 0.f;
-    const float sh = co_ok ? p.shift[co] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (!co_ok || m >= p.M) continue;
-        store_out(p, m, co, act16(acc[i][j][e] * sc + sh, p.act), hw);
+        if (co < p.cout && m < p.M) slab[(long long)m * p.cout + co] = acc[i][j][e];
       }
+    };
+    static_for([&](auto jc) { static_for([&](auto ic) { slab_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
+               std::make_integer_sequence<int, NT>{});
+    return;
   }
+  const float slope = p.act == ME_ACT_LEAKY ? 0.1f : 1.0f;
+  // Vector epilogue (the common case: full tile, bf16 output, no upsample): the MFMA result has lane = output channel,
+  // register = pixel row, so a direct store is 16 two-byte stores (+ 16 two-byte residual loads) per 32x32 block - at
+  // bf16 matrix rates that costs more than the whole K loop of the short-K layers.  Each wave instead passes its 32x32
+  // blocks through a private 32 x 36-float LDS patch (the stage buffers are dead by now): fp32 values after the affine +
+  // activation go in channel-major, come back as 8 consecutive channels of one pixel per lane, the residual is one 16-byte
+  // load, the result one 16-byte store (64 lanes = 16 pixels x 64 contiguous bytes).  Same arithmetic, same single RNE.
+  if (p.vec_epi && m0 + BM <= p.M && n0 + BN <= p.cout) {
+    constexpr int TP = 36;
+    __syncthreads();
+    float* tbuf = reinterpret_cast<float*>(smem16) + wave * (32 * TP);
+    const int prow = lane >> 2, c8 = (lane & 3) * 8;
+    unsigned short* __restrict__ yb = reinterpret_cast<unsigned short*>(p.y);
+    const unsigned short* __restrict__ rb = reinterpret_cast<const unsigned short*>(p.res);
+    auto block_out = [&](auto ic, auto jc) {
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      const int cb = n0 + wc * TN + j * 32;
+      const float sc = p.scale[cb + r32], sh = p.shift[cb + r32];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[i][j][e] * sc + sh;
+        v = v > 0.f ? v : v * slope;
+        tbuf[((e & 3) + 8 * (e >> 2) + 4 * hh) * TP + r32] = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its LDS operations complete in order
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 16 + prow;
+        const float4 lo = *reinterpret_cast<const float4*>(tbuf + row * TP + c8);
+        const float4 hi = *reinterpret_cast<const float4*>(tbuf + row * TP + c8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const long long m = m0 + wr * TM + i * 32 + row;
+        if (rb) {
+          const uint4 r = *reinterpret_cast<const uint4*>(rb + m * p.res_pitch + cb + c8);
+          const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] += __uint_as_float(rr[k] << 16);
+            v[2 * k + 1] += __uint_as_float(rr[k] & 0xffff0000u);
+          }
+        }
+        uint4 o;
+        o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+        o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+        o.z = (unsigned)to_bf16(v[4]) | ((unsigned)to_bf16(v[5]) << 16);
+        o.w = (unsigned)to_bf16(v[6]) | ((unsigned)to_bf16(v[7]) << 16);
+        *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch is free for the next block
+    };
+    static_for([&](auto jc) { static_for([&](auto ic) { block_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
+               std::make_integer_sequence<int, NT>{});
+    return;
+  }
+  // (i, j) are expanded by static_for (a 128-element pragma-unrolled nest is refused as "too large" for the 128x64 and
+  // 128x128 wave tiles, and a rolled loop would put the accumulators in scratch).  Fast path: plain store, leaky / linear
+  // activation (slope 0.1 / 1.0), residual and output type hoisted out of the element loop.
+  const bool fast = p.ups == 1 && p.act != ME_ACT_SIGMOID;
+  auto tile_out = [&](auto ic, auto jc) {
+    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+    const int co = n0 + wc * TN + j * 32 + r32;
+    if (co >= p.cout) return;
+    const float sc = p.scale[co], sh = p.shift[co];
+    const int mb = m0 + wr * TM + i * 32 + 4 * hh;
+    if (fast) {
+      auto run = [&](auto f32c, auto resc) {
+        constexpr bool F32 = decltype(f32c)::value, RES = decltype(resc)::value;
+        using T = std::conditional_t<F32, float, unsigned short>;
+        T* __restrict__ y = reinterpret_cast<T*>(p.y) + co;
+        const T* __restrict__ r = reinterpret_cast<const T*>(p.res) + co;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mb + (e & 3) + 8 * (e >> 2);
+          if (m >= p.M) continue;
+          float v = acc[i][j][e] * sc + sh;
+          v = v > 0.f ? v : v * slope;
+          if constexpr (RES) {
+            if constexpr (F32) v += r[(long long)m * p.res_pitch];
+            else v += from_bf16(r[(long long)m * p.res_pitch]);
+          }
+          if constexpr (F32) y[(long long)m * p.y_pitch] = v;
+          else y[(long long)m * p.y_pitch] = to_bf16(v);
+        }
+      };
+      if (p.y_f32) {
+        if (p.res) run(std::true_type{}, std::true_type{});
+        else run(std::true_type{}, std::false_type{});
+      } else {
+        if (p.res) run(std::false_type{}, std::true_type{});
+        else run(std::false_type{}, std::false_type{});
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m < p.M) store_out(p, m, co, act16(acc[i][j][e] * sc + sh, p.act), hw);
+      }
+    }
+  };
+  static_for([&](auto jc) { static_for([&](auto ic) { tile_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
+             std::make_integer_sequence<int, NT>{});
 }
 
 __global__ __launch_bounds__(256) void conv_splitk_reduce_bf16(Conv16P p) {
@@ -481,8 +591,9 @@ bool addressable16(const Conv16P& p, int bm) {
   return a_max < (1ll << 31) && b_max < (1ll << 31);
 }
 
-template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1>
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0>
 int launch16(Conv16P& p, hipStream_t stream) {
+  static_assert(BM <= 256, "addressable16 / the descriptor window assume tiles of at most 256 rows");
   ME_REQUIRE(addressable16(p, BM), ME_E_TOOBIG,
              "me_conv2d_bf16: one tile's input window exceeds the 2 GiB buffer-descriptor range");
   p.cs = p.cin / (32 * KSUB);
@@ -495,7 +606,7 @@ int launch16(Conv16P& p, hipStream_t stream) {
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
   const size_t lds = (size_t)3 * KSUB * LPW * NW * 1024;
-  auto kern = conv_igemm_buf_bf16<BM, BN, WR, WC, KSUB, MINW>;
+  auto kern = conv_igemm_buf_bf16<BM, BN, WR, WC, KSUB, MINW, ABL>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -538,6 +649,8 @@ int fill16(const me_conv16_desc* d, Conv16P& p) {
   p.partial = nullptr;
   p.splitk = 1;
   p.sps = 0;
+  p.vec_epi = !d->y_f32 && d->upsample == 1 && d->act != ME_ACT_SIGMOID && d->y_pitch % 8 == 0 && me::aligned16(d->y) &&
+              (!d->res || (d->res_pitch % 8 == 0 && me::aligned16(d->res)));
   return 0;
 }
 
@@ -633,11 +746,32 @@ int me_conv2d_bf16(const me_conv16_desc* d, void* stream_) {
     case 2: return k2 ? launch16<128, 64, 2, 2, 2>(p, stream) : launch16<128, 64, 2, 2, 1>(p, stream);
     case 3: return k2 ? launch16<64, 64, 2, 2, 2>(p, stream) : launch16<64, 64, 2, 2, 1>(p, stream);
     case 4: return k2 ? launch16<256, 128, 4, 2, 2, 2>(p, stream) : launch16<256, 128, 4, 2, 1, 2>(p, stream);
+    case 5: return k2 ? launch16<256, 128, 2, 2, 2>(p, stream) : launch16<256, 128, 2, 2, 1>(p, stream);  // wave tile 128x64
+    case 6: return launch16<256, 256, 2, 2, 1>(p, stream);                                                // wave tile 128x128
     // forced ids (tuning): single sub-stage variants
     case 11: return launch16<128, 128, 2, 2, 1>(p, stream);
     case 12: return launch16<128, 64, 2, 2, 1>(p, stream);
     case 13: return launch16<64, 64, 2, 2, 1>(p, stream);
     case 14: return launch16<256, 128, 4, 2, 1, 2>(p, stream);
+    case 15: return launch16<256, 128, 2, 2, 1>(p, stream);
+    case 16: return launch16<256, 256, 2, 2, 1>(p, stream);
+    case 25: return launch16<256, 128, 2, 2, 1, 2>(p, stream);  // <= 256 registers: two workgroups per CU
+    case 71: return launch16<128, 128, 2, 2, 1, 1, 3>(p, stream);
+    case 73: return launch16<64, 64, 2, 2, 1, 1, 3>(p, stream);
+    case 74: return launch16<256, 128, 4, 2, 1, 2, 3>(p, stream);
+    case 75: return launch16<256, 128, 2, 2, 1, 1, 3>(p, stream);
+    case 76: return launch16<256, 256, 2, 2, 1, 1, 3>(p, stream);
+    case 85: return launch16<256, 128, 2, 2, 1, 1, 1>(p, stream);
+    case 86: return launch16<256, 256, 2, 2, 1, 1, 1>(p, stream);
+    case 95: return launch16<256, 128, 2, 2, 1, 1, 2>(p, stream);
+    case 96: return launch16<256, 256, 2, 2, 1, 1, 2>(p, stream);
+    // ablations (wrong results): 8x = no memory traffic, 9x = no MFMAs
+    case 81: return launch16<128, 128, 2, 2, 1, 1, 1>(p, stream);
+    case 83: return launch16<64, 64, 2, 2, 1, 1, 1>(p, stream);
+    case 84: return launch16<256, 128, 4, 2, 1, 2, 1>(p, stream);
+    case 91: return launch16<128, 128, 2, 2, 1, 1, 2>(p, stream);
+    case 93: return launch16<64, 64, 2, 2, 1, 1, 2>(p, stream);
+    case 94: return launch16<256, 128, 4, 2, 1, 2, 2>(p, stream);
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_bf16: unknown tile id %d", tile);
   }
   return 0;

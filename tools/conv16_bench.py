@@ -8,6 +8,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from millieye_amd import hip  # noqa: E402
 
+TILES = (1, 2, 3, 4, 11, 12, 13, 14)
 LAYERS = [  # h, cin, cout, k, s, residual
     (416, 32, 64, 3, 2, False), (208, 64, 32, 1, 1, False), (208, 32, 64, 3, 1, True),
     (208, 64, 128, 3, 2, False), (104, 128, 64, 1, 1, False), (104, 64, 128, 3, 1, True),
@@ -19,6 +20,9 @@ LAYERS = [  # h, cin, cout, k, s, residual
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    global TILES
+    if len(sys.argv) > 2:
+        TILES = tuple(int(t) for t in sys.argv[2].split(","))
     dev = torch.device("cuda")
     tot_best = 0.0
     tot_flops = 0
@@ -32,10 +36,10 @@ def main():
         out = torch.empty((n, ho, ho, cout), device=dev, dtype=torch.bfloat16)
         flops = 2 * n * ho * ho * cout * k * k * cin
         rows = []
-        for tile in (1, 2, 3, 4, 11, 12, 13, 14):
-            if tile > 10 and cin % 64:
-                continue
-            for split in (1, 2, 4):
+        for tile in TILES:
+            if 10 < tile < 20 and cin % 64:
+                continue  # identical to tiles 1..4 for this shape
+            for split in ((1, 2, 4) if len(TILES) > 6 else (1,)):
                 try:
                     for _ in range(3):
                         hip.conv2d_bf16(x, w, sc, sh, k, s, pad, 1, residual=r, out=out, tile=tile, split_k=split)
@@ -49,13 +53,15 @@ def main():
                 except hip.MeError as exc:
                     rows.append((float("inf"), tile, split))
         rows.sort()
+        if not rows:
+            continue
         best = rows[0]
         tot_best += best[0]
         tot_flops += flops
         byts = 2 * (x.numel() + out.numel() * (2 if res else 1) + w.numel())
         print(f"{h:4d} {cin:5d}->{cout:5d} k{k} s{s} res={int(res)}  best {best[0]*1e3:8.1f} us  tile {best[1]:2d} split {best[2]}"
               f"  {flops / best[0] / 1e9:7.1f} TF  {byts / best[0] / 1e6:7.1f} GB/s   next: "
-              + " ".join(f"{t}/{sp}:{ms*1e3:.0f}" for ms, t, sp in rows[1:6]))
+              + " ".join(f"{t}/{sp}:{ms*1e3:.0f}" for ms, t, sp in rows[1:8]))
     print(f"sum of best: {tot_best:.3f} ms, {tot_flops / tot_best / 1e9:.1f} TF average")
 
 
