@@ -94,11 +94,12 @@ __device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float
 // ---------------------------------------------------------------------------------------------
 // ABL (tuning only, wrong results): 1 = every DMA lane out of range (zero fill: no L2 / HBM traffic), 2 = no MFMAs,
 // 3 = no DMA instructions at all.
-template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int NST = 3>
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16P p) {
+  constexpr int NST = 3;
   constexpr int NW = WR * WC;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  static_assert(NST == 3, "the unrolled stage loop assumes 3 slots");
+
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int MT = TM / 32, NT = TN / 32;
   constexpr int GA = BM / 16, G = (BM + BN) / 16;  // 16-row groups (1 KiB each): A first, then B
@@ -173,10 +174,10 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
   const int sid = blockIdx.y;
   const int s_begin = sid * p.sps;
   const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
-  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;
+  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;  // wave-uniform K walk: filter tap outer, channel chunk inner
   int ky = tap / p.ks, kx = tap - ky * p.ks;
   unsigned a_off = 0, b_off = 0;
-  auto enter_tap = [&]() {
+  auto enter_tap = [&]() {  // VALU work only here: once per filter tap
 #pragma unroll
     for (int j = 0; j < LA; ++j) v_cur[j] = (ABL == 1 || ((v_pad[j] >> tap) & 1u)) ? kOobOffset : v_base[j];
     a_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 2);
@@ -191,18 +192,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
     if (ABL == 3) return;  // ablation: no DMA at all (LDS reads + MFMAs + barriers only)
 #pragma unroll
     for (int u = 0; u < KSUB; ++u) {
-      if constexpr (LPW <= 4 && LA <= 2) {
-        dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off + 64u * u, b_off + 64u * u, lds_dst + u * SUB_B);
-      } else {  // large tiles: A groups, then B groups, at most 4 loads per asm block
-        constexpr int LB = LPW - LA;
-        static_assert(LA <= 8 && LB <= 8, "at most 8 groups per operand per wave");
-        dma_same<(LA < 4 ? LA : 4), NW * 1024, 0>(v_cur, rsrc_a, a_off + 64u * u, lds_dst + u * SUB_B);
-        if constexpr (LA > 4)
-          dma_same<LA - 4, NW * 1024, 4>(v_cur, rsrc_a, a_off + 64u * u, lds_dst + u * SUB_B + 4u * NW * 1024u);
-        dma_same<(LB < 4 ? LB : 4), NW * 1024, LA>(v_cur, rsrc_b, b_off + 64u * u, lds_dst + u * SUB_B + LA * NW * 1024u);
-        if constexpr (LB > 4)
-          dma_same<LB - 4, NW * 1024, LA + 4>(v_cur, rsrc_b, b_off + 64u * u, lds_dst + u * SUB_B + (LA + 4u) * NW * 1024u);
-      }
+      dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off + 64u * u, b_off + 64u * u, lds_dst + u * SUB_B);
     }
     a_off += 64u * KSUB;
     b_off += 64u * KSUB;
@@ -746,25 +736,14 @@ int me_conv2d_bf16(const me_conv16_desc* d, void* stream_) {
     case 2: return k2 ? launch16<128, 64, 2, 2, 2>(p, stream) : launch16<128, 64, 2, 2, 1>(p, stream);
     case 3: return k2 ? launch16<64, 64, 2, 2, 2>(p, stream) : launch16<64, 64, 2, 2, 1>(p, stream);
     case 4: return k2 ? launch16<256, 128, 4, 2, 2, 2>(p, stream) : launch16<256, 128, 4, 2, 1, 2>(p, stream);
-    case 5: return k2 ? launch16<256, 128, 2, 2, 2>(p, stream) : launch16<256, 128, 2, 2, 1>(p, stream);  // wave tile 128x64
-    case 6: return launch16<256, 256, 2, 2, 1>(p, stream);                                                // wave tile 128x128
     // forced ids (tuning): single sub-stage variants
     case 11: return launch16<128, 128, 2, 2, 1>(p, stream);
     case 12: return launch16<128, 64, 2, 2, 1>(p, stream);
     case 13: return launch16<64, 64, 2, 2, 1>(p, stream);
     case 14: return launch16<256, 128, 4, 2, 1, 2>(p, stream);
-    case 15: return launch16<256, 128, 2, 2, 1>(p, stream);
-    case 16: return launch16<256, 256, 2, 2, 1>(p, stream);
-    case 25: return launch16<256, 128, 2, 2, 1, 2>(p, stream);  // <= 256 registers: two workgroups per CU
     case 71: return launch16<128, 128, 2, 2, 1, 1, 3>(p, stream);
     case 73: return launch16<64, 64, 2, 2, 1, 1, 3>(p, stream);
     case 74: return launch16<256, 128, 4, 2, 1, 2, 3>(p, stream);
-    case 75: return launch16<256, 128, 2, 2, 1, 1, 3>(p, stream);
-    case 76: return launch16<256, 256, 2, 2, 1, 1, 3>(p, stream);
-    case 85: return launch16<256, 128, 2, 2, 1, 1, 1>(p, stream);
-    case 86: return launch16<256, 256, 2, 2, 1, 1, 1>(p, stream);
-    case 95: return launch16<256, 128, 2, 2, 1, 1, 2>(p, stream);
-    case 96: return launch16<256, 256, 2, 2, 1, 1, 2>(p, stream);
     // ablations (wrong results): 8x = no memory traffic, 9x = no MFMAs
     case 81: return launch16<128, 128, 2, 2, 1, 1, 1>(p, stream);
     case 83: return launch16<64, 64, 2, 2, 1, 1, 1>(p, stream);
