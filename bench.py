@@ -39,9 +39,9 @@ def parse():
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--cfg", default="yolov3")
     ap.add_argument("--workload", default="full", choices=["detector", "full", "train", "detector_train"])
-    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
-                    help="storage of the detector activations / weights: f32 (default, the parity mode) or bf16 "
-                         "(BASELINE configs[2]/[4]: bf16 operands, fp32 accumulate; inference workloads only)")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16"),
+                    help="storage of the detector activations / weights: f32 (default, the parity mode), bf16 or f16 "
+                         "(BASELINE configs[2]/[4]: 16-bit operands, fp32 accumulate; inference workloads only)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed clock ramp-up before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the extra bf16-storage-mode measurement")
@@ -81,7 +81,7 @@ def conv_roofline(model, x, steps):
     timed = {}  # module -> list of (start, end) events; launches stay IN SEQUENCE (real cache state)
     for _ in range(steps):
         for fn, args, _k, name in plan.launches:
-            mfma_conv = (fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_bf16) and descs[int(name[4:])].cin > 4
+            mfma_conv = (fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_h16) and descs[int(name[4:])].cin > 4
             if mfma_conv:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -124,7 +124,7 @@ def stage_roofline(model, net, x, step, rois, reps=5):
     stream = hip.stream_ptr()
     descs = {m: d for m, d in plan.conv_descs}
     n, size = x.shape[0], x.shape[-1]
-    bf16 = model.compute_dtype == "bf16"
+    bf16 = model.compute_dtype != "f32"
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TF
     acc = {}
 
@@ -147,7 +147,7 @@ def stage_roofline(model, net, x, step, rois, reps=5):
         torch.cuda.synchronize()
         for name, fn, a, b in evs:
             ms = a.elapsed_time(b)
-            if fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_bf16:
+            if fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_h16:
                 d = descs[int(name[4:])]
                 if d.cin <= 4:
                     add("stem conv (cin 3, direct)", ms,
@@ -441,7 +441,7 @@ def main():
     if rank == 0:
         frames = batch * world * args.steps
         plan = model.engine_for(model.compute_dtype).plan_for(x)
-        bf16 = args.dtype == "bf16"
+        bf16 = args.dtype != "f32"
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         ach, avg_us, launches, flops_per_launch, per_layer = conv_roofline(model, x, max(3, min(args.steps, 10)))
         out = {
@@ -459,7 +459,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.cfg}.cfg {args.size}x{args.size} "
-                            + ("bf16-storage (bf16 operands, fp32 accumulate)" if bf16 else "fp32")
+                            + (f"{args.dtype}-storage ({args.dtype} operands, fp32 accumulate)" if bf16 else "fp32")
                             + f" inference, batch={batch} per GPU, "
                             + ("Darknet.forward -> featuremap + yolo_outputs" if args.workload == "detector" else
                                "full milliEye: Darknet.forward -> NMS -> Network.forward mode 0 (R-CNN head + radar "
@@ -479,7 +479,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": ("conv_igemm_buf_bf16 (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv, all 3x3 / 1x1 layers)" if bf16
+                "kernel": (f"conv_igemm_buf_h16 (v_mfma_f32_32x32x16_{args.dtype} implicit-GEMM conv, all 3x3 / 1x1 layers)" if bf16
                            else "conv_igemm_buf_f32 (v_mfma_f32_32x32x2_f32 implicit-GEMM conv, all 3x3 / 1x1 layers)"),
                 "achieved": round(ach, 2),
                 "peak": peak,
@@ -499,7 +499,7 @@ def main():
                 "value": round(frames / alt["e"], 2),
                 "unit": "frames/s",
                 "ms_per_step": round(alt["e"] / args.steps * 1e3, 4),
-                "roofline": {"bound": "mfma", "kernel": "conv_igemm_buf_bf16", "achieved": round(alt["ach"], 2),
+                "roofline": {"bound": "mfma", "kernel": "conv_igemm_buf_h16", "achieved": round(alt["ach"], 2),
                              "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(alt["ach"] / BF16_MFMA_PEAK_TFLOPS, 4),
                              "launches_per_step": alt["launches"], "avg_launch_us": round(alt["avg_us"], 2)},

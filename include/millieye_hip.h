@@ -403,9 +403,9 @@ int me_radar_heatmap_f32(const double* points, const int32_t* offsets, const int
 int me_batch_statistics_f32(const float* rows, int32_t m, int32_t cols, const float* targets, int32_t q,
                             int32_t n_images, float iou_threshold, float* tp, void* stream);
 
-/* ---- 16-bit storage mode (BASELINE configs[2] / [4]: "bf16 inference") -------------------------------------------
- * The same conv block as me_conv2d_f32 (models.py:22-41) with bfloat16 activations and weights and fp32 accumulation on
- * v_mfma_f32_32x32x16_bf16.  Opt-in; the fp32 entry points stay the default and the ones the 1e-3 parity bar is quoted on.
+/* ---- 16-bit storage modes (BASELINE configs[2] / [4]: "bf16 inference", "fp16 MFMA convs") ------------------------
+ * The same conv block as me_conv2d_f32 (models.py:22-41) with 16-bit activations and weights - bfloat16 (half_type 0,
+ * v_mfma_f32_32x32x16_bf16) or IEEE half (half_type 1, v_mfma_f32_32x32x16_f16) - and fp32 accumulation.  Opt-in; the fp32 entry points stay the default and the ones the 1e-3 parity bar is quoted on.
  *   x    bf16 NHWC (pitches in elements, %% 8);   stem only (cin == 3): float32 NCHW (x_nchw = 1) or NHWC
  *   wgt  bf16 [cout][k][k][cin], cin %% 32 == 0;  stem: float32 [cout][3][3][3]
  *   res  same type as y (or NULL);  y bf16, or float32 when y_f32 != 0 (the detection convs that feed me_yolo_decode_f32)
@@ -425,21 +425,24 @@ typedef struct me_conv16_desc {
   int32_t upsample;
   int32_t x_nchw;
   int32_t y_f32;
+  int32_t half_type; /* 0 = bfloat16, 1 = IEEE half (x, wgt, res / y unless y_f32) */
   int32_t tile;    /* 0 = auto; 1..4 = 128x128 / 128x64 / 64x64 / 256x128; 11..14 = single sub-stage variants */
   int32_t split_k; /* as me_conv_desc */
   void* workspace;
   int64_t workspace_bytes;
 } me_conv16_desc;
-int me_conv2d_bf16(const me_conv16_desc* d, void* stream);
-int64_t me_conv2d_bf16_workspace_bytes(const me_conv16_desc* d);
-/* bf16 NHWC twins of me_maxpool_f32 / me_upsample_f32 / me_add_f32 / me_copy_f32 (channels and pitches %% 8) */
-int me_maxpool_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
-                    int32_t size, int32_t stride, int32_t pad, int32_t zero_ext, int32_t ho, int32_t wo, void* stream);
-int me_upsample_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+int me_conv2d_h16(const me_conv16_desc* d, void* stream);
+int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d);
+/* 16-bit NHWC twins of me_maxpool_f32 / me_upsample_f32 / me_add_f32 / me_copy_f32 (channels and pitches %% 8); upsample
+ * and copy move bytes and serve both types */
+int me_maxpool_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                   int32_t size, int32_t stride, int32_t pad, int32_t zero_ext, int32_t ho, int32_t wo, int32_t half_type,
+                   void* stream);
+int me_upsample_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
                      int32_t factor, void* stream);
-int me_add_bf16(const void* a, int64_t a_pitch, const void* b, int64_t b_pitch, void* y, int64_t y_pitch, int64_t pixels,
-                int32_t c, void* stream);
-int me_copy_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int64_t pixels, int32_t c, void* stream);
+int me_add_h16(const void* a, int64_t a_pitch, const void* b, int64_t b_pitch, void* y, int64_t y_pitch, int64_t pixels,
+               int32_t c, int32_t half_type, void* stream);
+int me_copy_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int64_t pixels, int32_t c, void* stream);
 
 /* sizes of the descriptor structs, so a binding can assert its mirror layout */
 int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights, 6 conv16 */

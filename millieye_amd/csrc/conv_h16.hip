@@ -1,14 +1,14 @@
-// conv_bf16.hip - the detector's conv blocks with 16-bit storage (bf16 activations and weights, fp32 accumulate) for
+// conv_h16.hip - the detector's conv blocks with 16-bit storage (bf16 activations and weights, fp32 accumulate) for
 // gfx950: BASELINE configs[2] / [4] ("bf16 inference").  Opt-in (MILLIEYE_DTYPE=bf16 / Darknet.compute_dtype); the
 // fp32 path of conv.hip stays the default and the one the 1e-3 parity bar is quoted on.
 //
-//   conv_igemm_buf_bf16 : the buffer-addressed LDS-DMA implicit GEMM of conv.hip on v_mfma_f32_32x32x16_bf16
+//   conv_igemm_buf_h16 : the buffer-addressed LDS-DMA implicit GEMM of conv.hip on v_mfma_f32_32x32x16_bf16
 //                         (2.5 PFLOP/s dense peak, 16x the fp32 matrix rate).  A stage is KSUB sub-stages of
 //                         (BM + BN) rows x 32 channels (64-byte rows - the same 1 KiB-per-DMA LDS image and XOR
 //                         swizzle as the fp32 kernel); one ds_read_b128 is one MFMA operand (8 bf16 per lane).
 //                         Epilogue: fp32 affine (folded BN / bias) + LeakyReLU + residual, one RNE rounding to bf16
 //                         (v_cvt_pk_bf16_f32) or fp32 output for the detection convs that feed the YOLO decode.
-//   conv_stem3_bf16     : the cin = 3 stem on the VALU (fp32 frames in, fp32 weights, bf16 NHWC out).
+//   conv_stem3_h16     : the cin = 3 stem on the VALU (fp32 frames in, fp32 weights, bf16 NHWC out).
 //   maxpool / upsample / add / copy on bf16 NHWC (16 bytes = 8 channels per lane).
 //
 // Rounding points (what oracle/darknet_ref.py's storage="bf16" mode restates): weights once (host, RNE), every
@@ -20,7 +20,32 @@
 #include "dma.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// The two 16-bit storage types: F16 = 0 bfloat16 (v_mfma_f32_32x32x16_bf16), F16 = 1 IEEE half (v_mfma_f32_32x32x16_f16;
+// BASELINE configs[4] "fp16 MFMA convs").  Same kernels, same layouts; only the operand type, the MFMA and the conversions
+// differ.  Both round to nearest even.
+template <int F16>
+struct H16;
+template <>
+struct H16<0> {
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned short to(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+  static __device__ __forceinline__ float from(unsigned b) { return __uint_as_float(b << 16); }
+};
+template <>
+struct H16<1> {
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned short to(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+  static __device__ __forceinline__ float from(unsigned b) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)b);
+  }
+};
 
 namespace {
 using namespace me_dma;
@@ -41,6 +66,7 @@ struct Conv16P {
   int tiles_m, tiles_n;
   float* partial;  // split-K slabs [splitk][M][cout] (raw fp32 accumulators), or nullptr
   int splitk, sps;
+  int f16;         // 0 = bfloat16 storage, 1 = IEEE half
   int vec_epi;     // 16-byte epilogue allowed (bf16 out, no upsample, leaky / linear, pitches % 8, 16-byte aligned)
 };
 
@@ -49,8 +75,10 @@ __device__ __forceinline__ float act16(float v, int act) {
   if (act == ME_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
   return v;
 }
-__device__ __forceinline__ unsigned short to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
-__device__ __forceinline__ float from_bf16(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+template <int F16>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  return (unsigned)H16<F16>::to(lo) | ((unsigned)H16<F16>::to(hi) << 16);
+}
 
 template <class F, int... J>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, J...>) {
@@ -58,17 +86,18 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, J..
 }
 
 // one output element through the fused epilogue tail: residual, rounding, (replicated) store
+template <int F16>
 __device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float v, int hw) {
   if (p.res) {
     v += p.y_f32 ? reinterpret_cast<const float*>(p.res)[(long long)m * p.res_pitch + co]
-                 : from_bf16(reinterpret_cast<const unsigned short*>(p.res)[(long long)m * p.res_pitch + co]);
+                 : H16<F16>::from(reinterpret_cast<const unsigned short*>(p.res)[(long long)m * p.res_pitch + co]);
   }
   if (p.ups == 1) {
     const long long o = (long long)m * p.y_pitch + co;
     if (p.y_f32)
       reinterpret_cast<float*>(p.y)[o] = v;
     else
-      reinterpret_cast<unsigned short*>(p.y)[o] = to_bf16(v);
+      reinterpret_cast<unsigned short*>(p.y)[o] = H16<F16>::to(v);
     return;
   }
   const int nimg = m / hw;
@@ -82,7 +111,7 @@ __device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float
 #pragma unroll
     for (int k = 0; k < 4; ++k) reinterpret_cast<float*>(p.y)[o[k]] = v;
   } else {
-    const unsigned short b = to_bf16(v);
+    const unsigned short b = H16<F16>::to(v);
 #pragma unroll
     for (int k = 0; k < 4; ++k) reinterpret_cast<unsigned short*>(p.y)[o[k]] = b;
   }
@@ -94,8 +123,9 @@ __device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float
 // ---------------------------------------------------------------------------------------------
 // ABL (tuning only, wrong results): 1 = every DMA lane out of range (zero fill: no L2 / HBM traffic), 2 = no MFMAs,
 // 3 = no DMA instructions at all.
-template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0>
-__global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16P p) {
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int F16 = 0>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P p) {
+  using frag = typename H16<F16>::v8;
   constexpr int NST = 3;
   constexpr int NW = WR * WC;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -226,17 +256,17 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
   const int offk[2] = {((0 + hh) ^ sw) * 16, ((2 + hh) ^ sw) * 16};
 
   auto compute_stage = [&](const unsigned char* Ab, const unsigned char* Bb) {
-    bf16x8 af[KSUB][2][MT], bf[KSUB][2][NT];
+    frag af[KSUB][2][MT], bf[KSUB][2][NT];
 #pragma unroll
     for (int u = 0; u < KSUB; ++u)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-          af[u][ks][i] = *reinterpret_cast<const bf16x8*>(Ab + u * SUB_B + i * 32 * 64 + offk[ks]);
+          af[u][ks][i] = *reinterpret_cast<const frag*>(Ab + u * SUB_B + i * 32 * 64 + offk[ks]);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          bf[u][ks][j] = *reinterpret_cast<const bf16x8*>(Bb + u * SUB_B + j * 32 * 64 + offk[ks]);
+          bf[u][ks][j] = *reinterpret_cast<const frag*>(Bb + u * SUB_B + j * 32 * 64 + offk[ks]);
       }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -247,7 +277,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u][ks][i], bf[u][ks][j], acc[i][j], 0, 0, 0);
+            if (ABL != 2) acc[i][j] = H16<F16>::mfma(af[u][ks][i], bf[u][ks][j], acc[i][j]);
             else acc[i][j][0] += (float)af[u][ks][i][0] + (float)bf[u][ks][j][0];
   };
 
@@ -331,15 +361,15 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
           const unsigned rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            v[2 * k] += __uint_as_float(rr[k] << 16);
-            v[2 * k + 1] += __uint_as_float(rr[k] & 0xffff0000u);
+            v[2 * k] += H16<F16>::from(rr[k] & 0xffffu);
+            v[2 * k + 1] += H16<F16>::from(rr[k] >> 16);
           }
         }
         uint4 o;
-        o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
-        o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
-        o.z = (unsigned)to_bf16(v[4]) | ((unsigned)to_bf16(v[5]) << 16);
-        o.w = (unsigned)to_bf16(v[6]) | ((unsigned)to_bf16(v[7]) << 16);
+        o.x = pack2<F16>(v[0], v[1]);
+        o.y = pack2<F16>(v[2], v[3]);
+        o.z = pack2<F16>(v[4], v[5]);
+        o.w = pack2<F16>(v[6], v[7]);
         *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch is free for the next block
@@ -372,10 +402,10 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
           v = v > 0.f ? v : v * slope;
           if constexpr (RES) {
             if constexpr (F32) v += r[(long long)m * p.res_pitch];
-            else v += from_bf16(r[(long long)m * p.res_pitch]);
+            else v += H16<F16>::from(r[(long long)m * p.res_pitch]);
           }
           if constexpr (F32) y[(long long)m * p.y_pitch] = v;
-          else y[(long long)m * p.y_pitch] = to_bf16(v);
+          else y[(long long)m * p.y_pitch] = H16<F16>::to(v);
         }
       };
       if (p.y_f32) {
@@ -389,7 +419,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
-        if (m < p.M) store_out(p, m, co, act16(acc[i][j][e] * sc + sh, p.act), hw);
+        if (m < p.M) store_out<F16>(p, m, co, act16(acc[i][j][e] * sc + sh, p.act), hw);
       }
     }
   };
@@ -397,7 +427,8 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_bf16(Conv16
              std::make_integer_sequence<int, NT>{});
 }
 
-__global__ __launch_bounds__(256) void conv_splitk_reduce_bf16(Conv16P p) {
+template <int F16>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_h16(Conv16P p) {
   const long long total = (long long)p.M * p.cout;
   const int hw = p.ho * p.wo;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -405,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_bf16(Conv16P p) {
     const int m = (int)(idx / p.cout);
     float a = p.partial[idx];
     for (int k = 1; k < p.splitk; ++k) a += p.partial[(long long)k * total + idx];
-    store_out(p, m, co, act16(a * p.scale[co] + p.shift[co], p.act), hw);
+    store_out<F16>(p, m, co, act16(a * p.scale[co] + p.shift[co], p.act), hw);
   }
 }
 
@@ -413,8 +444,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_bf16(Conv16P p) {
 // stem (cin == 3): fp32 frames (NCHW as the caller hands them, or NHWC) and fp32 weights in, bf16 NHWC out.
 // Same arithmetic and k order as conv_stem3_f32 (conv.hip); one thread = one pixel x CT output channels.
 // ---------------------------------------------------------------------------------------------
-template <int CT>
-__global__ __launch_bounds__(256) void conv_stem3_bf16(Conv16P p) {
+template <int CT, int F16>
+__global__ __launch_bounds__(256) void conv_stem3_h16(Conv16P p) {
   constexpr int K = 27;
   const int m = blockIdx.x * 256 + threadIdx.x;
   const int co0 = blockIdx.y * CT;
@@ -452,7 +483,7 @@ __global__ __launch_bounds__(256) void conv_stem3_bf16(Conv16P p) {
       for (int k = 0; k < K; ++k) a = fmaf(xin[k], wg[(j + t) * K + k], a);
       v[t] = act16(a * p.scale[co0 + j + t] + p.shift[co0 + j + t], p.act);
     }
-    packed[j / 2] = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+    packed[j / 2] = pack2<F16>(v[0], v[1]);
   }
   unsigned short* yrow = reinterpret_cast<unsigned short*>(p.y) + (long long)m * p.y_pitch + co0;
 #pragma unroll
@@ -479,16 +510,18 @@ struct Pool16P {
   int n, h, w, c, size, stride, pad, zero_ext, ho, wo;
 };
 
-__device__ __forceinline__ unsigned max_pair(unsigned a, unsigned b) {  // two packed bf16, fmaxf semantics per half
-  const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
-  const float hi = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
-  return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+template <int F16>
+__device__ __forceinline__ unsigned max_pair(unsigned a, unsigned b) {  // two packed 16-bit floats, fmaxf per half (exact)
+  const float lo = fmaxf(H16<F16>::from(a & 0xffffu), H16<F16>::from(b & 0xffffu));
+  const float hi = fmaxf(H16<F16>::from(a >> 16), H16<F16>::from(b >> 16));
+  return pack2<F16>(lo, hi);
 }
 
-__global__ __launch_bounds__(kThreads) void maxpool_bf16_kernel(Pool16P d) {
+template <int F16>
+__global__ __launch_bounds__(kThreads) void maxpool_h16_kernel(Pool16P d) {
   const int cv = d.c / 8;
   const long long total = (long long)d.n * d.ho * d.wo * cv;
-  const unsigned ninf = 0xff80ff80u;  // (-inf, -inf)
+  const unsigned ninf = F16 ? 0xfc00fc00u : 0xff80ff80u;  // (-inf, -inf)
   for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * kThreads) {
     const int c = (int)(idx % cv) * 8;
@@ -504,15 +537,15 @@ __global__ __launch_bounds__(kThreads) void maxpool_bf16_kernel(Pool16P d) {
         const int ix = ox * d.stride - d.pad + kx;
         if ((unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w) {
           const uint4 t = *reinterpret_cast<const uint4*>(d.x + ((long long)(nimg * d.h + iy) * d.w + ix) * d.x_pitch + c);
-          best.x = max_pair(best.x, t.x);
-          best.y = max_pair(best.y, t.y);
-          best.z = max_pair(best.z, t.z);
-          best.w = max_pair(best.w, t.w);
+          best.x = max_pair<F16>(best.x, t.x);
+          best.y = max_pair<F16>(best.y, t.y);
+          best.z = max_pair<F16>(best.z, t.z);
+          best.w = max_pair<F16>(best.w, t.w);
         } else if (d.zero_ext && iy >= 0 && ix >= 0 && iy <= d.h && ix <= d.w) {
-          best.x = max_pair(best.x, 0u);  // ZeroPad2d((0,1,0,1)): zeros take part in the max (quirk q16)
-          best.y = max_pair(best.y, 0u);
-          best.z = max_pair(best.z, 0u);
-          best.w = max_pair(best.w, 0u);
+          best.x = max_pair<F16>(best.x, 0u);  // ZeroPad2d((0,1,0,1)): zeros take part in the max (quirk q16)
+          best.y = max_pair<F16>(best.y, 0u);
+          best.z = max_pair<F16>(best.z, 0u);
+          best.w = max_pair<F16>(best.w, 0u);
         }
       }
     }
@@ -520,7 +553,7 @@ __global__ __launch_bounds__(kThreads) void maxpool_bf16_kernel(Pool16P d) {
   }
 }
 
-__global__ __launch_bounds__(kThreads) void upsample_bf16_kernel(const unsigned short* x, long long xp, unsigned short* y,
+__global__ __launch_bounds__(kThreads) void upsample_h16_kernel(const unsigned short* x, long long xp, unsigned short* y,
                                                                  long long yp, int n, int h, int w, int c, int f) {
   const int cv = c / 8;
   const int ho = h * f, wo = w * f;
@@ -538,14 +571,13 @@ __global__ __launch_bounds__(kThreads) void upsample_bf16_kernel(const unsigned 
   }
 }
 
+template <int F16>
 __device__ __forceinline__ unsigned add_pair(unsigned a, unsigned b) {
-  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
-  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
-  return (unsigned)to_bf16(lo) | ((unsigned)to_bf16(hi) << 16);
+  return pack2<F16>(H16<F16>::from(a & 0xffffu) + H16<F16>::from(b & 0xffffu), H16<F16>::from(a >> 16) + H16<F16>::from(b >> 16));
 }
 
-template <bool ADD>
-__global__ __launch_bounds__(kThreads) void addcopy_bf16_kernel(const unsigned short* a, long long ap,
+template <bool ADD, int F16>
+__global__ __launch_bounds__(kThreads) void addcopy_h16_kernel(const unsigned short* a, long long ap,
                                                                 const unsigned short* b, long long bp, unsigned short* y,
                                                                 long long yp, long long pixels, int c) {
   const int cv = c / 8;
@@ -557,10 +589,10 @@ __global__ __launch_bounds__(kThreads) void addcopy_bf16_kernel(const unsigned s
     uint4 u = *reinterpret_cast<const uint4*>(a + pix * ap + cc);
     if (ADD) {
       const uint4 t = *reinterpret_cast<const uint4*>(b + pix * bp + cc);
-      u.x = add_pair(u.x, t.x);
-      u.y = add_pair(u.y, t.y);
-      u.z = add_pair(u.z, t.z);
-      u.w = add_pair(u.w, t.w);
+      u.x = add_pair<F16>(u.x, t.x);
+      u.y = add_pair<F16>(u.y, t.y);
+      u.z = add_pair<F16>(u.z, t.z);
+      u.w = add_pair<F16>(u.w, t.w);
     }
     *reinterpret_cast<uint4*>(y + pix * yp + cc) = u;
   }
@@ -581,11 +613,11 @@ bool addressable16(const Conv16P& p, int bm) {
   return a_max < (1ll << 31) && b_max < (1ll << 31);
 }
 
-template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0>
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int F16 = 0>
 int launch16(Conv16P& p, hipStream_t stream) {
   static_assert(BM <= 256, "addressable16 / the descriptor window assume tiles of at most 256 rows");
   ME_REQUIRE(addressable16(p, BM), ME_E_TOOBIG,
-             "me_conv2d_bf16: one tile's input window exceeds the 2 GiB buffer-descriptor range");
+             "me_conv2d_h16: one tile's input window exceeds the 2 GiB buffer-descriptor range");
   p.cs = p.cin / (32 * KSUB);
   p.stages = p.ks * p.ks * p.cs;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -596,7 +628,7 @@ int launch16(Conv16P& p, hipStream_t stream) {
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
   const size_t lds = (size_t)3 * KSUB * LPW * NW * 1024;
-  auto kern = conv_igemm_buf_bf16<BM, BN, WR, WC, KSUB, MINW, ABL>;
+  auto kern = conv_igemm_buf_h16<BM, BN, WR, WC, KSUB, MINW, ABL, F16>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -606,33 +638,34 @@ int launch16(Conv16P& p, hipStream_t stream) {
     }
   }
   const long long blocks = (long long)p.tiles_m * p.tiles_n;
-  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_bf16: grid too large");
+  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(64 * NW), lds, stream, p);
-  int rc = me::check_launch("conv_igemm_buf_bf16");
+  int rc = me::check_launch("conv_igemm_buf_h16");
   if (rc || p.splitk == 1) return rc;
   long long rb = ((long long)p.M * p.cout + 255) / 256;
   if (rb > 256 * 16) rb = 256 * 16;
-  hipLaunchKernelGGL(conv_splitk_reduce_bf16, dim3((unsigned)rb), dim3(256), 0, stream, p);
-  return me::check_launch("conv_splitk_reduce_bf16");
+  hipLaunchKernelGGL(conv_splitk_reduce_h16<F16>, dim3((unsigned)rb), dim3(256), 0, stream, p);
+  return me::check_launch("conv_splitk_reduce_h16");
 }
 
 int fill16(const me_conv16_desc* d, Conv16P& p) {
-  ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_bf16: null descriptor");
+  ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_h16: null descriptor");
   ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
-             "me_conv2d_bf16: non-positive dimension");
-  ME_REQUIRE(d->ksize >= 1 && d->stride >= 1 && d->pad >= 0, ME_E_BADARG, "me_conv2d_bf16: bad ksize/stride/pad");
+             "me_conv2d_h16: non-positive dimension");
+  ME_REQUIRE(d->ksize >= 1 && d->stride >= 1 && d->pad >= 0, ME_E_BADARG, "me_conv2d_h16: bad ksize/stride/pad");
   const int ho = (d->h + 2 * d->pad - d->ksize) / d->stride + 1;
   const int wo = (d->w + 2 * d->pad - d->ksize) / d->stride + 1;
-  ME_REQUIRE(ho == d->ho && wo == d->wo, ME_E_BADARG, "me_conv2d_bf16: ho/wo (%d,%d) != derived (%d,%d)", d->ho, d->wo,
+  ME_REQUIRE(ho == d->ho && wo == d->wo, ME_E_BADARG, "me_conv2d_h16: ho/wo (%d,%d) != derived (%d,%d)", d->ho, d->wo,
              ho, wo);
-  ME_REQUIRE((long long)d->n * d->ho * d->wo < (1ll << 31), ME_E_TOOBIG, "me_conv2d_bf16: too many output pixels");
+  ME_REQUIRE((long long)d->n * d->ho * d->wo < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: too many output pixels");
+  ME_REQUIRE(d->half_type == 0 || d->half_type == 1, ME_E_BADARG, "me_conv2d_h16: half_type must be 0 (bf16) or 1 (f16)");
   p.x = reinterpret_cast<const unsigned short*>(d->x);
   p.wgt = reinterpret_cast<const unsigned short*>(d->wgt);
   p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
   p.x_pitch = d->x_pitch; p.res_pitch = d->res_pitch; p.y_pitch = d->y_pitch;
   p.n = d->n; p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout; p.ks = d->ksize;
   p.stride = d->stride; p.pad = d->pad; p.ho = d->ho; p.wo = d->wo; p.act = d->act; p.ups = d->upsample;
-  p.y_f32 = d->y_f32; p.x_nchw = d->x_nchw;
+  p.y_f32 = d->y_f32; p.x_nchw = d->x_nchw; p.f16 = d->half_type;
   p.M = d->n * d->ho * d->wo;
   p.ktot = d->ksize * d->ksize * d->cin;
   p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
@@ -668,7 +701,7 @@ void plan16(const Conv16P& p, int max_split, int* tile, int* split) {
 
 extern "C" {
 
-int64_t me_conv2d_bf16_workspace_bytes(const me_conv16_desc* d) {
+int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d) {
   Conv16P p;
   if (!d || fill16(d, p) != 0 || d->cin <= 4) return 0;
   int tile, split;
@@ -677,38 +710,41 @@ int64_t me_conv2d_bf16_workspace_bytes(const me_conv16_desc* d) {
   return split > 1 ? (int64_t)split * p.M * p.cout * (int64_t)sizeof(float) : 0;
 }
 
-int me_conv2d_bf16(const me_conv16_desc* d, void* stream_) {
+int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   Conv16P p;
   int rc = fill16(d, p);
   if (rc) return rc;
-  ME_REQUIRE(d->x && d->wgt && d->scale && d->shift && d->y, ME_E_NULLPTR, "me_conv2d_bf16: null tensor pointer");
-  ME_REQUIRE(d->upsample == 1 || d->upsample == 2, ME_E_BADARG, "me_conv2d_bf16: upsample must be 1 or 2");
-  ME_REQUIRE(d->act >= 0 && d->act <= 2, ME_E_BADARG, "me_conv2d_bf16: unknown activation %d", d->act);
-  ME_REQUIRE(d->y_pitch >= d->cout, ME_E_BADARG, "me_conv2d_bf16: y_pitch < cout");
+  ME_REQUIRE(d->x && d->wgt && d->scale && d->shift && d->y, ME_E_NULLPTR, "me_conv2d_h16: null tensor pointer");
+  ME_REQUIRE(d->upsample == 1 || d->upsample == 2, ME_E_BADARG, "me_conv2d_h16: upsample must be 1 or 2");
+  ME_REQUIRE(d->act >= 0 && d->act <= 2, ME_E_BADARG, "me_conv2d_h16: unknown activation %d", d->act);
+  ME_REQUIRE(d->y_pitch >= d->cout, ME_E_BADARG, "me_conv2d_h16: y_pitch < cout");
 
   if (d->cin <= 4) {  // stem: fp32 frames + fp32 weights -> bf16
-    ME_REQUIRE(d->cin == 3 && d->ksize == 3, ME_E_BADARG, "me_conv2d_bf16: the stem kernel needs cin 3, ksize 3");
+    ME_REQUIRE(d->cin == 3 && d->ksize == 3, ME_E_BADARG, "me_conv2d_h16: the stem kernel needs cin 3, ksize 3");
     ME_REQUIRE(d->cout % 16 == 0 && d->y_pitch % 8 == 0 && !d->y_f32, ME_E_BADARG,
-               "me_conv2d_bf16: stem needs cout %% 16 == 0, y_pitch %% 8 == 0, bf16 output");
-    ME_REQUIRE(d->res == nullptr && d->upsample == 1, ME_E_BADARG, "me_conv2d_bf16: stem has no residual/upsample epilogue");
-    ME_REQUIRE(d->x_nchw || d->x_pitch >= d->cin, ME_E_BADARG, "me_conv2d_bf16: x_pitch < cin");
-    ME_REQUIRE(me::aligned16(d->y), ME_E_ALIGN, "me_conv2d_bf16: y not 16-byte aligned");
+               "me_conv2d_h16: stem needs cout %% 16 == 0, y_pitch %% 8 == 0, bf16 output");
+    ME_REQUIRE(d->res == nullptr && d->upsample == 1, ME_E_BADARG, "me_conv2d_h16: stem has no residual/upsample epilogue");
+    ME_REQUIRE(d->x_nchw || d->x_pitch >= d->cin, ME_E_BADARG, "me_conv2d_h16: x_pitch < cin");
+    ME_REQUIRE(me::aligned16(d->y), ME_E_ALIGN, "me_conv2d_h16: y not 16-byte aligned");
     const unsigned mb = (unsigned)((p.M + 255) / 256);
-    if (d->cout % 32 == 0)
-      hipLaunchKernelGGL(conv_stem3_bf16<32>, dim3(mb, d->cout / 32), dim3(256), 0, stream, p);
-    else
-      hipLaunchKernelGGL(conv_stem3_bf16<16>, dim3(mb, d->cout / 16), dim3(256), 0, stream, p);
-    return me::check_launch("conv_stem3_bf16");
+    if (d->cout % 32 == 0) {
+      if (p.f16) hipLaunchKernelGGL((conv_stem3_h16<32, 1>), dim3(mb, d->cout / 32), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((conv_stem3_h16<32, 0>), dim3(mb, d->cout / 32), dim3(256), 0, stream, p);
+    } else {
+      if (p.f16) hipLaunchKernelGGL((conv_stem3_h16<16, 1>), dim3(mb, d->cout / 16), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((conv_stem3_h16<16, 0>), dim3(mb, d->cout / 16), dim3(256), 0, stream, p);
+    }
+    return me::check_launch("conv_stem3_h16");
   }
 
-  ME_REQUIRE(!d->x_nchw, ME_E_BADARG, "me_conv2d_bf16: NCHW input only for the stem");
-  ME_REQUIRE(d->cin % 32 == 0, ME_E_BADARG, "me_conv2d_bf16: cin %% 32 != 0 (cin=%d): pad the channels", d->cin);
-  ME_REQUIRE(d->x_pitch >= d->cin && d->x_pitch % 8 == 0, ME_E_ALIGN, "me_conv2d_bf16: x_pitch must be >= cin, %% 8");
-  ME_REQUIRE(me::aligned16(d->x) && me::aligned16(d->wgt), ME_E_ALIGN, "me_conv2d_bf16: x / wgt not 16-byte aligned");
-  ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_bf16: res_pitch < cout");
-  ME_REQUIRE(d->split_k >= 0 && d->split_k <= 64, ME_E_BADARG, "me_conv2d_bf16: split_k out of range");
-  ME_REQUIRE(d->ksize * d->ksize <= 32, ME_E_TOOBIG, "me_conv2d_bf16: filters with more than 32 taps are not supported");
+  ME_REQUIRE(!d->x_nchw, ME_E_BADARG, "me_conv2d_h16: NCHW input only for the stem");
+  ME_REQUIRE(d->cin % 32 == 0, ME_E_BADARG, "me_conv2d_h16: cin %% 32 != 0 (cin=%d): pad the channels", d->cin);
+  ME_REQUIRE(d->x_pitch >= d->cin && d->x_pitch % 8 == 0, ME_E_ALIGN, "me_conv2d_h16: x_pitch must be >= cin, %% 8");
+  ME_REQUIRE(me::aligned16(d->x) && me::aligned16(d->wgt), ME_E_ALIGN, "me_conv2d_h16: x / wgt not 16-byte aligned");
+  ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_h16: res_pitch < cout");
+  ME_REQUIRE(d->split_k >= 0 && d->split_k <= 64, ME_E_BADARG, "me_conv2d_h16: split_k out of range");
+  ME_REQUIRE(d->ksize * d->ksize <= 32, ME_E_TOOBIG, "me_conv2d_h16: filters with more than 32 taps are not supported");
 
   const long long slab = (long long)p.M * p.cout * (long long)sizeof(float);
   int max_split = 1;
@@ -725,12 +761,25 @@ int me_conv2d_bf16(const me_conv16_desc* d, void* stream_) {
   }
   if (d->split_k > 0) {
     ME_REQUIRE(d->split_k == 1 || (d->workspace && d->workspace_bytes >= d->split_k * slab), ME_E_BADARG,
-               "me_conv2d_bf16: split_k=%d needs a workspace of %lld bytes", d->split_k, d->split_k * slab);
+               "me_conv2d_h16: split_k=%d needs a workspace of %lld bytes", d->split_k, d->split_k * slab);
     split = d->split_k;
   }
   p.splitk = split;
   p.partial = reinterpret_cast<float*>(d->workspace);
   const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows
+  if (p.f16) {
+    switch (tile) {
+      case 1: return k2 ? launch16<128, 128, 2, 2, 2, 1, 0, 1>(p, stream) : launch16<128, 128, 2, 2, 1, 1, 0, 1>(p, stream);
+      case 2: return k2 ? launch16<128, 64, 2, 2, 2, 1, 0, 1>(p, stream) : launch16<128, 64, 2, 2, 1, 1, 0, 1>(p, stream);
+      case 3: return k2 ? launch16<64, 64, 2, 2, 2, 1, 0, 1>(p, stream) : launch16<64, 64, 2, 2, 1, 1, 0, 1>(p, stream);
+      case 4: return k2 ? launch16<256, 128, 4, 2, 2, 2, 0, 1>(p, stream) : launch16<256, 128, 4, 2, 1, 2, 0, 1>(p, stream);
+      case 11: return launch16<128, 128, 2, 2, 1, 1, 0, 1>(p, stream);
+      case 12: return launch16<128, 64, 2, 2, 1, 1, 0, 1>(p, stream);
+      case 13: return launch16<64, 64, 2, 2, 1, 1, 0, 1>(p, stream);
+      case 14: return launch16<256, 128, 4, 2, 1, 2, 0, 1>(p, stream);
+      default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown tile id %d (half_type 1)", tile);
+    }
+  }
   switch (tile) {
     case 1: return k2 ? launch16<128, 128, 2, 2, 2>(p, stream) : launch16<128, 128, 2, 2, 1>(p, stream);
     case 2: return k2 ? launch16<128, 64, 2, 2, 2>(p, stream) : launch16<128, 64, 2, 2, 1>(p, stream);
@@ -751,64 +800,74 @@ int me_conv2d_bf16(const me_conv16_desc* d, void* stream_) {
     case 91: return launch16<128, 128, 2, 2, 1, 1, 2>(p, stream);
     case 93: return launch16<64, 64, 2, 2, 1, 1, 2>(p, stream);
     case 94: return launch16<256, 128, 4, 2, 1, 2, 2>(p, stream);
-    default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_bf16: unknown tile id %d", tile);
+    default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown tile id %d", tile);
   }
   return 0;
 }
 
-int me_maxpool_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
-                    int32_t size, int32_t stride, int32_t pad, int32_t zero_ext, int32_t ho, int32_t wo, void* stream) {
-  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_maxpool_bf16: null pointer");
+int me_maxpool_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+                   int32_t size, int32_t stride, int32_t pad, int32_t zero_ext, int32_t ho, int32_t wo, int32_t half_type,
+                   void* stream) {
+  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_maxpool_h16: null pointer");
   ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && size >= 1 && stride >= 1 && pad >= 0, ME_E_BADARG,
-             "me_maxpool_bf16: bad dimensions");
+             "me_maxpool_h16: bad dimensions");
   ME_REQUIRE(c % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0 && x_pitch >= c && y_pitch >= c, ME_E_ALIGN,
-             "me_maxpool_bf16: channels and pitches must be multiples of 8");
-  ME_REQUIRE(me::aligned16(x) && me::aligned16(y), ME_E_ALIGN, "me_maxpool_bf16: pointers not 16-byte aligned");
+             "me_maxpool_h16: channels and pitches must be multiples of 8");
+  ME_REQUIRE(me::aligned16(x) && me::aligned16(y), ME_E_ALIGN, "me_maxpool_h16: pointers not 16-byte aligned");
   const int eh = (h + (zero_ext ? 1 : 0) + 2 * pad - size) / stride + 1, ew = (w + (zero_ext ? 1 : 0) + 2 * pad - size) / stride + 1;
-  ME_REQUIRE(eh == ho && ew == wo, ME_E_BADARG, "me_maxpool_bf16: ho/wo (%d,%d) != derived (%d,%d)", ho, wo, eh, ew);
+  ME_REQUIRE(eh == ho && ew == wo, ME_E_BADARG, "me_maxpool_h16: ho/wo (%d,%d) != derived (%d,%d)", ho, wo, eh, ew);
   Pool16P d{reinterpret_cast<const unsigned short*>(x), reinterpret_cast<unsigned short*>(y), x_pitch, y_pitch, n, h, w, c,
             size, stride, pad, zero_ext, ho, wo};
-  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(grid_for((long long)n * ho * wo * (c / 8))), dim3(kThreads), 0,
-                     reinterpret_cast<hipStream_t>(stream), d);
-  return me::check_launch("maxpool_bf16_kernel");
+  if (half_type)
+    hipLaunchKernelGGL(maxpool_h16_kernel<1>, dim3(grid_for((long long)n * ho * wo * (c / 8))), dim3(kThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), d);
+  else
+    hipLaunchKernelGGL(maxpool_h16_kernel<0>, dim3(grid_for((long long)n * ho * wo * (c / 8))), dim3(kThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), d);
+  return me::check_launch("maxpool_h16_kernel");
 }
 
-int me_upsample_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
+int me_upsample_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,
                      int32_t factor, void* stream) {
-  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_upsample_bf16: null pointer");
-  ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, ME_E_BADARG, "me_upsample_bf16: bad dimensions");
+  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_upsample_h16: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, ME_E_BADARG, "me_upsample_h16: bad dimensions");
   ME_REQUIRE(c % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0 && me::aligned16(x) && me::aligned16(y), ME_E_ALIGN,
-             "me_upsample_bf16: channels / pitches %% 8, pointers 16-byte aligned");
-  hipLaunchKernelGGL(upsample_bf16_kernel, dim3(grid_for((long long)n * h * factor * w * factor * (c / 8))), dim3(kThreads),
+             "me_upsample_h16: channels / pitches %% 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL(upsample_h16_kernel, dim3(grid_for((long long)n * h * factor * w * factor * (c / 8))), dim3(kThreads),
                      0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(x), x_pitch,
                      reinterpret_cast<unsigned short*>(y), y_pitch, n, h, w, c, factor);
-  return me::check_launch("upsample_bf16_kernel");
+  return me::check_launch("upsample_h16_kernel");
 }
 
-int me_add_bf16(const void* a, int64_t a_pitch, const void* b, int64_t b_pitch, void* y, int64_t y_pitch, int64_t pixels,
-                int32_t c, void* stream) {
-  ME_REQUIRE(a && b && y, ME_E_NULLPTR, "me_add_bf16: null pointer");
-  ME_REQUIRE(pixels > 0 && c > 0, ME_E_BADARG, "me_add_bf16: bad dimensions");
+int me_add_h16(const void* a, int64_t a_pitch, const void* b, int64_t b_pitch, void* y, int64_t y_pitch, int64_t pixels,
+               int32_t c, int32_t half_type, void* stream) {
+  ME_REQUIRE(a && b && y, ME_E_NULLPTR, "me_add_h16: null pointer");
+  ME_REQUIRE(pixels > 0 && c > 0, ME_E_BADARG, "me_add_h16: bad dimensions");
   ME_REQUIRE(c % 8 == 0 && a_pitch % 8 == 0 && b_pitch % 8 == 0 && y_pitch % 8 == 0 && me::aligned16(a) &&
                  me::aligned16(b) && me::aligned16(y),
-             ME_E_ALIGN, "me_add_bf16: channels / pitches %% 8, pointers 16-byte aligned");
-  hipLaunchKernelGGL((addcopy_bf16_kernel<true>), dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0,
-                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(a), a_pitch,
-                     reinterpret_cast<const unsigned short*>(b), b_pitch, reinterpret_cast<unsigned short*>(y), y_pitch,
-                     pixels, c);
-  return me::check_launch("addcopy_bf16_kernel");
+             ME_E_ALIGN, "me_add_h16: channels / pitches %% 8, pointers 16-byte aligned");
+  auto* ap = reinterpret_cast<const unsigned short*>(a);
+  auto* bp = reinterpret_cast<const unsigned short*>(b);
+  auto* yp = reinterpret_cast<unsigned short*>(y);
+  if (half_type)
+    hipLaunchKernelGGL((addcopy_h16_kernel<true, 1>), dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), ap, a_pitch, bp, b_pitch, yp, y_pitch, pixels, c);
+  else
+    hipLaunchKernelGGL((addcopy_h16_kernel<true, 0>), dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), ap, a_pitch, bp, b_pitch, yp, y_pitch, pixels, c);
+  return me::check_launch("addcopy_h16_kernel");
 }
 
-int me_copy_bf16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int64_t pixels, int32_t c, void* stream) {
-  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_copy_bf16: null pointer");
-  ME_REQUIRE(pixels > 0 && c > 0, ME_E_BADARG, "me_copy_bf16: bad dimensions");
+int me_copy_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int64_t pixels, int32_t c, void* stream) {
+  ME_REQUIRE(x && y, ME_E_NULLPTR, "me_copy_h16: null pointer");
+  ME_REQUIRE(pixels > 0 && c > 0, ME_E_BADARG, "me_copy_h16: bad dimensions");
   ME_REQUIRE(c % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0 && me::aligned16(x) && me::aligned16(y), ME_E_ALIGN,
-             "me_copy_bf16: channels / pitches %% 8, pointers 16-byte aligned");
-  hipLaunchKernelGGL((addcopy_bf16_kernel<false>), dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0,
+             "me_copy_h16: channels / pitches %% 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL((addcopy_h16_kernel<false, 0>), dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(x), x_pitch,
                      reinterpret_cast<const unsigned short*>(x), x_pitch, reinterpret_cast<unsigned short*>(y), y_pitch,
                      pixels, c);
-  return me::check_launch("addcopy_bf16_kernel");
+  return me::check_launch("addcopy_h16_kernel");
 }
 
 }  // extern "C"

@@ -27,7 +27,8 @@ from . import hip
 __all__ = ["DarknetEngine", "ConvWeights", "pick_tap_module"]
 
 _ALIGN = 256  # bytes
-_DTYPES = ("f32", "bf16")
+_DTYPES = ("f32", "bf16", "f16")
+_TORCH_HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
 def _resolve(idx, current):
@@ -67,8 +68,8 @@ class ConvWeights:
     whenever their version counters or storage change, so descriptor pointers stay valid."""
 
     def __init__(self, conv, bn=None, dtype="f32", cin_pad=0, cout_pad=0):
-        """``dtype="bf16"``: weights stored as bfloat16 (one RNE rounding; the cin <= 4 stem keeps fp32 - it runs on the
-        VALU).  ``cin_pad`` / ``cout_pad``: zero-extend the channel dimensions (bf16 MFMA kernel: cin % 32 == 0)."""
+        """``dtype="bf16"`` / ``"f16"``: weights stored as bfloat16 / IEEE half (one RNE rounding; the cin <= 4 stem keeps
+        fp32 - it runs on the VALU).  ``cin_pad`` / ``cout_pad``: zero-extend the channel dimensions (bf16 MFMA kernel: cin % 32 == 0)."""
         self.conv, self.bn = conv, bn
         self.dtype, self.cin_pad, self.cout_pad = dtype, cin_pad, cout_pad
         self.wgt = self.scale = self.shift = None
@@ -117,8 +118,8 @@ class ConvWeights:
                 packed = torch.nn.functional.pad(packed, (0, 0, 0, 0, 0, 0, 0, extra))
                 scale = torch.nn.functional.pad(scale, (0, extra))
                 shift = torch.nn.functional.pad(shift, (0, extra))
-            if self.dtype == "bf16" and cin > 4:
-                packed = packed.to(torch.bfloat16)
+            if self.dtype in _TORCH_HALF and cin > 4:
+                packed = packed.to(_TORCH_HALF[self.dtype])
             packed = packed.contiguous()
             realloc = (self.wgt is None or self.wgt.device != device or self.wgt.shape != packed.shape
                        or self.wgt.dtype != packed.dtype)
@@ -165,7 +166,7 @@ class DarknetEngine:
 
     def __init__(self, model, dtype="f32"):
         """``dtype``: storage of the activations and MFMA-conv weights between layers - ``"f32"`` (default; the mode the
-        1e-3 parity bar is quoted on) or ``"bf16"`` (BASELINE configs[2]/[4]: bf16 operands, fp32 accumulation and
+        1e-3 parity bar is quoted on) or ``"bf16"`` / ``"f16"`` (BASELINE configs[2]/[4]: 16-bit operands, fp32 accumulation and
         epilogue, fp32 detection maps into the YOLO decode; inference only)."""
         if dtype not in _DTYPES:
             raise ValueError(f"unknown engine dtype {dtype!r} (expected one of {_DTYPES})")
@@ -252,9 +253,10 @@ class DarknetEngine:
         tap = self.tap_module
 
         tensors = []
-        bf16 = self.dtype == "bf16"
+        bf16 = self.dtype in _TORCH_HALF  # any 16-bit storage mode
+        half_type = hip.HALF_TYPES[_TORCH_HALF[self.dtype]] if bf16 else 0
         if bf16 and keep_raw:
-            raise NotImplementedError("the bf16 storage mode is inference only (the YOLO loss / backward run in fp32)")
+            raise NotImplementedError("the 16-bit storage modes are inference only (the YOLO loss / backward run in fp32)")
         act_esize = 2 if bf16 else 4
 
         def new_tensor(hh, ww, cc, esize=None):
@@ -463,7 +465,7 @@ class DarknetEngine:
         def typed_view(tt, nchw):
             """torch view of an arena tensor ([n,h,w,c], or the NCHW permutation of it) - API boundary only"""
             root, coff = tt.root()
-            flat = plan.arena.view(torch.bfloat16 if tt.esize == 2 else torch.float32)
+            flat = plan.arena.view(_TORCH_HALF[self.dtype] if tt.esize == 2 else torch.float32)
             pitch, off = root.c, root.offset // tt.esize + coff
             if nchw:
                 return torch.as_strided(flat, (n, tt.c, tt.h, tt.w), (tt.h * tt.w * pitch, 1, tt.w * pitch, pitch), off)
@@ -502,16 +504,17 @@ class DarknetEngine:
                 dsc.split_k, dsc.workspace, dsc.workspace_bytes = 0, None, 0
                 if bf16:
                     dsc.y_f32 = 1 if y.esize == 4 else 0
-                launches.append((lib.me_conv2d_bf16 if bf16 else lib.me_conv2d_f32, (C.byref(dsc),), dsc,
+                    dsc.half_type = half_type
+                launches.append((lib.me_conv2d_h16 if bf16 else lib.me_conv2d_f32, (C.byref(dsc),), dsc,
                                  f"conv{op['module']}"))
                 plan.conv_descs.append((op["module"], dsc))
                 flops += 2 * n * op["ho"] * op["wo"] * op["cout"] * op["k"] * op["k"] * (x.c - x.padded)
             elif kind == "pool" and bf16:
                 x, y = op["x"], op["y"]
                 (xp, xpitch), (yp, ypitch) = view(x), view(y)
-                launches.append((lib.me_maxpool_bf16,
+                launches.append((lib.me_maxpool_h16,
                                  (xp, xpitch, yp, ypitch, n, x.h, x.w, x.c, op["k"], op["s"],
-                                  0 if op["zero_ext"] else op["pad"], op["zero_ext"], op["ho"], op["wo"]), None,
+                                  0 if op["zero_ext"] else op["pad"], op["zero_ext"], op["ho"], op["wo"], half_type), None,
                                  f"pool{op['module']}"))
             elif kind == "pool":
                 x, y = op["x"], op["y"]
@@ -526,19 +529,20 @@ class DarknetEngine:
             elif kind == "upsample":
                 x, y = op["x"], op["y"]
                 (xp, xpitch), (yp, ypitch) = view(x), view(y)
-                launches.append((lib.me_upsample_bf16 if x.esize == 2 else lib.me_upsample_f32,
+                launches.append((lib.me_upsample_h16 if x.esize == 2 else lib.me_upsample_f32,
                                  (xp, xpitch, yp, ypitch, n, x.h, x.w, x.c, op["f"]), None,
                                  f"upsample{op['module']}"))
             elif kind == "add":
                 a, b, y = op["a"], op["b"], op["y"]
                 (ap, apitch), (bp, bpitch), (yp, ypitch) = view(a), view(b), view(y)
-                launches.append((lib.me_add_bf16 if a.esize == 2 else lib.me_add_f32,
-                                 (ap, apitch, bp, bpitch, yp, ypitch, n * a.h * a.w, a.c), None,
+                launches.append((lib.me_add_h16 if a.esize == 2 else lib.me_add_f32,
+                                 (ap, apitch, bp, bpitch, yp, ypitch, n * a.h * a.w, a.c)
+                                 + ((half_type,) if a.esize == 2 else ()), None,
                                  f"add{op['module']}"))
             elif kind == "copy":
                 x, y = op["x"], op["y"]
                 (xp, xpitch), (yp, ypitch) = view(x), view(y)
-                launches.append((lib.me_copy_bf16 if x.esize == 2 else lib.me_copy_f32,
+                launches.append((lib.me_copy_h16 if x.esize == 2 else lib.me_copy_f32,
                                  (xp, xpitch, yp, ypitch, n * x.h * x.w, x.c), None,
                                  f"copy{op['module']}"))
             elif kind == "yolo":
@@ -562,7 +566,7 @@ class DarknetEngine:
                 yl.grid_size = op["g"]
                 yl.stride = stride
         # shared scratch for the deterministic split-K slabs (launches are serial on one stream)
-        ws_fn = lib.me_conv2d_bf16_workspace_bytes if bf16 else lib.me_conv2d_workspace_bytes
+        ws_fn = lib.me_conv2d_h16_workspace_bytes if bf16 else lib.me_conv2d_workspace_bytes
         need = max([ws_fn(C.byref(d)) for _m, d in plan.conv_descs] + [0])
         plan.conv_ws = None
         plan.graph = None
@@ -727,15 +731,15 @@ def _autotune(plan, lib):
 
     stream = hip.stream_ptr()
     _tune_load()
-    bf16 = plan.dtype == "bf16"
-    conv_fn = lib.me_conv2d_bf16 if bf16 else lib.me_conv2d_f32
+    bf16 = plan.dtype in _TORCH_HALF
+    conv_fn = lib.me_conv2d_h16 if bf16 else lib.me_conv2d_f32
     todo = []
     for _m, d in plan.conv_descs:
         if d.cin <= 4:
             continue
         key = (d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.upsample, int(bool(d.res)))
         if bf16:
-            key += (16 + d.y_f32,)
+            key += (16 + d.y_f32 + 2 * d.half_type,)
         hit = _TUNE_CACHE.get(key)
         if hit is not None:
             d.tile, d.split_k = hit

@@ -40,7 +40,7 @@ class ConvDesc(C.Structure):
 
 
 class Conv16Desc(C.Structure):
-    """me_conv16_desc: the bf16-storage twin of ConvDesc (adds ``y_f32``)."""
+    """me_conv16_desc: the 16-bit-storage twin of ConvDesc (adds ``y_f32`` and ``half_type``: 0 bfloat16, 1 IEEE half)."""
     _fields_ = [
         ("x", C.c_void_p), ("wgt", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
         ("res", C.c_void_p), ("y", C.c_void_p),
@@ -49,7 +49,7 @@ class Conv16Desc(C.Structure):
         ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("ho", C.c_int32), ("wo", C.c_int32),
         ("act", C.c_int32), ("upsample", C.c_int32), ("x_nchw", C.c_int32), ("y_f32", C.c_int32),
-        ("tile", C.c_int32), ("split_k", C.c_int32),
+        ("half_type", C.c_int32), ("tile", C.c_int32), ("split_k", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
@@ -126,14 +126,14 @@ SIGNATURES = {
     "me_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "me_conv2d_flops": (C.c_int64, [C.POINTER(ConvDesc)]),
     "me_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
-    "me_conv2d_bf16": (C.c_int, [C.POINTER(Conv16Desc), C.c_void_p]),
-    "me_conv2d_bf16_workspace_bytes": (C.c_int64, [C.POINTER(Conv16Desc)]),
-    "me_maxpool_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 10 + [C.c_void_p]),
-    "me_upsample_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+    "me_conv2d_h16": (C.c_int, [C.POINTER(Conv16Desc), C.c_void_p]),
+    "me_conv2d_h16_workspace_bytes": (C.c_int64, [C.POINTER(Conv16Desc)]),
+    "me_maxpool_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 11 + [C.c_void_p]),
+    "me_upsample_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p]),
-    "me_add_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
-                              C.c_int32, C.c_void_p]),
-    "me_copy_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "me_add_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                             C.c_int32, C.c_int32, C.c_void_p]),
+    "me_copy_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "me_maxpool_f32": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p]),
     "me_upsample_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
@@ -314,28 +314,32 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     return out
 
 
-def conv2d_bf16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-                x_nchw=False, y_f32=False, tile=0, split_k=0):
-    """bf16-storage twin of :func:`conv2d`.  ``x``: bf16 NHWC [N,H,W,Cin] (or a channel slice), or - stem, Cin == 3 -
-    float32 NCHW / NHWC; ``wgt_packed``: bf16 [Cout,k,k,Cin] (float32 for the stem); ``residual``: the output's dtype.
-    Returns bf16 NHWC (float32 when ``y_f32``)."""
+def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
+                x_nchw=False, y_f32=False, tile=0, split_k=0, half=torch.bfloat16):
+    """16-bit-storage twin of :func:`conv2d`; ``half`` = ``torch.bfloat16`` (default) or ``torch.float16``.  ``x``: 16-bit
+    NHWC [N,H,W,Cin] (or a channel slice), or - stem, Cin == 3 - float32 NCHW / NHWC; ``wgt_packed``: 16-bit [Cout,k,k,Cin]
+    (float32 for the stem); ``residual``: the output's dtype.  Returns 16-bit NHWC (float32 when ``y_f32``)."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda):
         raise MeError("x must be a CUDA tensor")
     if x_nchw:
         n, cin, h, w = x.shape
     else:
         n, h, w, cin = x.shape
-    want = torch.float32 if cin <= 4 else torch.bfloat16
+    if cin > 4:
+        half = x.dtype
+    if half not in HALF_TYPES:
+        raise MeError(f"me_conv2d_h16: 16-bit type must be bfloat16 or float16 (got {half})")
+    want = torch.float32 if cin <= 4 else half
     if x.dtype != want or wgt_packed.dtype != want:
-        raise MeError(f"me_conv2d_bf16: x / wgt must be {want} for cin={cin} (got {x.dtype} / {wgt_packed.dtype})")
+        raise MeError(f"me_conv2d_h16: x / wgt must be {want} for cin={cin} (got {x.dtype} / {wgt_packed.dtype})")
     cout = wgt_packed.shape[0]
     ho = (h + 2 * pad - ksize) // stride + 1
     wo = (w + 2 * pad - ksize) // stride + 1
-    odt = torch.float32 if y_f32 else torch.bfloat16
+    odt = torch.float32 if y_f32 else half
     if out is None:
         out = torch.empty((n, ho * upsample, wo * upsample, cout), device=x.device, dtype=odt)
     if out.dtype != odt or (residual is not None and residual.dtype != odt):
-        raise MeError("me_conv2d_bf16: out / residual dtype does not match y_f32")
+        raise MeError("me_conv2d_h16: out / residual dtype does not match y_f32")
     d = Conv16Desc()
     d.x, d.wgt, d.scale, d.shift = x.data_ptr(), wgt_packed.data_ptr(), scale.data_ptr(), shift.data_ptr()
     d.res = residual.data_ptr() if residual is not None else None
@@ -352,49 +356,54 @@ def conv2d_bf16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, stride, pad, ho, wo
     d.act, d.upsample, d.x_nchw, d.y_f32, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, 1 if y_f32 else 0, \
         tile, split_k
-    need = lib().me_conv2d_bf16_workspace_bytes(C.byref(d))
+    d.half_type = HALF_TYPES[half]
+    need = lib().me_conv2d_h16_workspace_bytes(C.byref(d))
     keep = None
     if need > 0:
         ws_ptr, keep = _workspace(need, x.device, slot="conv")
         d.workspace, d.workspace_bytes = ws_ptr, need
-    check(lib().me_conv2d_bf16(C.byref(d), stream_ptr()), "me_conv2d_bf16")
+    check(lib().me_conv2d_h16(C.byref(d), stream_ptr()), "me_conv2d_h16")
     return out
 
 
+HALF_TYPES = {torch.bfloat16: 0, torch.float16: 1}  # me_conv16_desc.half_type
+
+
 def _require_cuda_bf16(t, name):
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
-        raise MeError(f"{name} must be a contiguous CUDA bfloat16 tensor")
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in HALF_TYPES and t.is_contiguous()):
+        raise MeError(f"{name} must be a contiguous CUDA bfloat16 / float16 tensor")
 
 
-def maxpool_bf16(x_nhwc, size, stride, zero_ext=False):
+def maxpool_h16(x_nhwc, size, stride, zero_ext=False):
     _require_cuda_bf16(x_nhwc, "x")
     n, h, w, c = x_nhwc.shape
     pad = 0 if zero_ext else (size - 1) // 2
     ext = 1 if zero_ext else 0
     ho = (h + ext + 2 * pad - size) // stride + 1
     wo = (w + ext + 2 * pad - size) // stride + 1
-    out = torch.empty((n, ho, wo, c), device=x_nhwc.device, dtype=torch.bfloat16)
-    check(lib().me_maxpool_bf16(x_nhwc.data_ptr(), c, out.data_ptr(), c, n, h, w, c, size, stride, pad, ext, ho, wo,
-                                stream_ptr()), "me_maxpool_bf16")
+    out = torch.empty((n, ho, wo, c), device=x_nhwc.device, dtype=x_nhwc.dtype)
+    check(lib().me_maxpool_h16(x_nhwc.data_ptr(), c, out.data_ptr(), c, n, h, w, c, size, stride, pad, ext, ho, wo,
+                               HALF_TYPES[x_nhwc.dtype], stream_ptr()), "me_maxpool_h16")
     return out
 
 
-def upsample_bf16(x_nhwc, factor):
+def upsample_h16(x_nhwc, factor):
     _require_cuda_bf16(x_nhwc, "x")
     n, h, w, c = x_nhwc.shape
-    out = torch.empty((n, h * factor, w * factor, c), device=x_nhwc.device, dtype=torch.bfloat16)
-    check(lib().me_upsample_bf16(x_nhwc.data_ptr(), c, out.data_ptr(), c, n, h, w, c, factor, stream_ptr()),
-          "me_upsample_bf16")
+    out = torch.empty((n, h * factor, w * factor, c), device=x_nhwc.device, dtype=x_nhwc.dtype)
+    check(lib().me_upsample_h16(x_nhwc.data_ptr(), c, out.data_ptr(), c, n, h, w, c, factor, stream_ptr()),
+          "me_upsample_h16")
     return out
 
 
-def add_bf16(a, b):
+def add_h16(a, b):
     _require_cuda_bf16(a, "a")
     _require_cuda_bf16(b, "b")
     c = a.shape[-1]
     out = torch.empty_like(a)
-    check(lib().me_add_bf16(a.data_ptr(), c, b.data_ptr(), c, out.data_ptr(), c, a.numel() // c, c, stream_ptr()),
-          "me_add_bf16")
+    check(lib().me_add_h16(a.data_ptr(), c, b.data_ptr(), c, out.data_ptr(), c, a.numel() // c, c, HALF_TYPES[a.dtype],
+                           stream_ptr()),
+          "me_add_h16")
     return out
 
 

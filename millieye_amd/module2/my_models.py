@@ -126,16 +126,17 @@ class Network(nn.Module):
             raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         if self._packs is None:
             object.__setattr__(self, "_packs", dict(img=ConvWeights(self.fcn_layers.net[0], self.fcn_layers.net[1]),
-                                                    img16=ConvWeights(self.fcn_layers.net[0], self.fcn_layers.net[1], "bf16"),
+                                                    bf16=ConvWeights(self.fcn_layers.net[0], self.fcn_layers.net[1], "bf16"),
+                                                    f16=ConvWeights(self.fcn_layers.net[0], self.fcn_layers.net[1], "f16"),
                                                     heads=_HeadPack(self)))
-        tap16 = getattr(plan, "dtype", "f32") == "bf16"  # detector in bf16 storage mode (Darknet.compute_dtype)
-        self._packs["img16" if tap16 else "img"].refresh(dev)
+        tap16 = getattr(plan, "dtype", "f32") != "f32"  # detector in a 16-bit storage mode (Darknet.compute_dtype)
+        self._packs[plan.dtype if tap16 else "img"].refresh(dev)
         hw = self._packs["heads"].refresh(dev)
         fh, fw, fc = plan.tap_shape
         score_map = torch.empty((n, fh, fw, 490), **f32)
         from ..my_models import Network as _N3
         if tap16:
-            _N3._conv16(plan.tap_ptr, plan.tap_pitch, n, fh, fw, fc, self._packs["img16"], 1, 0, hip.ACT_LEAKY, score_map)
+            _N3._conv16(plan.tap_ptr, plan.tap_pitch, n, fh, fw, fc, self._packs[plan.dtype], 1, 0, hip.ACT_LEAKY, score_map)
         else:
             _N3._conv(plan.tap_ptr, plan.tap_pitch, False, n, fh, fw, fc, self._packs["img"], 1, 0, hip.ACT_LEAKY,
                       score_map)

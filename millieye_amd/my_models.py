@@ -269,7 +269,8 @@ class Network(nn.Module):
             rc = self.radar_cnn_layers
             packs = dict(
                 img=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1]),
-                img16=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1], "bf16"),
+                bf16=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1], "bf16"),
+                f16=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1], "f16"),
                 r1=ConvWeights(rc.conv1[0], rc.conv1[1]),
                 r2=ConvWeights(rc.conv2[0], rc.conv2[1]),
                 r3=ConvWeights(rc.conv3[0], rc.conv3[1]),
@@ -289,15 +290,16 @@ class Network(nn.Module):
 
     @staticmethod
     def _conv16(x_ptr, x_pitch, n, h, w, cin, cw, ksize, pad, act, out):
-        """bf16 feature tap (detector in bf16 storage mode) -> float32 score map: ``me_conv2d_bf16`` with ``y_f32``."""
+        """16-bit feature tap (detector in a 16-bit storage mode) -> float32 score map: ``me_conv2d_h16`` with ``y_f32``."""
         d = hip.Conv16Desc()
         d.x, d.x_pitch, d.x_nchw, d.y_f32 = x_ptr, x_pitch, 0, 1
+        d.half_type = hip.HALF_TYPES[cw.wgt.dtype]
         d.wgt, d.scale, d.shift, d.res, d.res_pitch = cw.wgt.data_ptr(), cw.scale.data_ptr(), cw.shift.data_ptr(), None, 0
         d.y, d.y_pitch = out.data_ptr(), out.shape[-1]
         d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cw.wgt.shape[0]
         d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, 1, pad, h, w
         d.act, d.upsample, d.tile, d.split_k = act, 1, 0, 1
-        hip.check(hip.lib().me_conv2d_bf16(C.byref(d), hip.stream_ptr()), "me_conv2d_bf16")
+        hip.check(hip.lib().me_conv2d_h16(C.byref(d), hip.stream_ptr()), "me_conv2d_h16")
         return out
 
     @staticmethod
@@ -328,13 +330,13 @@ class Network(nn.Module):
         (cnn_layers_3 on the radar maps) on the current stream; returns (roi_score_map, radar_score_map, fh, fw, mh, mw)."""
         f32 = dict(device=dev, dtype=torch.float32)
         packs = self._get_packs()
-        tap16 = getattr(plan, "dtype", "f32") == "bf16"
-        for key in ("img16" if tap16 else "img", "r1", "r2", "r3", "r4"):
+        tap16 = getattr(plan, "dtype", "f32") != "f32"
+        for key in (plan.dtype if tap16 else "img", "r1", "r2", "r3", "r4"):
             packs[key].refresh(dev)
         fh, fw, fc = plan.tap_shape
         roi_score_map = torch.empty((n, fh, fw, 490), **f32)
         if tap16:
-            self._conv16(plan.tap_ptr, plan.tap_pitch, n, fh, fw, fc, packs["img16"], 1, 0, hip.ACT_LEAKY, roi_score_map)
+            self._conv16(plan.tap_ptr, plan.tap_pitch, n, fh, fw, fc, packs[plan.dtype], 1, 0, hip.ACT_LEAKY, roi_score_map)
         else:
             self._conv(plan.tap_ptr, plan.tap_pitch, False, n, fh, fw, fc, packs["img"], 1, 0, hip.ACT_LEAKY, roi_score_map)
         maps = maps.contiguous()

@@ -224,7 +224,7 @@ class Darknet(nn.Module):
         # not a submodule / not in state_dict: plain attribute via object.__setattr__
         object.__setattr__(self, "_engines", {})
         # storage type of the accelerated inference path: "f32" (default, the mode the 1e-3 parity bar is quoted on) or
-        # "bf16" (BASELINE configs[2]/[4]; bf16 activations + weights, fp32 accumulation).  Training always runs fp32.
+        # "bf16" / "f16" (BASELINE configs[2]/[4]; 16-bit activations + weights, fp32 accumulation).  Training always runs fp32.
         object.__setattr__(self, "compute_dtype", os.environ.get("MILLIEYE_DTYPE", "f32"))
 
     # -- execution -----------------------------------------------------------------------------

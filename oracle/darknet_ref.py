@@ -91,7 +91,7 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
     """Evaluate the detector.  ``state_dict`` keys: ``{prefix}{i}.conv_{i}.weight`` etc.
     Returns ``(featuremap or None, yolo_outputs [N,R,5+C])`` (+ per-module outputs on request).
 
-    ``storage="bf16"`` restates the build's 16-bit storage mode (BASELINE configs[2]/[4]; no reference counterpart - the
+    ``storage="bf16"`` / ``"f16"`` restates the build's 16-bit storage modes (BASELINE configs[2]/[4]; no reference counterpart - the
     reference is fp32 only, so this mode is pinned to nothing but the fp32 path it approximates): same fp32 library ops,
     with one round-to-nearest-even to bfloat16 at every point where millieye_amd/csrc/conv_bf16.hip stores 16-bit data -
     the weights of every convolution with more than 4 input channels, and every activation written to memory, i.e. after
@@ -101,13 +101,14 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
     img_dim = x.shape[2]
     outs, yolo = [], []
     feat = None
-    bf16 = storage == "bf16"
-    if storage not in ("f32", "bf16"):
+    bf16 = storage in ("bf16", "f16")  # any 16-bit storage mode: same rounding points, other format
+    if storage not in ("f32", "bf16", "f16"):
         raise ValueError(storage)
+    half = torch.float16 if storage == "f16" else torch.bfloat16
     readers = _readers(blocks)
 
     def q(t):
-        return t.to(torch.bfloat16).to(torch.float32) if bf16 else t
+        return t.to(half).to(torch.float32) if bf16 else t
 
     pending = None  # unrounded output of a conv fused with the following shortcut
     with torch.no_grad():

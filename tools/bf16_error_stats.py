@@ -18,6 +18,9 @@ def stats(a, b):
            f"mean {float(rel.mean()):.3e}  rms/rms {rms:.3e}"
 
 
+DT = sys.argv[1] if len(sys.argv) > 1 else "bf16"   # bf16 | f16
+
+
 def main():
     from oracle import darknet_ref
     from millieye_amd.engine import pick_tap_module
@@ -27,14 +30,14 @@ def main():
         x = ph.frames(f"{name}/{n}/{s}", n, s)
         tap = pick_tap_module(model.module_defs)
         f32_fm, f32_y = darknet_ref.darknet_forward(ph.cfg_text(name), model.state_dict(), x, tap_module=tap)
-        b16_fm, b16_y = darknet_ref.darknet_forward(ph.cfg_text(name), model.state_dict(), x, tap_module=tap, storage="bf16")
+        b16_fm, b16_y = darknet_ref.darknet_forward(ph.cfg_text(name), model.state_dict(), x, tap_module=tap, storage=DT)
         model = model.cuda()
-        model.compute_dtype = "bf16"
+        model.compute_dtype = DT
         with torch.no_grad():
             fm, y = model(x.cuda())
         torch.cuda.synchronize()
         fm, y = fm.cpu(), y.cpu()
-        print(f"== {name} n={n} s={s}")
+        print(f"== {name} n={n} s={s} storage={DT}")
         print("  hip16 vs oracle16  yolo:", stats(y, b16_y))
         print("  hip16 vs oracle16  fmap:", stats(fm, b16_fm))
         print("  hip16 vs oracle32  yolo:", stats(y, f32_y))

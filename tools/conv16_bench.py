@@ -1,4 +1,4 @@
-"""Per-layer timing of me_conv2d_bf16 on Darknet-53 layer shapes (HIP events, every tile / split-K candidate).
+"""Per-layer timing of me_conv2d_h16 on Darknet-53 layer shapes (HIP events, every tile / split-K candidate).
 usage: python tools/conv16_bench.py [batch]   (run on the GPU box)"""
 import os
 import sys
@@ -42,11 +42,11 @@ def main():
             for split in ((1, 2, 4) if len(TILES) > 6 else (1,)):
                 try:
                     for _ in range(3):
-                        hip.conv2d_bf16(x, w, sc, sh, k, s, pad, 1, residual=r, out=out, tile=tile, split_k=split)
+                        hip.conv2d_h16(x, w, sc, sh, k, s, pad, 1, residual=r, out=out, tile=tile, split_k=split)
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
                     for _ in range(10):
-                        hip.conv2d_bf16(x, w, sc, sh, k, s, pad, 1, residual=r, out=out, tile=tile, split_k=split)
+                        hip.conv2d_h16(x, w, sc, sh, k, s, pad, 1, residual=r, out=out, tile=tile, split_k=split)
                     b.record()
                     torch.cuda.synchronize()
                     rows.append((a.elapsed_time(b) / 10, tile, split))
