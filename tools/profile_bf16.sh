@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence for the bf16 storage mode (run on the GPU box from the repo root):
+# Evidence for the 16-bit storage modes (bf16; f16 where noted) (run on the GPU box from the repo root):
 #   bash tools/profile_bf16.sh r01   ->  gpurun_out/prof/<tag>_bf16_*   (copy into profiles/)
 TAG=${1:-rXX}
 R=$PWD
@@ -22,7 +22,11 @@ d=json.loads(sys.stdin.read()); print('bf16 detector batch %3d: %8.1f frames/s  
 } > $OUT/${TAG}_bf16_batch_sweep.txt
 python tools/conv16_bench.py 32 > $OUT/${TAG}_bf16_conv_bench_b32.txt 2>&1
 python tools/conv16_bench.py 32 13,14,73,74,83,84,93,94 > $OUT/${TAG}_bf16_conv_ablation_b32.txt 2>&1
-python tools/bf16_error_stats.py > $OUT/${TAG}_bf16_error_stats.txt 2>&1
+python tools/bf16_error_stats.py bf16 > $OUT/${TAG}_bf16_error_stats.txt 2>&1
+python tools/bf16_error_stats.py f16 > $OUT/${TAG}_f16_error_stats.txt 2>&1
+# IEEE-half storage (BASELINE configs[4]: "608x608 input, fp16 MFMA convs", 16 frames per GPU) and the default shape
+python bench.py --dtype f16 --no-cpu-baseline --size 608 --batch 16 > $OUT/${TAG}_f16_bench_full_608_b16.json 2>> $OUT/bench_bf16.err
+python bench.py --dtype f16 --no-cpu-baseline > $OUT/${TAG}_f16_bench_full_b32.json 2>> $OUT/bench_bf16.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d /tmp/pf16_$TAG -o full -- python $R/bench.py --dtype bf16 --no-cpu-baseline > /tmp/pf16.log 2>&1
 python $R/tools/prof_summary.py /tmp/pf16_$TAG/full_results.db | head -40 > $OUT/${TAG}_bf16_bench_full_b32_kernel_stats.txt
