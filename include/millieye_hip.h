@@ -252,6 +252,12 @@ typedef struct me_heads_desc {
   float* save_small;
 } me_heads_desc;
 int me_roi_heads_f32(const me_heads_desc* d, void* stream);
+/* me_compact_sort_rows_f32 - the tail of Network.forward (my_models.py:517-539): keep the rows whose `keep` byte is set
+ * and order them by descending `key`, equal keys in ascending row order ( = torch.sort(key[nonzero(keep)], descending,
+ * stable) ).  rows [cap, cols], keep [cap] uint8, key [cap] (no NaN) -> out [cap, cols] with the first *count rows
+ * valid; count [1] int32.  One launch: every kept row computes its own rank against all keys (broadcast LDS reads). */
+int me_compact_sort_rows_f32(const float* rows, const uint8_t* keep, const float* key, int32_t cap, int32_t cols, float* out,
+                             int32_t* count, void* stream);
 
 /* Stage 2 (module2_mixed/my_models.py:299-364) heads for every box of every class: PS-RoIAlign (7x7, 490 -> 10 maps) on
  * img_map, refinement_head((490,256,class_num+1)) (net0 LeakyReLU, net1 -> regress [cap,4], net2 sigmoid -> refine

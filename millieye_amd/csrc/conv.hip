@@ -410,9 +410,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_dma_f32(ConvP p
   for (int s = 0; s < nstages; ++s) {
     // stage s landed? (the only younger DMAs are those of stage s+1)
     if (s + 1 < nstages)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's stage-s DMAs landed; everyone finished reading stage s-1
     asm volatile("" ::: "memory");
     if (s + 2 < nstages) issue_stage((s + 2) % NST);  // refills the slot stage s-1 just vacated
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
   // immediates, ~19 scalar instructions per step); the last <= 4 stages go through the generic tail below.
   auto step = [&](auto slot_c) {
     constexpr int SLOT = decltype(slot_c)::value;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue_stage(wave_lds + ((SLOT + 2) % NST) * STAGE_B);
@@ -747,9 +747,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
   int slot = 0;  // s is a multiple of 3 here
   for (; s < nstages; ++s) {
     if (s + 1 < nstages)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + 2 < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);

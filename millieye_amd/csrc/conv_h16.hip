@@ -281,9 +281,12 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
             else acc[i][j][0] += (float)af[u][ks][i][0] + (float)bf[u][ks][j][0];
   };
 
+  // lgkmcnt(0) in front of every barrier: the compiler is free to sink the tail of a stage's MFMAs - and the waits of the
+  // ds_reads that feed them - below the next barrier; a wave must not signal "done reading stage s-1" with reads in flight,
+  // because the other waves refill that slot right after the barrier.
   auto step = [&](auto slot_c) {
     constexpr int SLOT = decltype(slot_c)::value;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW * KSUB) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW * KSUB) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue_stage(wave_lds + ((SLOT + 2) % NST) * STAGE_B);
@@ -298,9 +301,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
   int slot = 0;
   for (; s < nstages; ++s) {
     if (s + 1 < nstages)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW * KSUB) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW * KSUB) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + 2 < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);

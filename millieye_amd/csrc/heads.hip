@@ -537,6 +537,42 @@ __global__ __launch_bounds__(256) void heads_tail_bwd_kernel(me_heads_desc d, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// output tail: compaction + stable descending sort by rank counting (one launch; replaces nonzero + sort + gather)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSortTile = 2048;
+
+__global__ __launch_bounds__(256) void compact_sort_kernel(const float* __restrict__ rows, const unsigned char* __restrict__ keep,
+                                                           const float* __restrict__ key, int cap, int cols,
+                                                           float* __restrict__ out, int* __restrict__ count) {
+  __shared__ __attribute__((aligned(16))) float sk[kSortTile];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool mine = i < cap && keep[i] != 0;
+  const float ki = mine ? key[i] : 0.f;
+  int rank = 0, total = 0;
+  for (int t0 = 0; t0 < cap; t0 += kSortTile) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < kSortTile; j += 256) {
+      const int g = t0 + j;
+      sk[j] = (g < cap && keep[g] != 0) ? key[g] : __builtin_nanf("");  // dropped rows never compare greater / equal
+    }
+    __syncthreads();
+    const int lim = (cap - t0 < kSortTile ? cap - t0 : kSortTile);
+    for (int j = 0; j < lim; j += 4) {  // every lane reads the same address: LDS broadcast
+      const float4 k4 = *reinterpret_cast<const float4*>(sk + j);
+      const float kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        rank += (kk[e] > ki) || (kk[e] == ki && t0 + j + e < i);
+        total += kk[e] == kk[e];
+      }
+    }
+  }
+  if (mine)
+    for (int c = 0; c < cols; ++c) out[(long long)rank * cols + c] = rows[(long long)i * cols + c];
+  if (i == 0) *count = total;
+}
+
 }  // namespace
 
 extern "C" {
@@ -660,6 +696,20 @@ int me_heads_tail_bwd_f32(const me_heads_desc* d, const float* small, const floa
   hipLaunchKernelGGL(heads_tail_bwd_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, *d, small, refine, mask1,
                      seed_p, seed_conf, k, g_o, g_hpre, h_act, xin, g_z2, g_rl, rl, g_rlogit);
   return me::check_launch("heads_tail_bwd_kernel");
+}
+
+int me_compact_sort_rows_f32(const float* rows, const uint8_t* keep, const float* key, int32_t cap, int32_t cols, float* out,
+                             int32_t* count, void* stream) {
+  ME_REQUIRE(count != nullptr, ME_E_NULLPTR, "me_compact_sort_rows_f32: null count");
+  ME_REQUIRE(cap >= 0 && cols > 0, ME_E_BADARG, "me_compact_sort_rows_f32: bad dimensions");
+  if (cap == 0) {
+    ME_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), reinterpret_cast<hipStream_t>(stream)));
+    return 0;
+  }
+  ME_REQUIRE(rows && keep && key && out, ME_E_NULLPTR, "me_compact_sort_rows_f32: null pointer");
+  hipLaunchKernelGGL(compact_sort_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), rows, keep, key, cap, cols, out, count);
+  return me::check_launch("compact_sort_kernel");
 }
 
 }  // extern "C"

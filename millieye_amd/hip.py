@@ -126,6 +126,8 @@ SIGNATURES = {
     "me_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "me_conv2d_flops": (C.c_int64, [C.POINTER(ConvDesc)]),
     "me_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "me_compact_sort_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "me_conv2d_h16": (C.c_int, [C.POINTER(Conv16Desc), C.c_void_p]),
     "me_conv2d_h16_workspace_bytes": (C.c_int64, [C.POINTER(Conv16Desc)]),
     "me_maxpool_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 11 + [C.c_void_p]),

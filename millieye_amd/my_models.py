@@ -452,10 +452,12 @@ class Network(nn.Module):
         mark("roi_heads")
         self.refinement_head.count += 1
 
-        # ---- keep positives, order by confidence (reference :517-539); the one host sync
-        idx = torch.nonzero(keep, as_tuple=False).flatten()
-        order = torch.sort(key[idx], descending=True, stable=True).indices
-        output = rows[idx[order]]
+        # ---- keep positives, order by confidence (reference :517-539): one launch, then the one host sync (the row count)
+        ordered = torch.empty((cap, 8), **f32)
+        n_out = torch.empty((1,), device=dev, dtype=torch.int32)
+        hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
+                                               n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+        output = ordered[:int(n_out.item())]
         mark("output")
         self._last = dict(regress=regress, refine=refine, mask1=mask1, n_img=n_img_dev, img_boxes=img_boxes)
         return output

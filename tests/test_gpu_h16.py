@@ -246,3 +246,21 @@ def test_bf16_mode_is_inference_only(hip_lib):
     assert torch.isfinite(torch.as_tensor(loss))
     with pytest.raises(NotImplementedError):
         model.engine_for("bf16").run(x, keep_raw=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_detector_determinism_stress(hip_lib, dtype):
+    """40 forward passes of the same frames are bit-identical (Darknet-53, batch 1 and 4).  Regression test for an LDS
+    slot-reuse race: the compiler sinks the tail of a stage's MFMAs and the waits of the ds_reads feeding them below the
+    next barrier, so without `s_waitcnt lgkmcnt(0)` in front of the barrier another wave's refill DMA could overtake reads
+    still in flight (10 % of batch-1 runs differed in the 16-bit modes; tools/determinism_stress.py)."""
+    from tests import parity_helpers as ph
+    for n in (1, 4):
+        model = ph.make_darknet("yolov3").cuda()
+        model.compute_dtype = dtype
+        x = ph.frames(f"stress/{n}", n, 416).cuda()
+        with torch.no_grad():
+            fm0, y0 = model(x)
+            for rep in range(40):
+                fm, y = model(x)
+                assert torch.equal(y, y0) and torch.equal(fm, fm0), f"{dtype} batch {n}: run {rep} differs"

@@ -170,3 +170,26 @@ def test_no_rois_at_all(hip_lib):
     ref = network_ref.network_forward(cfgs.KNOWN[cfg](), sd, x, maps, rboxes, 0, conf)
     _cmp_rows(out.cpu(), ref, "radar-only RoIs")
     assert out.shape[0] == ref.shape[0] > 0
+
+
+def test_compact_sort_rows_matches_torch(hip_lib):
+    """me_compact_sort_rows_f32 against the torch ops it replaces (nonzero -> stable descending sort -> gather), with
+    many equal keys (ties must stay in ascending row order), sizes across the 2048-key LDS tile boundary, and cap 0."""
+    import ctypes as C
+    from millieye_amd import hip
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(3)
+    for cap in (0, 1, 7, 255, 2048, 2049, 6464):
+        rows = torch.randn((cap, 8), generator=g).cuda()
+        keep = (torch.rand((cap,), generator=g) < 0.6).to(torch.uint8).cuda()
+        key = (torch.randint(0, 40, (cap,), generator=g).float() / 40).cuda()  # lots of ties
+        out = torch.full((cap, 8), float("nan")).cuda()
+        cnt = torch.full((1,), -1, dtype=torch.int32).cuda()
+        hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, out.data_ptr(),
+                                               cnt.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+        idx = torch.nonzero(keep, as_tuple=False).flatten()
+        order = torch.sort(key[idx], descending=True, stable=True).indices
+        ref = rows[idx[order]]
+        m = int(cnt.item())
+        assert m == ref.shape[0], (cap, m, ref.shape)
+        assert torch.equal(out[:m], ref), f"cap {cap}"
