@@ -381,8 +381,9 @@ def main():
     # untimed pre-warm: the GPU needs a few hundred ms of sustained load to reach its steady clocks (the first
     # ~100 ms run ~15 % slower, measured with tools/conv_bench.py); serving throughput is the steady state
     if args.dtype != "f32":
-        if args.workload not in ("full", "detector"):
-            raise SystemExit("--dtype bf16 is an inference mode (workloads: full, detector)")
+        if args.workload not in ("full", "detector", "train"):
+            raise SystemExit("--dtype bf16 / f16 applies to inference (workloads full, detector) and to the frozen detector "
+                             "of the stage-3 training step (workload train)")
         model.compute_dtype = args.dtype
     t_pre = time.perf_counter() + args.prewarm_seconds
     while time.perf_counter() < t_pre:

@@ -80,7 +80,7 @@ def forward_train(net, images, targets):
     c1 = net.class_num + 1
 
     with torch.no_grad():
-        plan, yolo_out = net.base_detector.engine.run(images)  # training: always the fp32 engine
+        plan, yolo_out = net.base_detector._run(images)  # frozen detector: Darknet.compute_dtype applies
         det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG, writeback_xyxy=False)
         num_classes = yolo_out.shape[2] - 5
         cols, cap = 8 + net.class_num, n * _DETECTIONS_PER_IMG
@@ -96,7 +96,7 @@ def forward_train(net, images, targets):
         if plan.tap is None:
             raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         fh, fw, fc = plan.tap_shape
-        fm = plan.tap.permute(0, 2, 3, 1).contiguous()
+        fm = plan.tap.permute(0, 2, 3, 1).float().contiguous()
         pix = n * fh * fw
         ws_t = torch.empty(int(lib.me_bn_workspace_bytes(512)) + 256, dtype=torch.uint8, device=dev)
         ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256

@@ -76,12 +76,15 @@ def allreduce_gradients(params, group=None):
     bucket, params = flatten_grads(params)
     if bucket.numel() == 0:
         return 0
-    had = torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], device=bucket.device)
+    had = [1.0 if p.grad is not None else 0.0 for p in params]
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(had, op=dist.ReduceOp.MAX, group=group)  # tiny: who has a gradient anywhere
+        had_t = torch.tensor(had, device=bucket.device)
+        dist.all_reduce(had_t, op=dist.ReduceOp.MAX, group=group)  # tiny: who has a gradient anywhere
+        had = had_t.tolist()
+    # single process: the local list is the answer - no device tensor, no host sync on the backward kernels
     off = 0
-    for p, h in zip(params, had.tolist()):
+    for p, h in zip(params, had):
         n = p.numel()
         if h > 0:
             g = bucket[off:off + n].view_as(p)

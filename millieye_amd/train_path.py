@@ -117,21 +117,27 @@ def iou_labels_vectorized(boxes, targets):
     target_location = torch.zeros((P, 4))
     if P == 0 or Q == 0:
         return iou_labels, target_location
-    b, t = boxes[:, 2:6], targets[:, 2:6]
-    ix1 = torch.max(b[:, None, 0], t[None, :, 0])
-    iy1 = torch.max(b[:, None, 1], t[None, :, 1])
-    ix2 = torch.min(b[:, None, 2], t[None, :, 2])
-    iy2 = torch.min(b[:, None, 3], t[None, :, 3])
-    inter = torch.clamp(ix2 - ix1 + 1, min=0) * torch.clamp(iy2 - iy1 + 1, min=0)
-    a1 = ((b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1))[:, None]
-    a2 = ((t[:, 2] - t[:, 0] + 1) * (t[:, 3] - t[:, 1] + 1))[None, :]
-    iou = inter / (a1 + a2 - inter + 1e-16)
-    same = (boxes[:, None, 0] == targets[None, :, 0]) & (boxes[:, None, 1] == targets[None, :, 1])
-    masked = torch.where(same, iou, torch.full_like(iou, -1.0))
-    best, arg = masked.max(1)  # first maximum, like ious.max(0) over the filtered targets in target order
+    # numpy float32, single-threaded: torch's CPU ops fan a [P, Q] reduction of a few thousand elements out over every
+    # core of the host and take ~10 ms for it on a 128-core box; the arithmetic (IEEE fp32, same operation order) is identical
+    bx = boxes.detach().to(torch.float32).numpy()
+    tg = targets.detach().to(torch.float32).numpy()
+    b, t = bx[:, 2:6], tg[:, 2:6]
+    one = np.float32(1.0)
+    ix1 = np.maximum(b[:, None, 0], t[None, :, 0])
+    iy1 = np.maximum(b[:, None, 1], t[None, :, 1])
+    ix2 = np.minimum(b[:, None, 2], t[None, :, 2])
+    iy2 = np.minimum(b[:, None, 3], t[None, :, 3])
+    inter = np.maximum(ix2 - ix1 + one, np.float32(0)) * np.maximum(iy2 - iy1 + one, np.float32(0))
+    a1 = ((b[:, 2] - b[:, 0] + one) * (b[:, 3] - b[:, 1] + one))[:, None]
+    a2 = ((t[:, 2] - t[:, 0] + one) * (t[:, 3] - t[:, 1] + one))[None, :]
+    iou = inter / (a1 + a2 - inter + np.float32(1e-16))
+    same = (bx[:, None, 0] == tg[None, :, 0]) & (bx[:, None, 1] == tg[None, :, 1])
+    masked = np.where(same, iou, np.float32(-1.0))
+    arg = masked.argmax(1)  # first maximum, like ious.max(0) over the filtered targets in target order
+    best = masked[np.arange(P), arg]
     has = same.any(1)
-    iou_labels[has, 0] = best[has]
-    target_location[has] = t[arg[has]]
+    iou_labels[:, 0] = torch.from_numpy(np.where(has, best, np.float32(0)).astype(np.float32))
+    target_location[:] = torch.from_numpy(np.where(has[:, None], t[arg], np.float32(0)).astype(np.float32))
     return iou_labels, target_location
 
 
@@ -196,7 +202,9 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
 
     # ---- frozen detector, NMS, proposal assembly (no grad) -------------------------------------------
     with torch.no_grad():
-        plan, yolo_out = net.base_detector.engine.run(images)  # training: always the fp32 engine
+        # the detector is frozen here: it runs in whatever storage mode Darknet.compute_dtype names (fp32 by default;
+        # "bf16" / "f16" = BASELINE configs[3]'s "bf16 compute" for the part of the step that is inference)
+        plan, yolo_out = net.base_detector._run(images)
         det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
                                    writeback_xyxy=False)
         num_classes = yolo_out.shape[2] - 5
@@ -211,7 +219,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
         if plan.tap is None:
             raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         fh, fw, fc = plan.tap_shape
-        fm = plan.tap.permute(0, 2, 3, 1).contiguous()  # NHWC copy: the arena is reused by the next forward
+        fm = plan.tap.permute(0, 2, 3, 1).float().contiguous()  # fp32 NHWC copy: the arena is reused by the next forward
         if len(radar_boxes_location) > 0:
             radar_boxes_location[:, 1:] *= size
         n_radar = int(radar_boxes_location.shape[0])
@@ -306,9 +314,11 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
             hip.check(lib.me_heads_tail_f32(C.byref(d), small.data_ptr(), k, hip.stream_ptr()), "me_heads_tail_f32")
 
         # ---- output rows (same ordering rule as inference, reference :517-539) -------------------------
-        idx = torch.nonzero(keep[:k], as_tuple=False).flatten()
-        order = torch.sort(key[:k][idx], descending=True, stable=True).indices
-        output = rows[idx[order]]
+        ordered = _f32(dev, cap, 8)
+        n_out = torch.empty((1,), device=dev, dtype=torch.int32)
+        hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), k, 8, ordered.data_ptr(),
+                                               n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+        output = ordered[:int(n_out.item())]
 
         # ---- labels on the host (reference :545-604) ---------------------------------------------------
         targets[:, 2:] = xywh2xyxy(targets[:, 2:])
