@@ -210,12 +210,12 @@ def _ev():
     return e
 
 
-def conv_traffic(batch):
+def conv_traffic(batch, half=False):
     """HBM bytes per conv launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, two separate
     passes over this same command; tools/pmc_traffic.py -> profiles/conv_traffic.json).  PMC counters cannot
     be read from inside this process, so the committed measurement is reported when it matches the
     configuration being run, else null."""
-    path = os.path.join(ROOT, "profiles", "conv_traffic.json")
+    path = os.path.join(ROOT, "profiles", "conv_traffic_bf16.json" if half else "conv_traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh)
@@ -486,7 +486,7 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4),
-                "traffic": None if bf16 else conv_traffic(batch),
+                "traffic": conv_traffic(batch, half=bf16) if args.dtype in ("f32", "bf16") else None,
                 "launches_per_step": launches,
                 "avg_launch_us": round(avg_us, 2),
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),
@@ -503,6 +503,7 @@ def main():
                 "roofline": {"bound": "mfma", "kernel": "conv_igemm_buf_h16", "achieved": round(alt["ach"], 2),
                              "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(alt["ach"] / BF16_MFMA_PEAK_TFLOPS, 4),
+                             "traffic": conv_traffic(batch, half=True),
                              "launches_per_step": alt["launches"], "avg_launch_us": round(alt["avg_us"], 2)},
             }
         if not args.no_cpu_baseline and world == 1 and args.workload not in ("train", "detector_train"):

@@ -21,5 +21,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmf_$TAG -o f -- python $R/ben
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmw_$TAG -o w -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pmw.log 2>&1
 python $R/tools/prof_summary.py /tmp/pmf_$TAG/f_results.db --pmc | grep -v "at::\|rocprim\|rocclr" > $OUT/${TAG}_bench_full_b32_pmc_fetch.txt
 python $R/tools/prof_summary.py /tmp/pmw_$TAG/w_results.db --pmc | grep -v "at::\|rocprim\|rocclr" > $OUT/${TAG}_bench_full_b32_pmc_write.txt
-python $R/tools/pmc_traffic.py /tmp/pmf_$TAG/f_results.db /tmp/pmw_$TAG/w_results.db conv_igemm > $OUT/conv_traffic.json
+python $R/tools/pmc_traffic.py /tmp/pmf_$TAG/f_results.db /tmp/pmw_$TAG/w_results.db conv_igemm_buf_f32 > $OUT/conv_traffic.json
+python $R/tools/pmc_traffic.py /tmp/pmf_$TAG/f_results.db /tmp/pmw_$TAG/w_results.db conv_igemm_buf_h16 > $OUT/conv_traffic_bf16.json
 cat $OUT/${TAG}_bench_full_b32.json
