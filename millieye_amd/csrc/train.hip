@@ -83,18 +83,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     }
 }
 
-// column sums of X[rows, cols] (pitch ld): out[c] = sum_r X[r][c]; one workgroup per 64 columns,
-// fixed-order tree -> deterministic
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long ld, int rows, int cols,
-                                                     float* out) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < cols)
-    for (int r = part; r < rows; r += 4) s += X[(long long)r * ld + c];
-  red[part][threadIdx.x & 63] = s;
+// column sums of X[rows, cols] (pitch ld): out[c] = sum_r X[r][c].  One 1024-thread workgroup per CW = min(64, pow2 >= cols)
+// columns; the 1024 / CW row lanes of a column stride over the rows with eight independent partial sums in flight (the old
+// version had 4 row lanes and one dependent chain: 130-300 us for the [1600 x 2] ... [5408 x 490] matrices of the stage-3
+// backward), then a fixed-order LDS tree -> deterministic.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, long long ld, int rows, int cols, int cw,
+                                                      float* out) {
+  __shared__ float red[1024];
+  const int parts = 1024 / cw;
+  const int lc = threadIdx.x % cw, part = threadIdx.x / cw;
+  const int c = blockIdx.x * cw + lc;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    const long long step = (long long)parts * ld;
+    const float* px = X + (long long)part * ld + c;
+    int r = part;
+    for (; r + 7 * parts < rows; r += 8 * parts, px += 8 * step) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += px[u * step];
+    }
+    for (int u = 0; r < rows; r += parts, px += step, ++u) acc[u] += px[0];
+  }
+  red[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (part == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  for (int half = parts >> 1; half >= 1; half >>= 1) {
+    if (part < half) red[threadIdx.x] += red[threadIdx.x + half * cw];
+    __syncthreads();
+  }
+  if (part == 0 && c < cols) out[c] = red[lc];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,7 +700,9 @@ int me_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float*
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ME_REQUIRE(out && (x || rows == 0), ME_E_NULLPTR, "me_colsum_f32: null pointer");
   ME_REQUIRE(rows >= 0 && cols > 0, ME_E_BADARG, "me_colsum_f32: bad dimensions");
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, stream, x, (long long)ld, rows, cols, out);
+  int cw = 1;
+  while (cw < cols && cw < 64) cw <<= 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + cw - 1) / cw), dim3(1024), 0, stream, x, (long long)ld, rows, cols, cw, out);
   return me::check_launch("colsum_kernel");
 }
 
