@@ -164,3 +164,29 @@ def test_batch_statistics_kernel_vs_host(hip_lib):
     assert batch_statistics_device(out[:0], tg, n_img, 0.5) == []
     none = batch_statistics_device(out, tg[:0], n_img, 0.5)         # no targets at all: every TP is 0
     assert sum(int(x[0].sum()) for x in none) == 0 and len(none) == len(ref)
+
+
+@pytest.mark.parametrize("dtype,ap_tol", [("bf16", 0.03), ("f16", 0.01)])
+def test_evaluate_in_16bit_storage_modes(hip_lib, dtype, ap_tol):
+    """mAP@0.5 of the whole evaluation chain with the detector in a 16-bit storage mode against the REAL reference's fp32
+    numbers on the mini-dataset (tests/golden/evaluate_small.npz): same detected classes, AP / precision / recall within
+    ``ap_tol`` absolute (bf16: 3 points, IEEE half: 1 point) - the storage error moves a few boxes across the IoU / confidence
+    thresholds, it must not change the picture."""
+    from millieye_amd.my_models import Network, define_yolo
+    from millieye_amd.test_fusion import evaluate
+    from tests.golden.make_golden import EVAL_SMALL, eval_small_weights_
+    from tests.parity_helpers import cfg_path
+    c = EVAL_SMALL
+    g = np.load(os.path.join(GOLD, c["name"] + ".npz"))
+    net = eval_small_weights_(Network(define_yolo(cfg_path(c["cfg"])), c["conf"]))
+    net = net.to(net.device)
+    net.base_detector.compute_dtype = dtype
+    for model_mode in (0, 3):
+        precision, recall, AP, f1, ap_class, box_stat, _pr = evaluate(
+            net, mode="test", model_mode=model_mode, illumination=["H", "L"], iou_thresh=0.5, nms_thresh=0.5,
+            img_size=c["size"], batch_size=c["batch"], test_list=c["test_list"], dataset_folder=DATASET_DIR, num_workers=0)
+        k = f"mode{model_mode}/"
+        assert list(ap_class) == list(g[k + "ap_class"])
+        for name, got in (("precision", precision), ("recall", recall), ("AP", AP)):
+            assert np.all(np.abs(np.asarray(got) - g[k + name]) <= ap_tol), (dtype, model_mode, name, got, g[k + name])
+        print(f"{dtype} mode {model_mode}: AP {np.asarray(AP)} (reference fp32 {g[k + 'AP']})")
