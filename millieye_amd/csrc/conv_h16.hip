@@ -222,7 +222,14 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
     if (ABL == 3) return;  // ablation: no DMA at all (LDS reads + MFMAs + barriers only)
 #pragma unroll
     for (int u = 0; u < KSUB; ++u) {
-      dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off + 64u * u, b_off + 64u * u, lds_dst + u * SUB_B);
+      if constexpr (LPW <= 4 && LA <= 2) {
+        dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off + 64u * u, b_off + 64u * u, lds_dst + u * SUB_B);
+      } else {  // 192-row tiles: three A groups + two B groups per wave
+        constexpr int LB = LPW - LA;
+        static_assert(LA <= 4 && LB <= 4, "at most 4 groups per operand per wave");
+        dma_same<LA, NW * 1024, 0>(v_cur, rsrc_a, a_off + 64u * u, lds_dst + u * SUB_B);
+        dma_same<LB, NW * 1024, LA>(v_cur, rsrc_b, b_off + 64u * u, lds_dst + u * SUB_B + LA * NW * 1024u);
+      }
     }
     a_off += 64u * KSUB;
     b_off += 64u * KSUB;
@@ -780,6 +787,7 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
       case 12: return launch16<128, 64, 2, 2, 1, 1, 0, 1>(p, stream);
       case 13: return launch16<64, 64, 2, 2, 1, 1, 0, 1>(p, stream);
       case 14: return launch16<256, 128, 4, 2, 1, 2, 0, 1>(p, stream);
+      case 5: case 15: return launch16<192, 128, 2, 2, 1, 2, 0, 1>(p, stream);
       default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown tile id %d (half_type 1)", tile);
     }
   }
@@ -793,6 +801,9 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
     case 12: return launch16<128, 64, 2, 2, 1>(p, stream);
     case 13: return launch16<64, 64, 2, 2, 1>(p, stream);
     case 14: return launch16<256, 128, 4, 2, 1, 2>(p, stream);
+    // 192 x 128 (4 waves, wave tile 96 x 64): a row count between the 128- and 256-row tiles for the layers whose tile count
+    // falls just above a multiple of the 512 resident workgroups (one sub-stage only: 61 KB of LDS, 2 workgroups per CU)
+    case 5: case 15: return launch16<192, 128, 2, 2, 1, 2>(p, stream);
     case 71: return launch16<128, 128, 2, 2, 1, 1, 3>(p, stream);
     case 73: return launch16<64, 64, 2, 2, 1, 1, 3>(p, stream);
     case 74: return launch16<256, 128, 4, 2, 1, 2, 3>(p, stream);

@@ -61,4 +61,46 @@ __device__ __forceinline__ void dma_stage(const unsigned (&v)[LPW], u32x4 ra, u3
 }
 
 
+// N loads through ONE descriptor (scalar offset s), LDS destinations dst, dst + STEP, ...; M0 saved / restored once.
+// OFF selects the first of the N per-lane offsets inside the caller's array (passed by reference and copied by value here:
+// the array must stay in registers).
+template <int N, int STEP, int OFF, int LEN>
+__device__ __forceinline__ void dma_same(const unsigned (&va)[LEN], u32x4 r, unsigned s, unsigned dst) {
+  unsigned keep;
+  static_assert(N >= 1 && N <= 4 && OFF + N <= LEN, "1..4 loads per block, inside the array");
+  unsigned v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = va[OFF + (i < N ? i : 0)];
+#define ME_DMA_HEAD "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+#define ME_DMA_NEXT "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\t"
+#define ME_DMA_L(i) "buffer_load_dwordx4 %[v" #i "], %[r], %[s] offen lds\n\t"
+#define ME_DMA_TAIL "s_mov_b32 m0, %[k]"
+  if constexpr (N == 1) {
+    asm volatile(ME_DMA_HEAD ME_DMA_L(0) ME_DMA_TAIL
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [st] "n"(STEP), [r] "s"(r), [s] "s"(s), [v0] "v"(v[0])
+                 : "memory", "scc");
+  } else if constexpr (N == 2) {
+    asm volatile(ME_DMA_HEAD ME_DMA_L(0) ME_DMA_NEXT ME_DMA_L(1) ME_DMA_TAIL
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [st] "n"(STEP), [r] "s"(r), [s] "s"(s), [v0] "v"(v[0]), [v1] "v"(v[1])
+                 : "memory", "scc");
+  } else if constexpr (N == 3) {
+    asm volatile(ME_DMA_HEAD ME_DMA_L(0) ME_DMA_NEXT ME_DMA_L(1) ME_DMA_NEXT ME_DMA_L(2) ME_DMA_TAIL
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [st] "n"(STEP), [r] "s"(r), [s] "s"(s), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2])
+                 : "memory", "scc");
+  } else {
+    asm volatile(ME_DMA_HEAD ME_DMA_L(0) ME_DMA_NEXT ME_DMA_L(1) ME_DMA_NEXT ME_DMA_L(2) ME_DMA_NEXT ME_DMA_L(3) ME_DMA_TAIL
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [st] "n"(STEP), [r] "s"(r), [s] "s"(s), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]),
+                   [v3] "v"(v[3])
+                 : "memory", "scc");
+  }
+#undef ME_DMA_HEAD
+#undef ME_DMA_NEXT
+#undef ME_DMA_L
+#undef ME_DMA_TAIL
+}
+
 }  // namespace me_dma

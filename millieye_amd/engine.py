@@ -674,9 +674,9 @@ _TUNE_CACHE = {}
 _TUNE_FILE_LOADED = [False]
 _TUNE_TILES = (1, 2, 3, 4, 5)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
-_TUNE_TILES_BF16 = (1, 2, 3, 4, 11, 12, 13, 14)  # 1x = one 32-channel sub-stage per pipeline stage (more workgroups / CU)
+_TUNE_TILES_BF16 = (1, 2, 3, 4, 11, 12, 13, 14, 15)  # 1x = one 32-channel sub-stage per pipeline stage (more workgroups / CU)
 _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
-                     11: (128, 128), 12: (128, 64), 13: (64, 64), 14: (256, 128)}
+                     11: (128, 128), 12: (128, 64), 13: (64, 64), 14: (256, 128), 15: (192, 128)}
 
 
 def _autotune_enabled():
@@ -690,7 +690,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v3.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v4.json")  # bump with every kernel generation
 
 
 def _tune_load():
@@ -793,7 +793,7 @@ def _autotune(plan, lib):
         tiles = _TUNE_TILES
         if bf16:
             stages = d.ksize * d.ksize * (d.cin // 32)
-            tiles = _TUNE_TILES_BF16 if d.cin % 64 == 0 else _TUNE_TILES_BF16[:4]
+            tiles = _TUNE_TILES_BF16 if d.cin % 64 == 0 else _TUNE_TILES_BF16[:4] + (15,)
         for tile in tiles:
             bm, bn = _TILE_SHAPES_BF16[tile] if bf16 else \
                 {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128)}[tile]

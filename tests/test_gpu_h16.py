@@ -78,7 +78,7 @@ def test_conv_bf16_tiles(hip_lib, case, half):
     packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
     xs, sc, sh = x.cuda(), scale.cuda(), shift.cuda()
     rs = res.cuda() if res is not None else None
-    tiles = (1, 2, 3, 4, 11, 12, 13, 14) if cin % 64 == 0 else (1, 2, 3, 4)
+    tiles = (1, 2, 3, 4, 5, 11, 12, 13, 14) if cin % 64 == 0 else (1, 2, 3, 4, 5)
     for tile in tiles:
         for split in (1, 2, 3):
             if split > k * k * (cin // 64 if cin % 64 == 0 and tile < 10 else cin // 32):
