@@ -76,7 +76,7 @@ class DetectorTrainer:
                     cout = cw.wgt.shape[0]
                     if cout > 2048:
                         raise hip.MeError("train-mode BatchNorm: more than 2048 channels")
-                    ones, zeros = torch.ones(cout, device=x.device), torch.zeros(cout, device=x.device)
+                    ones, zeros = _const_vectors(cout, x.device)
                     c_raw = hip.conv2d(src, cw.wgt, ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, x_nchw=(i == 0))
                     y = torch.empty_like(c_raw)
                     rows = c_raw.numel() // cout
@@ -198,8 +198,7 @@ class DetectorTrainer:
                                               dx.data_ptr(), cin, stream()), "me_gemm_f32")
                 else:
                     wt = cw.wgt.flip(1, 2).permute(3, 1, 2, 0).contiguous()  # [cin][k][k][cout], rotated 180 degrees
-                    ones = torch.ones(cin, device=dev)
-                    zeros = torch.zeros(cin, device=dev)
+                    ones, zeros = _const_vectors(cin, dev)
                     if s == 1:
                         dx = hip.conv2d(dc, wt, ones, zeros, k, 1, k - 1 - pad, hip.ACT_LINEAR)
                     else:
@@ -241,6 +240,19 @@ class DetectorTrainer:
                           "me_maxpool_bwd_f32")
             dout[i] = None  # free as we go
         return grads
+
+
+_CONST = {}
+
+
+def _const_vectors(n, device):
+    """(ones[n], zeros[n]) fp32 on ``device``: identity scale / shift of the plain convolutions of the training path, cached
+    (they are read-only; re-creating them cost four fill launches per layer and step)."""
+    key = (n, str(device))
+    hit = _CONST.get(key)
+    if hit is None:
+        hit = _CONST[key] = (torch.ones(n, device=device), torch.zeros(n, device=device))
+    return hit
 
 
 class _DarknetLoss(torch.autograd.Function):

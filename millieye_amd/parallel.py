@@ -61,12 +61,11 @@ def flatten_grads(params):
     total = sum(p.numel() for p in params)
     if total == 0:
         return torch.zeros(0), params
-    bucket = torch.zeros(total, dtype=torch.float32, device=params[0].device)
-    off = 0
-    for p in params:
-        if p.grad is not None:
-            bucket[off:off + p.numel()] = p.grad.reshape(-1)
-        off += p.numel()
+    dev = params[0].device
+    # one concatenation (a couple of batched-copy launches) instead of one slice assignment per parameter
+    pieces = [p.grad.reshape(-1).to(torch.float32) if p.grad is not None else torch.zeros(p.numel(), device=dev)
+              for p in params]
+    bucket = torch.cat(pieces) if len(pieces) > 1 else pieces[0].clone()
     return bucket, params
 
 
@@ -84,6 +83,7 @@ def allreduce_gradients(params, group=None):
         had = had_t.tolist()
     # single process: the local list is the answer - no device tensor, no host sync on the backward kernels
     off = 0
+    dst, src = [], []
     for p, h in zip(params, had):
         n = p.numel()
         if h > 0:
@@ -91,6 +91,9 @@ def allreduce_gradients(params, group=None):
             if p.grad is None:
                 p.grad = g.clone()
             else:
-                p.grad.copy_(g)
+                dst.append(p.grad)
+                src.append(g)
         off += n
+    if dst:
+        torch._foreach_copy_(dst, src)  # batched: one launch per ~100 tensors instead of one per parameter
     return bucket.numel() * 4
