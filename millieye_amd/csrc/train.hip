@@ -520,16 +520,33 @@ __global__ __launch_bounds__(256) void affine_bwd_partial_kernel(const float* __
   }
 }
 
-__global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(float* p0, float* p1, int C, int chunks) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+// second level of the fixed-order reduction: 64 channels x 16 chunk lanes per workgroup (a lane sums the chunks
+// k = lane, lane + 16, ... in double), then a fixed LDS tree - the one-thread-per-channel loop over up to 1024 chunks took 31 us
+__global__ __launch_bounds__(1024) void affine_bwd_reduce_kernel(float* p0, float* p1, int C, int chunks) {
+  __shared__ double r0[16][64], r1[16][64];
+  const int lc = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
   double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s0 += p0[(long long)k * C + c];
-    s1 += p1[(long long)k * C + c];
+  if (c < C)
+    for (int k = part; k < chunks; k += 16) {
+      s0 += p0[(long long)k * C + c];
+      s1 += p1[(long long)k * C + c];
+    }
+  r0[part][lc] = s0;
+  r1[part][lc] = s1;
+  __syncthreads();
+  for (int half = 8; half >= 1; half >>= 1) {
+    if (part < half) {
+      r0[part][lc] += r0[part + half][lc];
+      r1[part][lc] += r1[part + half][lc];
+    }
+    __syncthreads();
   }
-  p0[c] = (float)s0;
-  p1[c] = (float)s1;
+  // every lane of the block has finished reading the partials of this block's channels before row 0 is overwritten
+  if (part == 0 && c < C) {
+    p0[c] = (float)r0[0][lc];
+    p1[c] = (float)r1[0][lc];
+  }
 }
 
 __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __restrict__ Y, long long ldy,
@@ -772,7 +789,7 @@ int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t 
   float* p1 = p0 + (long long)chunks * channels;
   hipLaunchKernelGGL(affine_bwd_partial_kernel, dim3((channels + 63) / 64, chunks), dim3(256), 0, stream, y, (long long)ldy,
                      dy, (long long)lddy, rows, channels, gamma, beta, act, p0, p1, chunks);
-  hipLaunchKernelGGL(affine_bwd_reduce_kernel, dim3((channels + 255) / 256), dim3(256), 0, stream, p0, p1, channels, chunks);
+  hipLaunchKernelGGL(affine_bwd_reduce_kernel, dim3((channels + 63) / 64), dim3(1024), 0, stream, p0, p1, channels, chunks);
   hipLaunchKernelGGL(affine_bwd_apply_kernel, dim3(grid1d((long long)rows * channels)), dim3(256), 0, stream, y,
                      (long long)ldy, dy, (long long)lddy, (long long)rows, channels, scale, act, dc, (long long)lddc, p0, p1,
                      dshift, dgamma);
