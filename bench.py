@@ -10,6 +10,7 @@ communication.
 Workloads (``--workload``):
   detector  yolov3.cfg (Darknet-53) 416x416 fp32 forward -> (featuremap, yolo_outputs)   [BASELINE configs[1]]
   full      detector + NMS + R-CNN/radar-fusion heads (Network.forward, mode 0)          [metric's "+fusion"]
+  module2   the stage-2 network (module2_mixed: detector + NMS + every-class proposals + PS-RoIAlign heads)  [BASELINE configs[2]]
   train     stage-3 training step: forward + loss + backward + one SUM all-reduce (RCCL) of the flat
             gradient bucket + Adam step, batch 8 per GPU                                  [BASELINE configs[3] shape]
 """
@@ -38,7 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--cfg", default="yolov3")
-    ap.add_argument("--workload", default="full", choices=["detector", "full", "train", "detector_train"])
+    ap.add_argument("--workload", default="full", choices=["detector", "full", "module2", "train", "detector_train"])
     ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16"),
                     help="storage of the detector activations / weights: f32 (default, the parity mode), bf16 or f16 "
                          "(BASELINE configs[2]/[4]: 16-bit operands, fp32 accumulate; inference workloads only)")
@@ -287,7 +288,7 @@ def main():
     from millieye_amd import cfgs, synth  # noqa: E402
     from millieye_amd.yolov3.models import Darknet
 
-    batch = args.batch or (32 if args.workload == "full" else 8)
+    batch = args.batch or (32 if args.workload in ("full", "module2") else 8)
     conf_thresh = 0.2
     cfg_path = cfgs.write_cfg(args.cfg, os.path.join("/tmp", f"millieye_bench_cfg_{os.getuid()}_{rank}"))
     frames_cpu = torch.from_numpy(synth.uniform(f"bench/frames/{rank}", (batch, 3, args.size, args.size)))
@@ -317,6 +318,22 @@ def main():
             det_opt.zero_grad(set_to_none=True)
             last["loss"] = loss.detach()
             return yo
+    elif args.workload == "module2":
+        # BASELINE configs[2]: the stage-2 network (module2_mixed/my_models.py: detector + NMS + every-class proposals +
+        # PS-RoIAlign + refinement / ensemble heads, no radar branch), batch 32; rows come back on the host like the reference's
+        from millieye_amd.module2.my_models import Network as Network2
+        net2 = Network2(Darknet(cfg_path), conf_thresh).eval()
+        synth.fill_network_(net2, "bench/m2/" + args.cfg)
+        state_cpu = {}
+        net2 = net2.to(dev)
+        model = net2.base_detector
+        net = None   # no stage marks / RoI bookkeeping of the stage-3 network below
+        last = {}
+
+        def step():
+            with torch.no_grad():
+                last["out"] = net2(x)
+            return last["out"]
     elif args.workload == "detector":
         model = Darknet(cfg_path).eval()
         synth.fill_darknet_(model, "bench/" + args.cfg)
@@ -381,7 +398,7 @@ def main():
     # untimed pre-warm: the GPU needs a few hundred ms of sustained load to reach its steady clocks (the first
     # ~100 ms run ~15 % slower, measured with tools/conv_bench.py); serving throughput is the steady state
     if args.dtype != "f32":
-        if args.workload not in ("full", "detector", "train"):
+        if args.workload not in ("full", "detector", "module2", "train"):
             raise SystemExit("--dtype bf16 / f16 applies to inference (workloads full, detector) and to the frozen detector "
                              "of the stage-3 training step (workload train)")
         model.compute_dtype = args.dtype
@@ -410,7 +427,7 @@ def main():
     # The same K steps once more in the opt-in bf16 storage mode (BASELINE configs[2] / [4] name bf16 / fp16 for their
     # shapes), reported beside - never instead of - the fp32 `value` above: same barrier + max-over-ranks protocol.
     alt = None
-    if args.dtype == "f32" and args.workload in ("full", "detector") and not args.no_bf16_line:
+    if args.dtype == "f32" and args.workload in ("full", "detector", "module2") and not args.no_bf16_line:
         try:
             model.compute_dtype = "bf16"
             t_alt = time.perf_counter() + 0.5
@@ -469,6 +486,9 @@ def main():
                             + ("Darknet.forward -> featuremap + yolo_outputs" if args.workload == "detector" else
                                "full milliEye: Darknet.forward -> NMS -> Network.forward mode 0 (R-CNN head + radar "
                                "fusion, 2 radar boxes/frame) -> output rows" if args.workload == "full" else
+                               "stage-2 network (module2_mixed): Darknet.forward -> NMS -> every-class proposals -> "
+                               "PS-RoIAlign + refinement / ensemble heads -> output rows on the host"
+                               if args.workload == "module2" else
                                "Darknet.forward(x, targets) -> loss.backward() -> all-reduce -> SGD"
                                if args.workload == "detector_train" else
                                "stage-3 training step: frozen detector + NMS + train-mode heads + focal/BCE loss + "
@@ -512,7 +532,7 @@ def main():
                              "traffic": conv_traffic(batch, half=True),
                              "launches_per_step": alt["launches"], "avg_launch_us": round(alt["avg_us"], 2)},
             }
-        if not args.no_cpu_baseline and world == 1 and args.workload not in ("train", "detector_train"):
+        if not args.no_cpu_baseline and world == 1 and args.workload not in ("train", "detector_train", "module2"):
             from millieye_amd.engine import pick_tap_module
             out["cpu_baseline"] = cpu_baseline(args, frames_cpu, state_cpu, cfgs.KNOWN[args.cfg](),
                                                pick_tap_module(model.module_defs), args.cpu_seconds, radar)
@@ -520,6 +540,8 @@ def main():
             out["config"]["output_rows_last_step"] = int(last["out"].shape[0])
             out["config"]["rois_last_step"] = int(getattr(net, "_last", {}).get("n_img", torch.zeros(1)).sum().item()) \
                 + batch * 2 if args.workload == "full" else int(net._last_train["k"])
+        if args.workload == "module2":
+            out["config"]["output_rows_last_step"] = int(last["out"].shape[0])
         if args.workload == "detector_train":
             out["config"]["grad_bucket_bytes"] = int(last.get("bucket_bytes", 0))
             out["config"]["loss_last_step"] = round(float(last["loss"]), 5)

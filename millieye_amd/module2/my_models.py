@@ -153,7 +153,9 @@ class Network(nn.Module):
                                       cap, cols, self.class_num, C.byref(w), float(self.refine_threshold),
                                       regress.data_ptr(), refine.data_ptr(), mask.data_ptr(), rows.data_ptr(),
                                       keep.data_ptr(), key.data_ptr(), hip.stream_ptr()), "me_m2_heads_f32")
-        idx = torch.nonzero(keep, as_tuple=False).flatten()
-        order = torch.sort(key[idx], descending=True, stable=True).indices
+        ordered = torch.empty((cap, 8), **f32)
+        n_out = torch.empty((1,), device=dev, dtype=torch.int32)
+        hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
+                                               n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
         self._last = dict(regress=regress, refine=refine, mask=mask, n_boxes=n_dev, boxes=boxes)
-        return rows[idx[order]].cpu()
+        return ordered[:int(n_out.item())].cpu()
