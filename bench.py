@@ -13,6 +13,10 @@ Workloads (``--workload``):
   module2   the stage-2 network (module2_mixed: detector + NMS + every-class proposals + PS-RoIAlign heads)  [BASELINE configs[2]]
   train     stage-3 training step: forward + loss + backward + one SUM all-reduce (RCCL) of the flat
             gradient bucket + Adam step, batch 8 per GPU                                  [BASELINE configs[3] shape]
+  detector_train  Darknet.forward(x, targets) + HIP backward of every layer + full-gradient all-reduce + SGD
+``--dtype bf16 | f16``: the opt-in 16-bit storage modes of the detector for the inference workloads and for the
+frozen detector of ``train``; e.g. ``--dtype f16 --size 608 --batch 16`` is the per-GPU shape of BASELINE configs[4].  The default
+fp32 line also carries the same steps re-run in bf16 storage as ``bf16_storage_mode`` (never as ``value``).
 """
 import argparse
 import json
