@@ -277,6 +277,17 @@ def pack_conv_weight(weight):
     return weight.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
 
 
+def _nhwc_pitch(t, name):
+    """Elements between consecutive pixels of an NHWC tensor that is contiguous or a channel slice of a contiguous one."""
+    if t.is_contiguous():
+        return t.shape[-1]
+    n, h, w, _c = t.shape
+    pitch = t.stride(2)
+    if t.stride() != (h * w * pitch, w * pitch, pitch, 1):
+        raise MeError(f"{name} must be NHWC-contiguous or a channel slice of an NHWC-contiguous tensor")
+    return pitch
+
+
 def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
            x_nchw=False, tile=0, split_k=0):
     """x_nhwc: [N,H,W,Cin] contiguous (or NCHW [N,Cin,H,W] when ``x_nchw``).  Returns NHWC
@@ -302,8 +313,8 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
         if x_nhwc.stride() != (h * w * pitch, w * pitch, pitch, 1):
             raise MeError("x must be NHWC-contiguous or a channel slice of an NHWC-contiguous tensor")
         d.x_pitch = pitch
-    d.res_pitch = residual.shape[-1] if residual is not None else 0
-    d.y_pitch = out.shape[-1]
+    d.res_pitch = _nhwc_pitch(residual, "residual") if residual is not None else 0
+    d.y_pitch = _nhwc_pitch(out, "out")
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, stride, pad, ho, wo
     d.act, d.upsample, d.x_nchw, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, tile, split_k
@@ -352,8 +363,8 @@ def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=No
         if x.stride() != (h * w * pitch, w * pitch, pitch, 1):
             raise MeError("x must be NHWC-contiguous or a channel slice of an NHWC-contiguous tensor")
         d.x_pitch = pitch
-    d.res_pitch = residual.shape[-1] if residual is not None else 0
-    d.y_pitch = out.shape[-1]
+    d.res_pitch = _nhwc_pitch(residual, "residual") if residual is not None else 0
+    d.y_pitch = _nhwc_pitch(out, "out")
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, stride, pad, ho, wo
     d.act, d.upsample, d.x_nchw, d.y_f32, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, 1 if y_f32 else 0, \

@@ -8,6 +8,7 @@ equal the RNE rounding of that fp32 result except where the two fp32 values stra
 difference is one bf16 ulp (<= 2^-7 relative; + 1e-5 absolute where a sum cancels to ~0) - and such elements must stay
 below 0.5 % of the tensor.
 """
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -264,3 +265,42 @@ def test_detector_determinism_stress(hip_lib, dtype):
             for rep in range(40):
                 fm, y = model(x)
                 assert torch.equal(y, y0) and torch.equal(fm, fm0), f"{dtype} batch {n}: run {rep} differs"
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+def test_conv_h16_random_shapes(hip_lib, half):
+    """Seeded sweep over shapes the fixed cases do not hit: odd spatial sizes, M not a multiple of any tile, couts that are
+    not multiples of 8 (scalar epilogue) next to ones that are (16-byte epilogue), ragged last tiles in both directions,
+    stride 2, fused upsample, automatic tile / split choice, output written into a channel slice of a wider buffer."""
+    from millieye_amd import hip
+    half = HALVES[half]
+    rng = np.random.RandomState(7)
+    for case in range(14):
+        n = int(rng.randint(1, 4))
+        h, w = int(rng.randint(5, 40)), int(rng.randint(5, 40))
+        cin = int(rng.choice([32, 64, 96, 160]))
+        cout = int(rng.choice([8, 24, 33, 64, 100, 136, 255, 272]))
+        k = int(rng.choice([1, 3]))
+        s = int(rng.choice([1, 2])) if k == 3 else 1
+        ups = 2 if (k == 1 and rng.rand() < 0.3) else 1
+        act = int(rng.choice([0, 1]))
+        pad = (k - 1) // 2
+        ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        with_res = ups == 1 and rng.rand() < 0.5
+        g = torch.Generator().manual_seed(1000 + case)
+        x = _bf(torch.randn((n, h, w, cin), generator=g), half)
+        wgt = _bf(torch.randn((cout, cin, k, k), generator=g) / (k * k * cin) ** 0.5, half)
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+        res = _bf(torch.randn((n, ho, wo, cout), generator=g), half) if with_res else None
+        ref = _ref(x, wgt, scale, shift, k, s, pad, act, res, ups)
+        packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+        y = hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), k, s, pad, act,
+                           residual=res.cuda() if res is not None else None, upsample=ups)
+        what = f"case {case}: n{n} {h}x{w} {cin}->{cout} k{k} s{s} ups{ups} res{int(with_res)}"
+        _check_bf16(y, ref, what)
+        if ups == 1 and cout % 8 == 0:   # the same layer writing into a slice of a wider (route) buffer: pitched 16-byte stores
+            wide = torch.zeros((n, ho, wo, cout + 40), dtype=half).cuda()
+            hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), k, s, pad, act,
+                           residual=res.cuda() if res is not None else None, out=wide[..., 8:8 + cout])
+            assert torch.equal(wide[..., 8:8 + cout], y), what + " (pitched)"
+            assert float(wide[..., :8].abs().max()) == 0 and float(wide[..., 8 + cout:].abs().max()) == 0
