@@ -121,3 +121,23 @@ def test_tracker_life_cycle_and_proposals():
     cx, cy = (u[0] + u[1]) / 2, (v[0] + v[1]) / 2 + 0.16 * h
     assert np.allclose(box, [cx - 0.6 * w, cy - 0.7 * h, cx + 0.6 * w, cy + 0.7 * h], rtol=1e-12)
     assert len(rp.box_proposals(c, calib, max_size=1.5)) == 0   # largest extent 2.0 >= max_size: skipped
+
+
+def test_demo_glue_on_the_host():
+    """The two host-only pieces of millieye_amd/demo.py: run_mp's mode selection (auto = fusion below a mean brightness of
+    0.08) and the proposal -> radar_box normalisation (padding of the short side, division by the padded side, clamp, empty
+    boxes dropped; run_mp.py:119-135, 204-212)."""
+    import torch
+    from millieye_amd.demo import mode_selection, radar_boxes_for_network
+    assert [mode_selection(m, None) for m in (0, 1, 2)] == [0, 1, 2] and mode_selection(9, None) is None
+    assert mode_selection(3, torch.full((1, 3, 8, 8), 0.05)) == 0 and mode_selection(3, torch.full((1, 3, 8, 8), 0.5)) == 1
+    assert mode_selection(3, torch.full((1, 3, 8, 8), 0.09)) == 1 and mode_selection(3, torch.full((1, 3, 8, 8), 0.09), 0.1) == 0
+    # landscape frame 480 x 640: 80 rows of padding above and below, side 640
+    rb = radar_boxes_for_network([[10, 20, 110, 220], [700, 10, 650, 50], [-50, -50, 30, 30]], (480, 640))
+    assert rb.shape == (2, 5)
+    assert torch.allclose(rb[0], torch.tensor([0, 10 / 640, 100 / 640, 110 / 640, 300 / 640]))
+    assert torch.allclose(rb[1], torch.tensor([0, 0.0, 30 / 640, 30 / 640, 110 / 640]))   # clamped; the reversed box is gone
+    # portrait frame 640 x 480: the padding goes left / right
+    rb = radar_boxes_for_network([[0, 0, 480, 640]], (640, 480))
+    assert torch.allclose(rb[0], torch.tensor([0, 80 / 640, 0.0, 560 / 640, 1.0]))
+    assert radar_boxes_for_network([], (480, 640)).shape == (0, 5)
