@@ -52,7 +52,7 @@ def main():
                     rows.append((a.elapsed_time(b) / 10, tile, split))
                 except hip.MeError as exc:
                     rows.append((float("inf"), tile, split))
-        rows.sort()
+        rows = sorted(r for r in rows if r[0] != float('inf'))   # tiles that do not apply to this shape
         if not rows:
             continue
         best = rows[0]
