@@ -1,17 +1,20 @@
-// conv_h16.hip - the detector's conv blocks with 16-bit storage (bf16 activations and weights, fp32 accumulate) for
-// gfx950: BASELINE configs[2] / [4] ("bf16 inference").  Opt-in (MILLIEYE_DTYPE=bf16 / Darknet.compute_dtype); the
-// fp32 path of conv.hip stays the default and the one the 1e-3 parity bar is quoted on.
+// conv_h16.hip - the detector's conv blocks with 16-bit storage for gfx950: bfloat16 (half_type 0) or IEEE half
+// (half_type 1) activations and weights, fp32 accumulation - BASELINE configs[2] / [4] ("bf16 inference", "fp16 MFMA
+// convs").  Opt-in (Darknet.compute_dtype / MILLIEYE_DTYPE); the fp32 path of conv.hip stays the default and the one the
+// 1e-3 parity bar is quoted on.  Every kernel is templated on the storage type (H16<F16>: operand vector, MFMA, conversions).
 //
-//   conv_igemm_buf_h16 : the buffer-addressed LDS-DMA implicit GEMM of conv.hip on v_mfma_f32_32x32x16_bf16
-//                         (2.5 PFLOP/s dense peak, 16x the fp32 matrix rate).  A stage is KSUB sub-stages of
-//                         (BM + BN) rows x 32 channels (64-byte rows - the same 1 KiB-per-DMA LDS image and XOR
-//                         swizzle as the fp32 kernel); one ds_read_b128 is one MFMA operand (8 bf16 per lane).
-//                         Epilogue: fp32 affine (folded BN / bias) + LeakyReLU + residual, one RNE rounding to bf16
-//                         (v_cvt_pk_bf16_f32) or fp32 output for the detection convs that feed the YOLO decode.
-//   conv_stem3_h16     : the cin = 3 stem on the VALU (fp32 frames in, fp32 weights, bf16 NHWC out).
-//   maxpool / upsample / add / copy on bf16 NHWC (16 bytes = 8 channels per lane).
+//   conv_igemm_buf_h16 : the buffer-addressed LDS-DMA implicit GEMM of conv.hip on v_mfma_f32_32x32x16_bf16 / _f16
+//                        (2.5 PFLOP/s dense peak, 16x the fp32 matrix rate).  A stage is KSUB sub-stages of
+//                        (BM + BN) rows x 32 channels (64-byte rows - the same 1 KiB-per-DMA LDS image and XOR
+//                        swizzle as the fp32 kernel); one ds_read_b128 is one MFMA operand (8 values per lane).
+//                        Epilogue: fp32 affine (folded BN / bias) + LeakyReLU + residual, one RNE rounding to the
+//                        storage type - through a per-wave LDS transpose so that loads / stores are 16 bytes per lane -
+//                        or fp32 output for the detection convs that feed the YOLO decode.
+//   conv3x3_patch_h16  : experimental patch-resident variant for 3x3 / stride 1 layers (tile id 41, see its comment).
+//   conv_stem3_h16     : the cin = 3 stem on the VALU (fp32 frames in, fp32 weights, 16-bit NHWC out).
+//   maxpool / upsample / add / copy on 16-bit NHWC (16 bytes = 8 channels per lane).
 //
-// Rounding points (what oracle/darknet_ref.py's storage="bf16" mode restates): weights once (host, RNE), every
+// Rounding points (what oracle/darknet_ref.py's storage="bf16" / "f16" modes restate): weights once (host, RNE), every
 // stored activation once (after activation + residual), nothing else; accumulation and the affine are fp32.
 #include <math.h>
 #include <type_traits>
