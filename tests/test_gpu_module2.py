@@ -93,3 +93,31 @@ def test_module2_training_step_vs_oracle_and_reference(hip_lib):
     for key in g.files:
         if key.startswith("buf/"):
             assert np.allclose(sd[key[4:]].cpu().numpy(), g[key], rtol=1e-3, atol=1e-5), key
+
+
+@pytest.mark.parametrize("dtype,px,tol,share", [("bf16", 4.0, 0.1, 0.75), ("f16", 2.0, 0.02, 0.95)])
+def test_module2_forward_in_16bit_storage_modes(hip_lib, dtype, px, tol, share):
+    """BASELINE configs[2] literally ("module2 ... bf16 inference"): the stage-2 network with the detector in a 16-bit
+    storage mode stays close to its own fp32 run - same number of rows within 10 %, and ``share`` of the fp32 rows have a row
+    of the same image and class within ``px`` pixels on every corner and ``tol`` on the refined confidence.  (Random-weight
+    heads on this fixture regress every one of the 200 proposals with confidences packed into 0.47-0.57, which amplifies the
+    storage error: measured 83 % at 4 px for bf16, 100 % at 2 px for IEEE half.)"""
+    from millieye_amd.module2.my_models import Network, define_yolo
+    name, cfg, n, s, conf = M2_CASES[-1]
+    net = m2_fill_(Network(define_yolo(cfg_path(cfg)), conf), name).eval()
+    net = net.to(net.device)
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s))).cuda()
+    ref = net(x)
+    net.base_detector.compute_dtype = dtype
+    got, got2 = net(x), net(x)
+    assert torch.equal(got, got2)
+    assert ref.shape[0] >= 5 and abs(got.shape[0] - ref.shape[0]) <= max(1, 0.1 * ref.shape[0]), (got.shape, ref.shape)
+    matched = 0
+    for row in ref:
+        cand = got[(got[:, 0] == row[0]) & (got[:, 7] == row[7])]
+        if len(cand) == 0:
+            continue
+        d = (cand[:, 1:5] - row[1:5]).abs().max(dim=1).values
+        j = int(d.argmin())
+        matched += int(float(d[j]) <= px and abs(float(cand[j, 5] - row[5])) <= tol)
+    assert matched >= share * ref.shape[0], f"{dtype}: {matched} of {ref.shape[0]} fp32 rows have a counterpart"
