@@ -54,19 +54,47 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` outside a launcher: start the N ranks ourselves (one process per GPU) by re-running this
+    very command line under ``torch.distributed.run`` on 127.0.0.1, and hand its exit code back.  Rank 0 of that job
+    prints the JSON line to our stdout."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but only {have} GPU(s) are visible")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def init_dist(args):
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("BENCH_FORCE_SPAWN")):
+        spawn_ranks(args)  # does not return (BENCH_FORCE_SPAWN: the 1-GPU test of this very path)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world != args.gpus:
+        raise SystemExit(f"[bench] launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree")
+    if "WORLD_SIZE" in os.environ:  # under a launcher (the driver's, or spawn_ranks above): RCCL even at world size 1
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # n_gpus is what RCCL saw, not what the command line asked for
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"[bench] RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
+        probe = torch.ones(1, device=torch.device("cuda", local))
+        dist.all_reduce(probe)  # one real collective up front: every rank is there, on its own GPU
+        if int(probe.item()) != world:
+            raise SystemExit(f"[bench] all-reduce over {world} ranks returned {probe.item()}")
     else:
         torch.cuda.set_device(0)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     return world, rank, local
 
 
@@ -317,7 +345,7 @@ def main():
         def step():
             loss, _fm, yo = model(x, det_targets)
             loss.backward()
-            last["bucket_bytes"] = par.allreduce_gradients(det_params)
+            last["bucket_bytes"] = par.allreduce_gradients(det_params, static_pattern=True)
             det_opt.step()
             det_opt.zero_grad(set_to_none=True)
             last["loss"] = loss.detach()
@@ -393,7 +421,7 @@ def main():
             def step():  # noqa: F811
                 loss, out_rows, _metric, _att = net(x, maps_d, boxes_d.clone(), targets.clone())
                 loss.backward()
-                last["bucket_bytes"] = par.allreduce_gradients(heads)
+                last["bucket_bytes"] = par.allreduce_gradients(heads, static_pattern=True)
                 opt.step()
                 opt.zero_grad(set_to_none=True)
                 last["out"], last["loss"] = out_rows, loss.detach()
@@ -502,7 +530,10 @@ def main():
                 "batch_per_gpu": batch,
                 "global_batch": batch * world,
                 "img_size": args.size,
-                "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, "
+                               + ("one SUM all-reduce of the gradient bucket per step (RCCL)"
+                                  if args.workload in ("train", "detector_train") else "no data-path collective"),
+                "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
                 "conv_gflop_per_frame": round(plan.conv_flops / batch / 1e9, 3),
                 "arena_mb": round(plan.arena_bytes / 2 ** 20, 1),
             },
@@ -564,7 +595,7 @@ def main():
                 print(f"[layer] conv{mod}: {flops / 1e9:.3f} GF {ms * 1e3:.1f} us {flops / ms / 1e9:.1f} TF/s",
                       file=sys.stderr)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

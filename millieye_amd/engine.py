@@ -24,9 +24,25 @@ import torch
 
 from . import hip
 
-__all__ = ["DarknetEngine", "ConvWeights", "pick_tap_module"]
+__all__ = ["DarknetEngine", "ConvWeights", "pick_tap_module", "invalidate_weights", "bump_versions"]
 
 _ALIGN = 256  # bytes
+
+# Packed-weight caches compare ``(data_ptr, _version)`` stamps.  Writers that bypass the version counter - reference-style
+# ``param.data.copy_()`` / ``.data.normal_()`` in user code, or a kernel writing through a raw pointer - call
+# :func:`invalidate_weights` (or ``Darknet.invalidate_weights()``): the epoch is part of every stamp.
+_EPOCH = [0]
+
+
+def invalidate_weights():
+    """Force every packed device copy (conv weights, folded BN scale/shift, head packs) to be rebuilt before its next use."""
+    _EPOCH[0] += 1
+
+
+def bump_versions(*tensors):
+    """Make a raw-pointer write (HIP kernel) to ``tensors`` visible to the ``(data_ptr, _version)`` stamps - no launch."""
+    torch.autograd.graph.increment_version(tensors)
+
 _DTYPES = ("f32", "bf16", "f16")
 _TORCH_HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 
@@ -84,7 +100,7 @@ class ConvWeights:
         return ts
 
     def stamp(self):
-        return tuple((t.data_ptr(), t._version) for t in self._sources())
+        return tuple((t.data_ptr(), t._version) for t in self._sources()) + (_EPOCH[0],)
 
     def refresh(self, device):
         stamp = self.stamp()
@@ -219,7 +235,7 @@ class DarknetEngine:
                     "Darknet BatchNorm in training mode (batch statistics) is not on the accelerated "
                     "inference path; call model.eval() (the reference keeps base_detector.eval(), "
                     "module3_our_dataset/train.py:170)")
-        stamp = tuple([(t.data_ptr(), t._version) for t in [dct[key] for dct, key in slots]]) + (str(device),)
+        stamp = tuple([(t.data_ptr(), t._version) for t in [dct[key] for dct, key in slots]]) + (str(device), _EPOCH[0])
         if stamp == self._fast_stamp:
             return
         for i, d in enumerate(self.model.module_defs):

@@ -482,7 +482,7 @@ _ws_cache = {}
 def _workspace(nbytes, device, slot="nms"):
     key = (slot, device.index if device.index is not None else torch.cuda.current_device())
     ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
+    if ws is None or ws.numel() - ((-ws.data_ptr()) % 256) < nbytes:  # usable bytes behind the aligned start
         ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     off = (-ws.data_ptr()) % 256

@@ -66,7 +66,7 @@ class _HeadPack:
         rh, eh = self.net.refinement_head, self.net.ensemble_head
         src = [rh.net0[0].weight, rh.net0[0].bias, rh.net1[0].weight, rh.net1[0].bias, rh.net2[0].weight, rh.net2[0].bias,
                eh.fc1[0].weight, eh.fc1[0].bias, eh.fc2[0].weight, eh.fc2[0].bias]
-        stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(device),)
+        stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(device), _engine._EPOCH[0])
         if stamp != self._stamp:
             f = dict(device=device, dtype=torch.float32)
             with torch.no_grad():

@@ -22,6 +22,7 @@ import numpy as np  # noqa: F401
 import torch
 from torch import nn
 
+from . import engine as _engine
 from . import hip
 from .engine import ConvWeights
 from .utils.utils import *  # noqa: F401,F403  (reference re-exports its utils through this module)
@@ -215,7 +216,7 @@ class _HeadPack:
                 eh.fc2[0].weight, eh.fc2[0].bias]
 
     def refresh(self, device):
-        stamp = tuple((t.data_ptr(), t._version) for t in self._sources()) + (str(device),)
+        stamp = tuple((t.data_ptr(), t._version) for t in self._sources()) + (str(device), _engine._EPOCH[0])
         if stamp == self._stamp:
             return self.t
         rh, eh = self.net.refinement_head, self.net.ensemble_head

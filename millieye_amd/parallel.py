@@ -9,7 +9,9 @@ in this build and deliberately minimal, shaped for xGMI:
   405-406,617,631), so data parallelism is a SUM all-reduce of the gradients - not a mean.  The trainable
   state is 100 153 parameters (0.40 MB fp32): a single flat bucket and ONE RCCL call per optimizer step
   (pure latency on xGMI; bucketing / overlap machinery would only add launches).  Negative sampling uses
-  each rank's own ``random`` stream, BatchNorm statistics are per shard (like per-GPU BN in any DDP run).
+  each rank's own ``random`` stream, BatchNorm statistics are per shard (like per-GPU BN in any DDP run);
+  with eval-mode BatchNorm and no sub-sampling the summed shard gradients equal the 1-way step exactly
+  (tests/test_parallel_cpu.py::test_dp_stage3_step_equals_one_way).
 
 ``torch.distributed`` (backend ``nccl`` = RCCL on ROCm, ``gloo`` in the CPU tests) is the transport.
 """
@@ -69,24 +71,46 @@ def flatten_grads(params):
     return bucket, params
 
 
-def allreduce_gradients(params, group=None):
-    """SUM all-reduce of the gradients of ``params`` through one flat bucket (one collective per step).
-    Parameters whose gradient is ``None`` on every rank stay ``None``.  Returns the bucket size in bytes."""
-    bucket, params = flatten_grads(params)
-    if bucket.numel() == 0:
+_PATTERN = {}  # id(first parameter) -> tuple of "has a gradient somewhere" flags seen so far (see allreduce_gradients)
+
+
+def allreduce_gradients(params, group=None, static_pattern=False):
+    """SUM all-reduce of the gradients of ``params`` through ONE flat bucket = one collective per step.
+
+    The bucket carries, behind the gradients, one flag per parameter ("this rank produced a gradient"), so the question
+    "who has a gradient anywhere" (a rank whose shard yields no RoI returns ``None`` for everything; ``net1`` / ``net3`` /
+    ``fusion_head`` never get one) rides in the same collective instead of a second MAX all-reduce.  Parameters whose
+    gradient is ``None`` on every rank stay ``None``.  Reading the reduced flags back is a host sync (after the
+    collective, local to the rank).  ``static_pattern=True`` (the training loops of this package): the set of parameters
+    that can receive a gradient is a property of the model, and a rank produces either that whole set or - empty shard -
+    nothing; then the flags are only read when this rank's own pattern is empty or differs from the union it has seen,
+    i.e. in steady state the step issues one RCCL call and never waits on the device.  Returns the gradient bytes."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return 0
-    had = [1.0 if p.grad is not None else 0.0 for p in params]
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
-        had_t = torch.tensor(had, device=bucket.device)
-        dist.all_reduce(had_t, op=dist.ReduceOp.MAX, group=group)  # tiny: who has a gradient anywhere
-        had = had_t.tolist()
-    # single process: the local list is the answer - no device tensor, no host sync on the backward kernels
+    distributed = dist.is_available() and dist.is_initialized()
+    had = tuple(p.grad is not None for p in params)
+    if not distributed:
+        return sum(p.numel() for p in params) * 4  # single process: nothing to exchange, nothing to copy
+    dev = next((p.grad.device for p in params if p.grad is not None), params[0].device)
+    pieces = [p.grad.reshape(-1).to(torch.float32) if p.grad is not None else torch.zeros(p.numel(), device=dev)
+              for p in params]
+    pieces.append(torch.tensor([1.0 if h else 0.0 for h in had], device=dev))
+    bucket = torch.cat(pieces)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    n_grad = bucket.numel() - len(params)
+    key = (id(params[0]), len(params))
+    union = _PATTERN.get(key)
+    if static_pattern and union == had and any(had):
+        anywhere = had
+    else:  # first step / empty shard / caller makes no promise: look at the reduced flags (the step's only host sync)
+        anywhere = tuple(f > 0 for f in bucket[n_grad:].tolist())
+        _PATTERN[key] = anywhere if union is None else tuple(a or b for a, b in zip(anywhere, union))
     off = 0
     dst, src = [], []
-    for p, h in zip(params, had):
+    for p, h in zip(params, anywhere):
         n = p.numel()
-        if h > 0:
+        if h:
             g = bucket[off:off + n].view_as(p)
             if p.grad is None:
                 p.grad = g.clone()
@@ -96,4 +120,4 @@ def allreduce_gradients(params, group=None):
         off += n
     if dst:
         torch._foreach_copy_(dst, src)  # batched: one launch per ~100 tensors instead of one per parameter
-    return bucket.numel() * 4
+    return n_grad * 4

@@ -76,11 +76,24 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
     distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
     rank = torch.distributed.get_rank() if distributed else 0
     history = dict(losses=[], steps=[], checkpoints=[], evaluations=[])
+    trainable = [p for p in model.parameters() if p.requires_grad]
 
     for epoch in range(epochs):
         model.train()
         model.base_detector.eval()
         start_time = time.time()
+        if distributed:
+            # every rank must issue the same number of collectives: the step (and its all-reduce) is keyed on the local
+            # batch counter, so an uneven shard would hang the job - fail loudly instead
+            lens = torch.tensor([len(dataloader), -len(dataloader)], dtype=torch.int64, device=device if
+                                torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(lens, op=torch.distributed.ReduceOp.MAX)
+            if int(lens[0]) != -int(lens[1]):
+                raise RuntimeError(f"ranks see different batch counts per epoch (min {-int(lens[1])}, max {int(lens[0])}): "
+                                   "shard the dataset evenly (DistributedSampler pads to equal counts; main() does)")
+            sampler = getattr(dataloader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)
         for batch_i, (_, imgs, targets, radar_boxes, radar_maps) in enumerate(dataloader):
             batches_done = len(dataloader) * epoch + batch_i
             epoch_batches_left = len(dataloader) - (batch_i + 1)
@@ -93,7 +106,7 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
 
             if batches_done % gradient_accumulations == 0:
                 if distributed:
-                    parallel.allreduce_gradients([p for p in model.parameters() if p.requires_grad])
+                    parallel.allreduce_gradients(trainable, static_pattern=True)
                 optimizer.step()
                 optimizer.zero_grad()
                 history["steps"].append(batches_done)
@@ -118,7 +131,9 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
             torch.save(model.state_dict(), path)
             history["checkpoints"].append(path)
 
-        if epoch % evaluation_interval == 0 and evaluate_fn is not None:
+        if distributed and epoch % evaluation_interval == 0 and evaluate_fn is not None:
+            torch.distributed.barrier()  # the replicas are identical after the step: rank 0 evaluates, the others wait
+        if epoch % evaluation_interval == 0 and evaluate_fn is not None and rank == 0:
             log("\n---- Evaluating Model ----")
             precision, recall, AP, f1, ap_class, _, _ = result = evaluate_fn(
                 model, mode="test", model_mode=0, illumination=["L"], iou_thresh=0.5, nms_thresh=0.5,
@@ -165,6 +180,15 @@ def main(argv=None):
 
     opt = build_parser().parse_args(argv)
     class_names = load_classes(opt.classes_path)
+    # data parallel (new in this build): started under ``python -m torch.distributed.run --nproc-per-node N
+    # -m millieye_amd.train ...`` every process takes the GPU of its LOCAL_RANK and a 1/N shard of each epoch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     model = Network(define_yolo(opt.yolo_cfg), opt.conf_thresh)
     model = model.to(model.device)
     if opt.checkpoint:
@@ -174,9 +198,15 @@ def main(argv=None):
         init_yolo(model=model.base_detector, weights_path=opt.yolo_weights)
     if opt.pretrained_module2:
         load_pretrained_module2(model, torch.load(opt.pretrained_module2))
+    if world > 1:  # the random initialisation above drew from each process's own RNG: replicas start from rank 0's state
+        with torch.no_grad():
+            for t in model.state_dict().values():
+                torch.distributed.broadcast(t, 0)
+        model.base_detector.invalidate_weights()
     dataset = MyDataset(mode="train", illumination=opt.illumination, augment=False, multiscale=True)
-    dataloader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=True, num_workers=opt.n_cpu,
-                                             pin_memory=True, collate_fn=dataset.collate_fn)
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if world > 1 else None
+    dataloader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=sampler is None, sampler=sampler,
+                                             num_workers=opt.n_cpu, pin_memory=True, collate_fn=dataset.collate_fn)
     train_loop(model, dataloader, epochs=opt.epochs, gradient_accumulations=opt.gradient_accumulations,
                checkpoint_interval=opt.checkpoint_interval, evaluation_interval=opt.evaluation_interval,
                test_list=opt.test_list, img_size=opt.img_size, batch_size=opt.batch_size, class_names=class_names)

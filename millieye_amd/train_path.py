@@ -68,6 +68,9 @@ def _bn_fwd(x, ldx, rows, c, bn, act, y, ldy, ws):
                                             float(bn.momentum), _ptr(bn.running_mean), _ptr(bn.running_var), act,
                                             _ptr(y), ldy, _ptr(st.mean), _ptr(st.var), _ptr(st.rstd), ws,
                                             hip.stream_ptr()), "me_bn_train_fwd_f32")
+    # the kernel wrote the running statistics through raw pointers: bump their version counters so the packed
+    # scale/shift caches (engine.ConvWeights, my_models._HeadPack) re-fold them at the next eval-mode forward
+    torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
     with torch.no_grad():
         bn.num_batches_tracked += 1
     return st

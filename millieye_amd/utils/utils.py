@@ -61,13 +61,15 @@ def weights_init_normal(m):
     Linear kaiming-normal.  Class-name matching is kept so the torch RNG stream is
     consumed in the same order as the reference."""
     name = type(m).__name__
+    # the reference writes through ``.data`` (own version counter: the parameter's ``_version`` would stay put and the
+    # engine's packed copies would not notice); ``nn.init.*`` on the parameter draws the same numbers and bumps it
     if "Conv" in name:
-        torch.nn.init.normal_(m.weight.data, 0.0, 0.02)
+        torch.nn.init.normal_(m.weight, 0.0, 0.02)
     elif "BatchNorm2d" in name:
-        torch.nn.init.normal_(m.weight.data, 1.0, 0.02)
-        torch.nn.init.constant_(m.bias.data, 0.0)
+        torch.nn.init.normal_(m.weight, 1.0, 0.02)
+        torch.nn.init.constant_(m.bias, 0.0)
     elif "Linear" in name:
-        nn.init.kaiming_normal_(m.weight.data)
+        nn.init.kaiming_normal_(m.weight)
 
 
 def rescale_boxes(boxes, current_dim, original_shape):

@@ -334,7 +334,8 @@ class Darknet(nn.Module):
         def take(dst):
             nonlocal cursor
             count = dst.numel()
-            dst.data.copy_(torch.from_numpy(stream[cursor: cursor + count]).view_as(dst))
+            with torch.no_grad():  # not ``.data.copy_`` (reference style): that leaves ``dst._version`` where it was
+                dst.copy_(torch.from_numpy(stream[cursor: cursor + count]).view_as(dst))
             cursor += count
 
         for spec, module in self._conv_blocks(stop=cutoff):
@@ -346,6 +347,15 @@ class Darknet(nn.Module):
             else:
                 take(conv.bias)
             take(conv.weight)
+        self.invalidate_weights()
+
+    @staticmethod
+    def invalidate_weights():
+        """Rebuild every packed device copy of the parameters before the next forward.  Only needed after writes that
+        bypass the autograd version counter (``param.data.copy_()`` / ``.data.normal_()`` in reference-style user code);
+        ``load_state_dict``, optimizers, ``nn.init`` and this class's own loaders are tracked automatically."""
+        from ..engine import invalidate_weights
+        invalidate_weights()
 
     def save_darknet_weights(self, path, cutoff=-1):
         """Inverse of :meth:`load_darknet_weights`; ``cutoff`` slices ``module_defs[:cutoff]``

@@ -213,17 +213,20 @@ def obtain_iou_labels(boxes, targets, multi_boxes=True):
     return iou_labels, target_location
 
 
-def _bn_train(x, P, B, prefix):
+def _bn_train(x, P, B, prefix, training=True):
     return F.batch_norm(x, B[prefix + "running_mean"], B[prefix + "running_var"], P[prefix + "weight"],
-                        P[prefix + "bias"], True, 0.1, 1e-5)
+                        P[prefix + "bias"], training, 0.1, 1e-5)
 
 
 def network_train_step(cfg_text, sd, images, maps, radar_boxes, targets, conf_thresh=0.2, class_idx=0, class_num=1,
-                       tap_module=8, iou_thresh=(0.3, 0.7), alpha=0.75, balance_factor=5, loss_lambda=(6, 1)):
+                       tap_module=8, iou_thresh=(0.3, 0.7), alpha=0.75, balance_factor=5, loss_lambda=(6, 1),
+                       bn_training=True):
     """One training forward + backward on CPU autograd.  ``sd``: full Network state dict.  ``targets`` [q,6]
     (image_i, class, cx, cy, w, h in [0,1]) is NOT modified.  Python's ``random`` must be seeded by the
     caller (negative sampling, quirk q7).  Returns dict(loss, masks_loss, conf_loss, output, grads{name: tensor},
-    buffers{name: updated running stat}, internals)."""
+    buffers{name: updated running stat}, internals).  ``bn_training=False`` (not a reference mode; used by the
+    data-parallel equivalence tests): the head BatchNorms use their running statistics, which makes every loss term and
+    gradient a plain sum over frames."""
     det_sd = {k[len("base_detector."):]: v for k, v in sd.items() if k.startswith("base_detector.")}
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()
          if not k.startswith("base_detector.") and v.dtype == torch.float32 and "running_" not in k}
@@ -244,12 +247,12 @@ def network_train_step(cfg_text, sd, images, maps, radar_boxes, targets, conf_th
     num_img = len(img_boxes)
     p = "img_cnn_layers.net."
     x = F.conv2d(feature_map, P[p + "conv_0.weight"], P[p + "conv_0.bias"])
-    roi_score_map = F.leaky_relu(_bn_train(x, P, B, p + "batch_norm_0."), 0.1)
+    roi_score_map = F.leaky_relu(_bn_train(x, P, B, p + "batch_norm_0.", bn_training), 0.1)
     x = maps
     for name in ("conv1", "conv2", "conv3"):
         q = f"radar_cnn_layers.{name}."
         x = F.conv2d(x, P[q + "0.weight"], P[q + "0.bias"], padding=1)
-        x = F.leaky_relu(_bn_train(x, P, B, q + "1."), 0.1)
+        x = F.leaky_relu(_bn_train(x, P, B, q + "1.", bn_training), 0.1)
     radar_score_map = torch.sigmoid(F.conv2d(x, P["radar_cnn_layers.conv3.3.weight"], P["radar_cnn_layers.conv3.3.bias"]))
     radar_boxes = radar_boxes.clone()
     if len(radar_boxes) > 0:
@@ -262,7 +265,7 @@ def network_train_step(cfg_text, sd, images, maps, radar_boxes, targets, conf_th
     regress_param = F.linear(t, P[r + "net1.0.weight"], P[r + "net1.0.bias"])
     class_vector = torch.sigmoid(F.linear(t, P[r + "net2.0.weight"], P[r + "net2.0.bias"]))
     rr = F.conv2d(crop_radar, P[r + "radar_net.0.weight"], P[r + "radar_net.0.bias"])
-    rr = F.leaky_relu(_bn_train(rr, P, B, r + "radar_net.1."), 0.1)
+    rr = F.leaky_relu(_bn_train(rr, P, B, r + "radar_net.1.", bn_training), 0.1)
     rr = torch.sigmoid(F.conv2d(rr, P[r + "radar_net.3.weight"], P[r + "radar_net.3.bias"]))
     confidence = torch.sigmoid(rr.squeeze(-1).squeeze(-1) + class_vector[:, :1])
     refinement_vector = torch.cat((confidence, class_vector[:, 1:2]), -1)

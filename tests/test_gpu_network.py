@@ -234,3 +234,34 @@ def test_demo_frame_step(hip_lib):
     for f in range(4):
         rows2, _ = fuser2(dark, [radar_points(f)])
         assert torch.equal(rows2, outs[f][0])
+
+
+def test_headline_workload_batch32_vs_oracle(hip_lib):
+    """The configuration the metric is quoted on, end to end: yolov3.cfg (Darknet-53) 416x416, batch 32, full
+    ``Network.forward`` mode 0 with two radar boxes per frame.  The CPU oracle needs seconds per frame, so it runs on
+    four frames of the batch one at a time (frames are independent units; row order inside a frame is the batch run's
+    order because the descending-confidence sort is stable)."""
+    from oracle import network_ref
+    name, cfg, n, s, conf = "headline", "yolov3", 32, 416, 0.2
+    from millieye_amd.my_models import Network, define_yolo
+    net = Network(define_yolo(ph.cfg_path(cfg)), conf).eval()
+    synth.fill_network_(net, name, cls0_bias=3.0, cls_bias=-4.0)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    maps, rboxes = synth.radar_inputs(name + "/radar", n, s // 16, boxes_per_image=2)
+    maps, rboxes = torch.from_numpy(maps), torch.from_numpy(rboxes)
+    net = net.cuda()
+    with torch.no_grad():
+        out = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).cpu()
+    assert out.shape[0] > 32 and out.shape[1] == 8
+    text = cfgs.KNOWN[cfg]()
+    total = 0
+    for f in (0, 13, 22, 31):
+        rb = rboxes[rboxes[:, 0] == f].clone()
+        rb[:, 0] = 0
+        ref = network_ref.network_forward(text, sd, x[f:f + 1], maps[f:f + 1], rb, 0, conf_thresh=conf, tap_module=91)
+        got = out[out[:, 0] == f].clone()
+        got[:, 0] = 0
+        _cmp_rows(got, ref, f"headline batch-32 run, frame {f}")
+        total += ref.shape[0]
+    assert total >= 8, "the sampled frames must carry detections"

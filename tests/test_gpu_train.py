@@ -229,3 +229,63 @@ def test_frozen_parameters_get_no_gradient(hip_lib):
         if k in frozen:
             assert p.grad is None
     assert net.ensemble_head.fc2[0].weight.grad is not None
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_training_step_with_16bit_frozen_detector(hip_lib, dtype):
+    """BASELINE configs[3] names "bf16 training": in stage 3 the detector is frozen (train.py:170), so the 16-bit part of
+    the step is its inference pass (``Darknet.compute_dtype``); heads, loss, backward and the gradient bucket stay fp32.
+    The step must be the fp32 step up to the detector's storage error: same RoI population (+-10 %), loss within 10 %,
+    the concatenated head gradient pointing the same way (cosine >= 0.95; bf16 moves box corners by <= 2 px and the
+    feature tap by its 8-bit mantissa), finite everywhere, run-to-run deterministic given the python RNG seed."""
+    name, cfg, n, s, conf = "train16", "yolov3-tiny-12", 8, 416, 0.2
+    from millieye_amd.my_models import Network, define_yolo
+    net = Network(define_yolo(ph.cfg_path(cfg)), conf)
+    synth.fill_network_(net, name, cls0_bias=3.0, cls_bias=-4.0)
+    net = net.cuda().eval()
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s))).cuda()
+    maps, rboxes = synth.radar_inputs(name + "/radar", n, s // 16)
+    maps, rboxes = torch.from_numpy(maps).cuda(), torch.from_numpy(rboxes)
+    with torch.no_grad():
+        det = net(x, maps, rboxes.clone().cuda(), 1).cpu()
+    tg = []
+    for i in range(n):
+        rows_i = det[det[:, 0] == i]
+        for j in (0, 3):
+            if j < len(rows_i):
+                b = rows_i[j, 1:5] / s
+                tg.append([i, 0, float((b[0] + b[2]) / 2), float((b[1] + b[3]) / 2), float(b[2] - b[0]) * 1.05,
+                           float(b[3] - b[1]) * 0.95])
+    targets = torch.tensor(tg, dtype=torch.float32).reshape(-1, 6)
+    assert len(targets) >= n
+
+    def step(mode):
+        net.base_detector.compute_dtype = mode
+        net.train()
+        net.base_detector.eval()
+        for p in net.parameters():
+            p.grad = None
+        random.seed(99)
+        loss, rows, metric, _att = net(x, maps, rboxes.clone().cuda(), targets.clone())
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for k, p in net.named_parameters()
+                           if not k.startswith("base_detector.") and p.grad is not None]).cpu()
+        return float(loss), int(net._last_train["k"]), int(metric["true"]), grads, rows.detach().cpu()
+
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+    l32, k32, pos32, g32, _rows32 = step("f32")
+    net.load_state_dict(bn_state, strict=False)   # the same running statistics in front of both steps
+    l16, k16, pos16, g16, rows16 = step(dtype)
+    net.load_state_dict(bn_state, strict=False)
+    l16b, k16b, _p, g16b, rows16b = step(dtype)
+    assert (l16, k16) == (l16b, k16b) and torch.equal(rows16, rows16b), "16-bit step must be deterministic"
+    assert float((g16 - g16b).abs().max()) <= 1e-5 * float(g16.abs().max())  # RoI scatters use atomics (like torchvision)
+    assert pos32 > 0 and k32 > 50
+    assert abs(k16 - k32) <= 0.1 * k32, (k16, k32)
+    assert abs(l16 - l32) <= 0.1 * abs(l32), (l16, l32)
+    assert bool(torch.isfinite(g16).all()) and g16.shape == g32.shape
+    cos = float(torch.dot(g16.double(), g32.double()) / (g16.double().norm() * g32.double().norm()))
+    assert cos >= 0.95, f"gradient cosine {cos:.4f}"
+    for k, p in net.named_parameters():
+        if k.startswith("base_detector."):
+            assert p.grad is None

@@ -87,3 +87,99 @@ def test_allreduce_gradients_gloo_world2():
                 assert res[k] is None  # frozen, or no gradient on any rank
             else:
                 assert torch.allclose(torch.from_numpy(res[k]), p.grad, atol=1e-6), (rank, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data parallelism of the REAL stage-3 step: shard_batch + one flat-bucket all-reduce must reproduce the 1-way step.
+# The compute is the oracle's CPU training step (the HIP path needs a GPU; tests/test_gpu_parallel.py does the same on
+# it): eval-mode head BatchNorm and balance_factor = "all negatives" make every loss term a plain sum over frames.
+# ---------------------------------------------------------------------------------------------------------------------
+DP_CASE = ("dp_tiny12_s160_n4", "yolov3-tiny-12", 4, 160, 0.2)
+
+
+def _dp_problem():
+    import numpy as np
+    from millieye_amd import cfgs, synth
+    from millieye_amd.my_models import Network, define_yolo
+    from tests.parity_helpers import cfg_path
+    from tests.golden.make_golden import train_inputs
+    name, cfg, n, s, conf = DP_CASE
+    net = Network(define_yolo(cfg_path(cfg)), conf)
+    synth.fill_network_(net, name)
+    x, maps, rboxes = train_inputs(name, n, s)
+    # targets on top of two radar boxes per frame (radar rows are proposals of class 0, so IoU-positive samples exist)
+    tg = []
+    for row in rboxes.numpy():
+        i, x1, y1, x2, y2 = row
+        tg.append([i, 0, (x1 + x2) / 2, (y1 + y2) / 2, (x2 - x1) * 1.02, (y2 - y1) * 0.98])
+    targets = torch.tensor(np.array(tg, dtype=np.float32))
+    return cfgs.KNOWN[cfg](), net, x, maps, rboxes, targets, conf
+
+
+def _dp_step(cfg_text, sd, x, maps, rboxes, targets, conf):
+    import random
+    from oracle import network_ref
+    random.seed(0)
+    return network_ref.network_train_step(cfg_text, sd, x, maps, rboxes, targets, conf_thresh=conf, bn_training=False,
+                                          balance_factor=10 ** 9)
+
+
+def _dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    from millieye_amd.train_path import head_parameters
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg_text, net, x, maps, rboxes, targets, conf = _dp_problem()
+    xs, ms, rb, tg = par.shard_batch(x, maps, rboxes, targets, rank, world)
+    res = _dp_step(cfg_text, net.state_dict(), xs, ms, rb, tg, conf)
+    heads = head_parameters(net)
+    names = [k for k, _ in net.named_parameters() if not k.startswith("base_detector.")]
+    for step in range(2):  # second call: the steady-state path (static pattern, no flag read-back)
+        for name, p in zip(names, heads):  # (clone: the reduced values are written into p.grad in place)
+            p.grad = None if res["grads"][name] is None else res["grads"][name].clone()
+        nbytes = par.allreduce_gradients(heads, static_pattern=True)
+    out = {name: (None if p.grad is None else p.grad.numpy().copy()) for name, p in zip(names, heads)}
+    q.put((rank, nbytes, float(res["loss"]), res["num_img"], out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_stage3_step_equals_one_way():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, nbytes, loss, num_img, grads = q.get(timeout=600)
+        got[rank] = (nbytes, loss, num_img, grads)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg_text, net, x, maps, rboxes, targets, conf = _dp_problem()
+    torch.set_num_threads(4)
+    ref = _dp_step(cfg_text, net.state_dict(), x, maps, rboxes, targets, conf)
+    assert ref["n_pos"] > 0 and ref["num_img"] > 0
+    assert got[0][1] + got[1][1] == __import__("pytest").approx(float(ref["loss"]), rel=1e-5)  # the loss is a sum over frames
+    assert got[0][1] > 0 and got[1][1] > 0 and got[0][2] + got[1][2] == ref["num_img"]
+    n_checked = 0
+    for name, g in ref["grads"].items():
+        for rank in (0, 1):
+            mine = got[rank][3][name]
+            if g is None:
+                assert mine is None, name
+                continue
+            scale = max(float(g.abs().max()), 1e-6)
+            assert float((torch.from_numpy(mine) - g).abs().max()) <= 2e-5 * scale, (name, rank)
+        n_checked += g is not None
+    assert n_checked >= 20
+    assert got[0][0] == got[1][0] == 4 * sum(p.numel() for p in net.parameters()
+                                            if p.requires_grad) - 4 * sum(p.numel() for p in net.base_detector.parameters())
