@@ -22,104 +22,15 @@
 #include "common.h"
 #include "dma.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "conv16_common.h"
 
-// The two 16-bit storage types: F16 = 0 bfloat16 (v_mfma_f32_32x32x16_bf16), F16 = 1 IEEE half (v_mfma_f32_32x32x16_f16;
-// BASELINE configs[4] "fp16 MFMA convs").  Same kernels, same layouts; only the operand type, the MFMA and the conversions
-// differ.  Both round to nearest even.
-template <int F16>
-struct H16;
-template <>
-struct H16<0> {
-  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
-  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ unsigned short to(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
-  static __device__ __forceinline__ float from(unsigned b) { return __uint_as_float(b << 16); }
-};
-template <>
-struct H16<1> {
-  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
-  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ unsigned short to(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
-  static __device__ __forceinline__ float from(unsigned b) {
-    return (float)__builtin_bit_cast(_Float16, (unsigned short)b);
-  }
-};
+namespace me16 {  // conv_p8_h16.hip: patch-resident big-tile generation (tile ids >= 100)
+bool p8_eligible(const Conv16P& p, int tile);
+int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream);
+}  // namespace me16
 
 namespace {
 using namespace me_dma;
-
-struct Conv16P {
-  const unsigned short* x;
-  const unsigned short* wgt;
-  const float* scale;
-  const float* shift;
-  const void* res;
-  void* y;
-  long long x_pitch, res_pitch, y_pitch;  // elements
-  int n, h, w, cin, cout, ks, stride, pad, ho, wo, act, ups, y_f32, x_nchw;
-  int M;       // n*ho*wo
-  int ktot;    // ks*ks*cin
-  int cs;      // stages per filter tap = cin / (32*KSUB)
-  int stages;  // ks*ks*cs
-  int tiles_m, tiles_n;
-  float* partial;  // split-K slabs [splitk][M][cout] (raw fp32 accumulators), or nullptr
-  int splitk, sps;
-  int f16;         // 0 = bfloat16 storage, 1 = IEEE half
-  int vec_epi;     // 16-byte epilogue allowed (bf16 out, no upsample, leaky / linear, pitches % 8, 16-byte aligned)
-};
-
-__device__ __forceinline__ float act16(float v, int act) {
-  if (act == ME_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
-  if (act == ME_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
-  return v;
-}
-template <int F16>
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)H16<F16>::to(lo) | ((unsigned)H16<F16>::to(hi) << 16);
-}
-
-template <class F, int... J>
-__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, J...>) {
-  (f(std::integral_constant<int, J>{}), ...);
-}
-
-// one output element through the fused epilogue tail: residual, rounding, (replicated) store
-template <int F16>
-__device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float v, int hw) {
-  if (p.res) {
-    v += p.y_f32 ? reinterpret_cast<const float*>(p.res)[(long long)m * p.res_pitch + co]
-                 : H16<F16>::from(reinterpret_cast<const unsigned short*>(p.res)[(long long)m * p.res_pitch + co]);
-  }
-  if (p.ups == 1) {
-    const long long o = (long long)m * p.y_pitch + co;
-    if (p.y_f32)
-      reinterpret_cast<float*>(p.y)[o] = v;
-    else
-      reinterpret_cast<unsigned short*>(p.y)[o] = H16<F16>::to(v);
-    return;
-  }
-  const int nimg = m / hw;
-  const int rem = m - nimg * hw;
-  const int oy = rem / p.wo, ox = rem - oy * p.wo;
-  const int W2 = p.wo * 2;
-  const long long base = ((long long)nimg * (p.ho * 2) + 2 * oy) * W2 + 2 * ox;
-  const long long o[4] = {base * p.y_pitch + co, (base + 1) * p.y_pitch + co, (base + W2) * p.y_pitch + co,
-                          (base + W2 + 1) * p.y_pitch + co};
-  if (p.y_f32) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) reinterpret_cast<float*>(p.y)[o[k]] = v;
-  } else {
-    const unsigned short b = H16<F16>::to(v);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) reinterpret_cast<unsigned short*>(p.y)[o[k]] = b;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // implicit GEMM on the bf16 matrix cores.  M = n*ho*wo output pixels, N = cout, K = ks*ks*cin.
 // Needs cin % (32*KSUB) == 0 (the planner pads the one odd tensor of the tiny cfgs, engine.py).
@@ -1052,6 +963,7 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   p.splitk = split;
   p.partial = reinterpret_cast<float*>(d->workspace);
   if (tile == 41) return p.f16 ? launch_patch<1>(p, stream) : launch_patch<0>(p, stream);
+  if (tile >= 100) return me16::launch_p8_tile(p, tile, stream);
   const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows
   if (p.f16) {
     switch (tile) {

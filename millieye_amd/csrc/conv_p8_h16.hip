@@ -1,0 +1,369 @@
+// conv_p8_h16.hip - patch-resident, big-tile generation of the 16-bit 3x3 / stride-1 convolution (gfx950).
+//
+// Why (profiles/r01_h16_*: the per-tap kernel of conv_h16.hip pulls ~600 MB of operand re-reads through L2 per launch and
+// issues 0.46 DMA + 1.18 LDS instructions per MFMA; with no DMA at all the same loop runs at 1.4 PFLOP/s): the nine taps of a
+// 3x3 filter read the same input pixels shifted by one, so a tile's input is brought into LDS ONCE per 32-channel chunk and
+// the taps are walked by LDS row offset; only the weights stream per tap (3-slot ring).
+//
+// Index space.  Output pixels are numbered in a PADDED-LINEAR space: row pitch Wp = W + 1 (one zero column behind every row),
+// image pitch Ip = (H + 1) * Wp (one zero row behind every image), q = n * Ip + y * Wp + x.  The neighbour of q for tap
+// (dy, dx) is q + dy * Wp + dx for EVERY q - the zero column is the left neighbour of the next row and the right neighbour of
+// this one, the zero row is "above" the next image and "below" this one - so a tile of BM consecutive positions needs the
+// contiguous range [q0 - Wp - 1, q0 + BM + Wp + 1) whatever it contains: tiles may start anywhere and cross rows and images
+// (the first patch kernel, tile 41, had to stop at image borders: 22-34 % idle rows at 26x26 / 13x13).  Pad positions cost
+// MFMA work ((H+1)(W+1)/(HW) - 1: 4 % at 52x52, 16 % at 13x13) and are neither loaded (out-of-range DMA lanes zero-fill LDS)
+// nor stored.  HBM layouts do not change: dense NHWC in, dense NHWC out.
+//
+// Workgroup = 8 waves (WR x WC), tile BM x BN = (32 MT WR) x (32 NT WC), one workgroup per CU for the big tiles.
+// LDS: [weight ring: 3 x BN x 64 B][patch slot 0][patch slot 1], patch rows are 64 B (32 channels), XOR-swizzled by
+// (row >> 2) & 3 like every other tile of this library (ds_read_b128 conflict-free).
+// Stage = (chunk, tap): ONE barrier per 2 * MT * NT MFMAs per wave (the per-tap kernel: per 8), DMA instructions per wave and
+// stage: BN / 128 for the weights + the next chunk's patch once per nine stages.
+#include "conv16_common.h"
+
+namespace {
+using namespace me_dma;
+
+struct P8Args {
+  Conv16P c;
+  int Wp, Ip, halo;       // padded-linear pitches, halo = Wp + 1
+  long long Mp;           // n * Ip positions
+  unsigned ip_m, ip_s;    // magic division by Ip
+  unsigned wp_m, wp_s;    // magic division by Wp
+  int lpa;                // patch DMA instructions per wave and chunk = ceil(ceil(rows / 16) / 8)
+  int rows;               // BM + 2 * halo
+};
+
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) { return (__umulhi(n, m) + n) >> s; }
+
+__device__ __forceinline__ void dma1(unsigned v, u32x4 r, unsigned s, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[r], %[s] offen lds\n\t"
+               "s_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep)
+               : [d] "s"(dst), [r] "s"(r), [s] "s"(s), [v] "v"(v)
+               : "memory", "scc");
+}
+
+constexpr int kLpaMax = 7;
+
+// ABL (tuning only, wrong results): 1 = all DMA lanes out of range, 3 = no DMA instructions
+template <int WR, int WC, int MT, int NT, int F16, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3x3_p8_h16(P8Args a) {
+  using frag = typename H16<F16>::v8;
+  const Conv16P& p = a.c;
+  constexpr int NW = WR * WC;
+  static_assert(NW == 8, "8 waves");
+  constexpr int TM = 32 * MT, TN = 32 * NT, BM = TM * WR, BN = TN * WC;
+  constexpr int LPB = BN / 16 / NW;
+  static_assert(LPB >= 1 && BN % 128 == 0, "BN must be a multiple of 128");
+  constexpr unsigned B_SLOT = BN * 64u;
+  constexpr unsigned A_BASE = 3u * B_SLOT;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int r32 = lane & 31, hh = lane >> 5;
+
+  int tile_m, tile_n;
+  {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_n = wg % p.tiles_n;
+    tile_m = wg / p.tiles_n;
+  }
+  const int W = p.w, H = p.h;
+  const long long q0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int lpa = a.lpa;
+  const unsigned A_SLOT = (unsigned)lpa * (NW * 1024u);
+
+  // first image the patch can touch: descriptor base, so that per-lane offsets stay small and non-negative
+  const long long pq0 = q0 - a.halo;
+  const int nb = pq0 > 0 ? (int)udiv_magic((unsigned)pq0, a.ip_m, a.ip_s) : 0;
+  const u32x4 rsrc_a = make_rsrc(p.x + (long long)nb * H * W * p.x_pitch);
+  const u32x4 rsrc_b = make_rsrc(p.wgt + (long long)n0 * p.ktot);
+
+  unsigned v_a[kLpaMax], v_b[LPB];
+  auto setup_a = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int r = (wave + NW * j) * 16 + (lane >> 2);
+    const int qd = (lane & 3) ^ ((r >> 2) & 3);
+    const long long pq = pq0 + r;
+    unsigned off = kOobOffset;
+    if (ABL != 1 && j < lpa && r < a.rows && pq >= 0 && pq < a.Mp) {
+      const unsigned u = (unsigned)pq;
+      const unsigned n = udiv_magic(u, a.ip_m, a.ip_s);
+      const unsigned rem = u - n * (unsigned)a.Ip;
+      const unsigned y = udiv_magic(rem, a.wp_m, a.wp_s);
+      const unsigned x = rem - y * (unsigned)a.Wp;
+      if (y < (unsigned)H && x < (unsigned)W)
+        off = (unsigned)((((long long)(n - nb) * H + y) * W + x) * p.x_pitch * 2) + 16u * qd;
+    }
+    v_a[j] = off;
+  };
+  static_for(setup_a, std::make_integer_sequence<int, kLpaMax>{});
+  auto setup_b = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int row = (wave + NW * j) * 16 + (lane >> 2);
+    const int qd = (lane & 3) ^ ((row >> 2) & 3);
+    v_b[j] = (ABL != 1 && n0 + row < p.cout) ? (unsigned)row * (unsigned)p.ktot * 2u + 16u * qd : kOobOffset;
+  };
+  static_for(setup_b, std::make_integer_sequence<int, LPB>{});
+
+  // tap -> patch row shift: output row tr reads patch row tr + (1 + dy) * Wp + (1 + dx)
+  int tapoff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((t / 3) * a.Wp + (t % 3));
+
+  unsigned rowbase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rowbase[i] = (unsigned)(wr * TM + i * 32 + r32);
+  const int swb = (r32 >> 2) & 3;
+  const unsigned char* b_frag = smem16 + (wc * TN + r32) * 64;
+  const unsigned b_offk[2] = {(unsigned)(((0 + hh) ^ swb) * 16), (unsigned)(((2 + hh) ^ swb) * 16)};
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int cs = p.cin >> 5;
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+  auto issue_a = [&](int chunk, unsigned slot) {
+    if (ABL == 3) return;
+    const unsigned dst = wave_lds + A_BASE + slot * A_SLOT;
+    static_for(
+        [&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (j < lpa) dma1(v_a[j], rsrc_a, (unsigned)chunk * 64u, dst + (unsigned)j * (NW * 1024u));
+        },
+        std::make_integer_sequence<int, kLpaMax>{});
+  };
+  auto issue_b = [&](int chunk, int tap, unsigned ring) {
+    if (ABL == 3) return;
+    const unsigned soff = ((unsigned)tap * (unsigned)p.cin + (unsigned)chunk * 32u) * 2u;
+#pragma unroll
+    for (int j = 0; j < LPB; ++j) dma1(v_b[j], rsrc_b, soff, wave_lds + ring * B_SLOT + (unsigned)j * (NW * 1024u));
+  };
+  // s_waitcnt takes an immediate: the runtime patch count goes through a uniform switch
+  auto wait_b_plus_a = [&]() {
+    switch (lpa) {
+      case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 1) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 2) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 3) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 4) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 5) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 6) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 7) : "memory"); break;
+    }
+  };
+
+  issue_a(0, 0);
+  issue_b(0, 0, 0);
+  issue_b(0, 1, 1);
+
+  auto stage = [&](auto tc, int chunk) {
+    constexpr int T = decltype(tc)::value;
+    const bool more_chunks = chunk + 1 < cs;
+    // loads younger than this stage's weights: the next tap's weights, and - at taps 1 and 2 - the next chunk's patch
+    if (ABL == 3) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (T == 8 && !more_chunks) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else if ((T == 1 || T == 2) && more_chunks) {
+      wait_b_plus_a();
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {  // weights of stage s + 2
+      constexpr int T2 = (T + 2) % 9;
+      const int c2 = chunk + (T + 2 >= 9 ? 1 : 0);
+      if (c2 < cs) issue_b(c2, T2, (unsigned)(T2 % 3));
+    }
+    if (T == 0 && more_chunks) issue_a(chunk + 1, (unsigned)((chunk + 1) & 1));
+    const unsigned char* Ab = smem16 + A_BASE + (unsigned)(chunk & 1) * A_SLOT;
+    const unsigned char* Bb = b_frag + (T % 3) * B_SLOT;
+    frag af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const unsigned R = rowbase[i] + (unsigned)tapoff[T];
+      const unsigned o0 = (R << 6) + (((R >> 2) ^ (unsigned)hh) & 3u) * 16u;
+      af[0][i] = *reinterpret_cast<const frag*>(Ab + o0);
+      af[1][i] = *reinterpret_cast<const frag*>(Ab + (o0 ^ 32u));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[ks][j] = *reinterpret_cast<const frag*>(Bb + j * 32 * 64 + b_offk[ks]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = H16<F16>::mfma(af[ks][i], bf[ks][j], acc[i][j]);
+  };
+  for (int chunk = 0; chunk < cs; ++chunk)
+    static_for([&](auto tc) { stage(tc, chunk); }, std::make_integer_sequence<int, 9>{});
+
+  // ---- epilogue: per wave, 32x32 blocks through a private LDS transpose (see conv_h16.hip), rows decoded from the
+  // padded-linear position to the dense NHWC pixel; pad positions and positions behind the last image are skipped ------
+  const float slope = p.act == ME_ACT_LEAKY ? 0.1f : 1.0f;
+  constexpr int TP = 36;
+  __syncthreads();
+  float* tbuf = reinterpret_cast<float*>(smem16) + wave * (32 * TP);
+  const int prow = lane >> 2, c8 = (lane & 3) * 8;
+  unsigned short* __restrict__ yb = reinterpret_cast<unsigned short*>(p.y);
+  const unsigned short* __restrict__ rb = reinterpret_cast<const unsigned short*>(p.res);
+  auto block_out = [&](auto ic, auto jc, const long long (&mrow)[2]) {
+    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+    const int cb = n0 + wc * TN + j * 32;
+    const float sc = p.scale[cb + r32], sh = p.shift[cb + r32];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = acc[i][j][e] * sc + sh;
+      v = v > 0.f ? v : v * slope;
+      tbuf[((e & 3) + 8 * (e >> 2) + 4 * hh) * TP + r32] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 16 + prow;
+      const float4 lo = *reinterpret_cast<const float4*>(tbuf + row * TP + c8);
+      const float4 hi = *reinterpret_cast<const float4*>(tbuf + row * TP + c8 + 4);
+      const long long m = mrow[pass];
+      if (m >= 0) {
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (rb) {
+          const uint4 r = *reinterpret_cast<const uint4*>(rb + m * p.res_pitch + cb + c8);
+          const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] += H16<F16>::from(rr[k] & 0xffffu);
+            v[2 * k + 1] += H16<F16>::from(rr[k] >> 16);
+          }
+        }
+        uint4 o;
+        o.x = pack2<F16>(v[0], v[1]);
+        o.y = pack2<F16>(v[2], v[3]);
+        o.z = pack2<F16>(v[4], v[5]);
+        o.w = pack2<F16>(v[6], v[7]);
+        *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  static_for(
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        long long mrow[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const long long q = q0 + wr * TM + i * 32 + pass * 16 + prow;
+          long long m = -1;
+          if (q < a.Mp) {
+            const unsigned u = (unsigned)q;
+            const unsigned n = udiv_magic(u, a.ip_m, a.ip_s);
+            const unsigned rem = u - n * (unsigned)a.Ip;
+            const unsigned y = udiv_magic(rem, a.wp_m, a.wp_s);
+            const unsigned x = rem - y * (unsigned)a.Wp;
+            if (y < (unsigned)H && x < (unsigned)W) m = ((long long)n * H + y) * W + x;
+          }
+          mrow[pass] = m;
+        }
+        static_for([&](auto jc) { block_out(ic, jc, mrow); }, std::make_integer_sequence<int, NT>{});
+      },
+      std::make_integer_sequence<int, MT>{});
+}
+
+void magic_u32(unsigned d, unsigned* m, unsigned* s) {
+  unsigned sh = 0;
+  while ((1ull << sh) < d) ++sh;
+  *s = sh;
+  *m = (unsigned)(((1ull << 32) * ((1ull << sh) - d)) / d + 1);
+}
+
+template <int WR, int WC, int MT, int NT, int F16, int ABL = 0>
+int launch_p8(const Conv16P& p, hipStream_t stream) {
+  constexpr int BM = 32 * MT * WR, BN = 32 * NT * WC;
+  P8Args a;
+  a.c = p;
+  a.Wp = p.w + 1;
+  a.Ip = (p.h + 1) * a.Wp;
+  a.halo = a.Wp + 1;
+  a.Mp = (long long)p.n * a.Ip;
+  a.rows = BM + 2 * a.halo;
+  a.lpa = ((a.rows + 15) / 16 + 7) / 8;
+  ME_REQUIRE(a.lpa <= kLpaMax, ME_E_TOOBIG, "me_conv2d_h16: patch of %d rows does not fit (map too wide for this tile)", a.rows);
+  ME_REQUIRE(a.Mp < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: too many padded positions");
+  magic_u32((unsigned)a.Ip, &a.ip_m, &a.ip_s);
+  magic_u32((unsigned)a.Wp, &a.wp_m, &a.wp_s);
+  a.c.tiles_m = (int)((a.Mp + BM - 1) / BM);
+  a.c.tiles_n = p.cout / BN;
+  a.c.splitk = 1;
+  size_t lds = 3 * (size_t)BN * 64 + 2 * (size_t)a.lpa * 8 * 1024;
+  const size_t epi = 8 * 32 * 36 * sizeof(float);
+  if (lds < epi) lds = epi;
+  ME_REQUIRE(lds <= 160 * 1024, ME_E_TOOBIG, "me_conv2d_h16: tile needs %zu bytes of LDS", lds);
+  auto kern = conv3x3_p8_h16<WR, WC, MT, NT, F16, ABL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const long long blocks = (long long)a.c.tiles_m * a.c.tiles_n;
+  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a);
+  return me::check_launch("conv3x3_p8_h16");
+}
+
+}  // namespace
+
+namespace me16 {
+
+// tile ids 100 + ...: patch-resident big tiles (3x3, stride 1, pad 1, 16-byte epilogue, cout % BN == 0)
+bool p8_eligible(const Conv16P& p, int tile) {
+  if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.ups != 1 || p.x_nchw || p.cin % 32 || !p.vec_epi) return false;
+  const int bn = (tile % 10 == 1) ? 128 : 256;
+  if (p.cout % bn) return false;
+  if ((long long)p.n * (p.h + 1) * (p.w + 1) >= (1ll << 31)) return false;
+  // descriptor windows: a tile spans at most a few images / 256 weight rows
+  const long long img_bytes = (long long)p.h * p.w * p.x_pitch * 2;
+  const long long span = (1024 / ((long long)(p.h + 1) * (p.w + 1))) + 2;
+  return span * img_bytes < (1ll << 31) && 256ll * p.ktot * 2 < (1ll << 31);
+}
+
+int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
+  ME_REQUIRE(p8_eligible(p, tile), ME_E_BADARG,
+             "me_conv2d_h16: tile %d needs a 3x3 / stride 1 / pad 1 layer, cin %% 32 == 0, cout %% tile width == 0, 16-bit "
+             "output with the 16-byte epilogue", tile);
+#define ME_P8(WR, WC, MT, NT) (p.f16 ? launch_p8<WR, WC, MT, NT, 1>(p, stream) : launch_p8<WR, WC, MT, NT, 0>(p, stream))
+  switch (tile) {
+    case 100: return ME_P8(2, 4, 2, 2);   // 128 x 256
+    case 110: return ME_P8(2, 4, 3, 2);   // 192 x 256
+    case 120: return ME_P8(2, 4, 4, 2);   // 256 x 256
+    case 101: return ME_P8(4, 2, 1, 2);   // 128 x 128
+    case 121: return ME_P8(4, 2, 2, 2);   // 256 x 128
+    case 131: return ME_P8(4, 2, 3, 2);   // 384 x 128
+    case 141: return ME_P8(4, 2, 4, 2);   // 512 x 128
+    // ablations (wrong results): no memory traffic / no DMA instructions
+    case 180: return launch_p8<2, 4, 4, 2, 0, 1>(p, stream);
+    case 190: return launch_p8<2, 4, 4, 2, 0, 3>(p, stream);
+    default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown patch tile id %d", tile);
+  }
+#undef ME_P8
+  return 0;
+}
+
+}  // namespace me16

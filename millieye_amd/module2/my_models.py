@@ -18,6 +18,7 @@ import ctypes as C
 import torch
 from torch import nn
 
+from .. import engine as _engine
 from .. import hip
 from ..engine import ConvWeights
 from ..my_models import FocalLoss, _DETECTIONS_PER_IMG, _NMS_THRESH, box_regress, define_yolo, init_yolo  # noqa: F401

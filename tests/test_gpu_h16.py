@@ -337,3 +337,66 @@ def test_detector_16bit_608_batch16(hip_lib, dtype):
     assert e_batch <= 1.25 * e_one + 1e-4, f"{dtype}: batch-16 error {e_batch:.2e} vs batch-1 error {e_one:.2e}"
     bound = 2e-2 if dtype == "bf16" else 3e-3   # measured format error of a 75-layer random-weight network x ~6
     assert e_batch <= bound, f"{dtype}: mean relative error vs fp32 {e_batch:.2e}"
+
+
+P8_TILES_256 = (100, 110, 120)
+P8_TILES_128 = (101, 121, 131, 141)
+P8_CASES = [
+    # name, n, h, w, cin, cout, act, res
+    ("13x13 two images per tile", 5, 13, 13, 64, 256, 1, True),
+    ("26x26 residual", 3, 26, 26, 128, 256, 1, True),
+    ("rectangular 9x31 linear", 2, 9, 31, 32, 128, 0, False),
+    ("52x52 cout 512", 2, 52, 52, 96, 512, 1, True),
+    ("one tiny image", 1, 5, 7, 64, 128, 1, False),
+    ("104x104 wide patch", 1, 104, 104, 32, 128, 1, True),
+]
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("case", P8_CASES, ids=[c[0] for c in P8_CASES])
+def test_conv_p8_patch_resident_tiles(hip_lib, case, half):
+    """The patch-resident big-tile generation (csrc/conv_p8_h16.hip, tile ids >= 100): tiles are BM consecutive positions
+    of a padded-linear index space, so they start anywhere and cross rows and images; every tile shape against the fp32 CPU
+    convolution under the same bar as the per-tap tiles (equal to the RNE rounding of the fp32 result up to rounding flips),
+    also when the output is a channel slice of a wider buffer, and run-to-run deterministic."""
+    from millieye_amd import hip
+    half = HALVES[half]
+    name, n, h, w, cin, cout, act, with_res = case
+    g = torch.Generator().manual_seed(len(name) * 11 + cin)
+    x = _bf(torch.randn((n, h, w, cin), generator=g), half)
+    wgt = _bf(torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5, half)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = _bf(torch.randn((n, h, w, cout), generator=g), half) if with_res else None
+    ref = _ref(x, wgt, scale, shift, 3, 1, 1, act, res, 1)
+    packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+    xs, sc, sh = x.cuda(), scale.cuda(), shift.cuda()
+    rs = res.cuda() if res is not None else None
+    tiles = P8_TILES_128 + (P8_TILES_256 if cout % 256 == 0 else ())
+    for tile in tiles:
+        y = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, tile=tile, split_k=1)
+        _check_bf16(y, ref, f"{name} tile {tile}")
+        y2 = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, tile=tile, split_k=1)
+        assert torch.equal(y, y2), f"{name} tile {tile}: not deterministic"
+    wide = torch.zeros((n, h, w, cout + 48), dtype=half).cuda()
+    hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, out=wide[..., 16:16 + cout], tile=tiles[-1], split_k=1)
+    assert torch.equal(wide[..., 16:16 + cout], y) and float(wide[..., :16].abs().max()) == 0 \
+        and float(wide[..., 16 + cout:].abs().max()) == 0, f"{name}: pitched output"
+    # input read from a channel slice of a wider tensor (route buffers)
+    xw = torch.zeros((n, h, w, cin + 32), dtype=half).cuda()
+    xw[..., 32:] = xs
+    y3 = hip.conv2d_h16(xw[..., 32:], packed, sc, sh, 3, 1, 1, act, residual=rs, tile=tiles[0], split_k=1)
+    y0 = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, tile=tiles[0], split_k=1)
+    assert torch.equal(y3, y0), f"{name}: pitched input"
+
+
+def test_conv_p8_refuses_what_it_cannot_do(hip_lib):
+    from millieye_amd import hip
+    x = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16).cuda()
+    w1 = torch.zeros((128, 1, 1, 32), dtype=torch.bfloat16).cuda()
+    w3 = torch.zeros((72, 3, 3, 32), dtype=torch.bfloat16).cuda()
+    one = torch.ones(128).cuda()
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(x, w1, one, one, 1, 1, 0, 1, tile=121)          # 1x1
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(x, w3, one[:72], one[:72], 3, 1, 1, 1, tile=121)  # cout % 128 != 0
