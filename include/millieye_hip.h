@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 3
+#define ME_ABI_VERSION 4
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -432,10 +432,13 @@ typedef struct me_conv16_desc {
   int32_t x_nchw;
   int32_t y_f32;
   int32_t half_type; /* 0 = bfloat16, 1 = IEEE half (x, wgt, res / y unless y_f32) */
-  int32_t tile;    /* 0 = auto; 1..4 = 128x128 / 128x64 / 64x64 / 256x128; 11..14 = single sub-stage variants; 5 / 15 = 192x128; 41 = patch-resident 3x3 (experimental) */
+  int32_t tile;    /* 0 = auto; 1..4 = 128x128 / 128x64 / 64x64 / 256x128; 11..14 = single sub-stage variants; 5 / 15 = 192x128; 41 = patch-resident 3x3 (experimental); >= 100: patch-resident big tiles (conv_p8_h16.hip; need wgt_tiled) */
   int32_t split_k; /* as me_conv_desc */
   void* workspace;
   int64_t workspace_bytes;
+  const void* wgt_tiled; /* tile ids >= 100 (patch-resident 3x3 kernels) read the weights from this second packing:
+                            [ksize*ksize][cin/32][cout][32] - every (tap, 32-channel chunk) slab of cout rows x 64 bytes is
+                            contiguous, so one LDS-DMA instruction moves 1 KiB of whole 128-byte lines.  May be NULL otherwise. */
 } me_conv16_desc;
 int me_conv2d_h16(const me_conv16_desc* d, void* stream);
 int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d);

@@ -39,6 +39,7 @@ struct H16<1> {
 struct Conv16P {
   const unsigned short* x;
   const unsigned short* wgt;
+  const unsigned short* wgt_tiled;  // [taps][cin/32][cout][32] copy (patch-resident kernels), or nullptr
   const float* scale;
   const float* shift;
   const void* res;

@@ -857,6 +857,7 @@ int fill16(const me_conv16_desc* d, Conv16P& p) {
   ME_REQUIRE(d->half_type == 0 || d->half_type == 1, ME_E_BADARG, "me_conv2d_h16: half_type must be 0 (bf16) or 1 (f16)");
   p.x = reinterpret_cast<const unsigned short*>(d->x);
   p.wgt = reinterpret_cast<const unsigned short*>(d->wgt);
+  p.wgt_tiled = reinterpret_cast<const unsigned short*>(d->wgt_tiled);
   p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
   p.x_pitch = d->x_pitch; p.res_pitch = d->res_pitch; p.y_pitch = d->y_pitch;
   p.n = d->n; p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout; p.ks = d->ksize;

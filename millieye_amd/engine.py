@@ -89,6 +89,7 @@ class ConvWeights:
         self.conv, self.bn = conv, bn
         self.dtype, self.cin_pad, self.cout_pad = dtype, cin_pad, cout_pad
         self.wgt = self.scale = self.shift = None
+        self.wgt_tiled = None  # 16-bit 3x3 layers: second packing [taps][cin/32][cout][32] for the patch-resident kernels
         self._stamp = None
 
     def _sources(self):
@@ -139,12 +140,18 @@ class ConvWeights:
             packed = packed.contiguous()
             realloc = (self.wgt is None or self.wgt.device != device or self.wgt.shape != packed.shape
                        or self.wgt.dtype != packed.dtype)
+            tiled = None
+            if packed.dtype in hip.HALF_TYPES and packed.shape[1] == 3 and packed.shape[3] % 32 == 0:
+                tiled = hip.tile_weights_h16(packed)
             if realloc:
                 self.wgt, self.scale, self.shift = packed, scale.contiguous(), shift.contiguous()
+                self.wgt_tiled = tiled
             else:  # keep the pointers the plans hold
                 self.wgt.copy_(packed)
                 self.scale.copy_(scale)
                 self.shift.copy_(shift)
+                if tiled is not None:
+                    self.wgt_tiled.copy_(tiled)
         self._stamp = stamp
         return "realloc" if realloc else True
 
@@ -521,6 +528,7 @@ class DarknetEngine:
                 if bf16:
                     dsc.y_f32 = 1 if y.esize == 4 else 0
                     dsc.half_type = half_type
+                    dsc.wgt_tiled = cw.wgt_tiled.data_ptr() if cw.wgt_tiled is not None else None
                 launches.append((lib.me_conv2d_h16 if bf16 else lib.me_conv2d_f32, (C.byref(dsc),), dsc,
                                  f"conv{op['module']}"))
                 plan.conv_descs.append((op["module"], dsc))
@@ -692,7 +700,12 @@ _TUNE_TILES = (1, 2, 3, 4, 5)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
 _TUNE_TILES_BF16 = (1, 2, 3, 4, 11, 12, 13, 14, 15)  # 1x = one 32-channel sub-stage per pipeline stage (more workgroups / CU)
 _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
-                     11: (128, 128), 12: (128, 64), 13: (64, 64), 14: (256, 128), 15: (192, 128)}
+                     11: (128, 128), 12: (128, 64), 13: (64, 64), 14: (256, 128), 15: (192, 128),
+                     # patch-resident big tiles (csrc/conv_p8_h16.hip; 3x3 stride 1 only, no split-K): 1xx one workgroup per
+                     # CU with register-pipelined fragments, 2xx two workgroups per CU
+                     100: (128, 256), 110: (192, 256), 120: (256, 256), 101: (128, 128), 121: (256, 128), 131: (384, 128),
+                     141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128)}
+_TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221)
 
 
 def _autotune_enabled():
@@ -706,7 +719,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v4.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v5.json")  # bump with every kernel generation
 
 
 def _tune_load():
@@ -810,11 +823,13 @@ def _autotune(plan, lib):
         if bf16:
             stages = d.ksize * d.ksize * (d.cin // 32)
             tiles = _TUNE_TILES_BF16 if d.cin % 64 == 0 else _TUNE_TILES_BF16[:4] + (15,)
+            if d.ksize == 3 and d.stride == 1 and d.upsample == 1 and d.wgt_tiled and not d.y_f32:
+                tiles = tiles + _TUNE_TILES_P8  # the library refuses the ones that do not apply (cout % width, LDS)
         for tile in tiles:
             bm, bn = _TILE_SHAPES_BF16[tile] if bf16 else \
                 {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128)}[tile]
             tiles = -(-d.n * d.ho * d.wo // bm) * -(-d.cout // bn)
-            for split in _TUNE_SPLITS:
+            for split in (_TUNE_SPLITS if tile < 100 else (1,)):
                 if split > 1 and (split * slab > ws_bytes or tiles * split > 4096 or split > stages):
                     continue
                 d.tile, d.split_k = tile, split

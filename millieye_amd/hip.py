@@ -51,6 +51,7 @@ class Conv16Desc(C.Structure):
         ("act", C.c_int32), ("upsample", C.c_int32), ("x_nchw", C.c_int32), ("y_f32", C.c_int32),
         ("half_type", C.c_int32), ("tile", C.c_int32), ("split_k", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("wgt_tiled", C.c_void_p),
     ]
 
 
@@ -227,8 +228,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 3:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 3")
+    if lib_.me_abi_version() != 4:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 4")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
@@ -327,8 +328,17 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     return out
 
 
+def tile_weights_h16(wgt_packed):
+    """Second packing of 16-bit OHWI weights for the patch-resident kernels (tile ids >= 100): ``[k*k][cin/32][cout][32]``
+    - every (tap, 32-channel chunk) slab of cout rows x 64 bytes contiguous (``me_conv16_desc.wgt_tiled``)."""
+    cout, kh, kw, cin = wgt_packed.shape
+    if cin % 32:
+        raise MeError("tile_weights_h16: cin must be a multiple of 32")
+    return wgt_packed.reshape(cout, kh * kw, cin // 32, 32).permute(1, 2, 0, 3).contiguous()
+
+
 def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-                x_nchw=False, y_f32=False, tile=0, split_k=0, half=torch.bfloat16):
+                x_nchw=False, y_f32=False, tile=0, split_k=0, half=torch.bfloat16, wgt_tiled=None):
     """16-bit-storage twin of :func:`conv2d`; ``half`` = ``torch.bfloat16`` (default) or ``torch.float16``.  ``x``: 16-bit
     NHWC [N,H,W,Cin] (or a channel slice), or - stem, Cin == 3 - float32 NCHW / NHWC; ``wgt_packed``: 16-bit [Cout,k,k,Cin]
     (float32 for the stem); ``residual``: the output's dtype.  Returns 16-bit NHWC (float32 when ``y_f32``)."""
@@ -370,6 +380,9 @@ def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=No
     d.act, d.upsample, d.x_nchw, d.y_f32, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, 1 if y_f32 else 0, \
         tile, split_k
     d.half_type = HALF_TYPES[half]
+    if tile >= 100 and wgt_tiled is None and cin % 32 == 0:
+        wgt_tiled = tile_weights_h16(wgt_packed)  # callers that care about time pass their own copy
+    d.wgt_tiled = wgt_tiled.data_ptr() if wgt_tiled is not None else None
     need = lib().me_conv2d_h16_workspace_bytes(C.byref(d))
     keep = None
     if need > 0:

@@ -339,8 +339,8 @@ def test_detector_16bit_608_batch16(hip_lib, dtype):
     assert e_batch <= bound, f"{dtype}: mean relative error vs fp32 {e_batch:.2e}"
 
 
-P8_TILES_256 = (100, 110, 120)
-P8_TILES_128 = (101, 121, 131, 141)
+P8_TILES_256 = (100, 110, 120, 200)
+P8_TILES_128 = (101, 121, 131, 141, 201, 221)
 P8_CASES = [
     # name, n, h, w, cin, cout, act, res
     ("13x13 two images per tile", 5, 13, 13, 64, 256, 1, True),
@@ -372,12 +372,18 @@ def test_conv_p8_patch_resident_tiles(hip_lib, case, half):
     packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
     xs, sc, sh = x.cuda(), scale.cuda(), shift.cuda()
     rs = res.cuda() if res is not None else None
-    tiles = P8_TILES_128 + (P8_TILES_256 if cout % 256 == 0 else ())
-    for tile in tiles:
-        y = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, tile=tile, split_k=1)
+    tiles = []
+    for tile in P8_TILES_128 + (P8_TILES_256 if cout % 256 == 0 else ()):
+        try:
+            y = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, tile=tile, split_k=1)
+        except hip.MeError as exc:  # a wide map's patch does not fit the LDS budget of this tile: refused, never wrong
+            assert "LDS" in str(exc) or "does not fit" in str(exc), str(exc)
+            continue
+        tiles.append(tile)
         _check_bf16(y, ref, f"{name} tile {tile}")
         y2 = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, tile=tile, split_k=1)
         assert torch.equal(y, y2), f"{name} tile {tile}: not deterministic"
+    assert len(tiles) >= 4, tiles
     wide = torch.zeros((n, h, w, cout + 48), dtype=half).cuda()
     hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, act, residual=rs, out=wide[..., 16:16 + cout], tile=tiles[-1], split_k=1)
     assert torch.equal(wide[..., 16:16 + cout], y) and float(wide[..., :16].abs().max()) == 0 \

@@ -9,17 +9,20 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from millieye_amd import hip  # noqa: E402
 
 LAYERS = [(208, 32, 64), (104, 64, 128), (52, 128, 256), (26, 256, 512), (13, 512, 1024)]
+if os.environ.get("P8_KSCAN"):   # fixed output shape, K swept: fixed cost (prologue + epilogue) vs per-stage cost
+    LAYERS = [(26, 32, 512), (26, 64, 512), (26, 128, 512), (26, 256, 512), (26, 512, 512)]
 OLD = (1, 2, 3, 4, 11, 12, 13, 14)
-NEW = (100, 110, 120, 101, 121, 131, 141)
+NEW = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221)
 
 
 def time_tile(x, w, sc, sh, r, out, tile, reps=20):
+    wt = hip.tile_weights_h16(w)
     for _ in range(3):
-        hip.conv2d_h16(x, w, sc, sh, 3, 1, 1, 1, residual=r, out=out, tile=tile, split_k=1)
+        hip.conv2d_h16(x, w, sc, sh, 3, 1, 1, 1, residual=r, out=out, tile=tile, split_k=1, wgt_tiled=wt)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        hip.conv2d_h16(x, w, sc, sh, 3, 1, 1, 1, residual=r, out=out, tile=tile, split_k=1)
+        hip.conv2d_h16(x, w, sc, sh, 3, 1, 1, 1, residual=r, out=out, tile=tile, split_k=1, wgt_tiled=wt)
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
