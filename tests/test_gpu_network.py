@@ -68,6 +68,21 @@ def _cmp_rows(got, ref, what):
         ph.assert_close(got, ref, TOL, what)
 
 
+def _cmp_rows_ties(got, ref, what, tie=2e-6):
+    """_cmp_rows for long row lists: rows whose sort keys (fused confidence, column 5) are closer than ``tie`` may come in
+    either order (a 1e-7 difference between the device and the CPU arithmetic flips a stable sort) - they are matched as a
+    set; everything else must agree position by position."""
+    got, ref = got.detach().cpu(), torch.as_tensor(ref)
+    assert got.shape == ref.shape, f"{what}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    used = torch.zeros(len(ref), dtype=torch.bool)
+    for i in range(len(got)):
+        cands = [j for j in range(max(0, i - 4), min(len(ref), i + 5))
+                 if not used[j] and (j == i or abs(float(ref[j, 5] - got[i, 5])) <= tie)]
+        ok = [j for j in cands if ph.max_rel_err(got[i], ref[j]) <= TOL]
+        assert ok, f"{what}: row {i} {got[i].tolist()} has no counterpart (reference row {ref[i].tolist()})"
+        used[ok[0]] = True
+
+
 @pytest.mark.parametrize("name,cfg,n,s,conf", NETWORK_CASES)
 def test_network_modes_vs_oracle_and_reference_golden(hip_lib, name, cfg, n, s, conf):
     from oracle import network_ref
@@ -262,6 +277,6 @@ def test_headline_workload_batch32_vs_oracle(hip_lib):
         ref = network_ref.network_forward(text, sd, x[f:f + 1], maps[f:f + 1], rb, 0, conf_thresh=conf, tap_module=91)
         got = out[out[:, 0] == f].clone()
         got[:, 0] = 0
-        _cmp_rows(got, ref, f"headline batch-32 run, frame {f}")
+        _cmp_rows_ties(got, ref, f"headline batch-32 run, frame {f}")
         total += ref.shape[0]
     assert total >= 8, "the sampled frames must carry detections"
