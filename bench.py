@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed clock ramp-up before the warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the extra bf16-storage-mode measurement")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra batch 1 / 8 measurements")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -243,30 +244,52 @@ def _ev():
     return e
 
 
-def conv_traffic(batch, half=False):
-    """HBM bytes per conv launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, two separate
-    passes over this same command; tools/pmc_traffic.py -> profiles/conv_traffic.json).  PMC counters cannot
-    be read from inside this process, so the committed measurement is reported when it matches the
-    configuration being run, else null."""
-    path = os.path.join(ROOT, "profiles", "conv_traffic_bf16.json" if half else "conv_traffic.json")
+def kernel_generation(half=False):
+    """Short hash of the sources of the dominant conv kernel: a committed PMC measurement only speaks for the kernel it
+    was taken on."""
+    import hashlib
+    files = ["conv_h16.hip", "conv_p8_h16.hip", "conv16_common.h", "dma.h"] if half else ["conv.hip", "dma.h"]
+    h = hashlib.sha1()
+    for f in files:
+        with open(os.path.join(ROOT, "millieye_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:10]
+
+
+def conv_traffic(args, batch, half=False):
+    """HBM bytes per conv launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, two separate passes over
+    this very command: tools/pmc_only.sh -> tools/pmc_traffic.py -> profiles/conv_traffic*.json).  PMC counters cannot
+    be read from inside this process, so the committed measurement is reported ONLY when it was taken on this
+    configuration (cfg, size, batch, workload, storage type) and this kernel generation (source hash); otherwise
+    ``traffic`` is null and ``traffic_source`` says why.  Returns (bytes or None, source string)."""
+    name = "conv_traffic_bf16.json" if half else "conv_traffic.json"
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as fh:
             t = json.load(fh)
-        if int(t.get("batch", 32)) == batch:
-            return int(t["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    except (OSError, ValueError):
+        return None, f"no committed PMC measurement (profiles/{name} missing)"
+    want = dict(cfg=args.cfg, size=args.size, batch=batch, workload=args.workload,
+                dtype=("bf16" if half else "f32") if args.dtype == "f32" else args.dtype,
+                kernel_generation=kernel_generation(half))
+    if half and args.dtype == "f32":
+        want["dtype"] = "bf16"
+    have = {k: t.get(k) for k in want}
+    if have != want:
+        diff = ", ".join(f"{k}: measured {have[k]!r}, running {want[k]!r}" for k in want if have[k] != want[k])
+        return None, f"profiles/{name} does not match this run ({diff})"
+    return int(t["hbm_bytes_per_launch"]), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {t.get('date', 'n/a')})"
 
 
 def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s, radar=None):
-    """The oracle (stock torch CPU ops = the reference's CPU path, pinned by tests/golden) timed on the
-    host cores: a bounded sample of the same workload (batch-1 passes of the same cfg / size)."""
+    """The oracle (stock torch CPU ops = the reference's CPU path, pinned by tests/golden) timed on the host cores of
+    this box, in this run: a bounded sample of the same workload at batch 1, 8 and the benchmark's own batch (north_star:
+    "batch 1/8/32"), the same frames the GPU saw.  ``value`` is the rate at the benchmark's batch."""
     from oracle import darknet_ref, network_ref
 
-    # torch's intra-op pool at os.cpu_count() threads is far from optimal on a many-core host
-    # (256 threads on 13x13 maps: 60 s per frame); pick the best thread count on a probe conv so
-    # the baseline is the CPU path at its best, and report the count actually used.
+    # torch's intra-op pool at os.cpu_count() threads is far from optimal on a many-core host (256 threads on 13x13
+    # maps: 60 s per frame); pick the best thread count on a probe conv so the baseline is the CPU path at its best,
+    # and report both the count used and what the host has.
     import torch.nn.functional as F
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     probe_x = torch.randn(1, 256, 26, 26)
@@ -283,28 +306,38 @@ def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s, radar=No
             best = (dt, threads)
     cores = best[1]
     torch.set_num_threads(cores)
-    x1 = frames_cpu[:1]
-    if radar is None:
-        def one_pass():
-            darknet_ref.darknet_forward(cfg_text, state_dict, x1, tap_module=tap)
-        what = "detector forward (oracle/darknet_ref.py"
-    else:
-        maps1, boxes1, conf = radar[0][:1], radar[1][radar[1][:, 0] == 0], radar[2]
+    n_all = frames_cpu.shape[0]
 
-        def one_pass():
-            network_ref.network_forward(cfg_text, state_dict, x1, maps1, boxes1, 0, conf_thresh=conf, tap_module=tap)
-        what = "Network.forward mode 0: detector + NMS + RoI heads (oracle/network_ref.py + tv_ops.c"
+    def one_pass(b):
+        xb = frames_cpu[:b]
+        if radar is None:
+            darknet_ref.darknet_forward(cfg_text, state_dict, xb, tap_module=tap)
+        else:
+            maps_b, boxes_b, conf = radar[0][:b], radar[1][radar[1][:, 0] < b], radar[2]
+            network_ref.network_forward(cfg_text, state_dict, xb, maps_b, boxes_b, 0, conf_thresh=conf, tap_module=tap)
+
+    what = ("detector forward (oracle/darknet_ref.py" if radar is None else
+            "Network.forward mode 0: detector + NMS + RoI heads (oracle/network_ref.py + tv_ops.c")
+    batches = sorted({b for b in (1, 8, n_all) if b <= n_all})
+    share = budget_s / (len(batches) + 1)
     t0 = time.perf_counter()
-    one_pass()  # warm-up (also bounds one pass)
-    one = time.perf_counter() - t0
-    reps = max(1, min(10, int(budget_s / max(one, 1e-3)) - 1))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        one_pass()
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(1.0 / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} batch-1 passes of {args.cfg} {args.size}x{args.size} fp32 {what}, "
-                      f"torch {torch.__version__} CPU, {cores} threads)"}
+    one_pass(1)  # warm-up (also bounds one frame)
+    per_frame = time.perf_counter() - t0
+    by_batch, passes = {}, {}
+    for b in batches:
+        reps = max(1, min(10, int(share / max(per_frame * b, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one_pass(b)
+        dt = (time.perf_counter() - t0) / reps
+        by_batch[str(b)] = round(b / dt, 3)
+        passes[str(b)] = reps
+        per_frame = min(per_frame, dt / b)
+    return {"value": by_batch[str(n_all)], "unit": "frames/s", "cores": cores, "host_cpus": os.cpu_count(),
+            "kind": "port", "by_batch": by_batch,
+            "sample": f"{args.cfg} {args.size}x{args.size} fp32 {what}, torch {torch.__version__} CPU, {cores} threads "
+                      f"(best of a probe; the host has {os.cpu_count()}) ): "
+                      + ", ".join(f"{passes[str(b)]} pass(es) at batch {b}" for b in batches)}
 
 
 def main():
@@ -492,6 +525,46 @@ def main():
             alt = {"error": f"{type(exc).__name__}: {exc}"}
             model.compute_dtype = "f32"
 
+    # north_star: "frames/sec ... at batch 1/8/32": the same step at batch 1 and 8 (rank 0's frames; untimed plan building
+    # and autotuning first), fp32 and bf16 storage, reported beside - never instead of - `value`
+    sweep = []
+    if rank == 0 and args.workload in ("full", "detector") and args.dtype == "f32" and not args.no_batch_sweep:
+        for b in (1, 8):
+            if b >= batch:
+                continue
+            xb = x[:b].contiguous()
+            if args.workload == "full":
+                mb = maps_d[:b].contiguous()
+                bb = boxes_d[boxes_d[:, 0] < b].contiguous()
+
+                def step_b():
+                    with torch.no_grad():
+                        return net(xb, mb, bb.clone(), 0)
+            else:
+                def step_b():
+                    with torch.no_grad():
+                        return model(xb)
+            row = {"batch": b}
+            for mode in ("f32", "bf16"):
+                model.compute_dtype = mode
+                t_end = time.perf_counter() + 0.3
+                while time.perf_counter() < t_end:
+                    step_b()
+                    torch.cuda.synchronize()
+                k = max(args.steps, 20)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    step_b()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / k
+                ach_b = conv_roofline(model, xb, 5)[0]
+                peak_b = BF16_MFMA_PEAK_TFLOPS if mode == "bf16" else FP32_MFMA_PEAK_TFLOPS
+                row[mode] = {"value": round(b / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4),
+                             "conv_roofline_frac": round(ach_b / peak_b, 4)}
+            model.compute_dtype = "f32"
+            sweep.append(row)
+
     if rank == 0:
         frames = batch * world * args.steps
         plan = model.engine_for(model.compute_dtype).plan_for(x)
@@ -545,12 +618,15 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4),
-                "traffic": conv_traffic(batch, half=bf16) if args.dtype in ("f32", "bf16") else None,
+                "traffic": conv_traffic(args, batch, half=bf16)[0],
+                "traffic_source": conv_traffic(args, batch, half=bf16)[1],
                 "launches_per_step": launches,
                 "avg_launch_us": round(avg_us, 2),
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),
             },
         }
+        if sweep:
+            out["batch_sweep"] = sweep
         if alt is not None and "error" in alt:
             out["bf16_storage_mode"] = alt
         elif alt is not None:
@@ -564,7 +640,8 @@ def main():
                 "roofline": {"bound": "mfma", "kernel": "conv_igemm_buf_h16", "achieved": round(alt["ach"], 2),
                              "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(alt["ach"] / BF16_MFMA_PEAK_TFLOPS, 4),
-                             "traffic": conv_traffic(batch, half=True),
+                             "traffic": conv_traffic(args, batch, half=True)[0],
+                             "traffic_source": conv_traffic(args, batch, half=True)[1],
                              "launches_per_step": alt["launches"], "avg_launch_us": round(alt["avg_us"], 2)},
             }
         if not args.no_cpu_baseline and world == 1 and args.workload not in ("train", "detector_train", "module2"):
