@@ -1,6 +1,7 @@
 """One camera frame + its radar frames through the whole fusion path, the way the live demos do it
 (``module3_our_dataset/run_mp.py:65-160,296-330`` / ``run_sp.py:117-241``) - without the demos' I/O (video decoding,
-serial-port capture, OpenCV window, ``mp.Queue`` hand-over between the two processes):
+serial-port capture, OpenCV window).  ``millieye_amd/pipeline.py`` runs the two halves of
+:class:`FrameFuser` in two processes with run_mp's ``mp.Queue(maxsize=3)`` / ``mp.Event`` hand-over:
 
     radar frames --RadarProposalGenerator--> box proposals (pixels) + point cloud
     frame uint8 [h,w,3] --ToTensor / pad_to_square / resize(416)--> img [1,3,416,416]     (me_image_pad_resize_u8_f32)
@@ -63,15 +64,29 @@ class FrameFuser:
         self.generator = generator or RadarProposalGenerator(calib_param, **generator_kwargs)
 
     def __call__(self, frame, radar_frames):
+        return self.infer(self.prepare(frame, radar_frames))
+
+    # The two halves run_mp.py puts in two processes (millieye_amd/pipeline.py does the same): everything that needs only
+    # the host - radar tracking, proposal arithmetic, staging of the raw frame bytes / point cloud - and everything that
+    # needs the device.  ``prepare`` keeps the tracker state, so it must see the frames in order.
+    def prepare(self, frame, radar_frames):
+        """Host half (run_mp.py:65-152 ``pre_process``): a picklable payload for :meth:`infer`."""
         frame = torch.as_tensor(frame)
         if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3:
             raise hip.MeError(f"frame must be uint8 [h,w,3] (got {frame.dtype} {tuple(frame.shape)})")
         h, w = int(frame.shape[0]), int(frame.shape[1])
-        dev = getattr(self.model, "device", None) or hip.default_device()
         proposals, cloud = self.generator(radar_frames)
-        radar_box = radar_boxes_for_network(proposals, (h, w)).to(dev)
-        img = StagedImages([frame], self.img_size).to(dev)
-        radar_map = StagedRadarMaps([cloud], [(w, h)], map_size=32).to(dev)
+        return dict(hw=(h, w), proposals=proposals, points=int(len(cloud)),
+                    radar_box=radar_boxes_for_network(proposals, (h, w)),
+                    img=StagedImages([frame], self.img_size), radar_map=StagedRadarMaps([cloud], [(w, h)], map_size=32))
+
+    def infer(self, payload):
+        """Device half (run_mp.py:296-330): input kernels, mode selection, ``Network.forward``, second NMS, rescale."""
+        dev = getattr(self.model, "device", None) or hip.default_device()
+        h, w = payload["hw"]
+        radar_box = payload["radar_box"].to(dev)
+        img = payload["img"].to(dev)
+        radar_map = payload["radar_map"].to(dev)
         mode = mode_selection(self.model_mode, img, self.dark_threshold)
         with torch.no_grad():
             rows = self.model(img, radar_map, radar_box, mode)[:, 1:].cpu()
@@ -79,4 +94,5 @@ class FrameFuser:
         rows = rows[keep]
         if len(rows):
             rescale_boxes(rows, self.img_size, (h, w))
-        return rows, dict(mode=mode, proposals=proposals, radar_boxes=int(radar_box.shape[0]), points=int(len(cloud)))
+        return rows, dict(mode=mode, proposals=payload["proposals"], radar_boxes=int(radar_box.shape[0]),
+                          points=payload["points"])

@@ -281,13 +281,14 @@ class Network(nn.Module):
             object.__setattr__(self, "_packs", packs)
         return self._packs
 
+    def _head_bns(self):
+        return [self.img_cnn_layers.net[1], self.radar_cnn_layers.conv1[1], self.radar_cnn_layers.conv2[1],
+                self.radar_cnn_layers.conv3[1], self.refinement_head.radar_net[1]]
+
     def _check_eval(self):
-        bns = [self.img_cnn_layers.net[1], self.radar_cnn_layers.conv1[1], self.radar_cnn_layers.conv2[1],
-               self.radar_cnn_layers.conv3[1], self.refinement_head.radar_net[1]]
-        if any(b.training for b in bns):
-            raise NotImplementedError(
-                "Network.forward in train() mode (batch-statistics BatchNorm + the stage-3 loss/backward, "
-                "SURVEY.md rows a17/K14) is not built yet; call model.eval() for inference")
+        if any(b.training for b in self._head_bns()):  # (forward() sends an all-train()-mode model to train_path)
+            raise NotImplementedError("Network.forward: the head BatchNorms are partly in train() and partly in eval() "
+                                      "mode; call model.train() or model.eval() on the whole Network")
 
     @staticmethod
     def _conv16(x_ptr, x_pitch, n, h, w, cin, cw, ksize, pad, act, out):
@@ -371,6 +372,11 @@ class Network(nn.Module):
             return forward_train(self, images, maps, radar_boxes_location, targets)
         if not images.is_cuda:
             raise hip.MeError("Network.forward needs CUDA tensors (MI355X); there is no CPU fallback")
+        if model_mode != 1 and all(b.training for b in self._head_bns()):
+            # a model left in train() mode, called without targets (reference :433-539 under model.train()): same rows,
+            # BatchNorm on batch statistics - the training path's forward half
+            from .train_path import forward_train
+            return forward_train(self, images, maps, radar_boxes_location, None, model_mode)
         dev = images.device
         n = images.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)

@@ -184,8 +184,11 @@ class _StageThree(torch.autograd.Function):
         return (None,) + tuple(grads.get(n) for n in names)
 
 
-def forward_train(net, images, maps, radar_boxes_location, targets):
-    """Returns ``(loss, output, metric, radar_attention)`` like the reference's training call."""
+def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0):
+    """``targets`` given: returns ``(loss, output, metric, radar_attention)`` like the reference's training call
+    (my_models.py:545-641).  ``targets is None``: the inference return of a model left in ``train()`` mode (reference
+    :433-539 with batch-statistics BatchNorm: the score-map / radar-CNN BatchNorms normalise over the batch's pixels, the
+    ``radar_net`` BatchNorm over the RoIs, and every one of them updates its running statistics) -> ``output [m, 8]``."""
     from .my_models import _DETECTIONS_PER_IMG, _NMS_THRESH
     from .utils.utils import xywh2xyxy
 
@@ -201,7 +204,10 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
                 net.radar_cnn_layers.conv3[1], rh.radar_net[1]]
     if not all(b.training for b in head_bns):
         raise NotImplementedError("Network.forward(targets=...) needs the heads in train() mode (batch-statistics "
-                                  "BatchNorm), as module3_our_dataset/train.py:169 sets them")
+                                  "BatchNorm), as module3_our_dataset/train.py:169 sets them; a mix of train- and "
+                                  "eval-mode head BatchNorms is not supported")
+    if targets is None and model_mode == 2:  # radar only: permanent, like the reference (quirk q3)
+        net.refine_threshold_img = 1
 
     # ---- frozen detector, NMS, proposal assembly (no grad) -------------------------------------------
     with torch.no_grad():
@@ -244,9 +250,8 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
         # ---- radar CNN (train-mode BN) ---------------------------------------------------------------
         rc = net.radar_cnn_layers
         maps = maps.to(**f32)
-        mh, mw = maps.shape[2], maps.shape[3]
-        if (mh, mw) != (fh, fw):
-            raise NotImplementedError("radar map size != feature map size (demo-only configuration, quirk q15)")
+        mh, mw = maps.shape[2], maps.shape[3]  # may differ from (fh, fw): the demos feed the raw 32 x 32 map (quirk q15)
+        pix_r = n * mh * mw
         x0 = maps.permute(0, 2, 3, 1).contiguous()  # NHWC, 3 channels
         radar = {"x0": x0}
         prev, prev_c = x0, 3
@@ -258,7 +263,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
             _conv(prev, prev_c, n, mh, mw, prev_c, wp, torch.ones(cout, **f32), conv.bias.detach().contiguous(), 3, 1,
                   hip.ACT_LINEAR, c_raw)
             r_act = _f32(dev, n, mh, mw, cout)
-            st = _bn_fwd(c_raw, cout, pix, cout, bn, hip.ACT_LEAKY, r_act, cout, ws)
+            st = _bn_fwd(c_raw, cout, pix_r, cout, bn, hip.ACT_LEAKY, r_act, cout, ws)
             radar[f"c{li}"], radar[f"r{li}"], radar[f"st{li}"] = c_raw, r_act, st
             prev, prev_c = r_act, cout
         conv4 = rc.conv3[3]
@@ -293,7 +298,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
         d.img_boxes, d.n_img, d.n_img_cap, d.box_cols = img_boxes.data_ptr(), n_img_dev.data_ptr(), n_img, cols
         d.radar_boxes, d.n_radar = (rb.data_ptr() if n_radar else None), n_radar
         d.thr_img, d.thr_radar = float(net.refine_threshold_img), float(net.refine_threshold_radar)
-        d.regress = 1
+        d.regress = 0 if (targets is None and model_mode == 2) else 1
         for name, t in wts.items():
             setattr(d.wts, name, t.data_ptr())
         d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
@@ -322,6 +327,8 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
         hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), k, 8, ordered.data_ptr(),
                                                n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
         output = ordered[:int(n_out.item())]
+        if targets is None:
+            return output
 
         # ---- labels on the host (reference :545-604) ---------------------------------------------------
         targets[:, 2:] = xywh2xyxy(targets[:, 2:])
@@ -365,6 +372,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets):
         radar_attention = r4[..., :1].permute(0, 3, 1, 2).contiguous()
 
     state = dict(net=net, names=_head_names(net), loss=loss_value, n=n, fh=fh, fw=fw, fc=fc, pix=pix, k=k, n_img=n_img,
+                 mh=mh, mw=mw,
                  n_radar=n_radar, fm=fm, z1=z1, a1=a1, st_img=st_img, radar=radar, feat_img=feat_img,
                  feat_rad=feat_rad, hidden=hidden, small=small, refine=refine, mask1=mask1, seed_p=seed_p,
                  seed_c=seed_c, desc=d, keepalive=(wts, img_boxes, n_img_dev, rb, regress, rows, keep, key), st_r=st_r,
@@ -381,6 +389,8 @@ def _backward(S, grad_out):
     lib = hip.lib()
     f32 = dict(device=dev, dtype=torch.float32)
     k, n_img, n, fh, fw, fc, pix = S["k"], S["n_img"], S["n"], S["fh"], S["fw"], S["fc"], S["pix"]
+    mh, mw = S["mh"], S["mw"]
+    pix_r = n * mh * mw
     rh, eh, rc = net.refinement_head, net.ensemble_head, net.radar_cnn_layers
     ws = S["ws"][0]
     G = {}
@@ -434,10 +444,10 @@ def _backward(S, grad_out):
         # ---- RoI pooling backward (atomic scatter) ----------------------------------------------------------
         rois = S["rois"]
         d_a1 = torch.zeros((pix, 490), **f32)
-        d_r4 = torch.zeros((pix, 10), **f32)
+        d_r4 = torch.zeros((pix_r, 10), **f32)
         hip.check(lib.me_ps_roi_align_bwd_f32(d_pimg.data_ptr(), rois.data_ptr(), k, n, fh, fw, 490, 7, 1.0 / 16,
                                               d_a1.data_ptr(), 490, hip.stream_ptr()), "me_ps_roi_align_bwd_f32")
-        hip.check(lib.me_roi_align_bwd_f32(d_prad.data_ptr(), rois.data_ptr(), k, n, fh, fw, 10, 7, 1.0 / 16,
+        hip.check(lib.me_roi_align_bwd_f32(d_prad.data_ptr(), rois.data_ptr(), k, n, mh, mw, 10, 7, 1.0 / 16,
                                            d_r4.data_ptr(), 10, hip.stream_ptr()), "me_roi_align_bwd_f32")
         # ---- image score map: BN(+leaky) backward, 1x1 conv weight / bias gradient -------------------------
         icl = net.img_cnn_layers.net
@@ -449,28 +459,27 @@ def _backward(S, grad_out):
         G["img_cnn_layers.net.conv_0.weight"], G["img_cnn_layers.net.conv_0.bias"] = dw.view(490, fc, 1, 1), db
         # ---- radar CNN ---------------------------------------------------------------------------------------
         R = S["radar"]
-        dc4 = _f32(dev, pix, 10)
-        hip.check(lib.me_act_bwd_f32(R["r4"].data_ptr(), 10, d_r4.data_ptr(), 10, dc4.data_ptr(), 10, pix, 10,
+        dc4 = _f32(dev, pix_r, 10)
+        hip.check(lib.me_act_bwd_f32(R["r4"].data_ptr(), 10, d_r4.data_ptr(), 10, dc4.data_ptr(), 10, pix_r, 10,
                                      hip.ACT_SIGMOID, hip.stream_ptr()), "me_act_bwd_f32")
-        dw = torch.zeros((10, 128), **f32); _gemm(1, 0, 10, 128, pix, dc4, 10, R["r3"], 128, dw, 128)
-        db = _f32(dev, 10); _colsum(dc4, 10, pix, 10, db)
+        dw = torch.zeros((10, 128), **f32); _gemm(1, 0, 10, 128, pix_r, dc4, 10, R["r3"], 128, dw, 128)
+        db = _f32(dev, 10); _colsum(dc4, 10, pix_r, 10, db)
         G["radar_cnn_layers.conv3.3.weight"], G["radar_cnn_layers.conv3.3.bias"] = dw.view(10, 128, 1, 1), db
-        d_act = _f32(dev, pix, 128); _gemm(0, 0, pix, 128, 10, dc4, 10, S["w4"], 128, d_act, 128)
-        mh, mw = fh, fw
+        d_act = _f32(dev, pix_r, 128); _gemm(0, 0, pix_r, 128, 10, dc4, 10, S["w4"], 128, d_act, 128)
         for li, seq, cin in ((3, rc.conv3, 64), (2, rc.conv2, 32), (1, rc.conv1, 3)):
             conv, bn = seq[0], seq[1]
             cout = conv.weight.shape[0]
-            dc = _f32(dev, pix, cout)
-            dg, dbt = _bn_bwd(R[f"c{li}"], cout, d_act, cout, pix, cout, bn, R[f"st{li}"], hip.ACT_LEAKY, dc, cout, ws)
+            dc = _f32(dev, pix_r, cout)
+            dg, dbt = _bn_bwd(R[f"c{li}"], cout, d_act, cout, pix_r, cout, bn, R[f"st{li}"], hip.ACT_LEAKY, dc, cout, ws)
             G[f"radar_cnn_layers.conv{li}.1.weight"], G[f"radar_cnn_layers.conv{li}.1.bias"] = dg, dbt
             x_in = R["x0"] if li == 1 else R[f"r{li - 1}"]
             G[f"radar_cnn_layers.conv{li}.0.weight"] = _wgrad(x_in, cin, dc, cout, n, mh, mw, cin, cout, 3, 1)
-            db = _f32(dev, cout); _colsum(dc, cout, pix, cout, db)
+            db = _f32(dev, cout); _colsum(dc, cout, pix_r, cout, db)
             G[f"radar_cnn_layers.conv{li}.0.bias"] = db
             if li > 1:  # data gradient = the forward conv kernel on the rotated, transposed weights
                 wd = conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()  # [cin][ky][kx][cout]
                 d_prev = _f32(dev, n, mh, mw, cin)
                 _conv(dc, cout, n, mh, mw, cout, wd, torch.ones(cin, **f32), torch.zeros(cin, **f32), 3, 1,
                       hip.ACT_LINEAR, d_prev)
-                d_act = d_prev.view(pix, cin)
+                d_act = d_prev.view(pix_r, cin)
     return G

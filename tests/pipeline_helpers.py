@@ -1,0 +1,33 @@
+"""Picklable pieces for the two-process pipeline tests (the producer runs under the ``spawn`` start method)."""
+import time
+
+import numpy as np
+
+
+class SyntheticSource:
+    """``n`` dark 480x640 frames with the seeded radar frames of tests/golden/make_golden.radar_points; ``delay`` seconds
+    between frames (a slow camera)."""
+
+    def __init__(self, n, delay=0.0):
+        self.n, self.delay = n, delay
+
+    def __call__(self):
+        from millieye_amd import synth
+        from tests.golden.make_golden import radar_points
+        frame = (synth.uniform("demo/frame", (480, 640, 3)) * 255 * 0.1).astype(np.uint8)
+        for f in range(self.n):
+            if self.delay:
+                time.sleep(self.delay)
+            yield frame, [radar_points(f)]
+
+
+def fake_infer_slow_first(payload, _state={"n": 0}):
+    """Stand-in for the device half: the first call is slow (like the first GPU inference), the rest cost 5 ms."""
+    time.sleep(0.5 if _state["n"] == 0 else 0.005)
+    _state["n"] += 1
+    return payload["radar_box"].clone(), dict(points=payload["points"])
+
+
+class BrokenSource:
+    def __call__(self):
+        raise RuntimeError("camera unplugged")

@@ -280,3 +280,27 @@ def test_headline_workload_batch32_vs_oracle(hip_lib):
         _cmp_rows_ties(got, ref, f"headline batch-32 run, frame {f}")
         total += ref.shape[0]
     assert total >= 8, "the sampled frames must carry detections"
+
+
+def test_two_process_pipeline_equals_the_sequential_fuser(hip_lib):
+    """millieye_amd/pipeline.py (run_mp.py's producer / consumer split) with the real device half: the rows of every frame
+    equal those of the single-process FrameFuser on the same frames (back-pressure mode: no frame dropped)."""
+    from millieye_amd import radar_proposals as rp
+    from millieye_amd.demo import FrameFuser
+    from millieye_amd.pipeline import FusionPipeline
+    from tests.golden.make_golden import RADAR_CALIB
+    from tests.pipeline_helpers import SyntheticSource
+    net = _build("demo", "yolov3-tiny-12", 0.1).eval()
+    synth.fill_network_(net, "demo", cls0_bias=3.0, cls_bias=-4.0)
+    net = net.to(net.device)
+    n = 6
+    rp.KalmanClusterTracker.count = 0
+    seq = FrameFuser(net, RADAR_CALIB, model_mode=3, min_hits=2)
+    want = [seq(frame, radar) for frame, radar in SyntheticSource(n)()]
+    rp.KalmanClusterTracker.count = 0
+    pipe = FusionPipeline(FrameFuser(net, RADAR_CALIB, model_mode=3, min_hits=2), SyntheticSource(n), drop_oldest=False)
+    got = list(pipe)
+    assert [info["frame_idx"] for _r, info in got] == list(range(n)) and pipe.stats["dropped"] == 0
+    for (rows, info), (rows_w, info_w) in zip(got, want):
+        assert torch.equal(rows, rows_w) and info["mode"] == info_w["mode"] == 0
+    assert len(got[-1][0]) > 0

@@ -289,3 +289,81 @@ def test_training_step_with_16bit_frozen_detector(hip_lib, dtype):
     for k, p in net.named_parameters():
         if k.startswith("base_detector."):
             assert p.grad is None
+
+
+def test_train_mode_forward_without_targets(hip_lib):
+    """A model left in ``train()`` mode and called like at inference (reference my_models.py:433-539 under ``model.train()``):
+    the same rows as the training call's ``output`` (batch-statistics BatchNorm over pixels / RoIs) and the same running
+    statistics update - against the oracle's training forward; mode 1 never reaches a BatchNorm; a mix of modes is refused."""
+    from oracle import network_ref
+    name, cfg, n, s, conf, seed = TRAIN_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = _build(name, cfg, conf)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, maps, rboxes = train_inputs(name, n, s)
+    random.seed(seed)
+    ref = network_ref.network_train_step(cfgs.KNOWN[cfg](), sd0, x, maps, rboxes, torch.from_numpy(g["targets"]), conf_thresh=conf)
+    net = net.cuda()
+    net.eval()
+    with torch.no_grad():
+        out_eval = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+        out1_eval = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 1)
+    net.train()
+    net.base_detector.eval()
+    with torch.no_grad():
+        out1 = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 1)
+        out = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+    assert torch.equal(out1, out1_eval)
+    ph.assert_close(out.cpu(), ref["output"], 1e-3, "train()-mode forward rows vs the oracle's training forward")
+    ph.assert_close(out.cpu(), torch.from_numpy(g["output"]), 1e-3, "train()-mode forward rows vs the reference golden")
+    assert out.shape != out_eval.shape or not torch.allclose(out, out_eval, atol=1e-4), "batch statistics must matter"
+    for k, v in net.state_dict().items():
+        if "running_" in k and not k.startswith("base_detector."):
+            assert _rel(v, ref["buffers"][k]) < 1e-3, k
+    net.img_cnn_layers.eval()
+    with pytest.raises(NotImplementedError):
+        net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+
+
+def test_training_step_with_a_radar_map_of_another_size(hip_lib):
+    """utils/datasets.py resizes the radar map to S/16 for training, the demos feed the raw 32 x 32 map with the same
+    spatial_scale (quirk q15): the training step must take a radar map whose side differs from the feature map's
+    (12 x 12 maps on a 10 x 10 feature map here) - loss, rows and every gradient against the oracle."""
+    from oracle import network_ref
+    name, cfg, n, s, conf = "train_q15", "yolov3-tiny-12", 2, 160, 0.2
+    net = _build(name, cfg, conf)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    maps, rboxes = synth.radar_inputs(name + "/radar", n, 12)
+    maps, rboxes = torch.from_numpy(maps), torch.from_numpy(rboxes)
+    tg = []
+    for row in rboxes.numpy():
+        i, x1, y1, x2, y2 = row
+        tg.append([i, 0, (x1 + x2) / 2, (y1 + y2) / 2, (x2 - x1) * 1.02, (y2 - y1) * 0.98])
+    targets = torch.tensor(np.array(tg, dtype=np.float32))
+    random.seed(5)
+    ref = network_ref.network_train_step(cfgs.KNOWN[cfg](), sd0, x, maps, rboxes, targets, conf_thresh=conf)
+    assert ref["n_pos"] > 0
+    net = net.cuda()
+    net.train()
+    net.base_detector.eval()
+    random.seed(5)
+    loss, output, metric, att = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0, targets.clone())
+    loss.backward()
+    assert tuple(att.shape) == (n, 1, 12, 12)
+    assert abs(float(loss.detach()) - float(ref["loss"])) <= 1e-3 * max(1.0, abs(float(ref["loss"])))
+    ph.assert_close(output.detach().cpu(), ref["output"], 1e-3, "rows")
+    checked = 0
+    for k, p in net.named_parameters():
+        if k.startswith("base_detector."):
+            continue
+        rg = ref["grads"][k]
+        if rg is None:
+            assert p.grad is None, k
+            continue
+        if float(rg.abs().max()) < 1e-5:
+            assert float(p.grad.abs().max()) < 1e-4, k
+        else:
+            assert _rel(p.grad, rg) < 2e-3, f"grad {k}: {_rel(p.grad, rg):.2e}"
+        checked += 1
+    assert checked >= 20
