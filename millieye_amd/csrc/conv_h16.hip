@@ -11,7 +11,9 @@
 //                        storage type - through a per-wave LDS transpose so that loads / stores are 16 bytes per lane -
 //                        or fp32 output for the detection convs that feed the YOLO decode.
 //   conv3x3_patch_h16  : experimental patch-resident variant for 3x3 / stride 1 layers (tile id 41, see its comment).
-//   conv_stem3_h16     : the cin = 3 stem on the VALU (fp32 frames in, fp32 weights, 16-bit NHWC out).
+//   conv_stem3_h16     : the cin = 3 stem on the VALU (fp32 frames, rounded to the storage type here; fp32 weights holding
+//                        values already rounded by the host; 16-bit NHWC out) - the fallback of stem_mfma_h16.hip (same
+//                        rounding points) for couts other than 32.
 //   maxpool / upsample / add / copy on 16-bit NHWC (16 bytes = 8 channels per lane).
 //
 // Rounding points (what oracle/darknet_ref.py's storage="bf16" / "f16" modes restate): weights once (host, RNE), every
@@ -27,6 +29,8 @@
 namespace me16 {  // conv_p8_h16.hip: patch-resident big-tile generation (tile ids >= 100)
 bool p8_eligible(const Conv16P& p, int tile);
 int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream);
+bool stem_mfma_eligible(const Conv16P& p);  // stem_mfma_h16.hip
+int launch_stem_mfma(const Conv16P& p, hipStream_t stream);
 }  // namespace me16
 
 namespace {
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256) void conv_stem3_h16(Conv16P p) {
         if (ok)
           v = p.x_nchw ? xf[(((long long)nimg * 3 + c) * p.h + iy) * p.w + ix]
                        : xf[((long long)(nimg * p.h + iy) * p.w + ix) * p.x_pitch + c];
-        xin[(ky * 3 + kx) * 3 + c] = v;
+        xin[(ky * 3 + kx) * 3 + c] = H16<F16>::from(H16<F16>::to(v));  // the frame is rounded to the storage type
       }
     }
   const float* __restrict__ wg = reinterpret_cast<const float*>(p.wgt) + (long long)co0 * K;  // uniform -> s_load
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(256) void conv_stem3_h16(Conv16P p) {
     for (int t = 0; t < 2; ++t) {
       float a = 0.f;
 #pragma unroll
-      for (int k = 0; k < K; ++k) a = fmaf(xin[k], wg[(j + t) * K + k], a);
+      for (int k = 0; k < K; ++k) a = fmaf(xin[k], wg[(j + t) * K + k], a);  // (the weights come pre-rounded from the host)
       v[t] = act16(a * p.scale[co0 + j + t] + p.shift[co0 + j + t], p.act);
     }
     packed[j / 2] = pack2<F16>(v[0], v[1]);
@@ -924,6 +928,7 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
     ME_REQUIRE(d->res == nullptr && d->upsample == 1, ME_E_BADARG, "me_conv2d_h16: stem has no residual/upsample epilogue");
     ME_REQUIRE(d->x_nchw || d->x_pitch >= d->cin, ME_E_BADARG, "me_conv2d_h16: x_pitch < cin");
     ME_REQUIRE(me::aligned16(d->y), ME_E_ALIGN, "me_conv2d_h16: y not 16-byte aligned");
+    if (d->tile != 1 && me16::stem_mfma_eligible(p)) return me16::launch_stem_mfma(p, stream);  // tile 1 forces the VALU stem
     const unsigned mb = (unsigned)((p.M + 255) / 256);
     if (d->cout % 32 == 0) {
       if (p.f16) hipLaunchKernelGGL((conv_stem3_h16<32, 1>), dim3(mb, d->cout / 32), dim3(256), 0, stream, p);

@@ -45,7 +45,7 @@ __device__ __forceinline__ void dma1(unsigned v, u32x4 r, unsigned s, unsigned d
                : "memory", "scc");
 }
 
-constexpr int kLpaMax = 7;
+constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 waves: up to 896 patch rows; 4 waves: 448)
 
 // PIPE = 1: register double-buffered fragments - the ds_reads of stage s + 1 complete behind the MFMAs of stage s (one
 //           workgroup per CU, <= 256 VGPRs);  PIPE = 0: fragments are read inside their stage, MINB = 2 workgroups share
@@ -53,14 +53,16 @@ constexpr int kLpaMax = 7;
 //           reads + output writes, 88 MB at 52x52) runs beside the other workgroup's main loop instead of after it.
 // ABL (tuning only, wrong results): 1 = all DMA lanes out of range, 3 = no DMA instructions, 4 = 3 + no LDS fragment reads,
 //           5 = 4 + no barriers (pure MFMA stream), 6 = full main loop but no epilogue, 7 = weights out of range (patch
-//           traffic only), 8 = patch out of range (weight traffic only)
+//           traffic only), 8 = patch out of range (weight traffic only); 9 = correct results + s_memtime stamps of
+//           workgroup 0 / wave 0 into the workspace (per stage: before the wait, after the wait, after the barrier, at the end)
 template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2 * MINB))) void conv3x3_p8_h16(P8Args a) {
+__global__ __launch_bounds__(64 * WR * WC)
+    __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_h16(P8Args a) {
   using frag = typename H16<F16>::v8;
   using elem16 = std::conditional_t<F16 != 0, _Float16, __bf16>;
   const Conv16P& p = a.c;
   constexpr int NW = WR * WC;
-  static_assert(NW == 8, "8 waves");
+  static_assert(NW == 8 || NW == 4, "8 waves, or 4 (two independent 4-wave workgroups per CU: their barriers interleave)");
   constexpr int TM = 32 * MT, TN = 32 * NT, BM = TM * WR, BN = TN * WC;
   constexpr int LPB = BN / 16 / NW;
   static_assert(LPB >= 1 && BN % 128 == 0, "BN must be a multiple of 128");
@@ -128,6 +130,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
   int tapoff[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((t / 3) * a.Wp + (t % 3));
+
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.partial);
+  int dbg_n = 0;
+  auto stamp = [&]() {
+    if constexpr (ABL == 9) {
+      if (blockIdx.x == 0 && wave == 0 && dbg && dbg_n < 2040) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) dbg[dbg_n] = t;
+        ++dbg_n;
+      }
+    }
+  };
+  stamp();
 
   unsigned rowbase[MT];
 #pragma unroll
@@ -248,6 +263,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
     if constexpr (PIPE) {
       const bool has_next = T < 8 || more_chunks;  // stage s + 1 exists
       // stage s + 1's weights must have landed; younger loads: stage s + 2's weights, and - taps 1, 2 - the next patch
+      stamp();
       if (NODMA) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if (T >= 7 && !more_chunks) {
@@ -257,10 +273,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
       } else {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB) : "memory");
       }
+      stamp();
       if (has_next && ABL != 5) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
+      stamp();
       // The matrix pipe must not idle while this wave issues its DMAs and next-stage fragment reads: the stage is laid
       // out as 2 * MT groups of NT MFMAs with one slice of that work behind each group (scheduling barriers pin the order):
       //   group g < MT : A fragments of block row g for stage s + 1 (5 VALU + 2 ds_read_b128)
@@ -305,8 +323,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
             __builtin_amdgcn_sched_barrier(0);
           },
           std::make_integer_sequence<int, 2 * MT>{});
+      stamp();
     } else {
       // loads younger than this stage's weights: the next tap's weights, and - at taps 1 and 2 - the next chunk's patch
+      stamp();
       if (NODMA) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if (T == 8 && !more_chunks) {
@@ -316,10 +336,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
       } else {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB) : "memory");
       }
+      stamp();
       if (ABL != 5) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
+      stamp();
       {  // weights of stage s + 2
         constexpr int T2 = (T + 2) % 9;
         const int c2 = chunk + (T + 2 >= 9 ? 1 : 0);
@@ -329,6 +351,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
       load_frags(Z{}, tc, chunk);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(Z{});
+      stamp();
     }
   };
   {
@@ -341,6 +364,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
     }
     if (chunk < cs) static_for([&](auto tc) { stage(tc, P0{}, chunk); }, std::make_integer_sequence<int, 9>{});
   }
+  stamp();
   if (ABL == 6) {  // ablation: no epilogue (one store so that the loop is not dead code)
     float t = 0.f;
 #pragma unroll
@@ -440,6 +464,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * MINB, 2
         if constexpr (i + RD < MT) fetch_res(std::integral_constant<int, i + RD>{});  // into the slot this row just freed
       },
       std::make_integer_sequence<int, MT>{});
+  if constexpr (ABL == 9) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && dbg) dbg[2047] = (unsigned long long)dbg_n;
+  }
 }
 
 void magic_u32(unsigned d, unsigned* m, unsigned* s) {
@@ -459,7 +488,8 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   a.halo = a.Wp + 1;
   a.Mp = (long long)p.n * a.Ip;
   a.rows = BM + 2 * a.halo;
-  a.lpa = ((a.rows + 15) / 16 + 7) / 8;
+  constexpr int NWAVES = WR * WC;
+  a.lpa = ((a.rows + 15) / 16 + NWAVES - 1) / NWAVES;
   ME_REQUIRE(a.lpa <= kLpaMax, ME_E_TOOBIG, "me_conv2d_h16: patch of %d rows does not fit (map too wide for this tile)", a.rows);
   ME_REQUIRE(a.Mp < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: too many padded positions");
   magic_u32((unsigned)a.Ip, &a.ip_m, &a.ip_s);
@@ -467,8 +497,8 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   a.c.tiles_m = (int)((a.Mp + BM - 1) / BM);
   a.c.tiles_n = p.cout / BN;
   a.c.splitk = 1;
-  size_t lds = 3 * (size_t)BN * 64 + 2 * (size_t)a.lpa * 8 * 1024;
-  const size_t epi = 8 * 2 * 32 * 36 * sizeof(float);
+  size_t lds = 3 * (size_t)BN * 64 + 2 * (size_t)a.lpa * NWAVES * 1024;
+  const size_t epi = NWAVES * 2 * 32 * 36 * sizeof(float);
   if (lds < epi) lds = epi;
   ME_REQUIRE(lds <= (MINB == 2 ? 80 : 160) * 1024, ME_E_TOOBIG,
              "me_conv2d_h16: this tile needs %zu bytes of LDS for a %d-wide map", lds, p.w);
@@ -480,7 +510,7 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   }
   const long long blocks = (long long)a.c.tiles_m * a.c.tiles_n;
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
   return me::check_launch("conv3x3_p8_h16");
 }
 
@@ -520,6 +550,11 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 200: return ME_P8(2, 4, 2, 2, 0, 2);   // 128 x 256
     case 201: return ME_P8(4, 2, 1, 2, 0, 2);   // 128 x 128
     case 221: return ME_P8(4, 2, 2, 2, 0, 2);   // 256 x 128
+    // two independent 4-wave workgroups per CU (one wave per SIMD each, register-pipelined fragments, <= 256 VGPRs)
+    case 301: return ME_P8(2, 2, 2, 2, 1, 2);   // 128 x 128
+    case 311: return ME_P8(2, 2, 3, 2, 1, 2);   // 192 x 128
+    case 321: return ME_P8(2, 2, 4, 2, 1, 2);   // 256 x 128
+    case 331: return ME_P8(4, 1, 2, 4, 1, 2);   // 256 x 128, wave tile 64 x 128
     // ablations (wrong results)
     case 180: return launch_p8<2, 4, 4, 2, 1, 1, 0, 1>(p, stream);
     case 190: return launch_p8<2, 4, 4, 2, 1, 1, 0, 3>(p, stream);
@@ -529,6 +564,8 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 293: return launch_p8<4, 2, 2, 2, 0, 2, 0, 6>(p, stream);
     case 290: return launch_p8<4, 2, 2, 2, 0, 2, 0, 3>(p, stream);
     case 280: return launch_p8<4, 2, 2, 2, 0, 2, 0, 1>(p, stream);
+    case 299: return launch_p8<4, 2, 2, 2, 0, 2, 0, 9>(p, stream);   // 221 with time stamps
+    case 199: return launch_p8<4, 2, 3, 2, 1, 1, 0, 9>(p, stream);   // 131 with time stamps
     case 297: return launch_p8<4, 2, 2, 2, 0, 2, 0, 7>(p, stream);
     case 298: return launch_p8<4, 2, 2, 2, 0, 2, 0, 8>(p, stream);
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown patch tile id %d", tile);

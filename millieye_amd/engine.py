@@ -137,12 +137,17 @@ class ConvWeights:
                 shift = torch.nn.functional.pad(shift, (0, extra))
             if self.dtype in _TORCH_HALF and cin > 4:
                 packed = packed.to(_TORCH_HALF[self.dtype])
+            elif self.dtype in _TORCH_HALF:  # stem: fp32 container (the VALU fallback reads floats), 16-bit values
+                packed = packed.to(_TORCH_HALF[self.dtype]).to(torch.float32)
             packed = packed.contiguous()
             realloc = (self.wgt is None or self.wgt.device != device or self.wgt.shape != packed.shape
                        or self.wgt.dtype != packed.dtype)
             tiled = None
             if packed.dtype in hip.HALF_TYPES and packed.shape[1] == 3 and packed.shape[3] % 32 == 0:
                 tiled = hip.tile_weights_h16(packed)
+            elif self.dtype in _TORCH_HALF and cin == 3 and packed.shape[1] == 3 and packed.shape[0] == 32:
+                # MFMA stem (csrc/stem_mfma_h16.hip): [32 cout][32 taps] in the storage type, taps 27..31 zero
+                tiled = torch.nn.functional.pad(packed.reshape(32, 27), (0, 5)).to(_TORCH_HALF[self.dtype]).contiguous()
             if realloc:
                 self.wgt, self.scale, self.shift = packed, scale.contiguous(), shift.contiguous()
                 self.wgt_tiled = tiled
@@ -704,8 +709,9 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      # patch-resident big tiles (csrc/conv_p8_h16.hip; 3x3 stride 1 only, no split-K): 1xx one workgroup per
                      # CU with register-pipelined fragments, 2xx two workgroups per CU
                      100: (128, 256), 110: (192, 256), 120: (256, 256), 101: (128, 128), 121: (256, 128), 131: (384, 128),
-                     141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128)}
-_TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221)
+                     141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128), 301: (128, 128), 311: (192, 128),
+                     321: (256, 128), 331: (256, 128)}
+_TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321)
 
 
 def _autotune_enabled():
@@ -719,7 +725,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v5.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v6.json")  # bump with every kernel generation
 
 
 def _tune_load():

@@ -338,7 +338,7 @@ def tile_weights_h16(wgt_packed):
 
 
 def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-                x_nchw=False, y_f32=False, tile=0, split_k=0, half=torch.bfloat16, wgt_tiled=None):
+                x_nchw=False, y_f32=False, tile=0, split_k=0, half=torch.bfloat16, wgt_tiled=None, debug_ws=None):
     """16-bit-storage twin of :func:`conv2d`; ``half`` = ``torch.bfloat16`` (default) or ``torch.float16``.  ``x``: 16-bit
     NHWC [N,H,W,Cin] (or a channel slice), or - stem, Cin == 3 - float32 NCHW / NHWC; ``wgt_packed``: 16-bit [Cout,k,k,Cin]
     (float32 for the stem); ``residual``: the output's dtype.  Returns 16-bit NHWC (float32 when ``y_f32``)."""
@@ -388,6 +388,8 @@ def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=No
     if need > 0:
         ws_ptr, keep = _workspace(need, x.device, slot="conv")
         d.workspace, d.workspace_bytes = ws_ptr, need
+    if debug_ws is not None:  # instrumented tile ids (tools/p8_timeline.py): the kernel writes its time stamps here
+        d.workspace, d.workspace_bytes = debug_ws.data_ptr(), debug_ws.numel() * debug_ws.element_size()
     check(lib().me_conv2d_h16(C.byref(d), stream_ptr()), "me_conv2d_h16")
     return out
 

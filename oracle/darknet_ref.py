@@ -94,7 +94,7 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
     ``storage="bf16"`` / ``"f16"`` restates the build's 16-bit storage modes (BASELINE configs[2]/[4]; no reference counterpart - the
     reference is fp32 only, so this mode is pinned to nothing but the fp32 path it approximates): same fp32 library ops,
     with one round-to-nearest-even to bfloat16 at every point where millieye_amd/csrc/conv_bf16.hip stores 16-bit data -
-    the weights of every convolution with more than 4 input channels, and every activation written to memory, i.e. after
+    the frame and the weights of every convolution, and every activation written to memory, i.e. after
     conv+BN+LeakyReLU (and after the [shortcut] add when that convolution feeds only the shortcut - the add is then part of
     the same kernel and sees the unrounded value).  Detection convolutions (read only by a [yolo] block) stay fp32."""
     blocks = parse_cfg_text(cfg_text)[1:]
@@ -112,13 +112,14 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
 
     pending = None  # unrounded output of a conv fused with the following shortcut
     with torch.no_grad():
+        x = q(x)  # the stem reads the frame as 16-bit MFMA operands
         for i, b in enumerate(blocks):
             kind = b["type"]
             if kind == "convolutional":
                 k = int(b["size"])
                 w = state_dict[f"{prefix}{i}.conv_{i}.weight"]
                 bias = state_dict.get(f"{prefix}{i}.conv_{i}.bias")
-                if bf16 and w.shape[1] > 4:
+                if bf16:
                     w = q(w)
                 x = F.conv2d(x, w, bias, stride=int(b["stride"]), padding=(k - 1) // 2)
                 if int(b["batch_normalize"]):

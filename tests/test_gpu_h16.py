@@ -115,18 +115,38 @@ def test_conv_bf16_detection_and_slices(hip_lib):
 
 
 def test_stem_and_helpers_bf16(hip_lib):
+    """cin = 3 stem in the 16-bit modes: frame and weights are rounded once to the storage type, accumulation is fp32.  Both
+    implementations - the MFMA stem (cout 32, csrc/stem_mfma_h16.hip; needs the [32][32] tap-padded weight copy) and the VALU
+    fallback - against the fp32 CPU convolution of the rounded operands; NCHW and NHWC frames, an M that is not a multiple of
+    32, output written into a channel slice."""
     from millieye_amd import hip
     g = torch.Generator().manual_seed(9)
-    x = torch.rand((2, 3, 40, 40), generator=g)
-    for cout, half in ((16, torch.bfloat16), (32, torch.bfloat16), (64, torch.bfloat16), (32, torch.float16)):
-        w = torch.randn((cout, 3, 3, 3), generator=g) * 0.2
-        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
-        ref = F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
-        ref = torch.where(ref > 0, ref, 0.1 * ref).permute(0, 2, 3, 1).contiguous()
-        y = hip.conv2d_h16(x.cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), scale.cuda(), shift.cuda(), 3, 1, 1, 1,
-                           x_nchw=True, half=half)
-        assert y.dtype == half
-        _check_bf16(y, ref, f"stem cout {cout}")
+    for shape in ((2, 3, 40, 40), (3, 3, 13, 21)):
+        x = torch.rand(shape, generator=g)
+        for cout, half in ((16, torch.bfloat16), (32, torch.bfloat16), (64, torch.bfloat16), (32, torch.float16)):
+            w = torch.randn((cout, 3, 3, 3), generator=g) * 0.2
+            scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+            ref = F.conv2d(x.to(half).float(), w.to(half).float(), padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            ref = torch.where(ref > 0, ref, 0.1 * ref).permute(0, 2, 3, 1).contiguous()
+            packed = w.to(half).float().permute(0, 2, 3, 1).contiguous().cuda()  # fp32 container, values rounded by the host
+            y = hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), 3, 1, 1, 1, x_nchw=True, half=half)
+            assert y.dtype == half
+            _check_bf16(y, ref, f"VALU stem cout {cout} {shape}")
+            if cout == 32:
+                taps = F.pad(packed.reshape(32, 27), (0, 5)).to(half).contiguous()
+                ym = hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), 3, 1, 1, 1, x_nchw=True, half=half,
+                                    wgt_tiled=taps)
+                _check_bf16(ym, ref, f"MFMA stem {half} {shape} (NCHW frame)")
+                xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+                yh = hip.conv2d_h16(xh, packed, scale.cuda(), shift.cuda(), 3, 1, 1, 1, x_nchw=False, half=half, wgt_tiled=taps)
+                assert torch.equal(yh, ym), "NHWC frame"
+                wide = torch.zeros(ym.shape[:3] + (48,), dtype=half).cuda()
+                hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), 3, 1, 1, 1, x_nchw=True, half=half, wgt_tiled=taps,
+                               out=wide[..., 8:40])
+                assert torch.equal(wide[..., 8:40], ym) and float(wide[..., :8].abs().max()) == 0
+                yv = hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), 3, 1, 1, 1, x_nchw=True, half=half,
+                                    wgt_tiled=taps, tile=1)  # tile 1 forces the VALU stem: same rounding points
+                assert float((yv.float() - ym.float()).abs().max()) <= 2 * float(ULP[half]) * float(ref.abs().max())
     for half in (torch.bfloat16, torch.float16):
         _helpers(hip, g, half)
 
@@ -340,7 +360,7 @@ def test_detector_16bit_608_batch16(hip_lib, dtype):
 
 
 P8_TILES_256 = (100, 110, 120, 200)
-P8_TILES_128 = (101, 121, 131, 141, 201, 221)
+P8_TILES_128 = (101, 121, 131, 141, 201, 221, 301, 311, 321, 331)
 P8_CASES = [
     # name, n, h, w, cin, cout, act, res
     ("13x13 two images per tile", 5, 13, 13, 64, 256, 1, True),
