@@ -80,6 +80,9 @@ typedef struct me_conv_desc {
   int32_t split_k;  /* 0 = auto; 1 = never split; k > 1 forces k K-splits (needs the workspace) */
   void* workspace;  /* optional scratch for deterministic split-K slabs (256-byte aligned), or NULL */
   int64_t workspace_bytes;
+  const float* wgt_tiled; /* tile ids >= 100 (patch-resident 3x3 / stride 1 kernels, csrc/conv_p8_f32.hip) read the weights
+                             from this second packing: [ksize*ksize][cin/16][cout][16] - every (tap, 16-channel chunk) slab
+                             of cout rows x 64 bytes is contiguous.  May be NULL otherwise. */
 } me_conv_desc;
 int me_conv2d_f32(const me_conv_desc* d, void* stream);
 /* scratch the automatic plan would like for this descriptor (0 = none). Small-M layers (13x13, 26x26

@@ -19,34 +19,13 @@
 #include "common.h"
 #include "dma.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "conv32_common.h"
+
+namespace me32 {  // conv_p8_f32.hip: patch-resident big tiles (tile ids >= 100)
+int launch_p8_tile(const ConvP& p, int tile, hipStream_t stream);
+}  // namespace me32
 
 namespace {
-
-struct ConvP {
-  const float* x;
-  const float* wgt;
-  const float* scale;
-  const float* shift;
-  const float* res;
-  float* y;
-  long long x_pitch, res_pitch, y_pitch;
-  int n, h, w, cin, cout, ks, stride, pad, ho, wo, act, ups, x_nchw;
-  int M;       // n*ho*wo
-  int ktot;    // ks*ks*cin
-  int cs;      // channel chunks per tap = ceil(cin / BK)
-  int stages;  // ks*ks*cs
-  int tiles_m, tiles_n;
-  float* partial;  // split-K slabs [splitk][M][cout] (raw accumulators), or nullptr
-  int splitk;      // number of K splits (grid.y)
-  int sps;         // K stages per split
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == ME_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
-  if (act == ME_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
-  return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM MFMA kernel
@@ -1135,7 +1114,7 @@ int fill_params(const me_conv_desc* d, ConvP& p) {
   ME_REQUIRE(ho == d->ho && wo == d->wo, ME_E_BADARG, "me_conv2d_f32: ho/wo (%d,%d) != derived (%d,%d)", d->ho,
              d->wo, ho, wo);
   ME_REQUIRE((long long)d->n * d->ho * d->wo < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: too many output pixels");
-  p.x = d->x; p.wgt = d->wgt; p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
+  p.x = d->x; p.wgt = d->wgt; p.wgt_tiled = d->wgt_tiled; p.scale = d->scale; p.shift = d->shift; p.res = d->res; p.y = d->y;
   p.x_pitch = d->x_pitch; p.res_pitch = d->res_pitch; p.y_pitch = d->y_pitch;
   p.n = d->n; p.h = d->h; p.w = d->w; p.cin = d->cin; p.cout = d->cout; p.ks = d->ksize;
   p.stride = d->stride; p.pad = d->pad; p.ho = d->ho; p.wo = d->wo; p.act = d->act; p.ups = d->upsample;
@@ -1225,6 +1204,7 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   }
   p.splitk = plan.splitk;
   p.partial = reinterpret_cast<float*>(d->workspace);
+  if (plan.tile >= 100) return me32::launch_p8_tile(p, plan.tile, stream);
   switch (plan.tile) {
     // production tiles: buffer-addressed LDS-DMA pipeline (falls back to conv_igemm_dma_f32 when cin % 16 != 0
     // or the offsets do not fit the descriptor window)

@@ -1,0 +1,35 @@
+// conv32_common.h - parameter block and activation helper shared by the fp32 convolution kernels (conv.hip: per-tap
+// implicit GEMM, stems, split-K; conv_p8_f32.hip: the patch-resident big-tile generation).
+#pragma once
+#include <math.h>
+#include "common.h"
+#include "dma.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvP {
+  const float* x;
+  const float* wgt;
+  const float* wgt_tiled;  // [taps][cin/16][cout][16] copy (patch-resident kernels), or nullptr
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  long long x_pitch, res_pitch, y_pitch;
+  int n, h, w, cin, cout, ks, stride, pad, ho, wo, act, ups, x_nchw;
+  int M;       // n*ho*wo
+  int ktot;    // ks*ks*cin
+  int cs;      // channel chunks per tap = ceil(cin / BK)
+  int stages;  // ks*ks*cs
+  int tiles_m, tiles_n;
+  float* partial;  // split-K slabs [splitk][M][cout] (raw accumulators), or nullptr
+  int splitk;      // number of K splits (grid.y)
+  int sps;         // K stages per split
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ME_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+  if (act == ME_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+

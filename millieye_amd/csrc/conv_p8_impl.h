@@ -1,0 +1,526 @@
+// conv_p8_impl.h - the patch-resident big-tile 3x3 / stride-1 convolution kernel (gfx950), generic over the storage type:
+// conv_p8_h16.hip instantiates it for bfloat16 / IEEE half (v_mfma_f32_32x32x16), conv_p8_f32.hip for float32
+// (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains).  The design notes are in conv_p8_h16.hip's header.
+// A "chunk" is 64 bytes of the channel dimension: 32 channels of a 16-bit type, 16 floats.
+#pragma once
+#include <type_traits>
+#include <utility>
+#include "common.h"
+#include "dma.h"
+
+namespace me_p8 {
+using namespace me_dma;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <class F, int... J>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, J...>) {
+  (f(std::integral_constant<int, J>{}), ...);
+}
+
+// layout-neutral description of the convolution (filled by the 16-bit and the fp32 launchers)
+struct P8Conv {
+  const void* x;
+  const void* wgt_tiled;  // [taps][cin / CHUNK][cout][CHUNK]: every (tap, chunk) slab of cout rows x 64 bytes contiguous
+  const float* scale;
+  const float* shift;
+  const void* res;
+  void* y;
+  long long x_pitch, res_pitch, y_pitch;  // elements
+  int n, h, w, cin, cout, act;
+  int tiles_m, tiles_n;
+  void* partial;  // instrumented builds: time stamps
+};
+
+struct P8Args {
+  P8Conv c;
+  int Wp, Ip, halo;       // padded-linear pitches, halo = Wp + 1
+  long long Mp;           // n * Ip positions
+  unsigned ip_m, ip_s;    // magic division by Ip
+  unsigned wp_m, wp_s;    // magic division by Wp
+  int lpa;                // patch DMA instructions per wave and chunk = ceil(ceil(rows / 16) / 8)
+  int rows;               // BM + 2 * halo
+};
+
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) { return (__umulhi(n, m) + n) >> s; }
+
+__device__ __forceinline__ void dma1(unsigned v, u32x4 r, unsigned s, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[r], %[s] offen lds\n\t"
+               "s_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep)
+               : [d] "s"(dst), [r] "s"(r), [s] "s"(s), [v] "v"(v)
+               : "memory", "scc");
+}
+
+constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 waves: up to 896 patch rows; 4 waves: 448)
+
+// PIPE = 1: register double-buffered fragments - the ds_reads of stage s + 1 complete behind the MFMAs of stage s (one
+//           workgroup per CU, <= 256 VGPRs);  PIPE = 0: fragments are read inside their stage, MINB = 2 workgroups share
+//           a CU (<= 128 VGPRs, <= 80 KB of LDS each): their phases interleave, so the epilogue's memory traffic (residual
+//           reads + output writes, 88 MB at 52x52) runs beside the other workgroup's main loop instead of after it.
+// ABL (tuning only, wrong results): 1 = all DMA lanes out of range, 3 = no DMA instructions, 4 = 3 + no LDS fragment reads,
+//           5 = 4 + no barriers (pure MFMA stream), 6 = full main loop but no epilogue, 7 = weights out of range (patch
+//           traffic only), 8 = patch out of range (weight traffic only); 9 = correct results + s_memtime stamps of
+//           workgroup 0 / wave 0 into the workspace (per stage: before the wait, after the wait, after the barrier, at the end)
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0>
+__global__ __launch_bounds__(64 * WR * WC)
+    __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
+  using frag = typename DT::frag;
+  const P8Conv& p = a.c;
+  constexpr int NW = WR * WC;
+  static_assert(NW == 8 || NW == 4, "8 waves, or 4 (two independent 4-wave workgroups per CU: their barriers interleave)");
+  constexpr int TM = 32 * MT, TN = 32 * NT, BM = TM * WR, BN = TN * WC;
+  constexpr int LPB = BN / 16 / NW;
+  static_assert(LPB >= 1 && BN % 128 == 0, "BN must be a multiple of 128");
+  constexpr unsigned B_SLOT = BN * 64u;
+  constexpr unsigned A_BASE = 3u * B_SLOT;
+  constexpr int NSET = PIPE ? 2 : 1;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int r32 = lane & 31, hh = lane >> 5;
+
+  int tile_m, tile_n;
+  {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_n = wg % p.tiles_n;
+    tile_m = wg / p.tiles_n;
+  }
+  const int W = p.w, H = p.h;
+  const long long q0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int lpa = a.lpa;
+  const unsigned A_SLOT = (unsigned)lpa * (NW * 1024u);
+
+  // first image the patch can touch: descriptor base, so that per-lane offsets stay small and non-negative
+  const long long pq0 = q0 - a.halo;
+  const int nb = pq0 > 0 ? (int)udiv_magic((unsigned)pq0, a.ip_m, a.ip_s) : 0;
+  const u32x4 rsrc_a = make_rsrc(reinterpret_cast<const unsigned char*>(p.x) + (long long)nb * H * W * p.x_pitch * DT::kBytes);
+  const u32x4 rsrc_b = make_rsrc(p.wgt_tiled);  // [tap][chunk][cout][32]: a (tap, chunk) slab of BN rows is contiguous
+
+  unsigned v_a[kLpaMax], v_b[LPB];
+  auto setup_a = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int r = (wave + NW * j) * 16 + (lane >> 2);
+    const int qd = (lane & 3) ^ ((r >> 2) & 3);
+    const long long pq = pq0 + r;
+    unsigned off = kOobOffset;
+    if (ABL != 1 && ABL != 8 && j < lpa && r < a.rows && pq >= 0 && pq < a.Mp) {
+      const unsigned u = (unsigned)pq;
+      const unsigned n = udiv_magic(u, a.ip_m, a.ip_s);
+      const unsigned rem = u - n * (unsigned)a.Ip;
+      const unsigned y = udiv_magic(rem, a.wp_m, a.wp_s);
+      const unsigned x = rem - y * (unsigned)a.Wp;
+      if (y < (unsigned)H && x < (unsigned)W)
+        off = (unsigned)((((long long)(n - nb) * H + y) * W + x) * p.x_pitch * DT::kBytes) + 16u * qd;
+    }
+    v_a[j] = off;
+  };
+  static_for(setup_a, std::make_integer_sequence<int, kLpaMax>{});
+  auto setup_b = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int row = (wave + NW * j) * 16 + (lane >> 2);
+    const int qd = (lane & 3) ^ ((row >> 2) & 3);
+    v_b[j] = (ABL != 1 && ABL != 7) ? (unsigned)(n0 + row) * 64u + 16u * qd : kOobOffset;  // cout % BN == 0: always in range
+  };
+  static_for(setup_b, std::make_integer_sequence<int, LPB>{});
+
+  // tap -> patch row shift: output row tr reads patch row tr + (1 + dy) * Wp + (1 + dx)
+  int tapoff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((t / 3) * a.Wp + (t % 3));
+
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.partial);
+  int dbg_n = 0;
+  auto stamp = [&]() {
+    if constexpr (ABL == 9) {
+      if (blockIdx.x == 0 && wave == 0 && dbg && dbg_n < 2040) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) dbg[dbg_n] = t;
+        ++dbg_n;
+      }
+    }
+  };
+  stamp();
+
+  unsigned rowbase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rowbase[i] = (unsigned)(wr * TM + i * 32 + r32);
+  const int swb = (r32 >> 2) & 3;
+  const unsigned char* b_frag = smem16 + (wc * TN + r32) * 64;
+  const unsigned b_offk[2] = {(unsigned)(((0 + hh) ^ swb) * 16), (unsigned)(((2 + hh) ^ swb) * 16)};
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int cs = p.cin / DT::kChunk;  // 64-byte chunks of the channel dimension
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+  auto issue_a = [&](int chunk, unsigned slot) {
+    if (ABL >= 3 && ABL != 6) return;
+    const unsigned dst = wave_lds + A_BASE + slot * A_SLOT;
+    static_for(
+        [&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (j < lpa) dma1(v_a[j], rsrc_a, (unsigned)chunk * 64u, dst + (unsigned)j * (NW * 1024u));
+        },
+        std::make_integer_sequence<int, kLpaMax>{});
+  };
+  auto issue_b = [&](int chunk, int tap, unsigned ring) {
+    if (ABL >= 3 && ABL != 6) return;
+    const unsigned soff = ((unsigned)tap * (unsigned)cs + (unsigned)chunk) * (unsigned)p.cout * 64u;
+#pragma unroll
+    for (int j = 0; j < LPB; ++j) dma1(v_b[j], rsrc_b, soff, wave_lds + ring * B_SLOT + (unsigned)j * (NW * 1024u));
+  };
+  // s_waitcnt takes an immediate: the runtime patch count goes through a uniform switch
+  auto wait_b_plus_a = [&]() {
+    switch (lpa) {
+      case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 1) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 2) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 3) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 4) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 5) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 6) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 7) : "memory"); break;
+    }
+  };
+  constexpr bool NODMA = ABL >= 3 && ABL != 6;
+
+  frag afr[NSET][2][MT], bfr[NSET][2][NT];
+  if (ABL == 4 || ABL == 5) {  // ablation: the fragments never change - give them ordinary values
+#pragma unroll
+    for (int s2 = 0; s2 < NSET; ++s2)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          afr[s2][ks][i] = DT::fill(0.01f * (float)(lane + i));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          bfr[s2][ks][j] = DT::fill(0.02f * (float)(lane - j));
+      }
+  }
+  auto load_frags = [&](auto setc, auto tc, int chunk) {
+    constexpr int SET = decltype(setc)::value, T = decltype(tc)::value;
+    if (ABL == 4 || ABL == 5) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(afr[SET][0][i]), "+v"(afr[SET][1][i]));
+      return;
+    }
+    const unsigned char* Ab = smem16 + A_BASE + (unsigned)(chunk & 1) * A_SLOT;
+    const unsigned char* Bb = b_frag + (T % 3) * B_SLOT;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      unsigned rb0 = rowbase[i];
+      asm volatile("" : "+v"(rb0));  // opaque per stage: otherwise the 18 * MT fragment addresses are hoisted out of the
+                                     // chunk loop and live in registers for the whole kernel; 5 VALU per block instead
+      const unsigned R = rb0 + (unsigned)tapoff[T];
+      const unsigned o0 = (R << 6) + (((R >> 2) ^ (unsigned)hh) & 3u) * 16u;
+      afr[SET][0][i] = *reinterpret_cast<const frag*>(Ab + o0);
+      afr[SET][1][i] = *reinterpret_cast<const frag*>(Ab + (o0 ^ 32u));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[SET][ks][j] = *reinterpret_cast<const frag*>(Bb + j * 32 * 64 + b_offk[ks]);
+  };
+  auto mfmas = [&](auto setc) {
+    constexpr int SET = decltype(setc)::value;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) DT::mfma(afr[SET][ks][i], bfr[SET][ks][j], acc[i][j]);
+  };
+  using Z = std::integral_constant<int, 0>;
+
+  issue_a(0, 0);
+  issue_b(0, 0, 0);
+  issue_b(0, 1, 1);
+  if constexpr (PIPE) {
+    // ---- software pipeline: iteration s (after its barrier): DMA(s + 3) -> ring slot of stage s; LDS -> registers for
+    // stage s + 1 (fragment set P ^ 1); MFMAs of stage s from set P.  9 stages per chunk: the parity flips per chunk. ----
+    issue_b(0, 2, 2);
+    if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPB) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(Z{}, Z{}, 0);
+  }
+
+  auto stage = [&](auto tc, auto parc, int chunk) {
+    constexpr int T = decltype(tc)::value, PAR = decltype(parc)::value;
+    constexpr int SET = PIPE ? ((T + PAR) & 1) : 0;
+    const bool more_chunks = chunk + 1 < cs;
+    if constexpr (PIPE) {
+      const bool has_next = T < 8 || more_chunks;  // stage s + 1 exists
+      // stage s + 1's weights must have landed; younger loads: stage s + 2's weights, and - taps 1, 2 - the next patch
+      stamp();
+      if (NODMA) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if (T >= 7 && !more_chunks) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if ((T == 1 || T == 2) && more_chunks) {
+        wait_b_plus_a();
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB) : "memory");
+      }
+      stamp();
+      if (has_next && ABL != 5) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      stamp();
+      // The matrix pipe must not idle while this wave issues its DMAs and next-stage fragment reads: the stage is laid
+      // out as 2 * MT groups of NT MFMAs with one slice of that work behind each group (scheduling barriers pin the order):
+      //   group g < MT : A fragments of block row g for stage s + 1 (5 VALU + 2 ds_read_b128)
+      //   group MT     : weights of stage s + 3 into the ring slot of stage s (its fragments were read one iteration ago),
+      //                  at tap 0 also the next chunk's patch
+      //   groups > MT  : B fragments for stage s + 1, spread
+      constexpr int TN1 = T < 8 ? T + 1 : 0;
+      const int cn = T < 8 ? chunk : chunk + 1;
+      const unsigned char* Ab = smem16 + A_BASE + (unsigned)(cn & 1) * A_SLOT;
+      const unsigned char* Bb = b_frag + (TN1 % 3) * B_SLOT;
+      constexpr int NS = SET ^ 1;
+      static_for(
+          [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int ks = g / MT, i = g % MT;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) DT::mfma(afr[SET][ks][i], bfr[SET][ks][j], acc[i][j]);
+            if constexpr (g < MT) {
+              if (has_next && ABL != 4 && ABL != 5) {
+                unsigned rb0 = rowbase[g];
+                asm volatile("" : "+v"(rb0));
+                const unsigned R = rb0 + (unsigned)tapoff[TN1];
+                const unsigned o0 = (R << 6) + (((R >> 2) ^ (unsigned)hh) & 3u) * 16u;
+                afr[NS][0][g] = *reinterpret_cast<const frag*>(Ab + o0);
+                afr[NS][1][g] = *reinterpret_cast<const frag*>(Ab + (o0 ^ 32u));
+              }
+            }
+            if constexpr (g == MT) {
+              constexpr int T3 = (T + 3) % 9;
+              const int c3 = chunk + (T + 3 >= 9 ? 1 : 0);
+              if (c3 < cs) issue_b(c3, T3, (unsigned)(T3 % 3));
+              if (T == 0 && more_chunks) issue_a(chunk + 1, (unsigned)((chunk + 1) & 1));
+            }
+            if constexpr (g >= MT) {  // 2 * NT B-fragment reads over the MT groups MT .. 2 MT - 1
+              if (has_next && ABL != 4 && ABL != 5) {
+                constexpr int lo = (g - MT) * (2 * NT) / MT, hi = (g - MT + 1) * (2 * NT) / MT;
+#pragma unroll
+                for (int r = lo; r < hi; ++r)
+                  bfr[NS][r / NT][r % NT] = *reinterpret_cast<const frag*>(Bb + (r % NT) * 32 * 64 + b_offk[r / NT]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          },
+          std::make_integer_sequence<int, 2 * MT>{});
+      stamp();
+    } else {
+      // loads younger than this stage's weights: the next tap's weights, and - at taps 1 and 2 - the next chunk's patch
+      stamp();
+      if (NODMA) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if (T == 8 && !more_chunks) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if ((T == 1 || T == 2) && more_chunks) {
+        wait_b_plus_a();
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB) : "memory");
+      }
+      stamp();
+      if (ABL != 5) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      stamp();
+      {  // weights of stage s + 2
+        constexpr int T2 = (T + 2) % 9;
+        const int c2 = chunk + (T + 2 >= 9 ? 1 : 0);
+        if (c2 < cs) issue_b(c2, T2, (unsigned)(T2 % 3));
+      }
+      if (T == 0 && more_chunks) issue_a(chunk + 1, (unsigned)((chunk + 1) & 1));
+      load_frags(Z{}, tc, chunk);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(Z{});
+      stamp();
+    }
+  };
+  {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int chunk = 0;
+    for (; chunk + 2 <= cs; chunk += 2) {  // two chunks = 18 stages per trip: the fragment-set parity is static
+      static_for([&](auto tc) { stage(tc, P0{}, chunk); }, std::make_integer_sequence<int, 9>{});
+      static_for([&](auto tc) { stage(tc, P1{}, chunk + 1); }, std::make_integer_sequence<int, 9>{});
+    }
+    if (chunk < cs) static_for([&](auto tc) { stage(tc, P0{}, chunk); }, std::make_integer_sequence<int, 9>{});
+  }
+  stamp();
+  if (ABL == 6) {  // ablation: no epilogue (one store so that the loop is not dead code)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+    if (t == 123.456f) reinterpret_cast<float*>(p.y)[0] = t;
+    return;
+  }
+
+  if constexpr (DT::kBytes == 2) {
+    // ---- epilogue: per wave, 32x32 blocks through a private LDS transpose (lane = output channel -> 8 consecutive
+    // channels of one pixel per lane: 16-byte residual loads and stores).  Every residual piece of the wave is requested
+    // BEFORE the arithmetic starts (one memory latency per wave, not one per block), and there is no s_waitcnt between the
+    // transpose's writes and reads: the LDS executes one wave's operations in order.  Rows are decoded from the
+    // padded-linear position to the dense NHWC pixel; pad positions and positions behind the last image are skipped. ----
+    const float slope = p.act == ME_ACT_LEAKY ? 0.1f : 1.0f;
+    constexpr int TP = 36;
+    __syncthreads();
+    float* tbuf = reinterpret_cast<float*>(smem16) + wave * (2 * 32 * TP);
+    const int prow = lane >> 2, c8 = (lane & 3) * 8;
+    unsigned short* __restrict__ yb = reinterpret_cast<unsigned short*>(p.y);
+    const unsigned short* __restrict__ rb = reinterpret_cast<const unsigned short*>(p.res);
+    int mrow[MT][2];  // dense pixel index (< 2^31: checked by fill16), -1 = pad / out of range
+  #pragma unroll
+    for (int i = 0; i < MT; ++i)
+  #pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const long long q = q0 + wr * TM + i * 32 + pass * 16 + prow;
+        int m = -1;
+        if (q < a.Mp) {
+          const unsigned u = (unsigned)q;
+          const unsigned n = udiv_magic(u, a.ip_m, a.ip_s);
+          const unsigned rem = u - n * (unsigned)a.Ip;
+          const unsigned y = udiv_magic(rem, a.wp_m, a.wp_s);
+          const unsigned x = rem - y * (unsigned)a.Wp;
+          if (y < (unsigned)H && x < (unsigned)W) m = (int)((n * (unsigned)H + y) * (unsigned)W + x);
+        }
+        mrow[i][pass] = m;
+      }
+    constexpr int RD = MT <= 2 ? MT : 2;  // residual prefetch depth in block rows (all of them for the small wave tiles)
+    uint4 rres[RD][NT][2];
+    auto fetch_res = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (!rb) return;
+  #pragma unroll
+      for (int j = 0; j < NT; ++j)
+  #pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+          rres[i % RD][j][pass] = mrow[i][pass] >= 0
+                                      ? *reinterpret_cast<const uint4*>(rb + (long long)mrow[i][pass] * p.res_pitch + n0 + wc * TN + j * 32 + c8)
+                                      : make_uint4(0u, 0u, 0u, 0u);
+    };
+    static_for(fetch_res, std::make_integer_sequence<int, RD>{});
+    auto block_out = [&](auto ic, auto jc) {
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      float* tb = tbuf + ((i * NT + j) & 1) * (32 * TP);  // two patches per wave: block k + 1 is written while block k drains
+      const int cb = n0 + wc * TN + j * 32;
+      const float sc = p.scale[cb + r32], sh = p.shift[cb + r32];
+  #pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[i][j][e] * sc + sh;
+        v = fmaxf(v, v * slope);  // slope 0.1: == v > 0 ? v : 0.1 v;  slope 1: v
+        tb[((e & 3) + 8 * (e >> 2) + 4 * hh) * TP + r32] = v;
+      }
+  #pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 16 + prow;
+        const float4 lo = *reinterpret_cast<const float4*>(tb + row * TP + c8);
+        const float4 hi = *reinterpret_cast<const float4*>(tb + row * TP + c8 + 4);
+        const long long m = mrow[i][pass];
+        if (m >= 0) {
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          if (rb) {
+            const uint4 r4 = rres[i % RD][j][pass];
+            const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w};
+  #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[2 * k] += DT::from16(rr[k] & 0xffffu);
+              v[2 * k + 1] += DT::from16(rr[k] >> 16);
+            }
+          }
+          uint4 o;
+          o.x = DT::pack2(v[0], v[1]);
+          o.y = DT::pack2(v[2], v[3]);
+          o.z = DT::pack2(v[4], v[5]);
+          o.w = DT::pack2(v[6], v[7]);
+          *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
+        }
+      }
+    };
+    static_for(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          static_for([&](auto jc) { block_out(ic, jc); }, std::make_integer_sequence<int, NT>{});
+          if constexpr (i + RD < MT) fetch_res(std::integral_constant<int, i + RD>{});  // into the slot this row just freed
+        },
+        std::make_integer_sequence<int, MT>{});
+  } else {
+    // ---- fp32 epilogue: lane = output channel (32 consecutive floats = one 128-byte segment per pixel row), register =
+    // pixel; affine + activation + residual in place, rows decoded from the padded-linear position (16 per block row) ----
+    float* __restrict__ yf = reinterpret_cast<float*>(p.y);
+    const float* __restrict__ rf = reinterpret_cast<const float*>(p.res);
+    const bool leaky = p.act == ME_ACT_LEAKY;
+    static_for(
+        [&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          int mrow[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const long long q = q0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            int m = -1;
+            if (q < a.Mp) {
+              const unsigned u = (unsigned)q;
+              const unsigned n = udiv_magic(u, a.ip_m, a.ip_s);
+              const unsigned rem = u - n * (unsigned)a.Ip;
+              const unsigned y = udiv_magic(rem, a.wp_m, a.wp_s);
+              const unsigned x = rem - y * (unsigned)a.Wp;
+              if (y < (unsigned)H && x < (unsigned)W) m = (int)((n * (unsigned)H + y) * (unsigned)W + x);
+            }
+            mrow[e] = m;
+          }
+          static_for(
+              [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int co = n0 + wc * TN + j * 32 + r32;
+                const float sc = p.scale[co], sh = p.shift[co];
+                float rv[16];
+                if (rf) {
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) rv[e] = mrow[e] >= 0 ? rf[(long long)mrow[e] * p.res_pitch + co] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  float v = acc[i][j][e] * sc + sh;
+                  if (leaky) v = v > 0.f ? v : 0.1f * v;
+                  if (rf) v += rv[e];
+                  if (mrow[e] >= 0) yf[(long long)mrow[e] * p.y_pitch + co] = v;
+                }
+              },
+              std::make_integer_sequence<int, NT>{});
+        },
+        std::make_integer_sequence<int, MT>{});
+  }
+  if constexpr (ABL == 9) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && dbg) dbg[2047] = (unsigned long long)dbg_n;
+  }
+}
+
+
+}  // namespace me_p8

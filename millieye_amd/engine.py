@@ -145,6 +145,8 @@ class ConvWeights:
             tiled = None
             if packed.dtype in hip.HALF_TYPES and packed.shape[1] == 3 and packed.shape[3] % 32 == 0:
                 tiled = hip.tile_weights_h16(packed)
+            elif packed.dtype == torch.float32 and self.dtype == "f32" and packed.shape[1] == 3 and packed.shape[3] % 16 == 0:
+                tiled = hip.tile_weights_f32(packed)  # fp32 patch-resident kernels (csrc/conv_p8_f32.hip)
             elif self.dtype in _TORCH_HALF and cin == 3 and packed.shape[1] == 3 and packed.shape[0] == 32:
                 # MFMA stem (csrc/stem_mfma_h16.hip): [32 cout][32 taps] in the storage type, taps 27..31 zero
                 tiled = torch.nn.functional.pad(packed.reshape(32, 27), (0, 5)).to(_TORCH_HALF[self.dtype]).contiguous()
@@ -530,10 +532,10 @@ class DarknetEngine:
                 dsc.cout, dsc.ksize, dsc.stride, dsc.pad = cw.wgt.shape[0], op["k"], op["s"], op["pad"]
                 dsc.ho, dsc.wo, dsc.act, dsc.upsample, dsc.tile = op["ho"], op["wo"], op["act"], op["ups"], 0
                 dsc.split_k, dsc.workspace, dsc.workspace_bytes = 0, None, 0
+                dsc.wgt_tiled = cw.wgt_tiled.data_ptr() if cw.wgt_tiled is not None else None
                 if bf16:
                     dsc.y_f32 = 1 if y.esize == 4 else 0
                     dsc.half_type = half_type
-                    dsc.wgt_tiled = cw.wgt_tiled.data_ptr() if cw.wgt_tiled is not None else None
                 launches.append((lib.me_conv2d_h16 if bf16 else lib.me_conv2d_f32, (C.byref(dsc),), dsc,
                                  f"conv{op['module']}"))
                 plan.conv_descs.append((op["module"], dsc))
@@ -711,6 +713,8 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      100: (128, 256), 110: (192, 256), 120: (256, 256), 101: (128, 128), 121: (256, 128), 131: (384, 128),
                      141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128), 301: (128, 128), 311: (192, 128),
                      321: (256, 128), 331: (256, 128)}
+_TUNE_TILES_P8_F32 = (201, 221)  # fp32 is matrix-pipe bound: the big tiles' pad positions / quantisation cost more than
+# their traffic saves (tools/p8_bench_f32.py: only the 2-workgroup tiles come close to the 64x64 per-tap tile)
 _TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321)
 
 
@@ -831,8 +835,10 @@ def _autotune(plan, lib):
             tiles = _TUNE_TILES_BF16 if d.cin % 64 == 0 else _TUNE_TILES_BF16[:4] + (15,)
             if d.ksize == 3 and d.stride == 1 and d.upsample == 1 and d.wgt_tiled and not d.y_f32:
                 tiles = tiles + _TUNE_TILES_P8  # the library refuses the ones that do not apply (cout % width, LDS)
+        elif d.ksize == 3 and d.stride == 1 and d.upsample == 1 and d.wgt_tiled:
+            tiles = tiles + _TUNE_TILES_P8_F32
         for tile in tiles:
-            bm, bn = _TILE_SHAPES_BF16[tile] if bf16 else \
+            bm, bn = _TILE_SHAPES_BF16[tile] if (bf16 or tile >= 100) else \
                 {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128)}[tile]
             tiles = -(-d.n * d.ho * d.wo // bm) * -(-d.cout // bn)
             for split in (_TUNE_SPLITS if tile < 100 else (1,)):

@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("upsample", C.c_int32), ("x_nchw", C.c_int32), ("tile", C.c_int32),
         ("split_k", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("wgt_tiled", C.c_void_p),
     ]
 
 
@@ -290,7 +291,7 @@ def _nhwc_pitch(t, name):
 
 
 def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-           x_nchw=False, tile=0, split_k=0):
+           x_nchw=False, tile=0, split_k=0, wgt_tiled=None):
     """x_nhwc: [N,H,W,Cin] contiguous (or NCHW [N,Cin,H,W] when ``x_nchw``).  Returns NHWC
     [N,Ho*up,Wo*up,Cout]."""
     _require_cuda_f32(x_nhwc, "x")
@@ -319,6 +320,9 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.ksize, d.stride, d.pad, d.ho, d.wo = ksize, stride, pad, ho, wo
     d.act, d.upsample, d.x_nchw, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, tile, split_k
+    if tile >= 100 and wgt_tiled is None and wgt_packed.shape[3] % 16 == 0:
+        wgt_tiled = tile_weights_f32(wgt_packed)  # callers that care about time pass their own copy
+    d.wgt_tiled = wgt_tiled.data_ptr() if wgt_tiled is not None else None
     need = lib().me_conv2d_workspace_bytes(C.byref(d))
     keep = None
     if need > 0:
@@ -326,6 +330,15 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
         d.workspace, d.workspace_bytes = ws_ptr, need
     check(lib().me_conv2d_f32(C.byref(d), stream_ptr()), "me_conv2d_f32")
     return out
+
+
+def tile_weights_f32(wgt_packed):
+    """Second packing of fp32 OHWI weights for the patch-resident kernels (tile ids >= 100): ``[k*k][cin/16][cout][16]`` -
+    every (tap, 16-channel chunk) slab of cout rows x 64 bytes contiguous (``me_conv_desc.wgt_tiled``)."""
+    cout, kh, kw, cin = wgt_packed.shape
+    if cin % 16:
+        raise MeError("tile_weights_f32: cin must be a multiple of 16")
+    return wgt_packed.reshape(cout, kh * kw, cin // 16, 16).permute(1, 2, 0, 3).contiguous()
 
 
 def tile_weights_h16(wgt_packed):

@@ -210,3 +210,44 @@ def test_conv_random_shapes(hip_lib):
                    split_k=int(rng.choice([0, 0, 2, 3])))
         done += 1
     assert done >= 45
+
+
+P8_F32_TILES_128 = (121, 131, 201, 221, 311, 321)
+P8_F32_TILES_256 = (100, 110, 200)
+
+
+@pytest.mark.parametrize("tile", P8_F32_TILES_128 + P8_F32_TILES_256)
+def test_conv_p8_patch_resident_f32(hip_lib, tile):
+    """The patch-resident big tiles of the fp32 path (csrc/conv_p8_f32.hip = conv_p8_impl.h on v_mfma_f32_32x32x2_f32):
+    tiles are BM consecutive positions of the padded-linear index space (they cross rows and images); every tile shape
+    against the CPU convolution at the fp32 bar (1e-3), with residual, on rectangular / tiny / 2-images-per-tile maps, channel
+    slices on both sides, and bit-reproducible."""
+    from millieye_amd import hip
+    cout = 256 if tile in P8_F32_TILES_256 else 128
+    _conv_case(hip, f"p8f{tile}a", 5, 13, 13, 32, cout, 3, 1, 1, tile=tile, residual=True)       # two images per tile
+    _conv_case(hip, f"p8f{tile}b", 2, 9, 31, 16, cout, 3, 1, 0, tile=tile)                       # rectangular, linear, cs = 1
+    _conv_case(hip, f"p8f{tile}c", 1, 52, 52, 48, 2 * cout, 3, 1, 1, tile=tile, residual=True, x_slice=16)
+    _conv_case(hip, f"p8f{tile}d", 1, 5, 7, 64, cout, 3, 1, 1, tile=tile)                        # one tiny image
+    x = _t("p8fx", (3, 26, 26, 64)).cuda()
+    w = torch.from_numpy(synth.normal("p8fw", (cout, 3, 3, 64), 0, 0.04)).cuda()
+    s, b = torch.ones(cout).cuda(), torch.zeros(cout).cuda()
+    a1 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=tile, split_k=1)
+    a2 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=tile, split_k=1)
+    assert torch.equal(a1, a2)
+    a0 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=3, split_k=1)
+    assert_close(a1.cpu(), a0.cpu(), 1e-4, "patch-resident vs per-tap kernel")
+    wide = torch.zeros((3, 26, 26, cout + 32), device="cuda")
+    hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=tile, split_k=1, out=wide[..., 16:16 + cout])
+    assert torch.equal(wide[..., 16:16 + cout], a1) and float(wide[..., :16].abs().max()) == 0
+
+
+def test_conv_p8_f32_refuses_what_it_cannot_do(hip_lib):
+    from millieye_amd import hip
+    x = torch.zeros((1, 8, 8, 32)).cuda()
+    one = torch.ones(128).cuda()
+    with pytest.raises(hip.MeError):
+        hip.conv2d(x, torch.zeros((128, 1, 1, 32)).cuda(), one, one, 1, 1, 0, 1, tile=221)          # 1x1
+    with pytest.raises(hip.MeError):
+        hip.conv2d(x, torch.zeros((72, 3, 3, 32)).cuda(), one[:72], one[:72], 3, 1, 1, 1, tile=221)  # cout % 128
+    with pytest.raises(hip.MeError):
+        hip.conv2d(x, torch.zeros((128, 3, 3, 32)).cuda(), one, one, 3, 2, 1, 1, tile=221)           # stride 2
