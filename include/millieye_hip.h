@@ -301,6 +301,14 @@ int me_heads_tail_f32(const me_heads_desc* d, const float* small, int32_t k, voi
  *   focal (alpha, gamma=2, sum) on [1-p, p] for rows with in_focal, BCE(sum)/lambda on conf for rows with
  *   in_conf; label_pos marks IoU-positive rows.  terms [k,2] = (focal_i, bce_i) (sum them with
  *   me_colsum_f32); seed_p [k] = dL/dp, seed_conf [k] = dL/dconf (already divided by lambda). */
+/* IoU labels of the stage-3 proposals (my_models.py:317-375 with the call site's truthy multi_boxes, quirk q5; +1-pixel
+ * IoU of utils.py:269-274): proposals = n_img rows of img_boxes [*, cols] (image_i, x1,y1,x2,y2, conf, cls_score, cls_pred, ..)
+ * followed by n_radar rows of radar_boxes [*, 5] (image_i, x1,y1,x2,y2; class 0); targets [q,6] = (image_i, class, x1,y1,x2,y2)
+ * in pixels.  out [k,4] = (first-maximum IoU over the same image / class targets or 0, keep flag, conf_1, conf_2) - everything
+ * the host-side metric and negative sampling (python `random`, q7) read, in one buffer.  Bit-identical with the host code. */
+int me_iou_labels_f32(const float* img_boxes, int32_t n_img, int32_t cols, const float* radar_boxes, int32_t n_radar,
+                      const float* targets, int32_t q, const float* refine, const float* mask1, const uint8_t* keep, float* out,
+                      void* stream);
 int me_heads_loss_f32(const float* mask1, const float* refine, const uint8_t* label_pos, const uint8_t* in_focal,
                       const uint8_t* in_conf, int32_t k, float alpha, float conf_lambda, float* terms,
                       float* seed_p, float* seed_conf, void* stream);

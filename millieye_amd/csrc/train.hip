@@ -691,7 +691,61 @@ inline unsigned grid1d(long long work) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// IoU labels of the stage-3 proposals (reference my_models.py:317-375 obtain_iou_labels with the call site's always-truthy
+// multi_boxes, quirk q5): per proposal the FIRST maximum of the +1-pixel IoU over the targets of the same image and class,
+// 0 when there is none.  fp32, the reference's operation order, no FMA contraction: bit-identical with the host restatement
+// (train_path.iou_labels_vectorized).  One thread per proposal; also packs what the host needs for the metric and the
+// negative sampling into ONE buffer (iou, kept flag, conf_1, conf_2), so the training forward reads the device once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iou_labels_kernel(const float* img_boxes, int n_img, int cols, const float* radar_boxes,
+                                                         int n_radar, const float* targets, int q, const float* refine,
+                                                         const float* mask1, const unsigned char* keep, float* out) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k = n_img + n_radar;
+  if (i >= k) return;
+  float img, cls, b0, b1, b2, b3, conf1;
+  if (i < n_img) {
+    const float* r = img_boxes + (long long)i * cols;
+    img = r[0]; cls = r[7]; b0 = r[1]; b1 = r[2]; b2 = r[3]; b3 = r[4]; conf1 = r[5];
+  } else {
+    const float* r = radar_boxes + (long long)(i - n_img) * 5;
+    img = r[0]; cls = 0.f; b0 = r[1]; b1 = r[2]; b2 = r[3]; b3 = r[4]; conf1 = refine[2 * i];
+  }
+  const float a1 = (b2 - b0 + 1.f) * (b3 - b1 + 1.f);
+  float best = -1.f;
+  for (int t = 0; t < q; ++t) {
+    const float* tg = targets + (long long)t * 6;
+    if (tg[0] != img || tg[1] != cls) continue;
+    const float ix1 = fmaxf(b0, tg[2]), iy1 = fmaxf(b1, tg[3]);
+    const float ix2 = fminf(b2, tg[4]), iy2 = fminf(b3, tg[5]);
+    const float inter = fmaxf(ix2 - ix1 + 1.f, 0.f) * fmaxf(iy2 - iy1 + 1.f, 0.f);
+    const float a2 = (tg[4] - tg[2] + 1.f) * (tg[5] - tg[3] + 1.f);
+    const float iou = inter / (a1 + a2 - inter + 1e-16f);
+    if (iou > best) best = iou;
+  }
+  out[4 * i] = best < 0.f ? 0.f : best;
+  out[4 * i + 1] = keep[i] ? 1.f : 0.f;
+  out[4 * i + 2] = conf1;
+  out[4 * i + 3] = mask1[i];
+}
+
 extern "C" {
+
+int me_iou_labels_f32(const float* img_boxes, int32_t n_img, int32_t cols, const float* radar_boxes, int32_t n_radar,
+                      const float* targets, int32_t q, const float* refine, const float* mask1, const uint8_t* keep, float* out,
+                      void* stream) {
+  const int k = n_img + n_radar;
+  ME_REQUIRE(n_img >= 0 && n_radar >= 0 && q >= 0 && cols >= 8, ME_E_BADARG, "me_iou_labels_f32: bad sizes");
+  if (k == 0) return 0;
+  ME_REQUIRE(out && refine && mask1 && keep && (n_img == 0 || img_boxes) && (n_radar == 0 || radar_boxes) && (q == 0 || targets),
+             ME_E_NULLPTR, "me_iou_labels_f32: null pointer");
+  hipLaunchKernelGGL(iou_labels_kernel, dim3((k + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img_boxes,
+                     n_img, cols, radar_boxes, n_radar, targets, q, refine, mask1, keep, out);
+  return me::check_launch("iou_labels_kernel");
+}
+
 
 int me_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float* a,
                 int64_t lda, const float* b, int64_t ldb, float beta, float* c, int64_t ldc, void* stream_) {

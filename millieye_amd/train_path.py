@@ -179,9 +179,13 @@ class _StageThree(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        grads = _backward(ctx.state, grad_out)
         names = ctx.state["names"]
-        return (None,) + tuple(grads.get(n) for n in names)
+        # frozen tensors (train.py:146-149 freezes the stage-2 part: requires_grad = False) need no gradient: with the
+        # score-map conv / BatchNorm frozen, the largest GEMMs of the step (490 x 256 over every pixel, the PS-RoIAlign
+        # scatter, the BatchNorm backward over N*h*w x 490) are skipped altogether
+        needed = {n for n, need in zip(names, ctx.needs_input_grad[1:]) if need}
+        grads = _backward(ctx.state, grad_out, needed)
+        return (None,) + tuple(grads.get(n) if n in needed else None for n in names)
 
 
 def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0):
@@ -326,22 +330,31 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         n_out = torch.empty((1,), device=dev, dtype=torch.int32)
         hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), k, 8, ordered.data_ptr(),
                                                n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
-        output = ordered[:int(n_out.item())]
         if targets is None:
-            return output
+            return ordered[:int(n_out.item())]
 
-        # ---- labels on the host (reference :545-604) ---------------------------------------------------
+        # ---- labels (reference :545-604): the IoU labelling runs on the device (me_iou_labels_f32, bit-identical with
+        # iou_labels_vectorized); what the host-side metric and the python-`random` negative sampling (q7) need - labels,
+        # kept flags, the two confidences and the output row count - comes back in ONE copy: the step's second and last
+        # host read (the first is the proposal count that sizes everything) ------------------------------------------------
         targets[:, 2:] = xywh2xyxy(targets[:, 2:])
         targets[:, 2:] *= images.shape[3]
         ib = img_boxes[:n_img]
-        boxes_cpu = torch.cat((torch.cat((ib[:, :1], ib[:, 7:8], ib[:, 1:5]), 1),
-                               torch.cat((rb[:, :1], torch.zeros((n_radar, 1), **f32), rb[:, 1:5]), 1)), 0).cpu()
-        iou_labels, _target_location = iou_labels_vectorized(boxes_cpu, targets.cpu())
+        tg_d = targets.detach().to(**f32).contiguous()
+        packed = _f32(dev, 4 * cap + 1)
+        hip.check(lib.me_iou_labels_f32(img_boxes.data_ptr(), n_img, cols, rb.data_ptr() if n_radar else None, n_radar,
+                                        tg_d.data_ptr() if len(tg_d) else None, int(tg_d.shape[0]), refine.data_ptr(),
+                                        mask1.data_ptr(), keep.data_ptr(), packed.data_ptr(), hip.stream_ptr()),
+                  "me_iou_labels_f32")
+        packed[4 * cap:] = n_out  # (device-side cast + copy)
+        host = packed.cpu()
+        output = ordered[:int(host[4 * cap])]
+        host = host[:4 * k].view(k, 4)
+        iou_labels = host[:, 0:1].contiguous()
         pos_filter = (iou_labels > net.iou_thresh[1]).flatten()
         neg_filter = (iou_labels < net.iou_thresh[0]).flatten()
-        positive_masks = keep[:k].bool().cpu()
-        conf_1 = torch.cat((ib[:, 5], refine[n_img:k, 0])).cpu()
-        conf_2 = mask1[:k].cpu()
+        positive_masks = host[:, 1] > 0
+        conf_1, conf_2 = host[:, 2].contiguous(), host[:, 3].contiguous()
         flat = iou_labels.flatten()
         confs = dict(conf_1_pos=conf_1[flat > 0.5], conf_1_neg=conf_1[flat < 0.5], conf_2_pos=conf_2[flat > 0.5],
                      conf_2_neg=conf_2[flat < 0.5])
@@ -356,8 +369,8 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         in_conf = sample_filter.clone()
         in_focal = sample_filter.clone()
         in_focal[n_img:] = False
-        lab_d = pos_filter.to(torch.uint8).to(dev)
-        foc_d, cnf_d = in_focal.to(torch.uint8).to(dev), in_conf.to(torch.uint8).to(dev)
+        masks_d = torch.stack((pos_filter, in_focal, in_conf)).to(torch.uint8).to(dev)  # one upload
+        lab_d, foc_d, cnf_d = masks_d[0], masks_d[1], masks_d[2]
 
         # ---- loss terms + gradient seeds ----------------------------------------------------------------
         terms, seed_p, seed_c = _f32(dev, cap, 2), _f32(dev, cap), _f32(dev, cap)
@@ -383,8 +396,9 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
     return loss, output, metric, radar_attention
 
 
-def _backward(S, grad_out):
-    """Manual backward of the stage-3 graph; returns {parameter name: gradient}."""
+def _backward(S, grad_out, needed=None):
+    """Manual backward of the stage-3 graph; returns {parameter name: gradient}.  ``needed``: names whose gradient the
+    caller wants (None = all); whole branches whose every consumer is frozen are skipped."""
     net, dev = S["net"], S["fm"].device
     lib = hip.lib()
     f32 = dict(device=dev, dtype=torch.float32)
@@ -439,24 +453,31 @@ def _backward(S, grad_out):
         dw0 = torch.zeros((256, 490), **f32); _gemm(1, 0, 256, 490, k, g_pre, 256, S["feat_img"], 490, dw0, 490)
         db0 = _f32(dev, 256); _colsum(g_pre, 256, k, 256, db0)
         G["refinement_head.net0.0.weight"], G["refinement_head.net0.0.bias"] = dw0, db0
+        img_names = ("img_cnn_layers.net.batch_norm_0.weight", "img_cnn_layers.net.batch_norm_0.bias",
+                     "img_cnn_layers.net.conv_0.weight", "img_cnn_layers.net.conv_0.bias")
+        want_img = needed is None or any(nm in needed for nm in img_names)
         w0 = rh.net0[0].weight.detach().contiguous()
-        d_pimg = _f32(dev, k, 490); _gemm(0, 0, k, 490, 256, g_pre, 256, w0, 490, d_pimg, 490)
+        d_pimg = _f32(dev, k, 490)
+        if want_img:
+            _gemm(0, 0, k, 490, 256, g_pre, 256, w0, 490, d_pimg, 490)
         # ---- RoI pooling backward (atomic scatter) ----------------------------------------------------------
         rois = S["rois"]
-        d_a1 = torch.zeros((pix, 490), **f32)
         d_r4 = torch.zeros((pix_r, 10), **f32)
-        hip.check(lib.me_ps_roi_align_bwd_f32(d_pimg.data_ptr(), rois.data_ptr(), k, n, fh, fw, 490, 7, 1.0 / 16,
-                                              d_a1.data_ptr(), 490, hip.stream_ptr()), "me_ps_roi_align_bwd_f32")
+        if want_img:
+            d_a1 = torch.zeros((pix, 490), **f32)
+            hip.check(lib.me_ps_roi_align_bwd_f32(d_pimg.data_ptr(), rois.data_ptr(), k, n, fh, fw, 490, 7, 1.0 / 16,
+                                                  d_a1.data_ptr(), 490, hip.stream_ptr()), "me_ps_roi_align_bwd_f32")
         hip.check(lib.me_roi_align_bwd_f32(d_prad.data_ptr(), rois.data_ptr(), k, n, mh, mw, 10, 7, 1.0 / 16,
                                            d_r4.data_ptr(), 10, hip.stream_ptr()), "me_roi_align_bwd_f32")
         # ---- image score map: BN(+leaky) backward, 1x1 conv weight / bias gradient -------------------------
-        icl = net.img_cnn_layers.net
-        dz1 = _f32(dev, pix, 490)
-        dg, dbt = _bn_bwd(S["z1"], 490, d_a1, 490, pix, 490, icl[1], S["st_img"], hip.ACT_LEAKY, dz1, 490, ws)
-        G["img_cnn_layers.net.batch_norm_0.weight"], G["img_cnn_layers.net.batch_norm_0.bias"] = dg, dbt
-        dw = torch.zeros((490, fc), **f32); _gemm(1, 0, 490, fc, pix, dz1, 490, S["fm"], fc, dw, fc)
-        db = _f32(dev, 490); _colsum(dz1, 490, pix, 490, db)
-        G["img_cnn_layers.net.conv_0.weight"], G["img_cnn_layers.net.conv_0.bias"] = dw.view(490, fc, 1, 1), db
+        if want_img:
+            icl = net.img_cnn_layers.net
+            dz1 = _f32(dev, pix, 490)
+            dg, dbt = _bn_bwd(S["z1"], 490, d_a1, 490, pix, 490, icl[1], S["st_img"], hip.ACT_LEAKY, dz1, 490, ws)
+            G["img_cnn_layers.net.batch_norm_0.weight"], G["img_cnn_layers.net.batch_norm_0.bias"] = dg, dbt
+            dw = torch.zeros((490, fc), **f32); _gemm(1, 0, 490, fc, pix, dz1, 490, S["fm"], fc, dw, fc)
+            db = _f32(dev, 490); _colsum(dz1, 490, pix, 490, db)
+            G["img_cnn_layers.net.conv_0.weight"], G["img_cnn_layers.net.conv_0.bias"] = dw.view(490, fc, 1, 1), db
         # ---- radar CNN ---------------------------------------------------------------------------------------
         R = S["radar"]
         dc4 = _f32(dev, pix_r, 10)

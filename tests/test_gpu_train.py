@@ -367,3 +367,49 @@ def test_training_step_with_a_radar_map_of_another_size(hip_lib):
             assert _rel(p.grad, rg) < 2e-3, f"grad {k}: {_rel(p.grad, rg):.2e}"
         checked += 1
     assert checked >= 20
+
+
+def test_iou_labels_kernel_is_bit_identical_with_the_host_restatement(hip_lib):
+    """me_iou_labels_f32 (device-side obtain_iou_labels, quirk q5) against train_path.iou_labels_vectorized - itself pinned
+    bit for bit to the reference's per-box loop (tests/test_train_cpu.py): exact ties (first target wins), proposals with no
+    target of their image / class, zero targets, zero proposals, and the packed side columns."""
+    from millieye_amd import hip
+    from millieye_amd.train_path import iou_labels_vectorized
+    n_img, n_radar, q, cols = 700, 45, 23, 9
+    xy = synth.uniform("ilk/xy", (n_img + n_radar, 2), 0, 300)
+    wh = synth.uniform("ilk/wh", (n_img + n_radar, 2), 5, 120)
+    img = np.floor(synth.uniform("ilk/i", (n_img + n_radar, 1), 0, 5))
+    cls = np.floor(synth.uniform("ilk/c", (n_img, 1), 0, 2))
+    ib = np.zeros((n_img, cols), dtype=np.float32)
+    ib[:, 0:1], ib[:, 1:3], ib[:, 3:5], ib[:, 5], ib[:, 7:8] = img[:n_img], xy[:n_img], (xy + wh)[:n_img], 0.25, cls
+    rb = np.concatenate([img[n_img:], xy[n_img:], (xy + wh)[n_img:]], 1).astype(np.float32)
+    t_xy = synth.uniform("ilk/txy", (q, 2), 0, 300)
+    t_wh = synth.uniform("ilk/twh", (q, 2), 5, 120)
+    tg = np.concatenate([np.floor(synth.uniform("ilk/ti", (q, 1), 0, 4)), np.zeros((q, 1), np.float32), t_xy, t_xy + t_wh],
+                        1).astype(np.float32)
+    tg[5] = tg[4]                         # an exact tie: the first of the two wins either way (same label)
+    ib[:10, 1:5], ib[:10, 0], ib[:10, 7] = tg[:10, 2:6], tg[:10, 0], tg[:10, 1]   # perfect matches
+    rb[:5, 1:5], rb[:5, 0] = tg[10:15, 2:6] + 1.5, tg[10:15, 0]
+    boxes = np.concatenate([np.concatenate([ib[:, :1], ib[:, 7:8], ib[:, 1:5]], 1),
+                            np.concatenate([rb[:, :1], np.zeros((n_radar, 1), np.float32), rb[:, 1:5]], 1)], 0)
+    want, _loc = iou_labels_vectorized(torch.from_numpy(boxes), torch.from_numpy(tg))
+    k = n_img + n_radar
+    refine = torch.rand((k, 2)).cuda()
+    mask1 = torch.rand(k).cuda()
+    keep = (torch.rand(k) > 0.5).to(torch.uint8).cuda()
+    out = torch.full((k, 4), -7.0).cuda()
+    ibd, rbd, tgd = torch.from_numpy(ib).cuda(), torch.from_numpy(rb).cuda(), torch.from_numpy(tg).cuda()
+    hip.check(hip.lib().me_iou_labels_f32(ibd.data_ptr(), n_img, cols, rbd.data_ptr(), n_radar, tgd.data_ptr(), q,
+                                          refine.data_ptr(), mask1.data_ptr(), keep.data_ptr(), out.data_ptr(),
+                                          hip.stream_ptr()), "me_iou_labels_f32")
+    got = out.cpu()
+    assert torch.equal(got[:, 0:1], want), float((got[:, 0:1] - want).abs().max())
+    assert (want > 0.7).sum() >= 10 and (want == 0).sum() > 0
+    assert torch.equal(got[:, 1], keep.float().cpu()) and torch.equal(got[:, 3], mask1.cpu())
+    assert torch.equal(got[:n_img, 2], torch.full((n_img,), 0.25)) and torch.equal(got[n_img:, 2], refine[n_img:, 0].cpu())
+    out.fill_(-7.0)
+    hip.check(hip.lib().me_iou_labels_f32(ibd.data_ptr(), n_img, cols, rbd.data_ptr(), n_radar, None, 0, refine.data_ptr(),
+                                          mask1.data_ptr(), keep.data_ptr(), out.data_ptr(), hip.stream_ptr()), "no targets")
+    assert float(out[:, 0].abs().max()) == 0
+    hip.check(hip.lib().me_iou_labels_f32(None, 0, cols, None, 0, tgd.data_ptr(), q, refine.data_ptr(), mask1.data_ptr(),
+                                          keep.data_ptr(), out.data_ptr(), hip.stream_ptr()), "no proposals")
