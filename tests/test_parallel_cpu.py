@@ -165,7 +165,6 @@ def test_dp_stage3_step_equals_one_way():
         p.join(timeout=60)
         assert p.exitcode == 0
     cfg_text, net, x, maps, rboxes, targets, conf = _dp_problem()
-    torch.set_num_threads(4)
     ref = _dp_step(cfg_text, net.state_dict(), x, maps, rboxes, targets, conf)
     assert ref["n_pos"] > 0 and ref["num_img"] > 0
     assert got[0][1] + got[1][1] == __import__("pytest").approx(float(ref["loss"]), rel=1e-5)  # the loss is a sum over frames
