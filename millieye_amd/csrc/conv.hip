@@ -23,6 +23,8 @@
 
 namespace me32 {  // conv_p8_f32.hip: patch-resident big tiles (tile ids >= 100)
 int launch_p8_tile(const ConvP& p, int tile, hipStream_t stream);
+bool stem_mfma_eligible(const ConvP& p);  // stem_mfma_f32.hip
+int launch_stem_mfma(const ConvP& p, hipStream_t stream);
 }  // namespace me32
 
 namespace {
@@ -1162,6 +1164,7 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
                "me_conv2d_f32: small-cin kernel has no residual/upsample epilogue");
     ME_REQUIRE(d->x_nchw || d->x_pitch >= d->cin, ME_E_BADARG, "me_conv2d_f32: x_pitch < cin");
     ME_REQUIRE(me::aligned16(d->y), ME_E_ALIGN, "me_conv2d_f32: y not 16-byte aligned");
+    if (d->tile == 0 && me32::stem_mfma_eligible(p)) return me32::launch_stem_mfma(p, stream);  // tile 92 / 91: VALU versions
     if (d->cin == 3 && (d->y_pitch & 3) == 0 && d->tile != 91) {  // tile 91 forces the first version (A/B)
       const unsigned mb = (unsigned)((p.M + 255) / 256);
       if (d->cout % 32 == 0) {

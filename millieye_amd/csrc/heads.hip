@@ -141,36 +141,54 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* map, long l
 }
 
 // ---- proposal assembly --------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void gather_class_boxes_kernel(const float* det, const int* count, int n,
-                                                                  int max_det, int num_classes, int class_idx,
-                                                                  int class_num, float* boxes, int* total) {
-  __shared__ int s_wave[16];
+// One workgroup per image.  Rows keep the reference's image-major order, so image i starts at the number of rows the
+// images before it contribute: every workgroup counts those itself (<= n * max_det independent loads spread over 256
+// threads = one memory latency) instead of one workgroup walking all slots serially (7 dependent rounds of load + three
+// barriers at batch 32: 70 us -> see profiles/r02_kernel_evolution.md).
+__global__ __launch_bounds__(256) void gather_class_boxes_kernel(const float* det, const int* count, int n,
+                                                                 int max_det, int num_classes, int class_idx,
+                                                                 int class_num, float* boxes, int* total) {
+  __shared__ int s_wave[4];
   __shared__ int s_base;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int img = blockIdx.x;
   const int width = 7 + num_classes, cols = 8 + class_num;
-  if (t == 0) s_base = 0;
+  auto taken = [&](int im, int k) {
+    return k < count[im] && (class_idx < 0 || det[((long long)im * max_det + k) * width + 6] == (float)class_idx);
+  };
+  // rows of the images in front of this one
+  int before_imgs = 0;
+  if (class_idx < 0) {
+    for (int j = t; j < img; j += 256) before_imgs += count[j] < max_det ? count[j] : max_det;
+  } else {
+    const int slots = img * max_det;
+    for (int sidx = t; sidx < slots; sidx += 256) {
+      const int j = sidx / max_det;
+      before_imgs += taken(j, sidx - j * max_det) ? 1 : 0;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) before_imgs += __shfl_down(before_imgs, o, 64);
+  if (lane == 0) s_wave[wv] = before_imgs;
   __syncthreads();
-  // flat scan over the n * max_det slots, 1024 at a time (image-major order is the slot order): a slot is taken if it
-  // is below its image's count and passes the class test; ballot + prefix counts keep the order
-  const int slots = n * max_det;
-  for (int k0 = 0; k0 < slots; k0 += 1024) {
-    const int sidx = k0 + t;
-    const int img = sidx < slots ? sidx / max_det : 0;
-    const int k = sidx - img * max_det;
-    const bool in_range = sidx < slots && k < count[img];
-    const float* d = det + ((long long)img * max_det + (in_range ? k : 0)) * width;
-    const bool take = in_range && (class_idx < 0 || d[6] == (float)class_idx);  // class_idx < 0: every class (module 2)
+  if (t == 0) s_base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  __syncthreads();
+  // own rows, 256 slots at a time, order kept by ballot + prefix counts
+  for (int k0 = 0; k0 < max_det; k0 += 256) {
+    const int k = k0 + t;
+    const bool take = k < max_det && taken(img, k);
     const unsigned long long m = __ballot(take);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();  // s_wave is reused
     if (lane == 0) s_wave[wv] = __popcll(m);
     __syncthreads();
     int woff = 0, all = 0;
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 4; ++q) {
       if (q < wv) woff += s_wave[q];
       all += s_wave[q];
     }
     const int base = s_base;
     if (take) {
+      const float* d = det + ((long long)img * max_det + k) * width;
       float* o = boxes + (long long)(base + woff + before) * cols;
       o[0] = (float)img;
       for (int c = 0; c < 7 + class_num; ++c) o[1 + c] = d[c];
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(1024) void gather_class_boxes_kernel(const float* d
     if (t == 0) s_base = base + all;
     __syncthreads();
   }
-  if (t == 0) *total = s_base;
+  if (t == 0 && img == n - 1) *total = s_base;
 }
 
 // ---- fused RoI pooling + heads ---------------------------------------------------------------------
@@ -590,7 +608,7 @@ int me_gather_class_boxes_f32(const float* det, const int32_t* count, int32_t n,
   ME_REQUIRE(det && count && boxes && total, ME_E_NULLPTR, "me_gather_class_boxes_f32: null pointer");
   ME_REQUIRE(n > 0 && max_det > 0 && num_classes >= 1 && class_num >= 0 && class_num <= num_classes, ME_E_BADARG,
              "me_gather_class_boxes_f32: bad dimensions");  // class_idx < 0 gathers every class
-  hipLaunchKernelGGL(gather_class_boxes_kernel, dim3(1), dim3(1024), 0, stream, det, count, n, max_det, num_classes,
+  hipLaunchKernelGGL(gather_class_boxes_kernel, dim3(n), dim3(256), 0, stream, det, count, n, max_det, num_classes,
                      class_idx, class_num, boxes, total);
   return me::check_launch("gather_class_boxes_kernel");
 }

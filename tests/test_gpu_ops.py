@@ -116,6 +116,18 @@ def test_conv_stem_smallcin(hip_lib):
     _conv_case(hip, "stem16", 1, 40, 24, 3, 16, 3, 1, 1, nchw_in=True)
     _conv_case(hip, "radar", 2, 26, 26, 3, 32, 3, 1, 1, nchw_in=False)  # NHWC cin 3
     _conv_case(hip, "cin4", 1, 9, 9, 4, 20, 3, 1, 0, nchw_in=False)     # cout not multiple of 8
+    # couts that are multiples of 32 go to the MFMA stem (csrc/stem_mfma_f32.hip) by default; tile 92 / 91 force the two VALU
+    # versions: all three against the CPU convolution, ragged M (not a multiple of 32), sigmoid, 64 channels, pitched output
+    for tile in (0, 92, 91):
+        _conv_case(hip, f"stem32t{tile}", 3, 13, 21, 3, 32, 3, 1, 1, nchw_in=True, tile=tile)
+        _conv_case(hip, f"stem64t{tile}", 2, 17, 9, 3, 64, 3, 1, 2, nchw_in=False, tile=tile)
+    x = _t("stemx", (2, 3, 20, 20)).cuda()
+    w = torch.from_numpy(synth.normal("stemw", (32, 3, 3, 3), 0, 0.2)).cuda()
+    s1, b1 = torch.ones(32).cuda(), torch.zeros(32).cuda()
+    dense = hip.conv2d(x, w, s1, b1, 3, 1, 1, 1, x_nchw=True)
+    wide = torch.zeros((2, 20, 20, 48)).cuda()
+    hip.conv2d(x, w, s1, b1, 3, 1, 1, 1, x_nchw=True, out=wide[..., 8:40])
+    assert torch.equal(wide[..., 8:40], dense) and float(wide[..., :8].abs().max()) == 0
 
 
 def test_conv_pitched_concat_slice(hip_lib):
