@@ -10,7 +10,8 @@
 //                        Epilogue: fp32 affine (folded BN / bias) + LeakyReLU + residual, one RNE rounding to the
 //                        storage type - through a per-wave LDS transpose so that loads / stores are 16 bytes per lane -
 //                        or fp32 output for the detection convs that feed the YOLO decode.
-//   conv3x3_patch_h16  : experimental patch-resident variant for 3x3 / stride 1 layers (tile id 41, see its comment).
+//   (3x3 / stride 1 layers: the patch-resident big-tile generation lives in conv_p8_impl.h / conv_p8_h16.hip, tile ids >= 100;
+//   round 1's experimental tile 41 was its first, image-bounded version and is gone.)
 //   conv_stem3_h16     : the cin = 3 stem on the VALU (fp32 frames, rounded to the storage type here; fp32 weights holding
 //                        values already rounded by the host; 16-bit NHWC out) - the fallback of stem_mfma_h16.hip (same
 //                        rounding points) for couts other than 32.
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
         v = v > 0.f ? v : v * slope;
         tbuf[((e & 3) + 8 * (e >> 2) + 4 * hh) * TP + r32] = v;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its LDS operations complete in order
+      // (no wait between the transpose's writes and reads: the LDS executes one wave's operations in order, and the
+      // compiler orders them by the aliasing pointers - the explicit s_waitcnt pairs of round 1 serialised every block)
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         const int row = pass * 16 + prow;
@@ -300,7 +302,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
         o.w = pack2<F16>(v[6], v[7]);
         *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch is free for the next block
     };
     static_for([&](auto jc) { static_for([&](auto ic) { block_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
                std::make_integer_sequence<int, NT>{});
@@ -349,244 +350,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
         const int m = mb + (e & 3) + 8 * (e >> 2);
         if (m < p.M) store_out<F16>(p, m, co, act16(acc[i][j][e] * sc + sh, p.act), hw);
       }
-    }
-  };
-  static_for([&](auto jc) { static_for([&](auto ic) { tile_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
-             std::make_integer_sequence<int, NT>{});
-}
-
-// ---------------------------------------------------------------------------------------------
-// Patch-resident 3x3 / stride 1 / pad 1 variant (tile id 41).  The nine taps of a 3x3 filter read the same input pixels
-// shifted by one: instead of DMA-ing a fresh 128-row A tile per tap, the (rows + 2) x (W + 2) input patch of the tile's
-// 128 output pixels is brought into LDS ONCE per 32-channel chunk (zero padding = out-of-range DMA lanes, as always) and the
-// taps are walked by LDS offset (per lane: 18 precomputed fragment addresses per 32-row block).  Only the weights still
-// stream per tap (8 KiB, 3-slot ring).  A traffic through L2 drops ~5x, DMA instructions per MFMA ~2.5x.
-// Tiles never cross an image (tiles_m = n * ceil(hw / 128)); the patch holds at most 384 pixels, which covers every
-// feature map up to 64 columns wide - wider maps use the per-tap kernel above.
-// Stage = (chunk, tap); ring slot of the weights = tap % 3 (9 taps per chunk, 3 slots), patch slot = chunk & 1.
-// ---------------------------------------------------------------------------------------------
-constexpr int kPatchCap = 384;  // pixels (24 KiB per slot)
-
-__device__ __forceinline__ void dma_one(unsigned v, u32x4 r, unsigned s, unsigned dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[r], %[s] offen lds\n\t"
-               "s_mov_b32 m0, %[k]"
-               : [k] "=&s"(keep)
-               : [d] "s"(dst), [r] "s"(r), [s] "s"(s), [v] "v"(v)
-               : "memory", "scc");
-}
-
-template <int F16>
-__global__ __launch_bounds__(256, 2) void conv3x3_patch_h16(Conv16P p, int tiles_per_img) {
-  using frag = typename H16<F16>::v8;
-  constexpr int BM = 128, BN = 128, WC = 2, NW = 4, TM = 64, TN = 64, MT = 2, NT = 2;
-  constexpr int LPA = kPatchCap / 16 / NW;  // 6 patch DMAs per wave per chunk
-  constexpr int LPB = BN / 16 / NW;         // 2 weight DMAs per wave per tap
-  constexpr unsigned A_SLOT = kPatchCap * 64u, B_SLOT = BN * 64u;
-  constexpr unsigned B_BASE = 2u * A_SLOT;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem16;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WC, wc = wave % WC;
-  const int r32 = lane & 31, hh = lane >> 5;
-
-  int tile_m, tile_n;
-  {
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_n = wg % p.tiles_n;
-    tile_m = wg / p.tiles_n;
-  }
-  const int W = p.w, H = p.h, hw = H * W;
-  const int img = tile_m / tiles_per_img;
-  const int q0 = (tile_m - img * tiles_per_img) * BM;          // first output pixel of the tile inside its image
-  const int rows_valid = hw - q0 < BM ? hw - q0 : BM;
-  const int n0 = tile_n * BN;
-  const int oy0 = q0 / W, PC = W + 2;
-  const int NP = ((q0 + rows_valid - 1) / W - oy0 + 3) * PC;   // patch pixels (<= kPatchCap, checked on the host)
-
-  const u32x4 rsrc_a = make_rsrc(p.x + (long long)img * hw * p.x_pitch);
-  const u32x4 rsrc_b = make_rsrc(p.wgt + (long long)n0 * p.ktot);
-
-  // per-lane DMA offsets: patch pixel pp = 16 * group + lane / 4 lives at LDS row pp; its source is input pixel
-  // (oy0 - 1 + pp / PC, pp % PC - 1) or nothing (zero fill)
-  unsigned v_a[LPA], v_b[LPB];
-  auto setup_a = [&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int pp = (wave + NW * j) * 16 + (lane >> 2);
-    const int qd = (lane & 3) ^ ((pp >> 2) & 3);
-    const int pr = pp / PC, pcol = pp - pr * PC;
-    const int iy = oy0 - 1 + pr, ix = pcol - 1;
-    const bool ok = pp < NP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    v_a[j] = ok ? (unsigned)(((long long)iy * W + ix) * p.x_pitch * 2) + 16u * qd : kOobOffset;
-  };
-  static_for(setup_a, std::make_integer_sequence<int, LPA>{});
-  auto setup_b = [&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int row = (wave + NW * j) * 16 + (lane >> 2);
-    const int qd = (lane & 3) ^ ((row >> 2) & 3);
-    v_b[j] = (n0 + row < p.cout) ? (unsigned)row * (unsigned)p.ktot * 2u + 16u * qd : kOobOffset;
-  };
-  static_for(setup_b, std::make_integer_sequence<int, LPB>{});
-
-  // per-lane LDS offsets of the A fragments: block i, tap t, k-step ks
-  unsigned short a_off[MT][9][2];
-  {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      int m = wr * TM + i * 32 + r32;
-      if (m >= rows_valid) m = 0;
-      const int qq = q0 + m;
-      const int oy = qq / W, ox = qq - oy * W;
-      const int pp0 = (oy - oy0) * PC + ox;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int pp = pp0 + (t / 3) * PC + (t % 3);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a_off[i][t][ks] = (unsigned short)(pp * 64 + (((2 * ks + hh) ^ ((pp >> 2) & 3)) * 16));
-      }
-    }
-  }
-  const int swb = (r32 >> 2) & 3;
-  const unsigned b_row = (unsigned)(wc * TN + r32) * 64u;
-  const unsigned b_offk[2] = {(unsigned)(((0 + hh) ^ swb) * 16), (unsigned)(((2 + hh) ^ swb) * 16)};
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int cs = p.cin / 32;
-  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
-  auto issue_a = [&](int chunk, unsigned slot) {
-#pragma unroll
-    for (int j = 0; j < LPA; ++j) dma_one(v_a[j], rsrc_a, (unsigned)chunk * 64u, wave_lds + slot * A_SLOT + (unsigned)j * (NW * 1024u));
-  };
-  auto issue_b = [&](int chunk, int tap, unsigned ring) {
-    const unsigned soff = ((unsigned)tap * (unsigned)p.cin + (unsigned)chunk * 32u) * 2u;
-#pragma unroll
-    for (int j = 0; j < LPB; ++j) dma_one(v_b[j], rsrc_b, soff, wave_lds + B_BASE + ring * B_SLOT + (unsigned)j * (NW * 1024u));
-  };
-
-  issue_a(0, 0);
-  issue_b(0, 0, 0);
-  issue_b(0, 1, 1);
-
-  auto stage = [&](auto tc, auto parc, int chunk) {
-    constexpr int T = decltype(tc)::value, PAR = decltype(parc)::value;
-    const bool more_chunks = chunk + 1 < cs;
-    const bool last_stage = !more_chunks && T == 8;
-    // loads younger than this stage's weights: the next tap's weights, plus the next chunk's patch when it was issued at tap 0
-    if (last_stage) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    } else if ((T == 1 || T == 2) && more_chunks) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + LPA) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB) : "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    {  // weights of stage s + 2
-      constexpr int T2 = (T + 2) % 9;
-      const int c2 = chunk + (T + 2 >= 9 ? 1 : 0);
-      if (c2 < cs) issue_b(c2, T2, (unsigned)(T2 % 3));
-    }
-    if (T == 0 && more_chunks) issue_a(chunk + 1, PAR ^ 1);
-    const unsigned char* Ab = smem16 + PAR * A_SLOT;
-    const unsigned char* Bb = smem16 + B_BASE + (T % 3) * B_SLOT + b_row;
-    frag af[2][MT], bf[2][NT];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[ks][i] = *reinterpret_cast<const frag*>(Ab + a_off[i][T][ks]);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[ks][j] = *reinterpret_cast<const frag*>(Bb + j * 32 * 64 + b_offk[ks]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = H16<F16>::mfma(af[ks][i], bf[ks][j], acc[i][j]);
-  };
-  auto chunk_body = [&](auto parc, int chunk) {
-    static_for([&](auto tc) { stage(tc, parc, chunk); }, std::make_integer_sequence<int, 9>{});
-  };
-  for (int chunk = 0; chunk < cs; ++chunk) {
-    if (chunk & 1)
-      chunk_body(std::integral_constant<int, 1>{}, chunk);
-    else
-      chunk_body(std::integral_constant<int, 0>{}, chunk);
-  }
-
-  // ---- epilogue (rows of the tile are consecutive output pixels of image `img`) -----------------
-  const long long m_base = (long long)img * hw + q0;
-  const float slope = p.act == ME_ACT_LEAKY ? 0.1f : 1.0f;
-  if (p.vec_epi && rows_valid == BM && n0 + BN <= p.cout) {
-    constexpr int TP = 36;
-    __syncthreads();
-    float* tbuf = reinterpret_cast<float*>(smem16) + wave * (32 * TP);
-    const int prow = lane >> 2, c8 = (lane & 3) * 8;
-    unsigned short* __restrict__ yb = reinterpret_cast<unsigned short*>(p.y);
-    const unsigned short* __restrict__ rb = reinterpret_cast<const unsigned short*>(p.res);
-    auto block_out = [&](auto ic, auto jc) {
-      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-      const int cb = n0 + wc * TN + j * 32;
-      const float sc = p.scale[cb + r32], sh = p.shift[cb + r32];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = acc[i][j][e] * sc + sh;
-        v = v > 0.f ? v : v * slope;
-        tbuf[((e & 3) + 8 * (e >> 2) + 4 * hh) * TP + r32] = v;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 16 + prow;
-        const float4 lo = *reinterpret_cast<const float4*>(tbuf + row * TP + c8);
-        const float4 hi = *reinterpret_cast<const float4*>(tbuf + row * TP + c8 + 4);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const long long m = m_base + wr * TM + i * 32 + row;
-        if (rb) {
-          const uint4 r = *reinterpret_cast<const uint4*>(rb + m * p.res_pitch + cb + c8);
-          const unsigned rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[2 * k] += H16<F16>::from(rr[k] & 0xffffu);
-            v[2 * k + 1] += H16<F16>::from(rr[k] >> 16);
-          }
-        }
-        uint4 o;
-        o.x = pack2<F16>(v[0], v[1]);
-        o.y = pack2<F16>(v[2], v[3]);
-        o.z = pack2<F16>(v[4], v[5]);
-        o.w = pack2<F16>(v[6], v[7]);
-        *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    static_for([&](auto jc) { static_for([&](auto ic) { block_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
-               std::make_integer_sequence<int, NT>{});
-    return;
-  }
-  auto tile_out = [&](auto ic, auto jc) {
-    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-    const int co = n0 + wc * TN + j * 32 + r32;
-    if (co >= p.cout) return;
-    const float sc = p.scale[co], sh = p.shift[co];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ml = wr * TM + i * 32 + 4 * hh + (e & 3) + 8 * (e >> 2);
-      if (ml < rows_valid) store_out<F16>(p, (int)(m_base + ml), co, act16(acc[i][j][e] * sc + sh, p.act), hw);
     }
   };
   static_for([&](auto jc) { static_for([&](auto ic) { tile_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
@@ -814,40 +577,6 @@ int launch16(Conv16P& p, hipStream_t stream) {
   return me::check_launch("conv_splitk_reduce_h16");
 }
 
-// eligibility + launch of the patch-resident 3x3 kernel (tile id 41)
-bool patch_eligible(const Conv16P& p) {
-  if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.ups != 1 || p.x_nchw || p.cin % 32) return false;
-  const int W = p.w, hw = p.h * p.w;
-  // worst tile: 128 consecutive pixels starting at the last column of a row
-  const int max_rows = (W - 1 + 127) / W + 1;          // output rows a tile can touch
-  const int rows = (max_rows < p.h ? max_rows : p.h) + 2;
-  if ((long long)rows * (W + 2) > kPatchCap) return false;
-  const long long img_bytes = (long long)hw * p.x_pitch * 2 + (long long)p.cin * 2;
-  return img_bytes < (1ll << 31) && 256ll * p.ktot * 2 < (1ll << 31);
-}
-
-template <int F16>
-int launch_patch(Conv16P& p, hipStream_t stream) {
-  ME_REQUIRE(patch_eligible(p), ME_E_BADARG,
-             "me_conv2d_h16: tile 41 needs a 3x3 / stride 1 / pad 1 layer without upsample whose 128-pixel patch fits 384 pixels");
-  const int hw = p.h * p.w;
-  const int tiles_per_img = (hw + 127) / 128;
-  p.tiles_m = p.n * tiles_per_img;
-  p.tiles_n = (p.cout + 127) / 128;
-  p.splitk = 1;
-  const size_t lds = 2 * (size_t)kPatchCap * 64 + 3 * 128 * 64;
-  auto kern = conv3x3_patch_h16<F16>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  const long long blocks = (long long)p.tiles_m * p.tiles_n;
-  ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, tiles_per_img);
-  return me::check_launch("conv3x3_patch_h16");
-}
-
 int fill16(const me_conv16_desc* d, Conv16P& p) {
   ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_h16: null descriptor");
   ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
@@ -968,7 +697,6 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   }
   p.splitk = split;
   p.partial = reinterpret_cast<float*>(d->workspace);
-  if (tile == 41) return p.f16 ? launch_patch<1>(p, stream) : launch_patch<0>(p, stream);
   if (tile >= 100) return me16::launch_p8_tile(p, tile, stream);
   const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows
   if (p.f16) {

@@ -86,9 +86,9 @@ def test_conv_bf16_tiles(hip_lib, case, half):
                 continue
             y = hip.conv2d_h16(xs, packed, sc, sh, k, s, pad, act, residual=rs, upsample=ups, tile=tile, split_k=split)
             _check_bf16(y, ref, f"{name} tile {tile} split {split}")
-    if k == 3 and s == 1 and ups == 1:   # the patch-resident 3x3 variant
-        y = hip.conv2d_h16(xs, packed, sc, sh, k, s, pad, act, residual=rs, upsample=ups, tile=41, split_k=1)
-        _check_bf16(y, ref, f"{name} tile 41 (patch-resident)")
+    if k == 3 and s == 1 and ups == 1 and cout % 128 == 0:   # a patch-resident tile on the same case (more in the p8 tests)
+        y = hip.conv2d_h16(xs, packed, sc, sh, k, s, pad, act, residual=rs, upsample=ups, tile=221, split_k=1)
+        _check_bf16(y, ref, f"{name} tile 221 (patch-resident)")
     # fp32 output form (detection convs): accumulation order is the only difference from the CPU convolution
     rs32 = res.float().cuda() if res is not None else None
     y32 = hip.conv2d_h16(xs, packed, sc, sh, k, s, pad, act, residual=rs32, upsample=ups, y_f32=True)
