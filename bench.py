@@ -248,7 +248,8 @@ def kernel_generation(half=False):
     """Short hash of the sources of the dominant conv kernel: a committed PMC measurement only speaks for the kernel it
     was taken on."""
     import hashlib
-    files = ["conv_h16.hip", "conv_p8_h16.hip", "conv16_common.h", "dma.h"] if half else ["conv.hip", "dma.h"]
+    files = (["conv_h16.hip", "conv_p8_h16.hip", "conv_p8_impl.h", "conv16_common.h", "dma.h"] if half
+             else ["conv.hip", "conv32_common.h", "dma.h"])
     h = hashlib.sha1()
     for f in files:
         with open(os.path.join(ROOT, "millieye_amd", "csrc", f), "rb") as fh:
