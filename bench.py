@@ -565,6 +565,8 @@ def main():
                              "conv_roofline_frac": round(ach_b / peak_b, 4)}
             model.compute_dtype = "f32"
             sweep.append(row)
+        step()  # back to the benchmark's own batch: the per-stage accounting below reads the last forward's RoI count
+        torch.cuda.synchronize()
 
     if rank == 0:
         frames = batch * world * args.steps
