@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the extra bf16-storage-mode measurement")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra batch 1 / 8 measurements")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the mAP@0.5-vs-reference leg on the committed mini split")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -339,6 +340,41 @@ def cpu_baseline(args, frames_cpu, state_dict, cfg_text, tap, budget_s, radar=No
             "sample": f"{args.cfg} {args.size}x{args.size} fp32 {what}, torch {torch.__version__} CPU, {cores} threads "
                       f"(best of a probe; the host has {os.cpu_count()}) ): "
                       + ", ".join(f"{passes[str(b)]} pass(es) at batch {b}" for b in batches)}
+
+
+def accuracy_leg(dev):
+    """The metric's second half ("mAP@0.5 vs ref"): the whole evaluation chain of the product - jpg frames, labels and radar
+    pickles of the committed mini split (tests/golden/dataset_small, synthetic), device-side batch assembly, Network.forward
+    on the HIP path, get_batch_statistics, ap_per_class - against the numbers the REAL reference's `evaluate` produced on
+    the same files with the same deterministic weights (tests/golden/evaluate_small.npz, recorded by make_golden.py).  The
+    ExDark / our_dataset splits and trained checkpoints are not available here, so this is parity of the chain, not a
+    dataset-level accuracy claim."""
+    import numpy as np
+    from millieye_amd import cfgs, synth
+    from millieye_amd.my_models import Network, define_yolo
+    from millieye_amd.test_fusion import evaluate
+    gold = os.path.join(ROOT, "tests", "golden")
+    ref = np.load(os.path.join(gold, "evaluate_small.npz"))
+    cfg_path = cfgs.write_cfg("yolov3-tiny-12", os.path.join("/tmp", f"millieye_bench_cfg_{os.getuid()}_acc"))
+    net = Network(define_yolo(cfg_path), 0.2)
+    synth.fill_network_(net, "evaluate_small")       # the fixture's weights (tests/golden/make_golden.py:eval_small_weights_)
+    with torch.no_grad():
+        net.refinement_head.net1[0].weight.mul_(0.002)
+        net.refinement_head.net1[0].bias.mul_(0.002)
+    net = net.to(dev).eval()
+    out = {"dataset": "tests/golden/dataset_small (committed synthetic mini split; frames of test scene 4)", "iou": 0.5}
+    for mode, key in ((0, "fusion (mode 0)"), (3, "auto (mode 3)")):
+        row = {"reference": round(float(ref[f"mode{mode}/AP"].mean()), 6)}
+        for dtype in ("f32", "bf16"):
+            net.base_detector.compute_dtype = dtype
+            _p, _r, ap, _f1, _cls, _stat, _pr = evaluate(net, mode="test", model_mode=mode, illumination=["H", "L"],
+                                                         iou_thresh=0.5, nms_thresh=0.5, img_size=416, batch_size=2, test_list=4,
+                                                         dataset_folder=os.path.join(gold, "dataset_small"), num_workers=0)
+            row["hip_" + dtype] = round(float(np.mean(ap)), 6)
+        out[key] = row
+    net.base_detector.compute_dtype = "f32"
+    out["equal_fp32"] = all(out[k]["hip_f32"] == out[k]["reference"] for k in ("fusion (mode 0)", "auto (mode 3)"))
+    return out
 
 
 def main():
@@ -670,6 +706,11 @@ def main():
         if args.workload in ("full", "detector"):
             rois = out["config"].get("rois_last_step", 0)
             out["stages"] = stage_roofline(model, net, x, step, rois)
+        if args.workload == "full" and not args.no_accuracy:
+            try:
+                out["accuracy"] = accuracy_leg(dev)
+            except Exception as exc:  # never take the measurement down
+                out["accuracy"] = {"error": f"{type(exc).__name__}: {exc}"}
         if os.environ.get("BENCH_LAYERS"):
             for mod, flops, ms in per_layer:
                 print(f"[layer] conv{mod}: {flops / 1e9:.3f} GF {ms * 1e3:.1f} us {flops / ms / 1e9:.1f} TF/s",

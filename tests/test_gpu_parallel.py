@@ -18,7 +18,7 @@ def _bench(extra, env_extra):
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-           "--prewarm-seconds", "0.1", "--no-cpu-baseline", "--no-bf16-line"] + extra
+           "--prewarm-seconds", "0.1", "--no-cpu-baseline", "--no-bf16-line", "--no-accuracy"] + extra
     res = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
