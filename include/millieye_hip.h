@@ -76,13 +76,17 @@ typedef struct me_conv_desc {
   int32_t act;
   int32_t upsample; /* 1 or 2 */
   int32_t x_nchw;   /* 0 / 1 */
-  int32_t tile;     /* 0 = auto; else force a tile config id (testing / tuning) */
+  int32_t tile;     /* 0 = auto; else force a tile config id (testing / tuning): 1-5 per-tap tiles 128x128 / 128x64 / 64x64 /
+                       128x32 / 256x128; 41-45 the same with the last partial round of tiles cut split_k ways along K ("tail
+                       split": compact slabs, me_conv2d_workspace_bytes says how much); >= 100 patch-resident tiles */
   int32_t split_k;  /* 0 = auto; 1 = never split; k > 1 forces k K-splits (needs the workspace) */
   void* workspace;  /* optional scratch for deterministic split-K slabs (256-byte aligned), or NULL */
   int64_t workspace_bytes;
-  const float* wgt_tiled; /* tile ids >= 100 (patch-resident 3x3 / stride 1 kernels, csrc/conv_p8_f32.hip) read the weights
-                             from this second packing: [ksize*ksize][cin/16][cout][16] - every (tap, 16-channel chunk) slab
-                             of cout rows x 64 bytes is contiguous.  May be NULL otherwise. */
+  const float* wgt_tiled; /* second packing of the same weights, [ksize*ksize][cin/16][cout][16]: every (tap, 16-channel
+                             chunk) slab of cout rows x 64 bytes is contiguous.  Tile ids >= 100 (patch-resident 3x3 / stride 1
+                             kernels, csrc/conv_p8_f32.hip) need it; the per-tap MFMA kernel streams its weight tiles from it
+                             when given (cin % 16 == 0): the OHWI rows of a tile lie ksize^2*cin*4 bytes apart and thrash the
+                             L2 sets on the deep layers.  May be NULL. */
 } me_conv_desc;
 int me_conv2d_f32(const me_conv_desc* d, void* stream);
 /* scratch the automatic plan would like for this descriptor (0 = none). Small-M layers (13x13, 26x26

@@ -16,6 +16,8 @@
 //
 // Replaces the nn.Conv2d + BatchNorm2d + LeakyReLU blocks of
 // module3_our_dataset/yolov3/models.py:22-41 (see include/millieye_hip.h).
+#include <stdlib.h>
+
 #include "common.h"
 #include "dma.h"
 
@@ -546,8 +548,25 @@ __global__ __launch_bounds__(256) void conv_stem3_f32(ConvP p) {
 // ---------------------------------------------------------------------------------------------
 using namespace me_dma;
 
+// Tile index (XCD-contiguous, see the remap in the kernel) -> tile coordinates: column panels of p.gn tile columns, row-major
+// inside a panel (the last panel may be narrower).  p.gn == p.tiles_n is the plain row-major order.  With a panel whose weight
+// rows fit the XCD's L2 the weights are fetched once per XCD instead of once per (drifting) workgroup.
+__device__ __forceinline__ void tile_coords(const ConvP& p, int t, int& tile_m, int& tile_n) {
+  const int per_panel = p.tiles_m * p.gn;
+  const int panel = t / per_panel;
+  const int r = t - panel * per_panel;
+  const int left = p.tiles_n - panel * p.gn;
+  const int width = left < p.gn ? left : p.gn;
+  tile_m = r / width;
+  tile_n = panel * p.gn + (r - tile_m * width);
+}
+
 // BABL (ablation, tuning only): 1 = every DMA lane is out of range (zero fill, no L2 / HBM traffic at all).
-template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0>
+// HYB (tail split): a 1-D grid of p.bulk whole tiles (a multiple of 256: every CU gets the same number of them) followed by the
+// remaining tiles cut p.splitk ways along K, so that the last partial round of workgroups is made of pieces small enough to
+// spread over all CUs.  The pieces write raw accumulators into compact slabs [tail tile][split][BM][BN];
+// conv_tail_reduce_f32 sums them in a fixed order and applies the epilogue.
+template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0, int HYB = 0, int KORD = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p) {
   constexpr int NW = WR * WC;  // waves per workgroup (4 or 8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -570,14 +589,37 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
   const int r32 = lane & 31, hh = lane >> 5;
 
   int tile_m, tile_n;
+  int sid = blockIdx.y;  // K split this workgroup accumulates
+  int piece = -1;        // HYB: index of this workgroup's slab (tail pieces), -1 = a whole tile with the fused epilogue
   {
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
+    int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    int first = 0, per = 1;
+    if constexpr (HYB) {
+      if (bid < p.bulk) {
+        nwg = p.bulk;
+      } else {
+        bid -= p.bulk;  // p.bulk % 8 == 0: bid & 7 is still the XCD
+        first = p.bulk;
+        per = p.splitk;
+        nwg = (nwg - p.bulk) * p.splitk;
+      }
+    }
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_n = wg % p.tiles_n;
-    tile_m = wg / p.tiles_n;
+    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if constexpr (HYB) {
+      if (first || p.bulk == 0) {
+        piece = wg;
+        sid = wg % per;
+        wg = first + wg / per;
+      } else {
+        sid = 0;
+      }
+    }
+    tile_coords(p, wg, tile_m, tile_n);
+    tile_m = __builtin_amdgcn_readfirstlane(tile_m);
+    tile_n = __builtin_amdgcn_readfirstlane(tile_n);
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int hw = p.ho * p.wo;
@@ -588,7 +630,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
   const long long img_elems = (long long)p.h * p.w * p.x_pitch;
   const long long bias_elems = ((long long)p.pad * p.w + p.pad) * p.x_pitch;
   const u32x4 rsrc_a = make_rsrc(p.x + (long long)img0 * img_elems - bias_elems);
-  const u32x4 rsrc_b = make_rsrc(p.wgt + (long long)n0 * p.ktot);
+  // B: the weight rows of this tile - from the tiled copy [tap][cin/16][cout][16] when the caller has one (a K stage of
+  // the tile is then 64 B x BN contiguous: consecutive L2 sets; rows of the OHWI layout lie ktot*4 bytes apart and a stage of
+  // all cout rows lands in 1/16 of the sets), else from the OHWI rows.
+  const bool b_tiled = p.wgt_tiled != nullptr;
+  const u32x4 rsrc_b = make_rsrc(b_tiled ? p.wgt_tiled + (long long)n0 * 16 : p.wgt + (long long)n0 * p.ktot);
+  const unsigned b_row = b_tiled ? 64u : (unsigned)p.ktot * 4u;      // bytes between the rows of two output channels
+  const unsigned b_step = b_tiled ? (unsigned)p.cout * 64u : BK * 4u;  // ... between two K stages of one tap
 
   const int lrow = lane >> 2;  // row inside the 16-row group
   unsigned v_base[LPW];        // in-range byte offset of (lane, tap 0 / k 0)
@@ -620,44 +668,19 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
       v_pad[j] = padmask;
     } else if (g < G) {
       const int co_local = row - BM;
-      if (n0 + co_local < p.cout) v_base[j] = (unsigned)co_local * (unsigned)p.ktot * 4u + 16u * q;
+      if (n0 + co_local < p.cout) v_base[j] = (unsigned)co_local * b_row + 16u * q;
     }
     v_cur[j] = BABL == 1 ? kOobOffset : v_base[j];
   }
 
-  const int sid = blockIdx.y;
-  const int s_begin = sid * p.sps;
-  const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
-  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;  // wave-uniform K walk of the *issue* side
-  int ky = tap / p.ks, kx = tap - ky * p.ks;
-  unsigned a_off = 0, b_off = 0;  // scalar byte offsets of the next stage to issue
-  auto enter_tap = [&]() {        // VALU work only here: once per filter tap
-#pragma unroll
-    for (int j = 0; j < LA; ++j) v_cur[j] = (BABL == 1 || ((v_pad[j] >> tap) & 1u)) ? kOobOffset : v_base[j];
-    a_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 4);
-    b_off = (unsigned)tap * (unsigned)p.cin * 4u;
-  };
-  enter_tap();
-  a_off += (unsigned)cc * (BK * 4u);
-  b_off += (unsigned)cc * (BK * 4u);
-
-  constexpr unsigned STAGE_B = STAGE_F * 4u;
-  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);  // SGPR
-  auto issue_stage = [&](unsigned lds_dst) {
-    dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off, b_off, lds_dst);
-    a_off += BK * 4u;
-    b_off += BK * 4u;
-    if (++cc == p.cs) {
-      cc = 0;
-      ++tap;
-      if (++kx == p.ks) {
-        kx = 0;
-        ++ky;
-      }
-      enter_tap();
+  int s_begin = sid * p.sps;
+  int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
+  if constexpr (HYB) {
+    if (piece < 0) {
+      s_begin = 0;
+      s_end = p.stages;
     }
-  };
-
+  }
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -666,10 +689,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nstages = s_end - s_begin;
-  issue_stage(wave_lds);
-  if (nstages > 1) issue_stage(wave_lds + STAGE_B);
-
+  constexpr unsigned STAGE_B = STAGE_F * 4u;
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);  // SGPR
+  const unsigned pitch4 = (unsigned)p.x_pitch * 4u;
   const int sw = (r32 >> 2) & 3;
   const int off0 = ((0 + hh) ^ sw) * 4, off1 = ((2 + hh) ^ sw) * 4;
   const float* a_frag = smem + (wr * TM + r32) * BK;        // this lane's A / B fragment rows in stage slot 0
@@ -709,37 +731,142 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
 
   // Stage s lives in slot s % 3.  A "step" = wait for stage s (only stage s+1's DMAs are younger), barrier
   // (everyone's stage-s DMAs landed, everyone finished reading stage s-1), refill the slot stage s-1 vacated with
-  // stage s+2, multiply stage s.  The bulk runs three steps per loop trip with compile-time slots (LDS offsets are
-  // immediates, ~19 scalar instructions per step); the last <= 4 stages go through the generic tail below.
-  auto step = [&](auto slot_c) {
-    constexpr int SLOT = decltype(slot_c)::value;
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_stage(wave_lds + ((SLOT + 2) % NST) * STAGE_B);
-    compute_stage(a_frag + SLOT * STAGE_F, b_frag + SLOT * STAGE_F);
-  };
-  int s = 0;
-  for (; s + 3 <= nstages - 2; s += 3) {
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-  }
-  int slot = 0;  // s is a multiple of 3 here
-  for (; s < nstages; ++s) {
-    if (s + 1 < nstages)
+  // stage s+2, multiply stage s.
+  if constexpr (KORD == 0) {
+    // Tap-major K walk (tap outer, 16-channel chunk inner; wave-uniform): the per-lane work of entering a tap (padding
+    // select) is paid once per tap.  A workgroup sweeps its input rows once per tap, so those rows have to survive in L2
+    // from one sweep to the next - they do as long as the weights leave room (choose_order).
+    int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    unsigned a_off = 0, b_off = 0;  // scalar byte offsets of the next stage to issue
+    auto enter_tap = [&]() {        // VALU work only here: once per filter tap
+#pragma unroll
+      for (int j = 0; j < LA; ++j) v_cur[j] = (BABL == 1 || ((v_pad[j] >> tap) & 1u)) ? kOobOffset : v_base[j];
+      a_off = (unsigned)(ky * p.w + kx) * pitch4;
+      b_off = (unsigned)tap * (unsigned)p.cs * b_step;
+    };
+    enter_tap();
+    a_off += (unsigned)cc * (BK * 4u);
+    b_off += (unsigned)cc * b_step;
+    auto issue_stage = [&](unsigned lds_dst) {
+      dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off, b_off, lds_dst);
+      a_off += BK * 4u;
+      b_off += b_step;
+      if (++cc == p.cs) {
+        cc = 0;
+        ++tap;
+        if (++kx == p.ks) {
+          kx = 0;
+          ++ky;
+        }
+        enter_tap();
+      }
+    };
+    const int nstages = s_end - s_begin;
+    issue_stage(wave_lds);
+    if (nstages > 1) issue_stage(wave_lds + STAGE_B);
+    // The bulk runs three steps per loop trip with compile-time slots (LDS offsets are immediates, ~19 scalar
+    // instructions per step); the last <= 4 stages go through the generic tail below.
+    auto step = [&](auto slot_c) {
+      constexpr int SLOT = decltype(slot_c)::value;
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (s + 2 < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);
-    compute_stage(a_frag + slot * STAGE_F, b_frag + slot * STAGE_F);
-    slot = slot == NST - 1 ? 0 : slot + 1;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_stage(wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+      compute_stage(a_frag + SLOT * STAGE_F, b_frag + SLOT * STAGE_F);
+    };
+    int s = 0;
+    for (; s + 3 <= nstages - 2; s += 3) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+    }
+    int slot = 0;  // s is a multiple of 3 here
+    for (; s < nstages; ++s) {
+      if (s + 1 < nstages)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 2 < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);
+      compute_stage(a_frag + slot * STAGE_F, b_frag + slot * STAGE_F);
+      slot = slot == NST - 1 ? 0 : slot + 1;
+    }
+  } else {
+    // Chunk-major K walk, 3x3 filters only (chunk outer, the nine taps inner and unrolled: stage = 9 * chunk + tap, s_begin and
+    // s_end are multiples of 9).  The nine taps of a chunk re-read the same 64 bytes of every input row back to back, so the
+    // input is fetched into L2 once however little room it has there - the order for the deep layers, whose weight
+    // panels own the L2 (choose_order).  Per-tap DMA operands are set up once: the per-lane offsets (padding resolved) in
+    // registers, the tap offsets in SGPRs; a stage costs two scalar adds.
+    unsigned v_tap[9][LPW];
+    unsigned a_tap[9], b_tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int j = 0; j < LPW; ++j)
+        v_tap[t][j] = j < LA ? ((BABL == 1 || ((v_pad[j < LA ? j : 0] >> t) & 1u)) ? kOobOffset : v_base[j]) : v_cur[j];
+      a_tap[t] = (unsigned)((t / 3) * p.w + (t % 3)) * pitch4;
+      b_tap[t] = (unsigned)t * (unsigned)p.cs * b_step;
+    }
+    const int c_begin = s_begin / 9, c_end = s_end / 9;
+    unsigned ca = (unsigned)c_begin * (BK * 4u), cb = (unsigned)c_begin * b_step;  // offsets of the chunk being multiplied
+    auto issue = [&](auto tap_c, unsigned ca_, unsigned cb_, unsigned lds_dst) {
+      constexpr int T = decltype(tap_c)::value;
+      dma_stage<LPW, LA, NW * 1024>(v_tap[T], rsrc_a, rsrc_b, a_tap[T] + ca_, b_tap[T] + cb_, lds_dst);
+    };
+    auto step = [&](auto tap_c, auto last_c) {
+      constexpr int T = decltype(tap_c)::value;
+      constexpr bool LAST = decltype(last_c)::value;  // the last chunk of this workgroup: nothing to prefetch behind it
+      constexpr int SLOT = T % NST;
+      if constexpr (LAST && T == 8)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if constexpr (T + 2 < 9)
+        issue(std::integral_constant<int, (T + 2) % 9>{}, ca, cb, wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+      else if constexpr (!LAST)
+        issue(std::integral_constant<int, (T + 2) % 9>{}, ca + BK * 4u, cb + b_step, wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+      compute_stage(a_frag + SLOT * STAGE_F, b_frag + SLOT * STAGE_F);
+    };
+    auto chunk = [&](auto last_c) {
+      step(std::integral_constant<int, 0>{}, last_c);
+      step(std::integral_constant<int, 1>{}, last_c);
+      step(std::integral_constant<int, 2>{}, last_c);
+      step(std::integral_constant<int, 3>{}, last_c);
+      step(std::integral_constant<int, 4>{}, last_c);
+      step(std::integral_constant<int, 5>{}, last_c);
+      step(std::integral_constant<int, 6>{}, last_c);
+      step(std::integral_constant<int, 7>{}, last_c);
+      step(std::integral_constant<int, 8>{}, last_c);
+    };
+    issue(std::integral_constant<int, 0>{}, ca, cb, wave_lds);
+    issue(std::integral_constant<int, 1>{}, ca, cb, wave_lds + STAGE_B);
+    for (int c = c_begin; c + 1 < c_end; ++c) {
+      chunk(std::false_type{});
+      ca += BK * 4u;
+      cb += b_step;
+    }
+    chunk(std::true_type{});
   }
 
   // ---- epilogue (same as conv_igemm_dma_f32) ----------------------------------------------------
-  if (p.splitk > 1) {
+  if constexpr (HYB) {
+    if (piece >= 0) {
+      float* slab = p.partial + (long long)piece * (BM * BN);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            slab[(wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * BN + wc * TN + j * 32 + r32] = acc[i][j][e];
+      return;
+    }
+  }
+  if (!HYB && p.splitk > 1) {
     float* slab = p.partial + (long long)sid * p.M * p.cout;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -798,6 +925,41 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_f32(ConvP p) {
     const int m = (int)(idx / p.cout);
     float a = p.partial[idx];
     for (int k = 1; k < p.splitk; ++k) a += p.partial[(long long)k * total + idx];
+    float v = apply_act(a * p.scale[co] + p.shift[co], p.act);
+    if (p.res) v += p.res[(long long)m * p.res_pitch + co];
+    if (p.ups == 1) {
+      p.y[(long long)m * p.y_pitch + co] = v;
+    } else {
+      const int nimg = m / hw;
+      const int rem = m - nimg * hw;
+      const int oy = rem / p.wo, ox = rem - oy * p.wo;
+      const int W2 = p.wo * 2;
+      const long long base = ((long long)nimg * (p.ho * 2) + 2 * oy) * W2 + 2 * ox;
+      p.y[(base)*p.y_pitch + co] = v;
+      p.y[(base + 1) * p.y_pitch + co] = v;
+      p.y[(base + W2) * p.y_pitch + co] = v;
+      p.y[(base + W2 + 1) * p.y_pitch + co] = v;
+    }
+  }
+}
+
+// tail-split second pass (conv_igemm_buf_f32<HYB = 1>): slabs [tail tile][split][bm][bn] -> fixed-order sum + fused epilogue.
+__global__ __launch_bounds__(256) void conv_tail_reduce_f32(ConvP p, int bm, int bn) {
+  const int tile_elems = bm * bn;
+  const long long total = (long long)(p.tiles_m * p.tiles_n - p.bulk) * tile_elems;
+  const int hw = p.ho * p.wo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int t = (int)(idx / tile_elems);
+    const int rem_e = (int)(idx - (long long)t * tile_elems);
+    const int lm = rem_e / bn, lc = rem_e - lm * bn;
+    int tile_m, tile_n;
+    tile_coords(p, p.bulk + t, tile_m, tile_n);
+    const int m = tile_m * bm + lm;
+    const int co = tile_n * bn + lc;
+    if (m >= p.M || co >= p.cout) continue;
+    const float* src = p.partial + (long long)t * p.splitk * tile_elems + rem_e;
+    float a = src[0];
+    for (int k = 1; k < p.splitk; ++k) a += src[(long long)k * tile_elems];
     float v = apply_act(a * p.scale[co] + p.shift[co], p.act);
     if (p.res) v += p.res[(long long)m * p.res_pitch + co];
     if (p.ups == 1) {
@@ -988,6 +1150,16 @@ ConvPlan plan_conv(const ConvP& p, int forced_tile, int max_split) {
   return best;
 }
 
+// K split of conv_igemm_buf_f32: p.sps stages per split; the chunk-major walk splits on chunk boundaries (nine stages).
+inline void plan_split(ConvP& p) {
+  const int unit = p.kord ? 9 : 1;
+  const int units = p.stages / unit;
+  if (p.splitk > units) p.splitk = units;
+  if (p.splitk < 1) p.splitk = 1;
+  p.sps = (units + p.splitk - 1) / p.splitk * unit;
+  while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;  // no empty split
+}
+
 template <int BM, int BN, int BK, int WR, int WC, int ABL = 0, int PRIO = 0>
 int launch_igemm(ConvP& p, hipStream_t stream) {
   p.cs = (p.cin + BK - 1) / BK;
@@ -1026,9 +1198,7 @@ int launch_dma(ConvP& p, hipStream_t stream) {
   p.stages = p.ks * p.ks * p.cs;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.cout + BN - 1) / BN;
-  if (p.splitk > p.stages) p.splitk = p.stages;
-  p.sps = (p.stages + p.splitk - 1) / p.splitk;
-  while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;
+  plan_split(p);
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
   const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
@@ -1063,7 +1233,55 @@ bool buf_addressable(const ConvP& p) {
   const long long tap_bytes = ((long long)p.ks * p.w + p.ks) * p.x_pitch * 4 + (long long)p.cin * 4;
   const long long a_max = span_imgs * img_bytes + 2 * tap_bytes;
   const long long b_max = 256ll * p.ktot * 4 + (long long)p.ktot * 4;
-  return a_max < (1ll << 31) && b_max < (1ll << 31) && (long long)p.x_pitch * 4 < (1ll << 31);
+  const long long b_tiled_max = p.wgt_tiled ? (long long)p.ktot * p.cout * 4 + 256ll * 64 : 0;
+  return a_max < (1ll << 31) && b_max < (1ll << 31) && b_tiled_max < (1ll << 31) && (long long)p.x_pitch * 4 < (1ll << 31);
+}
+
+// Walk order of conv_igemm_buf_f32 (p.tiles_n set).
+//  * 3x3 layers take the chunk-major K walk (nine unrolled taps per 16-channel chunk: two scalar adds per stage instead of
+//    the tap-major walk's counters, compares and branches; the input rows are re-read within nine consecutive stages).
+//  * Layers whose weights fit the L2 beside everything else keep the row-major tile order.  For the deep layers (weights of
+//    several MB, e.g. 18.9 MB for 3x3 512->1024) the workgroups of an XCD drift apart along K, the working set becomes
+//    "all the weights" and every workgroup streams its own copy from the Infinity Cache (rocprofv3 FETCH_SIZE: 1.05 GB per
+//    launch against 52 MB of operands): there the tiles are walked in column panels whose weight rows (<= kPanelBytes)
+//    stay L2-resident while the input - fetched once per chunk thanks to the chunk-major walk - streams past
+//    (profiles/r02_layer_traffic_f32.txt: 1045 -> 177 MB per launch at 13x13, 451 -> 134 MB at 26x26, and 2-3 % faster).
+template <int BN>
+void choose_order(ConvP& p) {
+  static const long long kPanelBytes = [] {
+    const char* e = getenv("MILLIEYE_PANEL_KB");
+    return (e && atoi(e) > 0 ? (long long)atoi(e) : 1300ll) * 1024;
+  }();
+  static const int kChunkMajor = [] {
+    const char* e = getenv("MILLIEYE_KORD");  // experiments: 0 = tap-major everywhere, 1 = chunk-major only with panels
+    return e ? atoi(e) : 2;
+  }();
+  const long long col_bytes = (long long)BN * p.ktot * 4;  // weights of one tile column
+  p.gn = p.tiles_n;
+  // the chunk-major walk is built for nine taps; with two chunks (cin 32: the 416 / 208 maps) it measured 2 % slower
+  p.kord = (p.ks == 3 && p.cs >= 4 && kChunkMajor == 2) ? 1 : 0;
+  if (col_bytes * p.tiles_n <= kPanelBytes) return;
+  const long long fit = kPanelBytes / col_bytes;
+  p.gn = fit < 1 ? 1 : fit > p.tiles_n ? p.tiles_n : (int)fit;
+  if (p.ks == 3 && kChunkMajor >= 1) p.kord = 1;
+}
+
+template <int BM, int BN, int WR, int WC, int MINW, int BABL, int HYB, int KORD>
+int launch_buf_kernel(const ConvP& p, dim3 grid, hipStream_t stream) {
+  constexpr int NW = WR * WC;
+  constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
+  const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
+  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW, BABL, HYB, KORD>;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, p);
+  return me::check_launch(HYB ? "conv_igemm_buf_f32<tail split>" : "conv_igemm_buf_f32");
 }
 
 template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0>
@@ -1080,30 +1298,58 @@ int launch_buf(ConvP& p, hipStream_t stream) {
   p.stages = p.ks * p.ks * p.cs;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.cout + BN - 1) / BN;
-  if (p.splitk > p.stages) p.splitk = p.stages;
-  p.sps = (p.stages + p.splitk - 1) / p.splitk;
-  while (p.splitk > 1 && (p.splitk - 1) * p.sps >= p.stages) --p.splitk;
-  constexpr int NW = WR * WC;
-  constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
-  const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
-  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW, BABL>;
-  if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-      attr_set = true;
-    }
-  }
+  choose_order<BN>(p);
+  if (BABL) p.kord = 0;  // the ablation kernels exist for the tap-major walk only
+  plan_split(p);
   const long long blocks = (long long)p.tiles_m * p.tiles_n;
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splitk), dim3(64 * NW), lds, stream, p);
-  int rc = me::check_launch("conv_igemm_buf_f32");
+  const dim3 grid((unsigned)blocks, (unsigned)p.splitk);
+  int rc;
+  if constexpr (BABL == 0) {
+    rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 1>(p, grid, stream)
+                : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 0>(p, grid, stream);
+  } else {
+    rc = launch_buf_kernel<BM, BN, WR, WC, MINW, BABL, 0, 0>(p, grid, stream);
+  }
   if (rc || p.splitk == 1) return rc;
   long long rb = ((long long)p.M * p.cout + 255) / 256;
   if (rb > 256 * 16) rb = 256 * 16;
   hipLaunchKernelGGL(conv_splitk_reduce_f32, dim3((unsigned)rb), dim3(256), 0, stream, p);
   return me::check_launch("conv_splitk_reduce_f32");
+}
+
+// Tail-split launch (tile ids 41-45): whole tiles for the rounds that fill every CU, the rest cut p.splitk ways along K.
+template <int BM, int BN, int WR, int WC, int MINW = 1>
+int launch_buf_tail(ConvP& p, hipStream_t stream, long long ws_bytes) {
+  ME_REQUIRE(p.ks * p.ks <= 32 && buf_addressable<BM>(p), ME_E_BADARG,
+             "me_conv2d_f32: the tail-split tiles need cin %% 16 == 0 and offsets below 2^31");
+  constexpr int BK = 16;
+  p.cs = (p.cin + BK - 1) / BK;
+  p.stages = p.ks * p.ks * p.cs;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.cout + BN - 1) / BN;
+  choose_order<BN>(p);
+  const long long tiles = (long long)p.tiles_m * p.tiles_n;
+  ME_REQUIRE(tiles < (1ll << 24), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
+  plan_split(p);
+  p.bulk = (int)(tiles / 256 * 256);
+  const long long tail = tiles - p.bulk;
+  if (tail == 0 || p.splitk <= 1) {  // nothing to cut: the plain launch
+    p.splitk = 1;
+    p.bulk = 0;
+    return launch_buf<BM, BN, WR, WC, MINW>(p, stream);
+  }
+  const long long need = tail * p.splitk * BM * BN * (long long)sizeof(float);
+  ME_REQUIRE(p.partial && ws_bytes >= need, ME_E_BADARG, "me_conv2d_f32: tail split %d needs a workspace of %lld bytes",
+             p.splitk, need);
+  const dim3 grid((unsigned)(p.bulk + tail * p.splitk));
+  int rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 1, 1>(p, grid, stream)
+                  : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 1, 0>(p, grid, stream);
+  if (rc) return rc;
+  long long rb = (tail * BM * BN + 255) / 256;
+  if (rb > 256 * 16) rb = 256 * 16;
+  hipLaunchKernelGGL(conv_tail_reduce_f32, dim3((unsigned)rb), dim3(256), 0, stream, p, BM, BN);
+  return me::check_launch("conv_tail_reduce_f32");
 }
 
 int fill_params(const me_conv_desc* d, ConvP& p) {
@@ -1123,7 +1369,7 @@ int fill_params(const me_conv_desc* d, ConvP& p) {
   p.x_nchw = d->x_nchw;
   p.M = d->n * d->ho * d->wo;
   p.ktot = d->ksize * d->ksize * d->cin;
-  p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
+  p.cs = p.stages = p.tiles_m = p.tiles_n = p.bulk = p.gn = p.kord = 0;
   p.partial = nullptr;
   p.splitk = 1;
   p.sps = 0;
@@ -1142,6 +1388,13 @@ int64_t me_conv2d_flops(const me_conv_desc* d) {
 int64_t me_conv2d_workspace_bytes(const me_conv_desc* d) {
   ConvP p;
   if (!d || fill_params(d, p) != 0 || d->cin <= 4) return 0;
+  if (d->tile >= 41 && d->tile <= 45) {  // tail split: compact slabs of the last partial round only
+    static const int shape[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {256, 128}};
+    const int bm = shape[d->tile - 41][0], bn = shape[d->tile - 41][1];
+    const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.cout + bn - 1) / bn);
+    const int split = d->split_k > 0 ? d->split_k : 4;
+    return (int64_t)(tiles % 256) * split * bm * bn * (int64_t)sizeof(float);
+  }
   const ConvPlan plan = plan_conv(p, d->tile, d->split_k > 0 ? d->split_k : kMaxSplit);
   const int split = d->split_k > 0 ? d->split_k : plan.splitk;
   return split > 1 ? (int64_t)split * p.M * p.cout * (int64_t)sizeof(float) : 0;
@@ -1191,6 +1444,19 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   ME_REQUIRE(me::aligned16(d->x) && me::aligned16(d->wgt), ME_E_ALIGN, "me_conv2d_f32: x / wgt not 16-byte aligned");
   ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_f32: res_pitch < cout");
   ME_REQUIRE(d->split_k >= 0 && d->split_k <= 64, ME_E_BADARG, "me_conv2d_f32: split_k out of range");
+
+  if (d->tile >= 41 && d->tile <= 45) {  // tail split: split_k = pieces per tile of the last, partial round (0: 4)
+    p.splitk = d->split_k > 0 ? d->split_k : 4;
+    p.partial = reinterpret_cast<float*>(d->workspace);
+    const long long ws = d->workspace ? d->workspace_bytes : 0;
+    switch (d->tile) {
+      case 41: return launch_buf_tail<128, 128, 2, 2>(p, stream, ws);
+      case 42: return launch_buf_tail<128, 64, 2, 2>(p, stream, ws);
+      case 43: return launch_buf_tail<64, 64, 2, 2>(p, stream, ws);
+      case 44: return launch_buf_tail<128, 32, 4, 1>(p, stream, ws);
+      default: return launch_buf_tail<256, 128, 4, 2, 4>(p, stream, ws);
+    }
+  }
 
   // split-K only when the caller supplied a workspace that can hold the slabs
   const long long slab = (long long)p.M * p.cout * (long long)sizeof(float);

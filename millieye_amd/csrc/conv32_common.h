@@ -25,6 +25,9 @@ struct ConvP {
   float* partial;  // split-K slabs [splitk][M][cout] (raw accumulators), or nullptr
   int splitk;      // number of K splits (grid.y)
   int sps;         // K stages per split
+  int gn;          // conv_igemm_buf_f32: tile columns per panel of the tile walk (tiles_n = row-major)
+  int kord;        // conv_igemm_buf_f32: K walk, 0 tap-major / 1 chunk-major
+  int bulk;        // tail-split launches: tiles [0, bulk) run whole, tiles [bulk, tiles) cut splitk ways (0 otherwise)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

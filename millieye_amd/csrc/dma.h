@@ -20,33 +20,34 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base) {
   return r;
 }
 
-// All of one wave's DMAs of one stage in a single asm block (M0 saved / restored once).  LA A-type loads
+// All of one wave's DMAs of one stage in a single asm block.  M0 is left pointing at the last destination: nothing the
+// compiler emits for these kernels reads M0 (gfx950 LDS instructions do not; tools/check_m0.sh greps the ISA), and the two
+// s_mov of a save / restore per stage cost matrix-pipe issue slots.  LA A-type loads
 // (descriptor ra, scalar offset sa) are followed by LPW - LA B-type loads (rb, sb); LDS destinations advance by STEP.
 template <int LPW, int LA, int STEP>
 __device__ __forceinline__ void dma_stage(const unsigned (&v)[LPW], u32x4 ra, u32x4 rb, unsigned sa, unsigned sb,
                                           unsigned dst) {
-  unsigned keep;
   static_assert(LPW >= 2 && LPW <= 4 && LA >= 1 && LA <= 2, "unsupported DMA shape");
-#define ME_DMA_HEAD "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+#define ME_DMA_HEAD "s_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
 #define ME_DMA_NEXT "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\t"
 #define ME_DMA_A(i) "buffer_load_dwordx4 %[v" #i "], %[ra], %[sa] offen lds\n\t"
 #define ME_DMA_B(i) "buffer_load_dwordx4 %[v" #i "], %[rb], %[sb] offen lds\n\t"
-#define ME_DMA_TAIL "s_mov_b32 m0, %[k]"
+#define ME_DMA_TAIL ""
   if constexpr (LPW == 4 && LA == 2) {
     asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_A(1) ME_DMA_NEXT ME_DMA_B(2) ME_DMA_NEXT ME_DMA_B(3) ME_DMA_TAIL
-                 : [k] "=&s"(keep)
+                 :
                  : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
                    [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3])
                  : "memory", "scc");
   } else if constexpr (LPW == 3 && LA == 2) {
     asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_A(1) ME_DMA_NEXT ME_DMA_B(2) ME_DMA_TAIL
-                 : [k] "=&s"(keep)
+                 :
                  : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
                    [v1] "v"(v[1]), [v2] "v"(v[2])
                  : "memory", "scc");
   } else if constexpr (LPW == 2 && LA == 1) {
     asm volatile(ME_DMA_HEAD ME_DMA_A(0) ME_DMA_NEXT ME_DMA_B(1) ME_DMA_TAIL
-                 : [k] "=&s"(keep)
+                 :
                  : [d] "s"(dst), [st] "n"(STEP), [ra] "s"(ra), [rb] "s"(rb), [sa] "s"(sa), [sb] "s"(sb), [v0] "v"(v[0]),
                    [v1] "v"(v[1])
                  : "memory", "scc");

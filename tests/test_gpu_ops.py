@@ -74,6 +74,35 @@ def test_conv3x3_every_tile(hip_lib, tile):
     _conv_case(hip, f"c3t{tile}e", 2, 13, 13, 64, 96, 3, 1, 1, residual=True, split_k=3, tile=tile)
 
 
+@pytest.mark.parametrize("tile", [41, 42, 43, 44, 45])
+def test_conv_tail_split_tiles(hip_lib, tile):
+    """Tile ids 41-45 = tiles 1-5 with the last partial round of tiles cut split_k ways along K (compact slabs +
+    conv_tail_reduce_f32): fewer than 256 tiles (everything is tail), more than 256 (whole tiles + tail pieces in one
+    launch), ragged M / cout, 1x1, stride 2, channel-slice input, residual and upsample through the second pass,
+    run-to-run determinism."""
+    from millieye_amd import hip
+    _conv_case(hip, f"ts{tile}a", 2, 13, 11, 32, 72, 3, 1, 1, tile=tile, split_k=3)
+    _conv_case(hip, f"ts{tile}b", 1, 13, 13, 48, 255, 1, 1, 0, tile=tile, split_k=2)
+    _conv_case(hip, f"ts{tile}c", 2, 26, 26, 64, 128, 3, 2, 1, tile=tile, x_slice=32, split_k=4)
+    _conv_case(hip, f"ts{tile}d", 2, 13, 13, 48, 64, 3, 1, 1, residual=True, split_k=0, tile=tile)
+    _conv_case(hip, f"ts{tile}e", 1, 13, 13, 64, 48, 3, 1, 1, ups=2, split_k=5, tile=tile, x_slice=64)
+    bm, bn = {41: (128, 128), 42: (128, 64), 43: (64, 64), 44: (128, 32), 45: (256, 128)}[tile]
+    n, cout = {41: (4, 500), 42: (2, 500), 43: (2, 250), 44: (2, 250), 45: (8, 500)}[tile]
+    tiles = -(-n * 52 * 52 // bm) * -(-cout // bn)
+    assert 256 < tiles < 512 and tiles % 256, tiles
+    _conv_case(hip, f"ts{tile}f", n, 52, 52, 32, cout, 3, 1, 1, residual=True, split_k=3, tile=tile)
+    _conv_case(hip, f"ts{tile}g", n, 52, 52, 64, cout, 1, 1, 1, split_k=2, tile=tile)
+    x = _t("tsx", (2, 52, 52, 32)).cuda()
+    w = torch.from_numpy(synth.normal("tsw", (250, 3, 3, 32), 0, 0.05)).cuda()
+    s = torch.ones(250).cuda()
+    b = torch.zeros(250).cuda()
+    a1 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=tile, split_k=4)
+    a2 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=tile, split_k=4)
+    assert torch.equal(a1, a2), "the tail split must be run-to-run deterministic"
+    a0 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=tile - 40, split_k=1)
+    assert_close(a1.cpu(), a0.cpu(), 1e-4, "tail split vs whole tiles")
+
+
 def test_conv_variants(hip_lib):
     from millieye_amd import hip
     _conv_case(hip, "s2", 2, 32, 32, 32, 64, 3, 2, 1)                 # stride-2 downsample

@@ -76,7 +76,7 @@ def main():
         d.workspace, d.workspace_bytes = ws.data_ptr() + (-ws.data_ptr()) % 256, ws.numel() - 256
         for t, sk in [(t, sk) for t in tiles for sk in [int(v) for v in args.splits.split(",")]]:
             d.tile, d.split_k = t, sk
-            if sk > 1 and sk * n * ho * ho * cout * 4 > ws.numel() - 256:
+            if sk > 1 and not 41 <= t <= 45 and sk * n * ho * ho * cout * 4 > ws.numel() - 256:
                 continue
             stream = hip.stream_ptr()
             hip.check(lib.me_conv2d_f32(C.byref(d), stream), "conv")
