@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 4
+#define ME_ABI_VERSION 5
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -87,6 +87,11 @@ typedef struct me_conv_desc {
                              kernels, csrc/conv_p8_f32.hip) need it; the per-tap MFMA kernel streams its weight tiles from it
                              when given (cin % 16 == 0): the OHWI rows of a tile lie ksize^2*cin*4 bytes apart and thrash the
                              L2 sets on the deep layers.  May be NULL. */
+  int32_t* tile_counters; /* optional arrival counters for the in-launch split-K reduction: tile_counters_len ints, ALL ZERO on
+                             entry, left all zero on return (the last workgroup of a tile to arrive sums the slabs in the fixed
+                             order 0..k-1 and applies the epilogue - same bits as the two-pass form, one launch less).  NULL, or
+                             fewer counters than tiles: the slabs are reduced by a second launch.  One array per stream. */
+  int64_t tile_counters_len;
 } me_conv_desc;
 int me_conv2d_f32(const me_conv_desc* d, void* stream);
 /* scratch the automatic plan would like for this descriptor (0 = none). Small-M layers (13x13, 26x26
@@ -454,6 +459,8 @@ typedef struct me_conv16_desc {
   const void* wgt_tiled; /* tile ids >= 100 (patch-resident 3x3 kernels) read the weights from this second packing:
                             [ksize*ksize][cin/32][cout][32] - every (tap, 32-channel chunk) slab of cout rows x 64 bytes is
                             contiguous, so one LDS-DMA instruction moves 1 KiB of whole 128-byte lines.  May be NULL otherwise. */
+  int32_t* tile_counters; /* as in me_conv_desc: arrival counters of the in-launch split-K reduction (zero on entry and exit) */
+  int64_t tile_counters_len;
 } me_conv16_desc;
 int me_conv2d_h16(const me_conv16_desc* d, void* stream);
 int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d);

@@ -548,6 +548,15 @@ __global__ __launch_bounds__(256) void conv_stem3_f32(ConvP p) {
 // ---------------------------------------------------------------------------------------------
 using namespace me_dma;
 
+// f(integral_constant<int, 0>{}) ... f(integral_constant<int, N - 1>{}), in order
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+
 // Tile index (XCD-contiguous, see the remap in the kernel) -> tile coordinates: column panels of p.gn tile columns, row-major
 // inside a panel (the last panel may be narrower).  p.gn == p.tiles_n is the plain row-major order.  With a panel whose weight
 // rows fit the XCD's L2 the weights are fetched once per XCD instead of once per (drifting) workgroup.
@@ -566,11 +575,14 @@ __device__ __forceinline__ void tile_coords(const ConvP& p, int t, int& tile_m, 
 // remaining tiles cut p.splitk ways along K, so that the last partial round of workgroups is made of pieces small enough to
 // spread over all CUs.  The pieces write raw accumulators into compact slabs [tail tile][split][BM][BN];
 // conv_tail_reduce_f32 sums them in a fixed order and applies the epilogue.
-template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0, int HYB = 0, int KORD = 0>
+// DEEP: a longer LDS ring (6 stages tap-major / 9 chunk-major instead of 3: five / eight stages of DMAs in flight) for launches
+// that put one or two workgroups on a CU (batch 1 / 8): there a stage is bound by the latency of its DMAs, not by the matrix pipe.
+template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0, int HYB = 0, int KORD = 0, int DEEP = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p) {
   constexpr int NW = WR * WC;  // waves per workgroup (4 or 8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  constexpr int BK = 16, NST = 3;
+  constexpr int BK = 16, NST = DEEP ? (KORD ? 9 : 6) : 3;
+  constexpr int DEPTH = NST - 1;  // stages of DMAs in flight behind the one being multiplied
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int MT = TM / 32, NT = TN / 32;
   constexpr int GA = BM / 16, G = (BM + BN) / 16;  // 16-row groups (1 KiB each): A first, then B
@@ -749,7 +761,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
     a_off += (unsigned)cc * (BK * 4u);
     b_off += (unsigned)cc * b_step;
     auto issue_stage = [&](unsigned lds_dst) {
-      dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, a_off, b_off, lds_dst);
+      // (readfirstlane: a no-op on values that already live in SGPRs, a guard where the compiler moved the walk to VGPRs)
+      dma_stage<LPW, LA, NW * 1024>(v_cur, rsrc_a, rsrc_b, __builtin_amdgcn_readfirstlane(a_off),
+                                    __builtin_amdgcn_readfirstlane(b_off), lds_dst);
       a_off += BK * 4u;
       b_off += b_step;
       if (++cc == p.cs) {
@@ -763,33 +777,37 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
       }
     };
     const int nstages = s_end - s_begin;
-    issue_stage(wave_lds);
-    if (nstages > 1) issue_stage(wave_lds + STAGE_B);
-    // The bulk runs three steps per loop trip with compile-time slots (LDS offsets are immediates, ~19 scalar
-    // instructions per step); the last <= 4 stages go through the generic tail below.
+    for (int i = 0; i < DEPTH && i < nstages; ++i) issue_stage(wave_lds + (unsigned)i * STAGE_B);
+    // wait until only `younger` stages of this wave's DMAs are outstanding (vmcnt wants an immediate)
+    auto wait_landed = [&](int younger) {
+      bool done = false;
+      static_for<DEPTH>([&](auto r_c) {
+        constexpr int R = decltype(r_c)::value;
+        if (!done && younger <= R) {
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW * R) : "memory");
+          done = true;
+        }
+      });
+      if (!done) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW * (DEPTH - 1)) : "memory");
+    };
+    // The bulk runs NST steps per loop trip with compile-time slots (LDS offsets are immediates, ~19 scalar
+    // instructions per step); the last stages go through the generic tail below.
     auto step = [&](auto slot_c) {
       constexpr int SLOT = decltype(slot_c)::value;
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW * (DEPTH - 1)) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issue_stage(wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+      issue_stage(wave_lds + ((SLOT + DEPTH) % NST) * STAGE_B);
       compute_stage(a_frag + SLOT * STAGE_F, b_frag + SLOT * STAGE_F);
     };
     int s = 0;
-    for (; s + 3 <= nstages - 2; s += 3) {
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-    }
-    int slot = 0;  // s is a multiple of 3 here
+    for (; s + NST <= nstages - DEPTH; s += NST) static_for<NST>(step);
+    int slot = 0;  // s is a multiple of NST here
     for (; s < nstages; ++s) {
-      if (s + 1 < nstages)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      wait_landed(nstages - 1 - s);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (s + 2 < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);
+      if (s + DEPTH < nstages) issue_stage(wave_lds + (slot == 0 ? NST - 1 : slot - 1) * STAGE_B);
       compute_stage(a_frag + slot * STAGE_F, b_frag + slot * STAGE_F);
       slot = slot == NST - 1 ? 0 : slot + 1;
     }
@@ -813,37 +831,26 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
     unsigned ca = (unsigned)c_begin * (BK * 4u), cb = (unsigned)c_begin * b_step;  // offsets of the chunk being multiplied
     auto issue = [&](auto tap_c, unsigned ca_, unsigned cb_, unsigned lds_dst) {
       constexpr int T = decltype(tap_c)::value;
-      dma_stage<LPW, LA, NW * 1024>(v_tap[T], rsrc_a, rsrc_b, a_tap[T] + ca_, b_tap[T] + cb_, lds_dst);
+      dma_stage<LPW, LA, NW * 1024>(v_tap[T], rsrc_a, rsrc_b, __builtin_amdgcn_readfirstlane(a_tap[T] + ca_),
+                                    __builtin_amdgcn_readfirstlane(b_tap[T] + cb_), lds_dst);
     };
     auto step = [&](auto tap_c, auto last_c) {
       constexpr int T = decltype(tap_c)::value;
       constexpr bool LAST = decltype(last_c)::value;  // the last chunk of this workgroup: nothing to prefetch behind it
       constexpr int SLOT = T % NST;
-      if constexpr (LAST && T == 8)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW) : "memory");
+      constexpr int YOUNGER = (LAST && 8 - T < DEPTH - 1) ? 8 - T : DEPTH - 1;  // stages issued behind stage T, still in flight
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW * YOUNGER) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if constexpr (T + 2 < 9)
-        issue(std::integral_constant<int, (T + 2) % 9>{}, ca, cb, wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+      constexpr unsigned DST = ((SLOT + DEPTH) % NST) * STAGE_B;
+      if constexpr (T + DEPTH < 9)
+        issue(std::integral_constant<int, (T + DEPTH) % 9>{}, ca, cb, wave_lds + DST);
       else if constexpr (!LAST)
-        issue(std::integral_constant<int, (T + 2) % 9>{}, ca + BK * 4u, cb + b_step, wave_lds + ((SLOT + 2) % NST) * STAGE_B);
+        issue(std::integral_constant<int, (T + DEPTH) % 9>{}, ca + BK * 4u, cb + b_step, wave_lds + DST);
       compute_stage(a_frag + SLOT * STAGE_F, b_frag + SLOT * STAGE_F);
     };
-    auto chunk = [&](auto last_c) {
-      step(std::integral_constant<int, 0>{}, last_c);
-      step(std::integral_constant<int, 1>{}, last_c);
-      step(std::integral_constant<int, 2>{}, last_c);
-      step(std::integral_constant<int, 3>{}, last_c);
-      step(std::integral_constant<int, 4>{}, last_c);
-      step(std::integral_constant<int, 5>{}, last_c);
-      step(std::integral_constant<int, 6>{}, last_c);
-      step(std::integral_constant<int, 7>{}, last_c);
-      step(std::integral_constant<int, 8>{}, last_c);
-    };
-    issue(std::integral_constant<int, 0>{}, ca, cb, wave_lds);
-    issue(std::integral_constant<int, 1>{}, ca, cb, wave_lds + STAGE_B);
+    auto chunk = [&](auto last_c) { static_for<9>([&](auto tap_c) { step(tap_c, last_c); }); };
+    static_for<DEPTH>([&](auto tap_c) { issue(tap_c, ca, cb, wave_lds + decltype(tap_c)::value * STAGE_B); });
     for (int c = c_begin; c + 1 < c_end; ++c) {
       chunk(std::false_type{});
       ca += BK * 4u;
@@ -853,33 +860,66 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
   }
 
   // ---- epilogue (same as conv_igemm_dma_f32) ----------------------------------------------------
-  if constexpr (HYB) {
-    if (piece >= 0) {
-      float* slab = p.partial + (long long)piece * (BM * BN);
+  // K-split workgroups (split-K: grid.y; tail split: pieces) park their raw accumulators in slabs - [split][M][cout], or
+  // compact [piece][BM][BN] for the tail split.  With arrival counters (p.counters) the last workgroup of a tile to arrive
+  // reads the slabs back in the fixed order 0..k-1 and goes on to the fused epilogue; without, a second launch does that.
+  // Hand-over in the write-through form of the in-launch split-K recipe (cdna_hip_programming.md section 6, guideline 16):
+  // sc1 slab stores (relaxed agent-scope atomic stores of 4 bytes), drained by every wave, barrier, one lane draws the
+  // ticket; the last one's workgroup reads the slabs with sc1 loads.  No L2 write-back / invalidate fences.
+  const bool split = HYB ? piece >= 0 : p.splitk > 1;
+  if (split) {
+    const long long slab_stride = HYB ? (long long)(BM * BN) : (long long)p.M * p.cout;
+    float* slab0 = HYB ? p.partial + (long long)(piece - sid) * (BM * BN) : p.partial;  // split 0 of this tile
+    auto slab_index = [&](int i, int j, int e, long long& idx) {
+      const int lm = wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh, lc = wc * TN + j * 32 + r32;
+      if (HYB) {
+        idx = (long long)lm * BN + lc;
+        return true;
+      }
+      idx = (long long)(m0 + lm) * p.cout + (n0 + lc);
+      return m0 + lm < p.M && n0 + lc < p.cout;
+    };
+    float* mine = slab0 + (long long)sid * slab_stride;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            slab[(wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * BN + wc * TN + j * 32 + r32] = acc[i][j][e];
-      return;
-    }
-  }
-  if (!HYB && p.splitk > 1) {
-    float* slab = p.partial + (long long)sid * p.M * p.cout;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int co = n0 + wc * TN + j * 32 + r32;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (co < p.cout && m < p.M) slab[(long long)m * p.cout + co] = acc[i][j][e];
+          long long idx;
+          if (!slab_index(i, j, e, idx)) continue;
+          if (p.counters)  // write-through (sc1) store: visible to every XCD once this wave's vmcnt drains, no L2 write-back fence
+            __hip_atomic_store(mine + idx, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            mine[idx] = acc[i][j][e];
         }
+    if (p.counters == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* last_flag = reinterpret_cast<int*>(smem);  // the stage buffers are idle now
+    if (tid == 0) {
+      int* cnt = p.counters + (HYB ? piece / p.splitk : tile_m * p.tiles_n + tile_n);
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.splitk - 1;
+      if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all arrived: ready for the next launch
+      *last_flag = last;
     }
-    return;
+    __syncthreads();
+    if (*last_flag == 0) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          long long idx;
+          if (!slab_index(i, j, e, idx)) continue;
+          // sc1 loads (coherent at agent scope: served past this XCD's L2 lines that may be stale)
+          float a = __hip_atomic_load(slab0 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int k = 1; k < p.splitk; ++k)
+            a += __hip_atomic_load(slab0 + (long long)k * slab_stride + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j][e] = a;
+        }
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -1074,7 +1114,7 @@ const TileCfg kTiles[] = {
     {4, 128, 32, 16, 4, 1, 0.75f},
 };
 const TileCfg kExtraTiles[] = {  // forced ids only (engine autotuner, tools/conv_bench.py)
-    {5, 256, 128, 16, 2, 2, 1.02f},  {6, 256, 128, 16, 1, 2, 1.0f},   {21, 128, 128, 16, 3, 1, 1.0f}, {22, 128, 64, 16, 4, 1, 0.9f},
+    {5, 256, 128, 16, 2, 2, 1.02f},  {6, 256, 128, 16, 1, 2, 1.0f},   {7, 64, 64, 16, 2, 1, 0.85f},   {21, 128, 128, 16, 3, 1, 1.0f}, {22, 128, 64, 16, 4, 1, 0.9f},
     {23, 64, 64, 16, 8, 1, 0.85f},   {24, 128, 32, 16, 7, 1, 0.75f},  {25, 256, 128, 16, 2, 2, 1.02f},
     {51, 128, 128, 16, 3, 1, 1.0f},  {52, 128, 64, 16, 5, 1, 0.9f},  {53, 64, 64, 16, 8, 1, 0.85f},
     {54, 128, 32, 16, 7, 1, 0.75f},  {55, 128, 128, 32, 2, 1, 1.0f}, {31, 128, 128, 16, 3, 1, 1.0f},
@@ -1266,12 +1306,13 @@ void choose_order(ConvP& p) {
   if (p.ks == 3 && kChunkMajor >= 1) p.kord = 1;
 }
 
-template <int BM, int BN, int WR, int WC, int MINW, int BABL, int HYB, int KORD>
+template <int BM, int BN, int WR, int WC, int MINW, int BABL, int HYB, int KORD, int DEEP = 0>
 int launch_buf_kernel(const ConvP& p, dim3 grid, hipStream_t stream) {
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
-  const size_t lds = (size_t)3 * LPW * NW * 256 * sizeof(float);
-  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW, BABL, HYB, KORD>;
+  constexpr int NST = DEEP ? (KORD ? 9 : 6) : 3;
+  const size_t lds = (size_t)NST * LPW * NW * 256 * sizeof(float);
+  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW, BABL, HYB, KORD, DEEP>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1284,7 +1325,7 @@ int launch_buf_kernel(const ConvP& p, dim3 grid, hipStream_t stream) {
   return me::check_launch(HYB ? "conv_igemm_buf_f32<tail split>" : "conv_igemm_buf_f32");
 }
 
-template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0>
+template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0, int DEEP = 0>
 int launch_buf(ConvP& p, hipStream_t stream) {
   if (p.ks * p.ks > 32) {  // the DMA kernels keep a 32-bit "tap is padding" mask per lane: larger filters (6x6, 7x7)
     if constexpr (WR * WC == 4)  // go through the register-staged kernel, which tests bounds per stage
@@ -1304,14 +1345,15 @@ int launch_buf(ConvP& p, hipStream_t stream) {
   const long long blocks = (long long)p.tiles_m * p.tiles_n;
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
   const dim3 grid((unsigned)blocks, (unsigned)p.splitk);
+  if (blocks > p.counters_len || p.splitk == 1) p.counters = nullptr;  // in-launch slab reduction needs a counter per tile
   int rc;
   if constexpr (BABL == 0) {
-    rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 1>(p, grid, stream)
-                : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 0>(p, grid, stream);
+    rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 1, DEEP>(p, grid, stream)
+                : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 0, DEEP>(p, grid, stream);
   } else {
     rc = launch_buf_kernel<BM, BN, WR, WC, MINW, BABL, 0, 0>(p, grid, stream);
   }
-  if (rc || p.splitk == 1) return rc;
+  if (rc || p.splitk == 1 || p.counters) return rc;
   long long rb = ((long long)p.M * p.cout + 255) / 256;
   if (rb > 256 * 16) rb = 256 * 16;
   hipLaunchKernelGGL(conv_splitk_reduce_f32, dim3((unsigned)rb), dim3(256), 0, stream, p);
@@ -1319,7 +1361,7 @@ int launch_buf(ConvP& p, hipStream_t stream) {
 }
 
 // Tail-split launch (tile ids 41-45): whole tiles for the rounds that fill every CU, the rest cut p.splitk ways along K.
-template <int BM, int BN, int WR, int WC, int MINW = 1>
+template <int BM, int BN, int WR, int WC, int MINW = 1, int DEEP = 0>
 int launch_buf_tail(ConvP& p, hipStream_t stream, long long ws_bytes) {
   ME_REQUIRE(p.ks * p.ks <= 32 && buf_addressable<BM>(p), ME_E_BADARG,
              "me_conv2d_f32: the tail-split tiles need cin %% 16 == 0 and offsets below 2^31");
@@ -1337,15 +1379,16 @@ int launch_buf_tail(ConvP& p, hipStream_t stream, long long ws_bytes) {
   if (tail == 0 || p.splitk <= 1) {  // nothing to cut: the plain launch
     p.splitk = 1;
     p.bulk = 0;
-    return launch_buf<BM, BN, WR, WC, MINW>(p, stream);
+    return launch_buf<BM, BN, WR, WC, MINW, 0, DEEP>(p, stream);
   }
   const long long need = tail * p.splitk * BM * BN * (long long)sizeof(float);
   ME_REQUIRE(p.partial && ws_bytes >= need, ME_E_BADARG, "me_conv2d_f32: tail split %d needs a workspace of %lld bytes",
              p.splitk, need);
   const dim3 grid((unsigned)(p.bulk + tail * p.splitk));
-  int rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 1, 1>(p, grid, stream)
-                  : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 1, 0>(p, grid, stream);
-  if (rc) return rc;
+  if (tail > p.counters_len) p.counters = nullptr;
+  int rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 1, 1, DEEP>(p, grid, stream)
+                  : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 1, 0, DEEP>(p, grid, stream);
+  if (rc || p.counters) return rc;
   long long rb = (tail * BM * BN + 255) / 256;
   if (rb > 256 * 16) rb = 256 * 16;
   hipLaunchKernelGGL(conv_tail_reduce_f32, dim3((unsigned)rb), dim3(256), 0, stream, p, BM, BN);
@@ -1373,6 +1416,8 @@ int fill_params(const me_conv_desc* d, ConvP& p) {
   p.partial = nullptr;
   p.splitk = 1;
   p.sps = 0;
+  p.counters = d->tile_counters_len > 0 ? d->tile_counters : nullptr;
+  p.counters_len = p.counters ? d->tile_counters_len : 0;
   return 0;
 }
 
@@ -1388,8 +1433,8 @@ int64_t me_conv2d_flops(const me_conv_desc* d) {
 int64_t me_conv2d_workspace_bytes(const me_conv_desc* d) {
   ConvP p;
   if (!d || fill_params(d, p) != 0 || d->cin <= 4) return 0;
-  if (d->tile >= 41 && d->tile <= 45) {  // tail split: compact slabs of the last partial round only
-    static const int shape[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {256, 128}};
+  if ((d->tile >= 41 && d->tile <= 45) || d->tile == 47) {  // tail split: compact slabs of the last partial round only
+    static const int shape[7][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {256, 128}, {0, 0}, {64, 64}};
     const int bm = shape[d->tile - 41][0], bn = shape[d->tile - 41][1];
     const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.cout + bn - 1) / bn);
     const int split = d->split_k > 0 ? d->split_k : 4;
@@ -1445,7 +1490,7 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_f32: res_pitch < cout");
   ME_REQUIRE(d->split_k >= 0 && d->split_k <= 64, ME_E_BADARG, "me_conv2d_f32: split_k out of range");
 
-  if (d->tile >= 41 && d->tile <= 45) {  // tail split: split_k = pieces per tile of the last, partial round (0: 4)
+  if ((d->tile >= 41 && d->tile <= 45) || d->tile == 47) {  // tail split: split_k = pieces per tile of the last, partial round (0: 4)
     p.splitk = d->split_k > 0 ? d->split_k : 4;
     p.partial = reinterpret_cast<float*>(d->workspace);
     const long long ws = d->workspace ? d->workspace_bytes : 0;
@@ -1454,6 +1499,7 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
       case 42: return launch_buf_tail<128, 64, 2, 2>(p, stream, ws);
       case 43: return launch_buf_tail<64, 64, 2, 2>(p, stream, ws);
       case 44: return launch_buf_tail<128, 32, 4, 1>(p, stream, ws);
+      case 47: return launch_buf_tail<64, 64, 2, 2, 1, 1>(p, stream, ws);  // deep LDS ring (small batches)
       default: return launch_buf_tail<256, 128, 4, 2, 4>(p, stream, ws);
     }
   }
@@ -1482,6 +1528,7 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
     case 3: return launch_buf<64, 64, 2, 2>(p, stream);
     case 4: return launch_buf<128, 32, 4, 1>(p, stream);
     case 5: return launch_buf<256, 128, 4, 2, 4>(p, stream);  // 8 waves (512 threads), 4 waves / SIMD
+    case 7: return launch_buf<64, 64, 2, 2, 1, 0, 1>(p, stream);  // 64x64 with the deep LDS ring (6 / 9 stages): small batches
     // tuning / ablation variants (forced ids only, tools/conv_bench.py)
     case 21: return launch_dma<128, 128, 2, 2, 1>(p, stream);  // previous generation: global_load_lds + per-lane pointers
     case 22: return launch_dma<128, 64, 2, 2, 1>(p, stream);

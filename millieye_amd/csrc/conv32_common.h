@@ -27,6 +27,8 @@ struct ConvP {
   int sps;         // K stages per split
   int gn;          // conv_igemm_buf_f32: tile columns per panel of the tile walk (tiles_n = row-major)
   int kord;        // conv_igemm_buf_f32: K walk, 0 tap-major / 1 chunk-major
+  int* counters;   // per-tile arrival counters of the in-launch slab reduction (zero between launches), or nullptr
+  long long counters_len;
   int bulk;        // tail-split launches: tiles [0, bulk) run whole, tiles [bulk, tiles) cut splitk ways (0 otherwise)
 };
 

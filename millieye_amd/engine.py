@@ -19,6 +19,7 @@ alive.  Here the cfg graph is compiled once per input shape into a short list of
 Nothing in this file computes: it owns shapes, pointers and launch order.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -601,6 +602,15 @@ class DarknetEngine:
         # shared scratch for the deterministic split-K slabs (launches are serial on one stream)
         ws_fn = lib.me_conv2d_h16_workspace_bytes if bf16 else lib.me_conv2d_workspace_bytes
         need = max([ws_fn(C.byref(d)) for _m, d in plan.conv_descs] + [0])
+        # arrival counters of the in-launch split-K reduction (zero between launches; one array per plan = per stream).  Opt-in:
+        # on MI355X the serial tail of the last workgroup (drain, ticket, slab reads past the L2) costs more than the launch it
+        # saves - batch-1 detector 1.49 -> 1.89 ms, batch 8 4.93 -> 5.15 ms (profiles/r02_kernel_evolution.md)
+        plan.tile_counters = None
+        if os.environ.get("MILLIEYE_INLAUNCH_REDUCE", "0") == "1":
+            plan.tile_counters = torch.zeros(hip.TILE_COUNTERS, dtype=torch.int32, device=device)
+            for _m, d in plan.conv_descs:
+                if d.cin > 4:
+                    d.tile_counters, d.tile_counters_len = plan.tile_counters.data_ptr(), hip.TILE_COUNTERS
         plan.conv_ws = None
         plan.graph = None
         if need > 0:
@@ -705,7 +715,8 @@ def _graphs_enabled():
 # ------------------------------------------------------------------------------------------ autotuner
 _TUNE_CACHE = {}
 _TUNE_FILE_LOADED = [False]
-_TUNE_TILES = (1, 2, 3, 4, 5)
+_TUNE_TILES = (1, 2, 3, 4, 5)  # (7 / 47 = 64x64 with a 6 / 9-stage LDS ring: no gain at batch 1 / 8 - a lone wave per SIMD is bound by its
+# own MFMA chain, not by DMA latency - so they stay forced-only ids)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
 _TUNE_TILES_BF16 = (1, 2, 3, 4, 11, 12, 13, 14, 15)  # 1x = one 32-channel sub-stage per pipeline stage (more workgroups / CU)
 _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
@@ -732,7 +743,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v7.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v8.json")  # bump with every kernel generation
 
 
 def _tune_load():
@@ -800,7 +811,7 @@ def _autotune(plan, lib):
         return have
 
     def scratch_of(d2):
-        if not bf16 and 41 <= d2.tile <= 45:  # tail split: compact slabs of the last partial round (the library knows)
+        if not bf16 and d2.tile in _TUNE_TILES_TAIL + (47,):  # tail split: compact slabs of the last partial round (the library knows)
             return int(lib.me_conv2d_workspace_bytes(C.byref(d2)))
         return d2.split_k * d2.n * d2.ho * d2.wo * d2.cout * 4 if d2.split_k > 1 else 0
 
@@ -861,9 +872,9 @@ def _autotune(plan, lib):
                 tiles = tiles + _TUNE_TILES_P8_F32
         for tile in tiles:
             bm, bn = _TILE_SHAPES_BF16[tile] if (bf16 or tile >= 100) else \
-                {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128)}[tile % 40]
+                {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128), 7: (64, 64)}[tile % 40]
             ntiles = -(-d.n * d.ho * d.wo // bm) * -(-d.cout // bn)
-            tail = not bf16 and 41 <= tile <= 45
+            tail = not bf16 and tile in _TUNE_TILES_TAIL
             if tail and ntiles % 256 == 0:
                 continue
             for split in (_TUNE_SPLITS[1:] if tail else _TUNE_SPLITS if tile < 100 else (1,)):

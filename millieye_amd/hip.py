@@ -16,7 +16,7 @@ import torch
 __all__ = ["lib", "available", "default_device", "MeError"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmillieye_hip.so")
+LIB_PATH = os.environ.get("MILLIEYE_HIP_LIB") or os.path.join(_HERE, "libmillieye_hip.so")  # (the override: A/B runs of two builds)
 
 ACT_LINEAR, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 
@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("split_k", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("wgt_tiled", C.c_void_p),
+        ("tile_counters", C.c_void_p), ("tile_counters_len", C.c_int64),
     ]
 
 
@@ -53,6 +54,7 @@ class Conv16Desc(C.Structure):
         ("half_type", C.c_int32), ("tile", C.c_int32), ("split_k", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("wgt_tiled", C.c_void_p),
+        ("tile_counters", C.c_void_p), ("tile_counters_len", C.c_int64),
     ]
 
 
@@ -231,8 +233,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 4:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 4")
+    if lib_.me_abi_version() != 5:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 5")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
@@ -293,9 +295,10 @@ def _nhwc_pitch(t, name):
 
 
 def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-           x_nchw=False, tile=0, split_k=0, wgt_tiled=None):
+           x_nchw=False, tile=0, split_k=0, wgt_tiled=None, in_launch_reduce=False):
     """x_nhwc: [N,H,W,Cin] contiguous (or NCHW [N,Cin,H,W] when ``x_nchw``).  Returns NHWC
-    [N,Ho*up,Wo*up,Cout]."""
+    [N,Ho*up,Wo*up,Cout].  ``in_launch_reduce=True`` hands the library arrival counters: split-K slabs are then summed by the last
+    workgroup of each tile instead of a second launch (same bits; measured slower on MI355X - DESIGN.md section 5 - so off)."""
     _require_cuda_f32(x_nhwc, "x")
     if x_nchw:
         n, cin, h, w = x_nhwc.shape
@@ -330,6 +333,8 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     if need > 0:
         ws_ptr, keep = _workspace(need, x_nhwc.device, slot="conv")
         d.workspace, d.workspace_bytes = ws_ptr, need
+        if in_launch_reduce:
+            d.tile_counters, d.tile_counters_len, _keep2 = tile_counters(x_nhwc.device)
     check(lib().me_conv2d_f32(C.byref(d), stream_ptr()), "me_conv2d_f32")
     return out
 
@@ -507,6 +512,22 @@ def yolo_decode(x_nhwc, anchors, num_classes, img_dim, out=None, rows_total=None
 
 
 _ws_cache = {}
+
+
+_counter_cache = {}
+TILE_COUNTERS = 1 << 16
+
+
+def tile_counters(device, slot="conv"):
+    """``(pointer, length, keep-alive)`` of a zeroed int32 array for ``me_conv_desc.tile_counters`` (arrival counters of the
+    in-launch split-K reduction; the library leaves them zero).  One array per (slot, device, stream): launches that may run
+    concurrently must not share one."""
+    key = (slot, device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    t = _counter_cache.get(key)
+    if t is None:
+        t = _counter_cache[key] = torch.zeros(TILE_COUNTERS, dtype=torch.int32, device=device)
+    return t.data_ptr(), TILE_COUNTERS, t
 
 
 def _workspace(nbytes, device, slot="nms"):

@@ -48,7 +48,7 @@ def _conv_case(hip, tag, n, h, w, cin, cout, k, s, act, residual=False, ups=1, t
     return assert_close(got.cpu().permute(0, 3, 1, 2), ref, TOL, tag)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7])
 def test_conv_buffer_addressed_kernel(hip_lib, tile):
     """conv_igemm_buf_f32 (buffer_load ... lds with range-check zero padding): shapes that stress its addressing -
     tiles spanning 2-3 images, borders on every side, channel-slice inputs (pitch > cin), cin = 16 (a new filter tap
@@ -74,7 +74,7 @@ def test_conv3x3_every_tile(hip_lib, tile):
     _conv_case(hip, f"c3t{tile}e", 2, 13, 13, 64, 96, 3, 1, 1, residual=True, split_k=3, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [41, 42, 43, 44, 45])
+@pytest.mark.parametrize("tile", [41, 42, 43, 44, 45, 47])
 def test_conv_tail_split_tiles(hip_lib, tile):
     """Tile ids 41-45 = tiles 1-5 with the last partial round of tiles cut split_k ways along K (compact slabs +
     conv_tail_reduce_f32): fewer than 256 tiles (everything is tail), more than 256 (whole tiles + tail pieces in one
@@ -86,8 +86,8 @@ def test_conv_tail_split_tiles(hip_lib, tile):
     _conv_case(hip, f"ts{tile}c", 2, 26, 26, 64, 128, 3, 2, 1, tile=tile, x_slice=32, split_k=4)
     _conv_case(hip, f"ts{tile}d", 2, 13, 13, 48, 64, 3, 1, 1, residual=True, split_k=0, tile=tile)
     _conv_case(hip, f"ts{tile}e", 1, 13, 13, 64, 48, 3, 1, 1, ups=2, split_k=5, tile=tile, x_slice=64)
-    bm, bn = {41: (128, 128), 42: (128, 64), 43: (64, 64), 44: (128, 32), 45: (256, 128)}[tile]
-    n, cout = {41: (4, 500), 42: (2, 500), 43: (2, 250), 44: (2, 250), 45: (8, 500)}[tile]
+    bm, bn = {41: (128, 128), 42: (128, 64), 43: (64, 64), 44: (128, 32), 45: (256, 128), 47: (64, 64)}[tile]
+    n, cout = {41: (4, 500), 42: (2, 500), 43: (2, 250), 44: (2, 250), 45: (8, 500), 47: (2, 250)}[tile]
     tiles = -(-n * 52 * 52 // bm) * -(-cout // bn)
     assert 256 < tiles < 512 and tiles % 256, tiles
     _conv_case(hip, f"ts{tile}f", n, 52, 52, 32, cout, 3, 1, 1, residual=True, split_k=3, tile=tile)
@@ -101,6 +101,30 @@ def test_conv_tail_split_tiles(hip_lib, tile):
     assert torch.equal(a1, a2), "the tail split must be run-to-run deterministic"
     a0 = hip.conv2d(x, w, s, b, 3, 1, 1, 1, tile=tile - 40, split_k=1)
     assert_close(a1.cpu(), a0.cpu(), 1e-4, "tail split vs whole tiles")
+
+
+@pytest.mark.parametrize("tile,split", [(3, 4), (1, 3), (2, 9), (5, 2), (7, 5), (43, 3), (41, 4), (45, 2), (47, 3)])
+def test_conv_in_launch_split_reduce(hip_lib, tile, split):
+    """Split-K / tail-split slabs reduced inside the launch (arrival counter per tile, the last workgroup to arrive sums the
+    slabs in the fixed order and runs the fused epilogue) against the two-pass form (slabs + reduce launch): same bits, every
+    time (40 repeats on shapes with many tiles per XCD - a stale slab read across XCDs or a lost arrival would show), and
+    the counters are back at zero."""
+    from millieye_amd import hip
+    for tag, shape, cout, k in (("a", (2, 26, 26, 64), 250, 3), ("b", (4, 52, 52, 32), 500, 3), ("c", (8, 13, 13, 256), 255, 1)):
+        x = _t(f"ilr{tag}x", shape).cuda()
+        w = torch.from_numpy(synth.normal(f"ilr{tag}w", (cout, k, k, shape[3]), 0, 0.05)).cuda()
+        s = _t(f"ilr{tag}s", (cout,), 0.5, 1.5).cuda()
+        b = _t(f"ilr{tag}b", (cout,), -0.5, 0.5).cuda()
+        r = _t(f"ilr{tag}r", (shape[0], shape[1], shape[2], cout)).cuda()
+        pad = (k - 1) // 2
+        two = hip.conv2d(x, w, s, b, k, 1, pad, 1, residual=r, tile=tile, split_k=split, in_launch_reduce=False)
+        for _ in range(40):
+            one = hip.conv2d(x, w, s, b, k, 1, pad, 1, residual=r, tile=tile, split_k=split, in_launch_reduce=True)
+            assert torch.equal(one, two), f"in-launch reduction differs from the two-pass result ({tag}, tile {tile})"
+        _ptr, _n, counters = hip.tile_counters(x.device)
+        assert int(counters.abs().sum()) == 0, "arrival counters must be zero between launches"
+        ref = hip.conv2d(x, w, s, b, k, 1, pad, 1, residual=r, tile=tile % 40, split_k=1)
+        assert_close(one.cpu(), ref.cpu(), 1e-4, f"split vs whole ({tag}, tile {tile})")
 
 
 def test_conv_variants(hip_lib):
