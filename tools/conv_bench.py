@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--splits", default="0", help="comma list of split_k values (0 = auto)")
     ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed load before each measurement")
+    ap.add_argument("--res", action="store_true", help="fused residual add (the [shortcut] epilogue)")
     ap.add_argument("--custom", default="", help="extra shape 'hw,cin,cout,k,stride' (square input)")
     args = ap.parse_args()
     if args.custom:
@@ -66,8 +67,9 @@ def main():
         sh = torch.zeros(cout, device=dev)
         y = torch.empty((n, ho, ho, cout), device=dev)
         d = hip.ConvDesc()
-        d.x, d.wgt, d.scale, d.shift, d.res, d.y = x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr()
-        d.x_pitch, d.res_pitch, d.y_pitch = cin, 0, cout
+        r = torch.randn_like(y) if args.res else None
+        d.x, d.wgt, d.scale, d.shift, d.res, d.y = x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(), (r.data_ptr() if args.res else None), y.data_ptr()
+        d.x_pitch, d.res_pitch, d.y_pitch = cin, (cout if args.res else 0), cout
         d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.pad, d.ho, d.wo = n, hw, hw, cin, cout, k, s, pad, ho, ho
         d.act, d.upsample, d.x_nchw = 1, 1, 0
         flops = lib.me_conv2d_flops(d)
