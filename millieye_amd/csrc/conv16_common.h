@@ -51,7 +51,8 @@ struct Conv16P {
   int cs;      // stages per filter tap = cin / (32*KSUB)
   int stages;  // ks*ks*cs
   int tiles_m, tiles_n;
-  float* partial;  // split-K slabs [splitk][M][cout] (raw fp32 accumulators), or nullptr
+  float* partial;  // split-K slabs [splitk][M][cout] (raw fp32 accumulators; patch tiles: [tile][split][BM][BN]), or nullptr
+  long long partial_bytes;
   int splitk, sps;
   int f16;         // 0 = bfloat16 storage, 1 = IEEE half
   int vec_epi;     // 16-byte epilogue allowed (bf16 out, no upsample, leaky / linear, pitches % 8, 16-byte aligned)

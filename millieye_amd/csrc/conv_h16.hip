@@ -30,6 +30,7 @@
 namespace me16 {  // conv_p8_h16.hip: patch-resident big-tile generation (tile ids >= 100)
 bool p8_eligible(const Conv16P& p, int tile);
 int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream);
+long long p8_workspace_bytes(const Conv16P& p, int tile, int split);
 bool stem_mfma_eligible(const Conv16P& p);  // stem_mfma_h16.hip
 int launch_stem_mfma(const Conv16P& p, hipStream_t stream);
 }  // namespace me16
@@ -600,6 +601,7 @@ int fill16(const me_conv16_desc* d, Conv16P& p) {
   p.ktot = d->ksize * d->ksize * d->cin;
   p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
   p.partial = nullptr;
+  p.partial_bytes = 0;
   p.splitk = 1;
   p.sps = 0;
   p.vec_epi = !d->y_f32 && d->upsample == 1 && d->act != ME_ACT_SIGMOID && d->y_pitch % 8 == 0 && me::aligned16(d->y) &&
@@ -635,6 +637,7 @@ int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d) {
   Conv16P p;
   if (!d || fill16(d, p) != 0 || d->cin <= 4) return 0;
   int tile, split;
+  if (d->tile >= 100) return me16::p8_workspace_bytes(p, d->tile, d->split_k);  // patch tiles: split only when asked to
   plan16(p, d->split_k > 0 ? d->split_k : kMaxSplit16, &tile, &split);
   if (d->split_k > 0) split = d->split_k;
   return split > 1 ? (int64_t)split * p.M * p.cout * (int64_t)sizeof(float) : 0;
@@ -682,6 +685,12 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   if (d->workspace && d->workspace_bytes >= 2 * slab) {
     const long long fit = d->workspace_bytes / slab;
     max_split = fit < kMaxSplit16 ? (int)fit : kMaxSplit16;
+  }
+  if (d->tile >= 100) {  // patch-resident tiles: K split only on request (compact slabs, checked by the launcher)
+    p.splitk = d->split_k > 1 ? d->split_k : 1;
+    p.partial = reinterpret_cast<float*>(d->workspace);
+    p.partial_bytes = d->workspace ? d->workspace_bytes : 0;
+    return me16::launch_p8_tile(p, d->tile, stream);
   }
   int tile = d->tile, split = 1;
   if (tile == 0 || d->split_k == 0) {

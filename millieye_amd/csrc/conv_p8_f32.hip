@@ -43,6 +43,8 @@ int launch_p8(const ConvP& p, hipStream_t stream) {
   a.c.x_pitch = p.x_pitch; a.c.res_pitch = p.res_pitch; a.c.y_pitch = p.y_pitch;
   a.c.n = p.n; a.c.h = p.h; a.c.w = p.w; a.c.cin = p.cin; a.c.cout = p.cout; a.c.act = p.act;
   a.c.partial = p.partial;
+  a.c.splitk = 1;  // (the K split of the patch tiles is built for the 16-bit epilogue only)
+  a.c.cps = 0;
   a.Wp = p.w + 1;
   a.Ip = (p.h + 1) * a.Wp;
   a.halo = a.Wp + 1;

@@ -49,6 +49,65 @@ void magic_u32(unsigned d, unsigned* m, unsigned* s) {
   *m = (unsigned)(((1ull << 32) * ((1ull << sh) - d)) / d + 1);
 }
 
+// K split, second pass: slabs [tile][split][BM][BN] of raw accumulators -> fixed-order sum, then the epilogue of the one-pass
+// kernel (affine, leaky, + residual, round to the storage type; one thread = 8 consecutive channels of one position = one
+// 16-byte store).  Positions are padded-linear: pad positions and positions behind the last image are skipped.
+template <int F16>
+__global__ __launch_bounds__(256) void conv3x3_p8_reduce_h16(P8Args a, int bm, int bn) {
+  const P8Conv& p = a.c;
+  const int cols8 = bn / 8, tile_elems = bm * bn;
+  const long long total = (long long)p.tiles_m * p.tiles_n * bm * cols8;
+  const float* partial = reinterpret_cast<const float*>(p.partial);
+  const float slope = p.act == ME_ACT_LEAKY ? 0.1f : 1.0f;
+  unsigned short* __restrict__ yb = reinterpret_cast<unsigned short*>(p.y);
+  const unsigned short* __restrict__ rb = reinterpret_cast<const unsigned short*>(p.res);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c8 = (int)(idx % cols8) * 8;
+    const long long t2 = idx / cols8;
+    const int lm = (int)(t2 % bm);
+    const int tile = (int)(t2 / bm);
+    const long long q = (long long)(tile / p.tiles_n) * bm + lm;
+    if (q >= a.Mp) continue;
+    const unsigned u = (unsigned)q;
+    const unsigned n = udiv_magic(u, a.ip_m, a.ip_s);
+    const unsigned rem = u - n * (unsigned)a.Ip;
+    const unsigned y = udiv_magic(rem, a.wp_m, a.wp_s);
+    const unsigned x = rem - y * (unsigned)a.Wp;
+    if (y >= (unsigned)p.h || x >= (unsigned)p.w) continue;
+    const long long m = ((long long)n * p.h + y) * p.w + x;
+    const int co = (tile % p.tiles_n) * bn + c8;
+    const float* src = partial + (long long)tile * p.splitk * tile_elems + (long long)lm * bn + c8;
+    float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    for (int k = 1; k < p.splitk; ++k) {
+      const float4 l2 = *reinterpret_cast<const float4*>(src + (long long)k * tile_elems);
+      const float4 h2 = *reinterpret_cast<const float4*>(src + (long long)k * tile_elems + 4);
+      lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
+      hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
+    }
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float t = v[k] * p.scale[co + k] + p.shift[co + k];
+      v[k] = fmaxf(t, t * slope);
+    }
+    if (rb) {
+      const uint4 r4 = *reinterpret_cast<const uint4*>(rb + m * p.res_pitch + co);
+      const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] += DT16<F16>::from16(rr[k] & 0xffffu);
+        v[2 * k + 1] += DT16<F16>::from16(rr[k] >> 16);
+      }
+    }
+    uint4 o;
+    o.x = DT16<F16>::pack2(v[0], v[1]);
+    o.y = DT16<F16>::pack2(v[2], v[3]);
+    o.z = DT16<F16>::pack2(v[4], v[5]);
+    o.w = DT16<F16>::pack2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(yb + m * p.y_pitch + co) = o;
+  }
+}
+
 template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0>
 int launch_p8(const Conv16P& p, hipStream_t stream) {
   constexpr int BM = 32 * MT * WR, BN = 32 * NT * WC;
@@ -81,10 +140,27 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const long long blocks = (long long)a.c.tiles_m * a.c.tiles_n;
+  // K split (p.splitk > 1): every tile is cut into splitk workgroups along the 32-channel chunks - for the layers whose tile
+  // count leaves CUs idle or with a lone workgroup (13x13: 176 tiles of 256 x 128); slabs + a second launch
+  const int cs = p.cin / 32;
+  a.c.splitk = p.splitk > cs ? cs : (p.splitk < 1 ? 1 : p.splitk);
+  a.c.cps = (cs + a.c.splitk - 1) / a.c.splitk;
+  while (a.c.splitk > 1 && (a.c.splitk - 1) * a.c.cps >= cs) --a.c.splitk;
+  const long long tiles = (long long)a.c.tiles_m * a.c.tiles_n;
+  const long long blocks = tiles * a.c.splitk;
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: grid too large");
+  if (a.c.splitk > 1) {
+    const long long need = blocks * BM * BN * (long long)sizeof(float);
+    ME_REQUIRE(ABL == 0 && p.partial && p.partial_bytes >= need, ME_E_BADARG,
+               "me_conv2d_h16: tile with split_k=%d needs a workspace of %lld bytes", a.c.splitk, need);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
-  return me::check_launch("conv3x3_p8_h16");
+  int rc = me::check_launch("conv3x3_p8_h16");
+  if (rc || a.c.splitk == 1) return rc;
+  long long rb = (tiles * BM * (BN / 8) + 255) / 256;
+  if (rb > 256 * 16) rb = 256 * 16;
+  hipLaunchKernelGGL(conv3x3_p8_reduce_h16<F16>, dim3((unsigned)rb), dim3(256), 0, stream, a, BM, BN);
+  return me::check_launch("conv3x3_p8_reduce_h16");
 }
 
 }  // namespace
@@ -102,6 +178,30 @@ bool p8_eligible(const Conv16P& p, int tile) {
   const long long img_bytes = (long long)p.h * p.w * p.x_pitch * 2;
   const long long span = (1024 / ((long long)(p.h + 1) * (p.w + 1))) + 2;
   return span * img_bytes < (1ll << 31) && 256ll * p.ktot * 2 < (1ll << 31);
+}
+
+// BM x BN of a patch tile id (0 x 0: unknown id)
+void p8_tile_shape(int tile, int* bm, int* bn) {
+  static const int ids[][3] = {{100, 128, 256}, {110, 192, 256}, {120, 256, 256}, {101, 128, 128}, {121, 256, 128},
+                               {131, 384, 128}, {141, 512, 128}, {200, 128, 256}, {201, 128, 128}, {221, 256, 128},
+                               {301, 128, 128}, {311, 192, 128}, {321, 256, 128}, {331, 256, 128}};
+  *bm = *bn = 0;
+  for (const auto& t : ids)
+    if (t[0] == tile) {
+      *bm = t[1];
+      *bn = t[2];
+    }
+}
+
+// scratch of a K-split patch tile: compact slabs of every workgroup
+long long p8_workspace_bytes(const Conv16P& p, int tile, int split) {
+  int bm, bn;
+  p8_tile_shape(tile, &bm, &bn);
+  if (!bm || split <= 1 || p.cout % bn) return 0;
+  const long long mp = (long long)p.n * (p.h + 1) * (p.w + 1);
+  const int cs = p.cin / 32;
+  if (split > cs) split = cs;
+  return ((mp + bm - 1) / bm) * (p.cout / bn) * split * bm * bn * (long long)sizeof(float);
 }
 
 int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {

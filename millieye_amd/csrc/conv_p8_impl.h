@@ -28,7 +28,9 @@ struct P8Conv {
   long long x_pitch, res_pitch, y_pitch;  // elements
   int n, h, w, cin, cout, act;
   int tiles_m, tiles_n;
-  void* partial;  // instrumented builds: time stamps
+  void* partial;  // K split: fp32 slabs [tile][split][BM][BN] of raw accumulators; instrumented builds: time stamps
+  int splitk;     // workgroups per tile (each takes `cps` 64-byte chunks of the channel dimension), 1 = whole tiles
+  int cps;
 };
 
 struct P8Args {
@@ -83,13 +85,15 @@ __global__ __launch_bounds__(64 * WR * WC)
   const int wr = wave / WC, wc = wave % WC;
   const int r32 = lane & 31, hh = lane >> 5;
 
-  int tile_m, tile_n;
+  int tile_m, tile_n, piece, sid;
   {
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int nwg = p.tiles_m * p.tiles_n * p.splitk;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    piece = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int wg = piece / p.splitk;
+    sid = piece - wg * p.splitk;  // K split: this workgroup multiplies chunks [sid * cps, (sid + 1) * cps) of the tile
     tile_n = wg % p.tiles_n;
     tile_m = wg / p.tiles_n;
   }
@@ -165,7 +169,9 @@ __global__ __launch_bounds__(64 * WR * WC)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int cs = p.cin / DT::kChunk;  // 64-byte chunks of the channel dimension
+  const int cs_all = p.cin / DT::kChunk;  // 64-byte chunks of the channel dimension
+  const int cbase = __builtin_amdgcn_readfirstlane(sid * p.cps);
+  const int cs = p.splitk > 1 ? (cbase + p.cps < cs_all ? p.cps : cs_all - cbase) : cs_all;  // ... this workgroup walks
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
   auto issue_a = [&](int chunk, unsigned slot) {
     if (ABL >= 3 && ABL != 6) return;
@@ -173,13 +179,13 @@ __global__ __launch_bounds__(64 * WR * WC)
     static_for(
         [&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          if (j < lpa) dma1(v_a[j], rsrc_a, (unsigned)chunk * 64u, dst + (unsigned)j * (NW * 1024u));
+          if (j < lpa) dma1(v_a[j], rsrc_a, (unsigned)(cbase + chunk) * 64u, dst + (unsigned)j * (NW * 1024u));
         },
         std::make_integer_sequence<int, kLpaMax>{});
   };
   auto issue_b = [&](int chunk, int tap, unsigned ring) {
     if (ABL >= 3 && ABL != 6) return;
-    const unsigned soff = ((unsigned)tap * (unsigned)cs + (unsigned)chunk) * (unsigned)p.cout * 64u;
+    const unsigned soff = ((unsigned)tap * (unsigned)cs_all + (unsigned)(cbase + chunk)) * (unsigned)p.cout * 64u;
 #pragma unroll
     for (int j = 0; j < LPB; ++j) dma1(v_b[j], rsrc_b, soff, wave_lds + ring * B_SLOT + (unsigned)j * (NW * 1024u));
   };
@@ -378,6 +384,18 @@ __global__ __launch_bounds__(64 * WR * WC)
 #pragma unroll
         for (int e = 0; e < 16; ++e) t += acc[i][j][e];
     if (t == 123.456f) reinterpret_cast<float*>(p.y)[0] = t;
+    return;
+  }
+
+  if (ABL == 0 && p.splitk > 1) {  // K split: raw accumulators to this piece's slab; the launcher's reduce pass finishes the tile
+    float* slab = reinterpret_cast<float*>(p.partial) + (long long)piece * (BM * BN);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          slab[(wr * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * BN + wc * TN + j * 32 + r32] = acc[i][j][e];
     return;
   }
 

@@ -743,7 +743,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v8.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v9.json")  # bump with every kernel generation
 
 
 def _tune_load():
@@ -813,6 +813,8 @@ def _autotune(plan, lib):
     def scratch_of(d2):
         if not bf16 and d2.tile in _TUNE_TILES_TAIL + (47,):  # tail split: compact slabs of the last partial round (the library knows)
             return int(lib.me_conv2d_workspace_bytes(C.byref(d2)))
+        if bf16 and d2.tile >= 100:  # patch tiles cut along K: compact slabs of every workgroup
+            return int(lib.me_conv2d_h16_workspace_bytes(C.byref(d2)))
         return d2.split_k * d2.n * d2.ho * d2.wo * d2.cout * 4 if d2.split_k > 1 else 0
 
     def required():
@@ -828,8 +830,7 @@ def _autotune(plan, lib):
         slab = d.n * d.ho * d.wo * d.cout * 4
         if slab * 2 <= 512 * 2 ** 20:
             need = max(need, min(8 * slab, 512 * 2 ** 20))
-        if not bf16:
-            need = max(need, 64 * 2 ** 20)  # tail-split candidates: up to 255 tiles x split of raw accumulators
+        need = max(need, (128 if bf16 else 64) * 2 ** 20)  # tail-split / K-split patch-tile candidates: compact slabs
     ws_bytes = ensure_workspace(max(need, required()))
 
     def run(d, reps):
@@ -877,9 +878,12 @@ def _autotune(plan, lib):
             tail = not bf16 and tile in _TUNE_TILES_TAIL
             if tail and ntiles % 256 == 0:
                 continue
-            for split in (_TUNE_SPLITS[1:] if tail else _TUNE_SPLITS if tile < 100 else (1,)):
+            # (patch tiles can be cut along K - split_k > 1, compact fp32 slabs + a reduce launch - but the slabs are twice the
+            #  fp32 size of the layer's output: 60 -> 76 us at 13x13, tools/p8_bench.py 32 121,121/2; not offered to the tuner)
+            p8_split = False
+            for split in (_TUNE_SPLITS[1:] if tail else _TUNE_SPLITS if tile < 100 else (1, 2, 3, 4) if p8_split else (1,)):
                 d.tile, d.split_k = tile, split
-                if tail:
+                if tail or (tile >= 100 and split > 1):
                     if split > stages or scratch_of(d) > ws_bytes:
                         continue
                 elif split > 1 and (split * slab > ws_bytes or ntiles * split > 4096 or split > stages):

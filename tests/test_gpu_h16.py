@@ -416,6 +416,40 @@ def test_conv_p8_patch_resident_tiles(hip_lib, case, half):
     assert torch.equal(y3, y0), f"{name}: pitched input"
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("tile", [121, 221, 201, 100, 131])
+def test_conv_p8_k_split(hip_lib, tile, half):
+    """Patch tiles with split_k > 1: every tile is cut along the 32-channel chunks into split_k workgroups (compact fp32
+    slabs), conv3x3_p8_reduce_h16 sums them in a fixed order and applies the epilogue - same bar against the fp32 CPU
+    convolution as the one-pass tiles, residual and pad positions through the second pass, uneven chunk counts (5 chunks cut
+    2 / 3 / 4 ways), more splits than chunks (clamped), deterministic."""
+    from millieye_amd import hip
+    half = HALVES[half]
+    for name, n, h, w, cin, cout, with_res, splits in (("a", 3, 13, 13, 160, 256, True, (2, 3, 4)),
+                                                        ("b", 2, 26, 26, 64, 512, False, (2, 5)),
+                                                        ("c", 1, 9, 7, 96, 256, True, (3,))):
+        g = torch.Generator().manual_seed(tile * 7 + cin)
+        x = _bf(torch.randn((n, h, w, cin), generator=g), half)
+        wgt = _bf(torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5, half)
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g) * 0.1
+        res = _bf(torch.randn((n, h, w, cout), generator=g), half) if with_res else None
+        ref = _ref(x, wgt, scale, shift, 3, 1, 1, 1, res, 1)
+        packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+        xs, sc, sh = x.cuda(), scale.cuda(), shift.cuda()
+        rs = res.cuda() if res is not None else None
+        for split in splits:
+            y = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, 1, residual=rs, tile=tile, split_k=split)
+            _check_bf16(y, ref, f"{name} tile {tile} split {split}")
+            y2 = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, 1, residual=rs, tile=tile, split_k=split)
+            assert torch.equal(y, y2), f"{name} tile {tile} split {split}: not deterministic"
+        wide = torch.zeros((n, h, w, cout + 48), dtype=half).cuda()
+        hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, 1, residual=rs, out=wide[..., 16:16 + cout], tile=tile, split_k=splits[0])
+        y0 = hip.conv2d_h16(xs, packed, sc, sh, 3, 1, 1, 1, residual=rs, tile=tile, split_k=splits[0])
+        assert torch.equal(wide[..., 16:16 + cout], y0) and float(wide[..., :16].abs().max()) == 0 \
+            and float(wide[..., 16 + cout:].abs().max()) == 0, f"{name}: pitched output through the reduce pass"
+
+
 def test_conv_p8_refuses_what_it_cannot_do(hip_lib):
     from millieye_amd import hip
     x = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16).cuda()
