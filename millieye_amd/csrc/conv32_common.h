@@ -17,6 +17,7 @@ struct ConvP {
   float* y;
   long long x_pitch, res_pitch, y_pitch;
   int n, h, w, cin, cout, ks, stride, pad, ho, wo, act, ups, x_nchw;
+  unsigned hw_m, hw_s, wo_m, wo_s;  // magic numbers of the divisions by ho*wo and wo (conv_igemm_buf_f32)
   int M;       // n*ho*wo
   int ktot;    // ks*ks*cin
   int cs;      // channel chunks per tap = ceil(cin / BK)

@@ -46,7 +46,7 @@ def main():
         "fetch_bytes_per_launch": round(fetch_bytes), "write_bytes_per_launch": round(write_bytes),
         "hbm_bytes_per_launch": round(fetch_bytes + write_bytes),
         "note": "FETCH_SIZE x2 (gfx950 half-count of wide reads), KiB -> bytes; WRITE_SIZE uncalibrated; "
-                "average over every conv_igemm launch of `python bench.py --steps 3 --warmup 1`",
+                "average over every matching launch of `python bench.py --no-batch-sweep --no-accuracy --no-bf16-line [--dtype bf16] --steps 3 --warmup 1`",
     }))
 
 

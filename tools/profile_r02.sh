@@ -11,16 +11,24 @@ python bench.py --workload train --no-cpu-baseline --steps 20 > $OUT/${TAG}_benc
 python bench.py --workload train --dtype bf16 --no-cpu-baseline --steps 20 > $OUT/${TAG}_bf16_bench_train_b8.json 2>/dev/null
 python bench.py --dtype f16 --size 608 --batch 16 --no-cpu-baseline --no-batch-sweep --steps 20 > $OUT/${TAG}_f16_bench_full_608_b16.json 2>/dev/null
 cd /tmp
-CMD="python $R/bench.py --no-cpu-baseline --no-batch-sweep --steps 3 --warmup 1"
+CMD="python $R/bench.py --no-cpu-baseline --no-batch-sweep --no-accuracy --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o k -- $CMD > /tmp/kt.log 2>&1
 python $R/tools/prof_summary.py /tmp/kt_$TAG/k_results.db > $OUT/${TAG}_bench_full_b32_kernel_stats.txt 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmf_$TAG -o f -- $CMD > /tmp/pmf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmw_$TAG -o w -- $CMD > /tmp/pmw.log 2>&1
+# HBM traffic: FETCH_SIZE / WRITE_SIZE need separate passes; one pair per storage mode, every forward of the pass at batch 32
+C32="$CMD --no-bf16-line --prewarm-seconds 0.3"
+C16="$C32 --dtype bf16"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmf_$TAG -o f -- $C32 > /tmp/pmf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmw_$TAG -o w -- $C32 > /tmp/pmw.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmf16_$TAG -o f -- $C16 > /tmp/pmf16.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmw16_$TAG -o w -- $C16 > /tmp/pmw16.log 2>&1
 python $R/tools/pmc_traffic.py /tmp/pmf_$TAG/f_results.db /tmp/pmw_$TAG/w_results.db conv_igemm_buf_f32 cfg=yolov3 size=416 batch=32 workload=full dtype=f32 date=$DATE > $OUT/conv_traffic.json
-python $R/tools/pmc_traffic.py /tmp/pmf_$TAG/f_results.db /tmp/pmw_$TAG/w_results.db conv_igemm_buf_h16,conv3x3_p8 cfg=yolov3 size=416 batch=32 workload=full dtype=bf16 date=$DATE > $OUT/conv_traffic_bf16.json
+python $R/tools/pmc_traffic.py /tmp/pmf16_$TAG/f_results.db /tmp/pmw16_$TAG/w_results.db conv_igemm_buf_h16,conv3x3_p8 cfg=yolov3 size=416 batch=32 workload=full dtype=bf16 date=$DATE > $OUT/conv_traffic_bf16.json
+python $R/tools/pmc_layers.py /tmp/pmf_$TAG/f_results.db /tmp/pmw_$TAG/w_results.db 32 416 f32 > $OUT/${TAG}_layer_traffic_f32.txt 2>&1
+python $R/tools/pmc_layers.py /tmp/pmf16_$TAG/f_results.db /tmp/pmw16_$TAG/w_results.db 32 416 bf16 > $OUT/${TAG}_layer_traffic_bf16.txt 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES --kernel-trace -d /tmp/pms_$TAG -o s -- $CMD > /tmp/pms.log 2>&1
 python $R/tools/prof_summary.py /tmp/pms_$TAG/s_results.db --pmc | grep -v "at::\|rocprim\|rocclr" > $OUT/${TAG}_bench_full_b32_pmc_sq.txt 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace -d /tmp/pmg_$TAG -o g -- $CMD > /tmp/pmg.log 2>&1
 python $R/tools/prof_summary.py /tmp/pmg_$TAG/g_results.db --pmc | grep -v "at::\|rocprim\|rocclr" > $OUT/${TAG}_bench_full_b32_pmc_grbm.txt 2>&1
 cat $OUT/conv_traffic.json $OUT/conv_traffic_bf16.json
+tail -n 2 $OUT/${TAG}_layer_traffic_f32.txt $OUT/${TAG}_layer_traffic_bf16.txt
 ls -la $OUT
