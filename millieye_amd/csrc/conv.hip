@@ -655,6 +655,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
 
   const int lrow = lane >> 2;  // row inside the 16-row group
   unsigned v_base[LPW];        // in-range byte offset of (lane, tap 0 / k 0)
+  constexpr bool KS3 = KORD == 1;  // the chunk-major walk is launched for 3x3 filters only
   unsigned v_pad[LA];          // A-type: bit t set = tap t is padding (or the row is beyond M)
   unsigned v_cur[LPW];         // what the DMA uses: v_base or kOobOffset
 #pragma unroll
@@ -673,10 +674,19 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
         const int rem = m - nimg * hw;
         const int oy = (int)udiv_magic32((unsigned)rem, p.wo_m, p.wo_s), ox = rem - oy * p.wo;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        unsigned cols = 0;
-        for (int kx = 0; kx < p.ks; ++kx) cols |= ((unsigned)(ix0 + kx) < (unsigned)p.w ? 1u : 0u) << kx;
         unsigned ok = 0;
-        for (int ky = 0; ky < p.ks; ++ky) ok |= ((unsigned)(iy0 + ky) < (unsigned)p.h ? cols : 0u) << (ky * p.ks);
+        auto in_w = [&](int kx) { return (unsigned)(ix0 + kx) < (unsigned)p.w ? 1u : 0u; };
+        auto in_h = [&](int ky) { return (unsigned)(iy0 + ky) < (unsigned)p.h; };
+        if (KS3 || p.ks == 3) {  // straight-line for the filter sizes of the networks (a runtime-ks loop is ~100 instructions)
+          const unsigned cols = in_w(0) | in_w(1) << 1 | in_w(2) << 2;
+          ok = (in_h(0) ? cols : 0u) | (in_h(1) ? cols << 3 : 0u) | (in_h(2) ? cols << 6 : 0u);
+        } else if (p.ks == 1) {
+          ok = in_h(0) ? in_w(0) : 0u;
+        } else {
+          unsigned cols = 0;
+          for (int kx = 0; kx < p.ks; ++kx) cols |= in_w(kx) << kx;
+          for (int ky = 0; ky < p.ks; ++ky) ok |= (in_h(ky) ? cols : 0u) << (ky * p.ks);
+        }
         padmask = ~ok;
         const long long e = (long long)(nimg - img0) * img_elems + ((long long)iy0 * p.w + ix0) * p.x_pitch + bias_elems;
         v_base[j] = (unsigned)(e * 4) + 16u * q;

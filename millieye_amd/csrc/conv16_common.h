@@ -51,6 +51,7 @@ struct Conv16P {
   int cs;      // stages per filter tap = cin / (32*KSUB)
   int stages;  // ks*ks*cs
   int tiles_m, tiles_n;
+  unsigned hw_m, hw_s, wo_m, wo_s;  // magic numbers of the divisions by ho*wo and wo: n / d == (umulhi(n, m) + n) >> s, n < 2^31
   float* partial;  // split-K slabs [splitk][M][cout] (raw fp32 accumulators; patch tiles: [tile][split][BM][BN]), or nullptr
   long long partial_bytes;
   int splitk, sps;
@@ -105,3 +106,11 @@ __device__ __forceinline__ void store_out(const Conv16P& p, int m, int co, float
   }
 }
 
+__device__ __forceinline__ unsigned udiv_magic16(unsigned n, unsigned m, unsigned s) { return (__umulhi(n, m) + n) >> s; }
+
+inline void magic16(unsigned d, unsigned* m, unsigned* s) {
+  unsigned sh = 0;
+  while ((1ull << sh) < d) ++sh;
+  *s = sh;
+  *m = (unsigned)(((1ull << 32) * ((1ull << sh) - d)) / d + 1);
+}

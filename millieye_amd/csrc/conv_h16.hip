@@ -81,13 +81,14 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int hw = p.ho * p.wo;
 
-  const int img0 = m0 / hw;
+  const int img0 = (int)udiv_magic16((unsigned)m0, p.hw_m, p.hw_s);
   const long long img_elems = (long long)p.h * p.w * p.x_pitch;
   const long long bias_elems = ((long long)p.pad * p.w + p.pad) * p.x_pitch;
   const u32x4 rsrc_a = make_rsrc(p.x + (long long)img0 * img_elems - bias_elems);
   const u32x4 rsrc_b = make_rsrc(p.wgt + (long long)n0 * p.ktot);
 
   const int lrow = lane >> 2;
+  constexpr bool KS3 = false;
   unsigned v_base[LPW], v_pad[LA], v_cur[LPW];
   auto setup_lane = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -99,15 +100,25 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
       unsigned padmask = 0xFFFFFFFFu;
       const int m = m0 + row;
       if (m < p.M) {
-        const int nimg = m / hw;
+        // (every wave of every tile pays this setup, and at 16-bit matrix rates a 1x1 layer's tile is ~500 clocks of MFMAs:
+        //  multiply-shift divisions with the host's magic numbers, tap mask from ks row flags x ks column flags)
+        const int nimg = (int)udiv_magic16((unsigned)m, p.hw_m, p.hw_s);
         const int rem = m - nimg * hw;
-        const int oy = rem / p.wo, ox = rem - oy * p.wo;
+        const int oy = (int)udiv_magic16((unsigned)rem, p.wo_m, p.wo_s), ox = rem - oy * p.wo;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         unsigned ok = 0;
-        for (int ky = 0; ky < p.ks; ++ky)
-          for (int kx = 0; kx < p.ks; ++kx)
-            if ((unsigned)(iy0 + ky) < (unsigned)p.h && (unsigned)(ix0 + kx) < (unsigned)p.w)
-              ok |= 1u << (ky * p.ks + kx);
+        auto in_w = [&](int kx) { return (unsigned)(ix0 + kx) < (unsigned)p.w ? 1u : 0u; };
+        auto in_h = [&](int ky) { return (unsigned)(iy0 + ky) < (unsigned)p.h; };
+        if (KS3 || p.ks == 3) {  // straight-line for the filter sizes of the networks (a runtime-ks loop is ~100 instructions)
+          const unsigned cols = in_w(0) | in_w(1) << 1 | in_w(2) << 2;
+          ok = (in_h(0) ? cols : 0u) | (in_h(1) ? cols << 3 : 0u) | (in_h(2) ? cols << 6 : 0u);
+        } else if (p.ks == 1) {
+          ok = in_h(0) ? in_w(0) : 0u;
+        } else {
+          unsigned cols = 0;
+          for (int kx = 0; kx < p.ks; ++kx) cols |= in_w(kx) << kx;
+          for (int ky = 0; ky < p.ks; ++ky) ok |= (in_h(ky) ? cols : 0u) << (ky * p.ks);
+        }
         padmask = ~ok;
         const long long e = (long long)(nimg - img0) * img_elems + ((long long)iy0 * p.w + ix0) * p.x_pitch + bias_elems;
         v_base[j] = (unsigned)(e * 2) + 16u * q;
@@ -124,8 +135,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
   const int sid = blockIdx.y;
   const int s_begin = sid * p.sps;
   const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
-  int tap = s_begin / p.cs, cc = s_begin - (s_begin / p.cs) * p.cs;  // wave-uniform K walk: filter tap outer, channel chunk inner
-  int ky = tap / p.ks, kx = tap - ky * p.ks;
+  int tap = 0, cc = 0, ky = 0, kx = 0;  // wave-uniform K walk: filter tap outer, channel chunk inner
+  if (s_begin != 0) {                   // (K-split pieces only: whole tiles skip the divisions)
+    tap = s_begin / p.cs;
+    cc = s_begin - tap * p.cs;
+    ky = tap / p.ks;
+    kx = tap - ky * p.ks;
+  }
   unsigned a_off = 0, b_off = 0;
   auto enter_tap = [&]() {  // VALU work only here: once per filter tap
 #pragma unroll
@@ -274,9 +290,8 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
       const float sc = p.scale[cb + r32], sh = p.shift[cb + r32];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float v = acc[i][j][e] * sc + sh;
-        v = v > 0.f ? v : v * slope;
-        tbuf[((e & 3) + 8 * (e >> 2) + 4 * hh) * TP + r32] = v;
+        const float v = acc[i][j][e] * sc + sh;
+        tbuf[((e & 3) + 8 * (e >> 2) + 4 * hh) * TP + r32] = fmaxf(v, v * slope);  // slope 0.1: leaky; 1: linear
       }
       // (no wait between the transpose's writes and reads: the LDS executes one wave's operations in order, and the
       // compiler orders them by the aliasing pointers - the explicit s_waitcnt pairs of round 1 serialised every block)
@@ -599,6 +614,8 @@ int fill16(const me_conv16_desc* d, Conv16P& p) {
   p.y_f32 = d->y_f32; p.x_nchw = d->x_nchw; p.f16 = d->half_type;
   p.M = d->n * d->ho * d->wo;
   p.ktot = d->ksize * d->ksize * d->cin;
+  magic16((unsigned)(d->ho * d->wo), &p.hw_m, &p.hw_s);
+  magic16((unsigned)d->wo, &p.wo_m, &p.wo_s);
   p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
   p.partial = nullptr;
   p.partial_bytes = 0;
