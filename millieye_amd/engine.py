@@ -856,6 +856,10 @@ def _autotune(plan, lib):
         run(d0, 5)
         torch.cuda.synchronize()
     for key, d in todo:
+        hit = _TUNE_CACHE.get(key)
+        if hit is not None:  # the same layer shape earlier in this list (Darknet-53 repeats its blocks up to eight times)
+            d.tile, d.split_k = hit
+            continue
         slab = d.n * d.ho * d.wo * d.cout * 4
         stages = d.ksize * d.ksize * ((d.cin + 15) // 16)
         best = (float("inf"), 0, 1)
