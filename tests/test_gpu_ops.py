@@ -127,6 +127,17 @@ def test_conv_in_launch_split_reduce(hip_lib, tile, split):
         assert_close(one.cpu(), ref.cpu(), 1e-4, f"split vs whole ({tag}, tile {tile})")
 
 
+@pytest.mark.parametrize("tile", [3, 43, 2, 5])
+def test_conv_column_panels_ragged(hip_lib, tile):
+    """Deep layers walk their tiles in column panels (weights of a panel L2-resident, chunk-major K): a case whose tile columns
+    do not divide into panels (448 output channels = 7 columns of 64 in panels of 2, 2, 2, 1; 4 columns of 128 in panels of
+    1), with whole tiles + tail pieces in one launch (tile 43), ragged M, residual."""
+    from millieye_amd import hip
+    _conv_case(hip, f"pan{tile}a", 8, 26, 26, 256, 448, 3, 1, 1, residual=True, tile=tile, split_k=3 if tile > 40 else 1)
+    _conv_case(hip, f"pan{tile}b", 3, 13, 13, 512, 320, 3, 1, 1, tile=tile, split_k=2 if tile > 40 else 1)
+    _conv_case(hip, f"pan{tile}c", 2, 13, 13, 1024, 448, 1, 1, 1, tile=tile, split_k=2 if tile > 40 else 1)  # 1x1: panels, tap-major
+
+
 def test_conv_variants(hip_lib):
     from millieye_amd import hip
     _conv_case(hip, "s2", 2, 32, 32, 32, 64, 3, 2, 1)                 # stride-2 downsample
