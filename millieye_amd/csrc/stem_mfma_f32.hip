@@ -6,6 +6,8 @@
 // straight from the frame, next block prefetched) and 14 MFMAs produce 32 pixels x 32 channels in exact fp32 FMA chains
 // (the numerics class of the CPU reference).  The accumulator block has lane = output channel: every store instruction
 // writes two 128-byte rows, no LDS involved.
+#include <stdlib.h>
+
 #include "conv32_common.h"
 
 namespace {
@@ -83,6 +85,95 @@ __global__ __launch_bounds__(256) void conv_stem3_mfma_f32(StemArgs32 a) {
   }
 }
 
+// Row-staged version for NCHW frames (the network input): a workgroup owns RY consecutive image rows.  Its input window -
+// 3 channels x (RY + 2) rows x (W + 2) pixels, zero halo - is brought into LDS with coalesced loads (0.8 loads per lane and
+// 32-pixel block instead of 14 predicated gathers), and the im2col rows come out of LDS with one add + ds_read_b32 per tap:
+// no bounds logic, no 64-bit addresses in the block loop - 156 VGPRs (3 waves / SIMD) became ~80, and the texture addresser
+// no longer paces the kernel (conv_stem3_mfma_f32 above: 3.1 TB/s of the 6.8 TB/s a plain fill reaches on this GPU).
+constexpr int kStemRows = 4;
+
+__global__ __launch_bounds__(256) void conv_stem3_rows_f32(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float win[];  // [3][RY + 2][WP]
+  constexpr int RY = kStemRows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int H = p.h, W = p.w, WP = W + 2;
+  const int groups = (H + RY - 1) / RY;
+  const int n = blockIdx.x / groups, y0 = (blockIdx.x - n * groups) * RY;
+  const int co = blockIdx.y * 32 + r32;  // cout % 32 == 0
+
+  // stage the window: per 256-pixel column chunk the loads of all 3 (RY + 2) planes are in flight together (one memory latency
+  // per chunk - a load -> store -> next load loop would serialise ~20 latencies per workgroup)
+  const float* __restrict__ img = p.x + (long long)n * 3 * H * W;
+  for (int x0 = 0; x0 < WP; x0 += 256) {
+    const int xx = x0 + (int)threadIdx.x;
+    const bool col_ok = xx >= 1 && xx <= W;
+    float v[3 * (RY + 2)];
+#pragma unroll
+    for (int plane = 0; plane < 3 * (RY + 2); ++plane) {  // plane = c * (RY + 2) + ry
+      const int c = plane / (RY + 2), ry = plane % (RY + 2);
+      const int iy = y0 + ry - 1;
+      v[plane] = (col_ok && (unsigned)iy < (unsigned)H) ? img[((long long)c * H + iy) * W + (xx - 1)] : 0.f;
+    }
+    if (xx < WP) {
+#pragma unroll
+      for (int plane = 0; plane < 3 * (RY + 2); ++plane) win[plane * WP + xx] = v[plane];
+    }
+  }
+
+  float wreg[14];
+  int toff[14];  // LDS float offset of this lane's tap of step s, relative to (row 0 of the block, pixel x)
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k = 2 * s + hh;
+    const int tap = k / 3, c = k - tap * 3;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const bool ok = k < 27;
+    wreg[s] = ok ? p.wgt[(long long)co * 27 + k] : 0.f;
+    toff[s] = ok ? (c * (RY + 2) + dy) * WP + dx : 0;
+  }
+  const float sc = p.scale[co], sh = p.shift[co];
+  const float slope = p.act == ME_ACT_LEAKY ? 0.1f : 1.0f;
+  __syncthreads();
+
+  const int nbx = (W + 31) >> 5;
+  const int rows = H - y0 < RY ? H - y0 : RY;
+  for (int b = wave; b < rows * nbx; b += 4) {
+    const int ry = b / nbx, bx = b - ry * nbx;
+    const int x = bx * 32 + r32;
+    const int xs = x < W ? x : W - 1;  // ragged last block: lanes beyond the row read a valid pixel, their results are not stored
+    const int base = ry * WP + xs;
+    float cur[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) cur[s] = win[base + toff[s]];
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], wreg[s], acc, 0, 0, 0);
+    // lane = output channel, register e = pixel (e & 3) + 8 (e >> 2) + 4 hh of the block
+    const long long m0 = ((long long)n * H + (y0 + ry)) * W + bx * 32 + 4 * hh;
+    float* yp = p.y + m0 * p.y_pitch + co;
+    const long long ystep = p.y_pitch;
+    const int left = W - bx * 32 - 4 * hh;  // pixels of this lane half's first column still inside the row
+    if (W - bx * 32 >= 32 && p.act != ME_ACT_SIGMOID) {  // whole block, leaky / linear: no per-pixel tests, leaky as max(t, 0.1 t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float t = acc[e] * sc + sh;
+        *yp = fmaxf(t, t * slope);
+        yp += (e & 3) == 3 ? 5 * ystep : ystep;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = (e & 3) + 8 * (e >> 2);
+        if (px < left) *yp = apply_act(acc[e] * sc + sh, p.act);
+        yp += (e & 3) == 3 ? 5 * ystep : ystep;
+      }
+    }
+  }
+}
+
 void magic_u32s(unsigned d, unsigned* m, unsigned* s) {
   unsigned sh = 0;
   while ((1ull << sh) < d) ++sh;
@@ -100,6 +191,15 @@ bool stem_mfma_eligible(const ConvP& p) {
 }
 
 int launch_stem_mfma(const ConvP& p, hipStream_t stream) {
+  const size_t win_bytes = (size_t)3 * (kStemRows + 2) * (p.w + 2) * sizeof(float);
+  static const bool rows_ok = [] { const char* e = getenv("MILLIEYE_STEM_ROWS"); return !e || atoi(e) != 0; }();
+  if (p.x_nchw && win_bytes <= 60 * 1024 && rows_ok) {  // row-staged version: NCHW frames up to ~1270 pixels wide
+    const long long groups = (long long)p.n * ((p.h + kStemRows - 1) / kStemRows);
+    if (groups < (1ll << 31)) {
+      hipLaunchKernelGGL(conv_stem3_rows_f32, dim3((unsigned)groups, p.cout / 32), dim3(256), win_bytes, stream, p);
+      return me::check_launch("conv_stem3_rows_f32");
+    }
+  }
   StemArgs32 a;
   a.c = p;
   magic_u32s((unsigned)p.w, &a.w_m, &a.w_s);
