@@ -914,7 +914,8 @@ def _autotune(plan, lib):
                     score.setdefault(c, []).append(ms)
         ranked = sorted((sorted(v)[len(v) // 2], c) for c, v in score.items())
         if os.environ.get("MILLIEYE_TUNE_VERBOSE"):
-            print("[tune]", key, " ".join(f"{c[1]}/{c[2]}:{1e3 * c[0]:.0f}>{1e3 * t:.0f}us" for t, c in ranked), flush=True)
+            import sys
+            print("[tune]", key, " ".join(f"{c[1]}/{c[2]}:{1e3 * c[0]:.0f}>{1e3 * t:.0f}us" for t, c in ranked), file=sys.stderr, flush=True)
         if ranked:
             best = ranked[0]
             whole = [r for r in ranked if not r[1][3]]
