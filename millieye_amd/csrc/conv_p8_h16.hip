@@ -19,6 +19,8 @@
 // (row >> 2) & 3 like every other tile of this library (ds_read_b128 conflict-free).
 // Stage = (chunk, tap): ONE barrier per 2 * MT * NT MFMAs per wave (the per-tap kernel: per 8), DMA instructions per wave and
 // stage: BN / 128 for the weights + the next chunk's patch once per nine stages.
+#include <cstdlib>
+
 #include "conv16_common.h"
 #include "conv_p8_impl.h"
 
@@ -228,7 +230,21 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 311: return ME_P8(2, 2, 3, 2, 1, 2);   // 192 x 128
     case 321: return ME_P8(2, 2, 4, 2, 1, 2);   // 256 x 128
     case 331: return ME_P8(4, 1, 2, 4, 1, 2);   // 256 x 128, wave tile 64 x 128
-    // ablations (wrong results)
+    default: break;
+  }
+  // Ablation / instrumented instances of the tuning tools (tools/p8_timeline.py, tools/p8_bench.py --ablate): they skip parts
+  // of the kernel and produce WRONG results, so the public ``tile`` field only reaches them when the process opted in.
+  static const bool ablation_ok = [] {
+    const char* e = getenv("MILLIEYE_ABLATION");
+    return e && e[0] == '1';
+  }();
+  ME_REQUIRE(ablation_ok || !((tile >= 180 && tile <= 199) || (tile >= 280 && tile <= 299)), ME_E_BADARG,
+             "me_conv2d_h16: tile id %d is an ablation instance with wrong results (tuning tools only: MILLIEYE_ABLATION=1)",
+             tile);
+  if (tile == 199 || tile == 299)  // 2048 x 8 bytes of time stamps go to the workspace
+    ME_REQUIRE(p.partial && p.partial_bytes >= 16384, ME_E_BADARG,
+               "me_conv2d_h16: the time-stamp instances need a workspace of at least 16384 bytes");
+  switch (tile) {
     case 180: return launch_p8<2, 4, 4, 2, 1, 1, 0, 1>(p, stream);
     case 190: return launch_p8<2, 4, 4, 2, 1, 1, 0, 3>(p, stream);
     case 191: return launch_p8<2, 4, 4, 2, 1, 1, 0, 4>(p, stream);

@@ -61,6 +61,7 @@ class FrameFuser:
                  **generator_kwargs):
         self.model, self.model_mode, self.img_size = model, model_mode, img_size
         self.nms_iou, self.dark_threshold = nms_iou, dark_threshold
+        self.generator_is_default = generator is None   # pipeline.py: re-created in the producer vs sent by pickle
         self.generator = generator or RadarProposalGenerator(calib_param, **generator_kwargs)
 
     def __call__(self, frame, radar_frames):

@@ -15,6 +15,8 @@ in this build and deliberately minimal, shaped for xGMI:
 
 ``torch.distributed`` (backend ``nccl`` = RCCL on ROCm, ``gloo`` in the CPU tests) is the transport.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -71,7 +73,25 @@ def flatten_grads(params):
     return bucket, params
 
 
-_PATTERN = {}  # id(first parameter) -> tuple of "has a gradient somewhere" flags seen so far (see allreduce_gradients)
+_CHECK_EVERY = 64  # static_pattern: the reduced flags are still read (and checked) on every 64th step
+
+
+class _PatternState:
+    """Per-model bookkeeping of allreduce_gradients(static_pattern=True).  It hangs on the first Parameter object itself
+    (``_me_dp_state``), so it lives and dies with the model - no id()-keyed global that a garbage-collected model's id
+    could alias."""
+    __slots__ = ("n", "union", "steps")
+
+    def __init__(self, n):
+        self.n, self.union, self.steps = n, None, 0
+
+
+def _pattern_state(params):
+    st = getattr(params[0], "_me_dp_state", None)
+    if st is None or st.n != len(params):
+        st = _PatternState(len(params))
+        params[0]._me_dp_state = st
+    return st
 
 
 def allreduce_gradients(params, group=None, static_pattern=False):
@@ -84,7 +104,10 @@ def allreduce_gradients(params, group=None, static_pattern=False):
     collective, local to the rank).  ``static_pattern=True`` (the training loops of this package): the set of parameters
     that can receive a gradient is a property of the model, and a rank produces either that whole set or - empty shard -
     nothing; then the flags are only read when this rank's own pattern is empty or differs from the union it has seen,
-    i.e. in steady state the step issues one RCCL call and never waits on the device.  Returns the gradient bytes."""
+    i.e. in steady state the step issues one RCCL call and never waits on the device.  The promise is enforced: every
+    ``_CHECK_EVERY``-th step (every step with ``MILLIEYE_DP_CHECK=1``) the reduced flags are read anyway and a rank that
+    produced a gradient outside the assumed set raises instead of letting the replicas diverge.  Returns the gradient
+    bytes."""
     params = [p for p in params if p.requires_grad]
     if not params:
         return 0
@@ -99,13 +122,19 @@ def allreduce_gradients(params, group=None, static_pattern=False):
     bucket = torch.cat(pieces)
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     n_grad = bucket.numel() - len(params)
-    key = (id(params[0]), len(params))
-    union = _PATTERN.get(key)
-    if static_pattern and union == had and any(had):
+    st = _pattern_state(params)
+    st.steps += 1
+    assumed = static_pattern and st.union == had and any(had)
+    check = assumed and (st.steps % _CHECK_EVERY == 0 or os.environ.get("MILLIEYE_DP_CHECK") == "1")
+    if assumed and not check:
         anywhere = had
-    else:  # first step / empty shard / caller makes no promise: look at the reduced flags (the step's only host sync)
+    else:  # first step / empty shard / caller makes no promise / periodic check: look at the reduced flags (a host sync)
         anywhere = tuple(f > 0 for f in bucket[n_grad:].tolist())
-        _PATTERN[key] = anywhere if union is None else tuple(a or b for a, b in zip(anywhere, union))
+        if check and anywhere != had:
+            extra = [i for i, (a, h) in enumerate(zip(anywhere, had)) if a and not h]
+            raise RuntimeError(f"allreduce_gradients(static_pattern=True): another rank produced gradients for parameters "
+                               f"{extra} that this rank's static pattern does not contain; the replicas would diverge")
+        st.union = anywhere if st.union is None else tuple(a or b for a, b in zip(anywhere, st.union))
     off = 0
     dst, src = [], []
     for p, h in zip(params, anywhere):

@@ -12,10 +12,16 @@ Video decoding, the serial-port capture and the OpenCV window are not part of th
 inside the producer process (like the reference opens ``cv2.VideoCapture`` there).
 """
 import multiprocessing as mp
+import pickle
 import queue as _queue
 import time
+import traceback
 
-__all__ = ["FusionPipeline", "QUEUE_SIZE"]
+__all__ = ["FusionPipeline", "ProducerError", "QUEUE_SIZE"]
+
+
+class ProducerError(RuntimeError):
+    """The producer process failed (source iterator, radar tracking, staging); carries its traceback text."""
 
 QUEUE_SIZE = 3      # run_mp.py:289
 _END = "__end__"
@@ -24,6 +30,7 @@ _END = "__end__"
 def _producer(q, first_done, all_done, source_factory, prepare_factory, drop_oldest):
     """run_mp.py:42-160.  ``prepare_factory()`` builds the host half inside this process (tracker state lives here)."""
     dropped = 0
+    error = None
     try:
         prepare = prepare_factory()
         for idx, (frame, radar_frames) in enumerate(source_factory()):
@@ -39,8 +46,10 @@ def _producer(q, first_done, all_done, source_factory, prepare_factory, drop_old
                         dropped += 1
                 except (NotImplementedError, _queue.Empty):
                     pass
+    except BaseException as exc:  # reported through the END payload: a crash must not look like the end of the stream
+        error = f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"
     finally:
-        q.put({"frame_idx": _END, "dropped": dropped})
+        q.put({"frame_idx": _END, "dropped": dropped, "error": error})
         # tensors travel as shared-memory handles served by THIS process: stay until the consumer has taken everything
         all_done.wait(timeout=120)
 
@@ -48,11 +57,14 @@ def _producer(q, first_done, all_done, source_factory, prepare_factory, drop_old
 class _PrepareFactory:
     """Picklable recipe of the host half: builds a fresh ``FrameFuser`` (without a model) in the producer."""
 
-    def __init__(self, calib_param, img_size, generator_kwargs):
+    def __init__(self, calib_param, img_size, generator_kwargs, generator=None):
         self.calib_param, self.img_size, self.generator_kwargs = calib_param, img_size, generator_kwargs
+        self.generator = generator   # a caller-supplied generator instance travels by pickle (checked by FusionPipeline)
 
     def __call__(self):
         from .demo import FrameFuser
+        if self.generator is not None:
+            return FrameFuser(None, self.calib_param, img_size=self.img_size, generator=self.generator).prepare
         return FrameFuser(None, self.calib_param, img_size=self.img_size, **self.generator_kwargs).prepare
 
 
@@ -60,16 +72,27 @@ class FusionPipeline:
     """``for rows, info in FusionPipeline(fuser, source_factory): ...`` - detections per frame, in frame order, frames the
     producer dropped are skipped (``info["frame_idx"]`` says which one this is).
 
-    ``fuser``: a :class:`millieye_amd.demo.FrameFuser` (its model stays in this process; its generator parameters are
-    re-created in the producer).  ``infer``: override of the device half (tests).  ``drop_oldest=False`` turns the
-    reference's newest-wins policy into back-pressure (every frame is processed)."""
+    ``fuser``: a :class:`millieye_amd.demo.FrameFuser` (its model stays in this process).  A default
+    ``RadarProposalGenerator`` is re-created from its parameters inside the producer; a generator the caller passed to
+    ``FrameFuser(generator=...)`` is sent there by pickle as it is now, and refused (``TypeError``) when it cannot be
+    pickled - never silently replaced.  ``infer``: override of the device half (tests).  ``drop_oldest=False`` turns the
+    reference's newest-wins policy into back-pressure (every frame is processed).  A failure in the producer (source,
+    tracking, staging) ends the iteration with :class:`ProducerError` carrying the producer's traceback."""
 
     def __init__(self, fuser, source_factory, infer=None, drop_oldest=True, prepare_factory=None, start_method="spawn"):
         self.fuser, self.source_factory, self.drop_oldest = fuser, source_factory, drop_oldest
         self.infer = infer or fuser.infer
         if prepare_factory is None:
             g = fuser.generator
-            prepare_factory = _PrepareFactory(g.calib_param, fuser.img_size, g.kwargs)
+            if getattr(fuser, "generator_is_default", False):
+                prepare_factory = _PrepareFactory(g.calib_param, fuser.img_size, g.kwargs)
+            else:
+                try:
+                    pickle.dumps(g)
+                except Exception as exc:
+                    raise TypeError("FusionPipeline: the FrameFuser was built with a custom generator= that cannot be "
+                                    f"pickled into the producer process ({exc}); pass prepare_factory= instead") from exc
+                prepare_factory = _PrepareFactory(getattr(g, "calib_param", None), fuser.img_size, {}, generator=g)
         self.prepare_factory = prepare_factory
         self.ctx = mp.get_context(start_method)      # run_mp.py:287: spawn
         self.stats = {}
@@ -88,6 +111,8 @@ class FusionPipeline:
                 payload = q.get()
                 if payload["frame_idx"] == _END:
                     dropped = payload["dropped"]
+                    if payload.get("error"):
+                        raise ProducerError("the producer process failed:\n" + payload["error"])
                     break
                 rows, info = self.infer(payload)
                 first_done.set()               # run_mp.py:316

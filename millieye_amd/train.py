@@ -126,14 +126,18 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
                 % (epoch, epochs, batch_i, len(dataloader), loss_value, time_left))
             model.seen += imgs.size(0)
 
+        if distributed:
+            # parameters are identical on every rank after the summed-gradient step; the head BatchNorms' running statistics
+            # are not (each rank normalises its own shard): average them once per epoch so that the replicas - and what
+            # rank 0 checkpoints / evaluates - do not drift apart
+            sync_batchnorm_buffers(model)
         if epoch % checkpoint_interval == 0 and rank == 0:
             path = os.path.join(checkpoint_dir, f"{test_list}_ckpt_{epoch}.pth")
             torch.save(model.state_dict(), path)
             history["checkpoints"].append(path)
 
-        if distributed and epoch % evaluation_interval == 0 and evaluate_fn is not None:
-            torch.distributed.barrier()  # the replicas are identical after the step: rank 0 evaluates, the others wait
-        if epoch % evaluation_interval == 0 and evaluate_fn is not None and rank == 0:
+        evaluating = epoch % evaluation_interval == 0 and evaluate_fn is not None
+        if evaluating and rank == 0:
             log("\n---- Evaluating Model ----")
             precision, recall, AP, f1, ap_class, _, _ = result = evaluate_fn(
                 model, mode="test", model_mode=0, illumination=["L"], iou_thresh=0.5, nms_thresh=0.5,
@@ -147,7 +151,33 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
                 rows.append([c, class_names[i] if class_names else str(c), "%.5f" % AP[i]])
             log("\n".join(" | ".join(str(v) for v in r) for r in rows))
             log(f"---- mAP {AP.mean()}")
+        if distributed and evaluating:
+            # rank 0 evaluated, the others wait HERE - behind the evaluation, not in the next epoch's first collective
+            # (main() raises the process-group timeout above the default 10 min for exactly this wait)
+            torch.distributed.barrier()
     return history
+
+
+def sync_batchnorm_buffers(model):
+    """Data-parallel runs: replace every non-detector BatchNorm running statistic by its mean over the ranks (one small
+    all-reduce; ``num_batches_tracked`` is the same everywhere).  The packed eval-mode copies are re-folded at the next
+    forward because the version counters move."""
+    world = torch.distributed.get_world_size()
+    bufs = [b for name, b in model.named_buffers()
+            if not name.startswith("base_detector.") and b.is_floating_point() and "running_" in name]
+    if not bufs or world == 1:
+        return 0
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    if torch.distributed.get_backend() != "nccl":
+        flat = flat.cpu()
+    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+    flat = (flat / world).to(bufs[0].device)
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    return off
 
 
 def build_parser():
@@ -188,7 +218,9 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # rank 0 evaluates alone at the end of an epoch while the others wait in a barrier: well past the default 10 min
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                             timeout=datetime.timedelta(hours=4))
     model = Network(define_yolo(opt.yolo_cfg), opt.conf_thresh)
     model = model.to(model.device)
     if opt.checkpoint:

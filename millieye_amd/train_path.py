@@ -84,6 +84,35 @@ def _bn_bwd(x, ldx, dy, lddy, rows, c, bn, st, act, dx, lddx, ws):
     return dg, db
 
 
+class _BnEval:
+    """Eval-mode BatchNorm = the per-channel affine ``scale * x + shift`` from the running statistics (no update)."""
+
+    def __init__(self, bn, dev):
+        with torch.no_grad():
+            scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+            shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+        self.scale = scale.to(dev, torch.float32).contiguous()
+        self.shift = shift.to(dev, torch.float32).contiguous()
+
+    def with_bias(self, bias):
+        """shift of ``scale * (conv + bias) + shift`` folded for the conv epilogue."""
+        return (self.shift + bias.detach().to(self.shift) * self.scale).contiguous()
+
+
+def _bn_eval_bwd(y, ldy, dy, lddy, rows, c, bn, st, act, dc, lddc):
+    """Backward of ``y = act(scale * x + shift)`` (eval-mode BatchNorm, like ``F.batch_norm(training=False)`` under
+    autograd): dx, d gamma = sum dy act' xhat, d beta = sum dy act' (me_affine_act_bwd_f32, fixed-order reductions)."""
+    dev = y.device
+    dg, db = _f32(dev, c), _f32(dev, c)
+    lib = hip.lib()
+    ws = torch.empty(max(int(lib.me_affine_bwd_workspace_bytes(rows, c)), 256), dtype=torch.uint8, device=dev)
+    gam, bet = bn.weight.detach().contiguous(), bn.bias.detach().contiguous()
+    hip.check(lib.me_affine_act_bwd_f32(_ptr(y), ldy, _ptr(dy), lddy, rows, c, _ptr(st.scale), _ptr(gam), _ptr(bet), act,
+                                        _ptr(dc), lddc, _ptr(db), _ptr(dg), ws.data_ptr(), hip.stream_ptr()),
+              "me_affine_act_bwd_f32")
+    return dg, db
+
+
 def _conv(x, x_pitch, n, h, w, cin, wgt, scale, shift, k, pad, act, out):
     d = hip.ConvDesc()
     d.x, d.x_pitch, d.x_nchw = _ptr(x), x_pitch, 0
@@ -206,10 +235,13 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
     rh, eh = net.refinement_head, net.ensemble_head
     head_bns = [net.img_cnn_layers.net[1], net.radar_cnn_layers.conv1[1], net.radar_cnn_layers.conv2[1],
                 net.radar_cnn_layers.conv3[1], rh.radar_net[1]]
-    if not all(b.training for b in head_bns):
-        raise NotImplementedError("Network.forward(targets=...) needs the heads in train() mode (batch-statistics "
-                                  "BatchNorm), as module3_our_dataset/train.py:169 sets them; a mix of train- and "
-                                  "eval-mode head BatchNorms is not supported")
+    bn_train = all(b.training for b in head_bns)
+    if not bn_train and any(b.training for b in head_bns):
+        raise NotImplementedError("Network.forward(targets=...): the head BatchNorms are partly in train() and partly in "
+                                  "eval() mode; call model.train() or model.eval() on the whole Network")
+    # bn_train False = an eval()-mode model called with targets: the reference computes the same loss tuple with
+    # running-statistics BatchNorm (my_models.py:545-641 has no mode check) and its autograd still reaches every head
+    # parameter; nothing updates the running statistics
     if targets is None and model_mode == 2:  # radar only: permanent, like the reference (quirk q3)
         net.refine_threshold_img = 1
 
@@ -246,10 +278,16 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         icl = net.img_cnn_layers.net
         w_img = icl[0].weight.detach().reshape(490, fc).contiguous()
         ones490, b_img = torch.ones(490, **f32), icl[0].bias.detach().contiguous()
-        z1 = _f32(dev, pix, 490)
-        _conv(fm, fc, n, fh, fw, fc, w_img.view(490, 1, 1, fc), ones490, b_img, 1, 0, hip.ACT_LINEAR, z1.view(n, fh, fw, 490))
         a1 = _f32(dev, pix, 490)
-        st_img = _bn_fwd(z1, 490, pix, 490, icl[1], hip.ACT_LEAKY, a1, 490, ws)
+        if bn_train:
+            z1 = _f32(dev, pix, 490)
+            _conv(fm, fc, n, fh, fw, fc, w_img.view(490, 1, 1, fc), ones490, b_img, 1, 0, hip.ACT_LINEAR,
+                  z1.view(n, fh, fw, 490))
+            st_img = _bn_fwd(z1, 490, pix, 490, icl[1], hip.ACT_LEAKY, a1, 490, ws)
+        else:  # folded affine + LeakyReLU in the conv epilogue; the backward recovers the pre-activation from a1
+            z1, st_img = None, _BnEval(icl[1], dev)
+            _conv(fm, fc, n, fh, fw, fc, w_img.view(490, 1, 1, fc), st_img.scale, st_img.with_bias(b_img), 1, 0,
+                  hip.ACT_LEAKY, a1.view(n, fh, fw, 490))
 
         # ---- radar CNN (train-mode BN) ---------------------------------------------------------------
         rc = net.radar_cnn_layers
@@ -263,11 +301,15 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
             conv, bn = seq[0], seq[1]
             cout = conv.weight.shape[0]
             wp = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
-            c_raw = _f32(dev, n, mh, mw, cout)
-            _conv(prev, prev_c, n, mh, mw, prev_c, wp, torch.ones(cout, **f32), conv.bias.detach().contiguous(), 3, 1,
-                  hip.ACT_LINEAR, c_raw)
             r_act = _f32(dev, n, mh, mw, cout)
-            st = _bn_fwd(c_raw, cout, pix_r, cout, bn, hip.ACT_LEAKY, r_act, cout, ws)
+            if bn_train:
+                c_raw = _f32(dev, n, mh, mw, cout)
+                _conv(prev, prev_c, n, mh, mw, prev_c, wp, torch.ones(cout, **f32), conv.bias.detach().contiguous(), 3, 1,
+                      hip.ACT_LINEAR, c_raw)
+                st = _bn_fwd(c_raw, cout, pix_r, cout, bn, hip.ACT_LEAKY, r_act, cout, ws)
+            else:
+                c_raw, st = None, _BnEval(bn, dev)
+                _conv(prev, prev_c, n, mh, mw, prev_c, wp, st.scale, st.with_bias(conv.bias), 3, 1, hip.ACT_LEAKY, r_act)
             radar[f"c{li}"], radar[f"r{li}"], radar[f"st{li}"] = c_raw, r_act, st
             prev, prev_c = r_act, cout
         conv4 = rc.conv3[3]
@@ -317,10 +359,14 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         bn_r = rh.radar_net[1]
         st_r = None
         if k > 0:
-            dummy = _f32(dev, k, 10)
-            st_r = _bn_fwd(small[:, 6:], 16, k, 10, bn_r, hip.ACT_LINEAR, dummy, 10, ws)
-            rscale = bn_r.weight.detach() * st_r.rstd
-            rshift = bn_r.bias.detach() - st_r.mean * rscale
+            if bn_train:
+                dummy = _f32(dev, k, 10)
+                st_r = _bn_fwd(small[:, 6:], 16, k, 10, bn_r, hip.ACT_LINEAR, dummy, 10, ws)
+                rscale = bn_r.weight.detach() * st_r.rstd
+                rshift = bn_r.bias.detach() - st_r.mean * rscale
+            else:
+                st_r = _BnEval(bn_r, dev)
+                rscale, rshift = st_r.scale, st_r.shift
             wts["rscale"], wts["rshift"] = rscale.contiguous(), rshift.contiguous()
             d.wts.rscale, d.wts.rshift = wts["rscale"].data_ptr(), wts["rshift"].data_ptr()
             hip.check(lib.me_heads_tail_f32(C.byref(d), small.data_ptr(), k, hip.stream_ptr()), "me_heads_tail_f32")
@@ -384,7 +430,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         loss_value = sums[0] + sums[1]  # masks_loss + conf_loss / lambda (reference :635)
         radar_attention = r4[..., :1].permute(0, 3, 1, 2).contiguous()
 
-    state = dict(net=net, names=_head_names(net), loss=loss_value, n=n, fh=fh, fw=fw, fc=fc, pix=pix, k=k, n_img=n_img,
+    state = dict(net=net, names=_head_names(net), loss=loss_value, bn_train=bn_train, n=n, fh=fh, fw=fw, fc=fc, pix=pix, k=k, n_img=n_img,
                  mh=mh, mw=mw,
                  n_radar=n_radar, fm=fm, z1=z1, a1=a1, st_img=st_img, radar=radar, feat_img=feat_img,
                  feat_rad=feat_rad, hidden=hidden, small=small, refine=refine, mask1=mask1, seed_p=seed_p,
@@ -434,7 +480,10 @@ def _backward(S, grad_out, needed=None):
         G["refinement_head.radar_net.3.weight"], G["refinement_head.radar_net.3.bias"] = dw.view(1, 10, 1, 1), db
         bn_r = rh.radar_net[1]
         g_rconv = _f32(dev, k, 10)
-        dg, dbt = _bn_bwd(S["small"][:, 6:], 16, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10, ws)
+        if S["bn_train"]:
+            dg, dbt = _bn_bwd(S["small"][:, 6:], 16, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10, ws)
+        else:  # rl = leaky(rscale * small + rshift), the stored activated value
+            dg, dbt = _bn_eval_bwd(rl, 10, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10)
         G["refinement_head.radar_net.1.weight"], G["refinement_head.radar_net.1.bias"] = dg, dbt
         dw = torch.zeros((10, 490), **f32); _gemm(1, 0, 10, 490, k, g_rconv, 10, S["feat_rad"], 490, dw, 490)
         db = _f32(dev, 10); _colsum(g_rconv, 10, k, 10, db)
@@ -473,7 +522,10 @@ def _backward(S, grad_out, needed=None):
         if want_img:
             icl = net.img_cnn_layers.net
             dz1 = _f32(dev, pix, 490)
-            dg, dbt = _bn_bwd(S["z1"], 490, d_a1, 490, pix, 490, icl[1], S["st_img"], hip.ACT_LEAKY, dz1, 490, ws)
+            if S["bn_train"]:
+                dg, dbt = _bn_bwd(S["z1"], 490, d_a1, 490, pix, 490, icl[1], S["st_img"], hip.ACT_LEAKY, dz1, 490, ws)
+            else:
+                dg, dbt = _bn_eval_bwd(S["a1"], 490, d_a1, 490, pix, 490, icl[1], S["st_img"], hip.ACT_LEAKY, dz1, 490)
             G["img_cnn_layers.net.batch_norm_0.weight"], G["img_cnn_layers.net.batch_norm_0.bias"] = dg, dbt
             dw = torch.zeros((490, fc), **f32); _gemm(1, 0, 490, fc, pix, dz1, 490, S["fm"], fc, dw, fc)
             db = _f32(dev, 490); _colsum(dz1, 490, pix, 490, db)
@@ -491,7 +543,10 @@ def _backward(S, grad_out, needed=None):
             conv, bn = seq[0], seq[1]
             cout = conv.weight.shape[0]
             dc = _f32(dev, pix_r, cout)
-            dg, dbt = _bn_bwd(R[f"c{li}"], cout, d_act, cout, pix_r, cout, bn, R[f"st{li}"], hip.ACT_LEAKY, dc, cout, ws)
+            if S["bn_train"]:
+                dg, dbt = _bn_bwd(R[f"c{li}"], cout, d_act, cout, pix_r, cout, bn, R[f"st{li}"], hip.ACT_LEAKY, dc, cout, ws)
+            else:
+                dg, dbt = _bn_eval_bwd(R[f"r{li}"], cout, d_act, cout, pix_r, cout, bn, R[f"st{li}"], hip.ACT_LEAKY, dc, cout)
             G[f"radar_cnn_layers.conv{li}.1.weight"], G[f"radar_cnn_layers.conv{li}.1.bias"] = dg, dbt
             x_in = R["x0"] if li == 1 else R[f"r{li - 1}"]
             G[f"radar_cnn_layers.conv{li}.0.weight"] = _wgrad(x_in, cin, dc, cout, n, mh, mw, cin, cout, 3, 1)

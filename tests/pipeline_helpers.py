@@ -31,3 +31,13 @@ def fake_infer_slow_first(payload, _state={"n": 0}):
 class BrokenSource:
     def __call__(self):
         raise RuntimeError("camera unplugged")
+
+
+class TaggedGenerator:
+    """A caller-supplied generator (picklable): proposals that no default RadarProposalGenerator would produce."""
+
+    def __init__(self, calib_param):
+        self.calib_param = calib_param
+
+    def __call__(self, radar_frames):
+        return np.array([[11.0, 22.0, 133.0, 144.0]], dtype=np.float32), np.zeros((0, 4))

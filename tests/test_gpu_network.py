@@ -130,11 +130,20 @@ def test_network_darknet53_extension_tap(hip_lib):
 
 
 def test_train_py_call_form_is_recognised(hip_lib):
-    """train.py:185 passes targets in the model_mode slot: must not be read as a mode."""
+    """train.py:185 passes targets in the model_mode slot: must not be read as a mode.  The model is in
+    eval() mode here: the reference has no mode check (my_models.py:545-641), so the call returns the training tuple
+    computed with running-statistics BatchNorm (numerics: test_gpu_train.py::test_eval_mode_training_step_...)."""
     net = _build("callform", "yolov3-tiny-12", 0.2).cuda()
-    x, maps, rboxes = _inputs("callform", 1, 96)
-    with pytest.raises(NotImplementedError):  # recognised as the training call (tail not built yet), not a crash
-        net(x.cuda(), maps.cuda(), rboxes.cuda(), torch.zeros((1, 6)))
+    x, maps, rboxes = _inputs("callform", 2, 96)
+    tg = torch.tensor([[0, 0, 0.5, 0.5, 0.3, 0.3], [1, 0, 0.4, 0.6, 0.2, 0.3]])
+    res = net(x.cuda(), maps.cuda(), rboxes.cuda(), tg)
+    assert isinstance(res, tuple) and len(res) == 4
+    loss, output, metric, att = res
+    assert loss.requires_grad and output.shape[1] == 8 and metric["total"] >= 0 and tuple(att.shape) == (2, 1, 6, 6)
+    # a mix of train- and eval-mode head BatchNorms is refused, loudly
+    net.img_cnn_layers.train()
+    with pytest.raises(NotImplementedError):
+        net(x.cuda(), maps.cuda(), rboxes.cuda(), tg.clone())
 
 
 def test_demo_radar_map_size_quirk(hip_lib):

@@ -54,3 +54,94 @@ def test_bench_more_gpus_than_visible_fails_loudly(hip_lib):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env,
                          cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode != 0 and "visible" in (res.stderr + res.stdout)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data parallelism of the stage-3 step ON THE HIP PATH: two processes share the one leased GPU, each runs
+# Network.forward(..., targets) + loss.backward() through libmillieye_hip on its shard_batch() of one global batch and the
+# gradients go through allreduce_gradients (gloo over CUDA tensors: the lease has one GPU, and RCCL refuses two ranks on
+# one device; the collective call site is the one the RCCL runs use).  eval()-mode model + balance_factor = "all
+# negatives" make every loss term a plain sum over frames, so the reduced gradients must equal the 1-way HIP step - and the
+# CPU oracle's (tests/test_parallel_cpu.py does the same with the oracle as the compute).
+# ---------------------------------------------------------------------------------------------------------------------
+def _hip_dp_step(net, x, maps, rboxes, targets):
+    import random
+    import torch
+    random.seed(0)
+    net.balance_factor = 10 ** 9
+    loss, output, metric, _att = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0, targets.clone())
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss, metric
+
+
+def _hip_dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    from millieye_amd.train_path import head_parameters
+    from tests.test_parallel_cpu import _dp_problem
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _text, net, x, maps, rboxes, targets, _conf = _dp_problem()
+    net = net.cuda().eval()
+    xs, ms, rb, tg = par.shard_batch(x, maps, rboxes, targets, rank, world)
+    loss, metric = _hip_dp_step(net, xs, ms, rb, tg)
+    heads = head_parameters(net)
+    nbytes = par.allreduce_gradients(heads, static_pattern=True)
+    names = [k for k, _ in net.named_parameters() if not k.startswith("base_detector.")]
+    out = {name: (None if p.grad is None else p.grad.cpu().numpy().copy()) for name, p in zip(names, heads)}
+    q.put((rank, nbytes, float(loss.detach()), int(metric["total"]), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_stage3_hip_step_two_ranks_equals_one_way(hip_lib):
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from millieye_amd.train_path import head_parameters
+    from oracle import network_ref
+    from tests.test_parallel_cpu import _dp_problem, _dp_step
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, nbytes, loss, total, grads = q.get(timeout=900)
+        got[rank] = (nbytes, loss, total, grads)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    text, net, x, maps, rboxes, targets, conf = _dp_problem()
+    ref = _dp_step(text, net.state_dict(), x, maps, rboxes, targets, conf)       # CPU oracle, 1-way
+    net = net.cuda().eval()
+    loss1, metric1 = _hip_dp_step(net, x, maps, rboxes, targets)                 # HIP path, 1-way
+    assert int(metric1["total"]) == got[0][2] + got[1][2] > 0 and ref["n_pos"] > 0
+    assert got[0][1] > 0 and got[1][1] > 0
+    assert got[0][1] + got[1][1] == pytest.approx(float(loss1.detach()), rel=1e-4)
+    assert got[0][1] + got[1][1] == pytest.approx(float(ref["loss"]), rel=1e-3)
+    names = [k for k, _ in net.named_parameters() if not k.startswith("base_detector.")]
+    checked = 0
+    for name, p in zip(names, head_parameters(net)):
+        rg = ref["grads"][name]
+        for rank in (0, 1):
+            mine = got[rank][3][name]
+            if p.grad is None:
+                assert mine is None and rg is None, name
+                continue
+            g1 = p.grad.cpu()
+            scale = max(float(g1.abs().max()), 1e-6)
+            # two-rank HIP vs one-way HIP: same kernels, sums regrouped by shard (RoI scatters are atomic): 1e-4
+            assert float((torch.from_numpy(mine) - g1).abs().max()) <= 1e-4 * scale, (name, rank)
+            assert float((torch.from_numpy(mine) - rg).abs().max()) <= 2e-3 * max(float(rg.abs().max()), 1e-6), (name, rank)
+        checked += p.grad is not None
+    assert checked >= 20
+    assert got[0][0] == got[1][0] == 4 * sum(p.numel() for p in head_parameters(net))

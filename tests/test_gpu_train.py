@@ -210,6 +210,51 @@ def test_training_step_vs_oracle_and_reference_golden(hip_lib):
     assert out2.shape[1] == 8
 
 
+def test_eval_mode_training_step_vs_oracle_and_reference_golden(hip_lib):
+    """``Network.forward(..., targets)`` on a model left in eval() mode: the reference has no mode check
+    (my_models.py:545-641) - the loss tuple comes from running-statistics BatchNorm, autograd reaches every head parameter
+    (the conv biases in front of the BatchNorms included) and no running statistic moves.  HIP path (folded affine in the
+    conv epilogue, me_affine_act_bwd_f32 backward) against the oracle and the real reference's eval-mode run."""
+    from oracle import network_ref
+    from tests.golden.make_golden import TRAIN_EVAL_NAME
+    name, cfg, n, s, conf, seed = TRAIN_CASE
+    g = np.load(os.path.join(GOLD, TRAIN_EVAL_NAME + ".npz"))
+    net = _build(name, cfg, conf)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    x, maps, rboxes = train_inputs(name, n, s)
+    targets = torch.from_numpy(g["targets"])
+    random.seed(seed)
+    ref = network_ref.network_train_step(cfgs.KNOWN[cfg](), sd0, x, maps, rboxes, targets, conf_thresh=conf,
+                                         bn_training=False)
+    net = net.cuda().eval()
+    random.seed(seed)
+    loss, output, metric, att = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0, targets.clone())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-3 * max(1.0, abs(float(ref["loss"])))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * max(1.0, abs(float(g["loss"])))
+    assert int(metric["true"]) == int(g["n_pos"]) and metric["total"] == int(g["total"])
+    ph.assert_close(output.detach().cpu(), torch.from_numpy(g["output"]), 1e-3, "eval-mode output rows")
+    checked = 0
+    for k, p in net.named_parameters():
+        if k.startswith("base_detector."):
+            assert p.grad is None
+            continue
+        rg = ref["grads"][k]
+        if rg is None:
+            assert p.grad is None, f"{k} must not receive a gradient"
+            continue
+        assert p.grad is not None, k
+        err = _rel(p.grad, rg)
+        assert err < 2e-3, f"grad {k}: rel err {err:.2e}"
+        assert abs(float(p.grad.double().norm().cpu()) - float(g["gnorm/" + k])) <= 2e-3 * float(g["gnorm/" + k]) + 1e-9, k
+        checked += 1
+    assert checked >= 20
+    for k, v in net.state_dict().items():
+        if "running_" in k or "num_batches_tracked" in k:
+            assert torch.equal(v.cpu(), sd0[k]), f"{k} moved in eval mode"
+
+
 def test_frozen_parameters_get_no_gradient(hip_lib):
     """train.py:146-149 freezes the stage-2 tensors by requires_grad=False."""
     name, cfg, n, s, conf, seed = TRAIN_CASE

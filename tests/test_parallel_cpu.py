@@ -89,6 +89,67 @@ def test_allreduce_gradients_gloo_world2():
                 assert torch.allclose(torch.from_numpy(res[k]), p.grad, atol=1e-6), (rank, k)
 
 
+def _pattern_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MILLIEYE_DP_CHECK="1")
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.Linear(2, 1))
+    params = list(model.parameters())
+    x = torch.ones(1, 3)
+    outcome = []
+    for step in range(3):
+        for p in params:
+            p.grad = None
+        # steps 0, 1: both ranks produce layer-0 gradients only (the static set); step 2: rank 1 breaks the promise
+        (model(x) if (step == 2 and rank == 1) else model[0](x)).sum().backward()
+        try:
+            par.allreduce_gradients(params, static_pattern=True)
+            outcome.append("ok")
+        except RuntimeError as exc:
+            outcome.append("raised" if "static pattern" in str(exc) else "other:" + str(exc))
+    # train.sync_batchnorm_buffers: head running statistics become the mean over the ranks, the detector's stay
+    from millieye_amd.train import sync_batchnorm_buffers
+    net = torch.nn.Module()
+    net.base_detector = torch.nn.BatchNorm1d(2)
+    net.head = torch.nn.BatchNorm1d(3)
+    with torch.no_grad():
+        net.head.running_mean.fill_(float(rank))
+        net.head.running_var.fill_(1.0 + 2 * rank)
+        net.base_detector.running_mean.fill_(float(rank))
+    n_synced = sync_batchnorm_buffers(net)
+    outcome.append((n_synced, net.head.running_mean.tolist(), net.head.running_var.tolist(),
+                    net.base_detector.running_mean.tolist()))
+    q.put((rank, outcome, getattr(params[0], "_me_dp_state").steps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_static_pattern_promise_is_enforced():
+    """with ``static_pattern=True`` a rank that sees another rank's gradient outside the assumed set must not
+    diverge silently.  MILLIEYE_DP_CHECK=1 reads the reduced flags every step: the rank that kept its promise raises; the
+    bookkeeping hangs on the Parameter object (no id()-keyed global)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pattern_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (o, n)) for r, o, n in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0][:3] == ["ok", "ok", "raised"], got   # rank 0's static set lacks layer 1: refuses to go on
+    assert got[1][0][:3] == ["ok", "ok", "ok"], got       # rank 1's own pattern changed: it re-reads the flags, as documented
+    for r in (0, 1):
+        assert got[r][0][3] == (6, [0.5] * 3, [2.0] * 3, [float(r)] * 2), got[r][0][3]
+    assert got[0][1] == got[1][1] == 3
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # data parallelism of the REAL stage-3 step: shard_batch + one flat-bucket all-reduce must reproduce the 1-way step.
 # The compute is the oracle's CPU training step (the HIP path needs a GPU; tests/test_gpu_parallel.py does the same on

@@ -10,7 +10,7 @@ from millieye_amd import radar_proposals as rp
 from millieye_amd.demo import FrameFuser
 from millieye_amd.pipeline import QUEUE_SIZE, FusionPipeline
 from tests.golden.make_golden import RADAR_CALIB
-from tests.pipeline_helpers import BrokenSource, SyntheticSource, fake_infer_slow_first
+from tests.pipeline_helpers import BrokenSource, SyntheticSource, TaggedGenerator, fake_infer_slow_first
 
 
 def _fuser():
@@ -62,6 +62,29 @@ def test_first_frame_rendezvous():
     assert QUEUE_SIZE == 3
 
 
-def test_producer_failure_ends_the_stream():
-    got = list(FusionPipeline(_fuser(), BrokenSource(), infer=slow_infer))
-    assert got == []
+def test_producer_failure_is_reported_not_mistaken_for_the_end():
+    """an exception in the source / prepare half must not look like exhaustion: the frames delivered before it
+    arrive, then the iteration raises ProducerError with the producer's traceback."""
+    import pytest
+    from millieye_amd.pipeline import ProducerError
+    pipe = FusionPipeline(_fuser(), BrokenSource(), infer=slow_infer, drop_oldest=False)
+    got = []
+    with pytest.raises(ProducerError) as err:
+        for rows, info in pipe:
+            got.append(info["frame_idx"])
+    assert "BrokenSource" in str(err.value) or "Error" in str(err.value)
+    assert got == list(range(len(got))) and pipe.stats["frames"] == len(got)
+
+
+def test_custom_generator_reaches_the_producer_or_is_refused():
+    import pytest
+    fuser = FrameFuser(None, RADAR_CALIB, model_mode=0, generator=TaggedGenerator(RADAR_CALIB))
+    got = list(FusionPipeline(fuser, SyntheticSource(3), infer=lambda p: (p["radar_box"].clone(), dict(p=p["proposals"])),
+                              drop_oldest=False))
+    assert len(got) == 3
+    for rows, info in got:
+        assert np.allclose(np.asarray(info["p"]), [[11.0, 22.0, 133.0, 144.0]]) and rows.shape == (1, 5)
+    unpicklable = TaggedGenerator(RADAR_CALIB)
+    unpicklable.fn = lambda x: x
+    with pytest.raises(TypeError):
+        FusionPipeline(FrameFuser(None, RADAR_CALIB, generator=unpicklable), SyntheticSource(1))

@@ -44,6 +44,39 @@ def test_oracle_training_step_matches_reference():
         assert res["grads"][k] is None  # regression loss excluded / layers unused
 
 
+def test_oracle_eval_mode_training_step_matches_reference():
+    """The same call on a model left in eval() mode (the reference has no mode check, my_models.py:545-641): the oracle's
+    ``bn_training=False`` step against the real reference's eval-mode run (train_tiny12_s160_n2_bneval.npz): loss, rows,
+    every gradient - the conv biases in front of the BatchNorms now receive real gradients - and untouched running
+    statistics."""
+    from millieye_amd.my_models import Network, define_yolo
+    from tests.golden.make_golden import TRAIN_EVAL_NAME
+    from tests.parity_helpers import cfg_path
+    name, cfg, n, s, conf, seed = TRAIN_CASE
+    g = np.load(os.path.join(GOLD, TRAIN_EVAL_NAME + ".npz"))
+    net = Network(define_yolo(cfg_path(cfg)), conf)
+    synth.fill_network_(net, name)
+    sd = net.state_dict()
+    x, maps, rboxes = train_inputs(name, n, s)
+    random.seed(seed)
+    res = network_ref.network_train_step(cfgs.KNOWN[cfg](), sd, x, maps, rboxes, torch.from_numpy(g["targets"]),
+                                         conf_thresh=conf, bn_training=False)
+    assert abs(float(res["loss"]) - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert res["n_pos"] == int(g["n_pos"]) and res["n_pos"] > 0
+    assert np.allclose(res["output"].numpy(), g["output"], rtol=1e-5, atol=1e-5)
+    seen = 0
+    for key in g.files:
+        if key.startswith("gnorm/"):
+            k = key[6:]
+            gr = res["grads"][k]
+            assert abs(float(gr.double().norm()) - float(g[key])) <= 1e-4 * max(1e-6, float(g[key])), k
+            seen += 1
+        elif key.startswith("buf/"):
+            assert np.array_equal(g[key], sd[key[4:]].numpy()), f"{key}: eval mode must not update running statistics"
+    assert seen >= 20
+    assert float(g["gnorm/img_cnn_layers.net.conv_0.bias"]) > 1e-6
+
+
 def test_vectorised_iou_labels_equal_the_reference_loop():
     """train_path.iou_labels_vectorized must reproduce the reference's per-box loop bit for bit
     (ties, empty filters, NaN-free inputs), incl. against the oracle's own restatement."""

@@ -4,6 +4,8 @@ s_memtime stamps of workgroup 0 / wave 0: [kernel start] then per stage (before 
 import os
 import sys
 
+os.environ.setdefault("MILLIEYE_ABLATION", "1")  # the instrumented tile ids are refused without this opt-in
+
 import numpy as np
 import torch
 
