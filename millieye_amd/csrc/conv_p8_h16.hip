@@ -244,6 +244,14 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
   if (tile == 199 || tile == 299)  // 2048 x 8 bytes of time stamps go to the workspace
     ME_REQUIRE(p.partial && p.partial_bytes >= 16384, ME_E_BADARG,
                "me_conv2d_h16: the time-stamp instances need a workspace of at least 16384 bytes");
+  if (tile == 196 || tile == 296) {  // six 8-byte words per workgroup
+    int bm, bn;
+    p8_tile_shape(tile == 196 ? 131 : 221, &bm, &bn);
+    const long long mp = (long long)p.n * (p.h + 1) * (p.w + 1);
+    const long long need = ((mp + bm - 1) / bm) * (p.cout / bn) * 48;
+    ME_REQUIRE(p.partial && p.partial_bytes >= need, ME_E_BADARG,
+               "me_conv2d_h16: the per-workgroup stamp instances need a workspace of %lld bytes", need);
+  }
   switch (tile) {
     case 180: return launch_p8<2, 4, 4, 2, 1, 1, 0, 1>(p, stream);
     case 190: return launch_p8<2, 4, 4, 2, 1, 1, 0, 3>(p, stream);
@@ -255,6 +263,8 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 280: return launch_p8<4, 2, 2, 2, 0, 2, 0, 1>(p, stream);
     case 299: return launch_p8<4, 2, 2, 2, 0, 2, 0, 9>(p, stream);   // 221 with time stamps
     case 199: return launch_p8<4, 2, 3, 2, 1, 1, 0, 9>(p, stream);   // 131 with time stamps
+    case 296: return launch_p8<4, 2, 2, 2, 0, 2, 0, 10>(p, stream);  // 221 with per-workgroup stamps
+    case 196: return launch_p8<4, 2, 3, 2, 1, 1, 0, 10>(p, stream);  // 131 with per-workgroup stamps
     case 297: return launch_p8<4, 2, 2, 2, 0, 2, 0, 7>(p, stream);
     case 298: return launch_p8<4, 2, 2, 2, 0, 2, 0, 8>(p, stream);
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown patch tile id %d", tile);

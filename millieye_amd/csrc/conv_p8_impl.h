@@ -63,7 +63,9 @@ constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 wave
 // ABL (tuning only, wrong results): 1 = all DMA lanes out of range, 3 = no DMA instructions, 4 = 3 + no LDS fragment reads,
 //           5 = 4 + no barriers (pure MFMA stream), 6 = full main loop but no epilogue, 7 = weights out of range (patch
 //           traffic only), 8 = patch out of range (weight traffic only); 9 = correct results + s_memtime stamps of
-//           workgroup 0 / wave 0 into the workspace (per stage: before the wait, after the wait, after the barrier, at the end)
+//           workgroup 0 / wave 0 into the workspace (per stage: before the wait, after the wait, after the barrier, at the end);
+//           10 = correct results + four s_memrealtime stamps (100 MHz, chip-wide clock) of EVERY workgroup's wave 0 (start,
+//           main loop start, main loop end, end) and its HW_ID / XCC_ID: dispatch rounds, co-residency, epilogue overlap
 template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * WC)
     __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
@@ -153,6 +155,21 @@ __global__ __launch_bounds__(64 * WR * WC)
     }
   };
   stamp();
+  auto wg_stamp = [&](int k) {
+    if constexpr (ABL == 10) {
+      if (wave == 0 && dbg) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) dbg[(long long)blockIdx.x * 6 + k] = t;
+      }
+    }
+  };
+  wg_stamp(0);
+  if constexpr (ABL == 10) {
+    if (wave == 0 && lane == 0 && dbg) {
+      dbg[(long long)blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+      dbg[(long long)blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    }
+  }
 
   unsigned rowbase[MT];
 #pragma unroll
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(64 * WR * WC)
     load_frags(Z{}, Z{}, 0);
   }
 
+  wg_stamp(1);
   auto stage = [&](auto tc, auto parc, int chunk) {
     constexpr int T = decltype(tc)::value, PAR = decltype(parc)::value;
     constexpr int SET = PIPE ? ((T + PAR) & 1) : 0;
@@ -375,6 +393,7 @@ __global__ __launch_bounds__(64 * WR * WC)
     if (chunk < cs) static_for([&](auto tc) { stage(tc, P0{}, chunk); }, std::make_integer_sequence<int, 9>{});
   }
   stamp();
+  wg_stamp(2);
   if (ABL == 6) {  // ablation: no epilogue (one store so that the loop is not dead code)
     float t = 0.f;
 #pragma unroll
@@ -532,6 +551,10 @@ __global__ __launch_bounds__(64 * WR * WC)
               std::make_integer_sequence<int, NT>{});
         },
         std::make_integer_sequence<int, MT>{});
+  }
+  if constexpr (ABL == 10) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_stamp(3);
   }
   if constexpr (ABL == 9) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -28,9 +28,13 @@ def _frame_rows(rows, f):
 def _m2_net(tag):
     from millieye_amd.module2.my_models import Network, define_yolo
     net = Network(define_yolo(ph.cfg_path("yolov3")), 0.2).eval()
-    # class-0 / every-class logits around the objectness so that a realistic number of proposals (tens per frame) of
-    # several classes reaches the heads with random backbone weights
-    synth.fill_network_(net, tag, obj_bias=-3.0, cls0_bias=-2.0)
+    # objectness statistics tuned (on the CPU oracle) so that tens of proposals per frame, of several classes, reach the
+    # heads with random backbone weights; a small box-regression layer keeps the refined boxes box-sized (random net1
+    # weights give exp(tw) factors of 1e2, which would turn the pixel tolerances below into 1e-6 relative ones)
+    synth.fill_network_(net, tag, obj_bias=-3.4, obj_std=3.0, cls0_bias=-2.0)
+    with torch.no_grad():
+        net.refinement_head.net1[0].weight.mul_(0.002)
+        net.refinement_head.net1[0].bias.mul_(0.002)
     return net
 
 
