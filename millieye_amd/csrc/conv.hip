@@ -960,7 +960,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const float t = acc[i][j][e] * sc + sh;
-            *yp = fmaxf(t, t * slope) + *rp;
+            me::store4(yp, fmaxf(t, t * slope) + *rp, p.store_mode);
             yp += (e & 3) == 3 ? 5 * ystep : ystep;
             rp += (e & 3) == 3 ? 5 * rstep : rstep;
           }
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const float t = acc[i][j][e] * sc + sh;
-            *yp = fmaxf(t, t * slope);
+            me::store4(yp, fmaxf(t, t * slope), p.store_mode);
             yp += (e & 3) == 3 ? 5 * ystep : ystep;
           }
         }
@@ -1460,6 +1460,7 @@ int launch_buf_tail(ConvP& p, hipStream_t stream, long long ws_bytes) {
 }
 
 int fill_params(const me_conv_desc* d, ConvP& p) {
+  p.store_mode = me::store_mode();
   ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_f32: null descriptor");
   ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
              "me_conv2d_f32: non-positive dimension");

@@ -57,6 +57,7 @@ struct Conv16P {
   int splitk, sps;
   int f16;         // 0 = bfloat16 storage, 1 = IEEE half
   int vec_epi;     // 16-byte epilogue allowed (bf16 out, no upsample, leaky / linear, pitches % 8, 16-byte aligned)
+  int store_mode;  // me::store_mode(): 16-byte epilogue stores plain (0), nt (1) or sc1 write-through (2)
 };
 
 __device__ __forceinline__ float act16(float v, int act) {

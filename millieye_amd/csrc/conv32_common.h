@@ -31,6 +31,7 @@ struct ConvP {
   int* counters;   // per-tile arrival counters of the in-launch slab reduction (zero between launches), or nullptr
   long long counters_len;
   int bulk;        // tail-split launches: tiles [0, bulk) run whole, tiles [bulk, tiles) cut splitk ways (0 otherwise)
+  int store_mode;  // me::store_mode(): output stores of the fast epilogue plain (0) or streaming (nt)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

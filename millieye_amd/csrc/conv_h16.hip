@@ -31,6 +31,8 @@ namespace me16 {  // conv_p8_h16.hip: patch-resident big-tile generation (tile i
 bool p8_eligible(const Conv16P& p, int tile);
 int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream);
 long long p8_workspace_bytes(const Conv16P& p, int tile, int split);
+bool ws1x1_eligible(const Conv16P& p);      // conv1x1_ws_h16.hip: tile id 50, weight-stationary streaming 1x1
+int launch_ws1x1(const Conv16P& p, hipStream_t stream);
 bool stem_mfma_eligible(const Conv16P& p);  // stem_mfma_h16.hip
 int launch_stem_mfma(const Conv16P& p, hipStream_t stream);
 }  // namespace me16
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
         o.y = pack2<F16>(v[2], v[3]);
         o.z = pack2<F16>(v[4], v[5]);
         o.w = pack2<F16>(v[6], v[7]);
-        *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
+        me::store16(yb + m * p.y_pitch + cb + c8, o, p.store_mode);
       }
     };
     static_for([&](auto jc) { static_for([&](auto ic) { block_out(ic, jc); }, std::make_integer_sequence<int, MT>{}); },
@@ -594,6 +596,7 @@ int launch16(Conv16P& p, hipStream_t stream) {
 }
 
 int fill16(const me_conv16_desc* d, Conv16P& p) {
+  p.store_mode = me::store_mode();
   ME_REQUIRE(d != nullptr, ME_E_NULLPTR, "me_conv2d_h16: null descriptor");
   ME_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, ME_E_BADARG,
              "me_conv2d_h16: non-positive dimension");
@@ -724,6 +727,7 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   p.splitk = split;
   p.partial = reinterpret_cast<float*>(d->workspace);
   if (tile >= 100) return me16::launch_p8_tile(p, tile, stream);
+  if (tile == 50) return me16::launch_ws1x1(p, stream);
   const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows
   if (p.f16) {
     switch (tile) {

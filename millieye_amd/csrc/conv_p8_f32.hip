@@ -38,7 +38,7 @@ void magic_u32(unsigned d, unsigned* m, unsigned* s) {
 template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int ABL = 0>
 int launch_p8(const ConvP& p, hipStream_t stream) {
   constexpr int BM = 32 * MT * WR, BN = 32 * NT * WC, NWAVES = WR * WC;
-  P8Args a;
+  P8Args a = {};
   a.c.x = p.x; a.c.wgt_tiled = p.wgt_tiled; a.c.scale = p.scale; a.c.shift = p.shift; a.c.res = p.res; a.c.y = p.y;
   a.c.x_pitch = p.x_pitch; a.c.res_pitch = p.res_pitch; a.c.y_pitch = p.y_pitch;
   a.c.n = p.n; a.c.h = p.h; a.c.w = p.w; a.c.cin = p.cin; a.c.cout = p.cout; a.c.act = p.act;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void conv3x3_p8_reduce_h16(P8Args a, int bm, i
 template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0>
 int launch_p8(const Conv16P& p, hipStream_t stream) {
   constexpr int BM = 32 * MT * WR, BN = 32 * NT * WC;
-  P8Args a;
+  P8Args a = {};
   a.c.x = p.x; a.c.wgt_tiled = p.wgt_tiled; a.c.scale = p.scale; a.c.shift = p.shift; a.c.res = p.res; a.c.y = p.y;
   a.c.x_pitch = p.x_pitch; a.c.res_pitch = p.res_pitch; a.c.y_pitch = p.y_pitch;
   a.c.n = p.n; a.c.h = p.h; a.c.w = p.w; a.c.cin = p.cin; a.c.cout = p.cout; a.c.act = p.act;
@@ -136,15 +136,18 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   if (lds < epi) lds = epi;
   ME_REQUIRE(lds <= (MINB == 2 ? 80 : 160) * 1024, ME_E_TOOBIG,
              "me_conv2d_h16: this tile needs %zu bytes of LDS for a %d-wide map", lds, p.w);
-  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL>;
+  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL, false>;
+  auto kern_sk = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL == 0 ? 0 : ABL, ABL == 0>;  // K-split instance
   static bool attr_set = false;
   if (!attr_set) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   // K split (p.splitk > 1): every tile is cut into splitk workgroups along the 32-channel chunks - for the layers whose tile
   // count leaves CUs idle or with a lone workgroup (13x13: 176 tiles of 256 x 128); slabs + a second launch
   const int cs = p.cin / 32;
+  a.c.store_mode = me::store_mode();
   a.c.splitk = p.splitk > cs ? cs : (p.splitk < 1 ? 1 : p.splitk);
   a.c.cps = (cs + a.c.splitk - 1) / a.c.splitk;
   while (a.c.splitk > 1 && (a.c.splitk - 1) * a.c.cps >= cs) --a.c.splitk;
@@ -156,7 +159,10 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
     ME_REQUIRE(ABL == 0 && p.partial && p.partial_bytes >= need, ME_E_BADARG,
                "me_conv2d_h16: tile with split_k=%d needs a workspace of %lld bytes", a.c.splitk, need);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
+  if (a.c.splitk > 1)
+    hipLaunchKernelGGL(kern_sk, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
+  else
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
   int rc = me::check_launch("conv3x3_p8_h16");
   if (rc || a.c.splitk == 1) return rc;
   long long rb = (tiles * BM * (BN / 8) + 255) / 256;

@@ -31,7 +31,11 @@ struct P8Conv {
   void* partial;  // K split: fp32 slabs [tile][split][BM][BN] of raw accumulators; instrumented builds: time stamps
   int splitk;     // workgroups per tile (each takes `cps` 64-byte chunks of the channel dimension), 1 = whole tiles
   int cps;
+  int store_mode;  // epilogue stores: 0 plain, 1 nt (streaming), 2 sc1 (write-through: the line leaves the XCD's L2 at once
+                   // instead of waiting dirty for the end-of-kernel release)
 };
+
+using me::store16;
 
 struct P8Args {
   P8Conv c;
@@ -66,7 +70,10 @@ constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 wave
 //           workgroup 0 / wave 0 into the workspace (per stage: before the wait, after the wait, after the barrier, at the end);
 //           10 = correct results + four s_memrealtime stamps (100 MHz, chip-wide clock) of EVERY workgroup's wave 0 (start,
 //           main loop start, main loop end, end) and its HW_ID / XCC_ID: dispatch rounds, co-residency, epilogue overlap
-template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0>
+// SK: the instance with the K-split slab epilogue (p.splitk > 1).  It is a separate instance on purpose: merely containing
+// that path cost the whole-tile kernel 20 % (106 scalar registers + 24 spilled against 56, and a slower main loop: 58.9 vs
+// 46.6 us on the 52 x 52 128 -> 256 layer, measured with the stamp instance that never had it - profiles/r03_kernel_evolution.md)
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false>
 __global__ __launch_bounds__(64 * WR * WC)
     __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
   using frag = typename DT::frag;
@@ -94,8 +101,8 @@ __global__ __launch_bounds__(64 * WR * WC)
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     piece = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int wg = piece / p.splitk;
-    sid = piece - wg * p.splitk;  // K split: this workgroup multiplies chunks [sid * cps, (sid + 1) * cps) of the tile
+    const int wg = SK ? piece / p.splitk : piece;
+    sid = SK ? piece - wg * p.splitk : 0;  // K split: this workgroup multiplies chunks [sid * cps, (sid + 1) * cps) of the tile
     tile_n = wg % p.tiles_n;
     tile_m = wg / p.tiles_n;
   }
@@ -187,11 +194,11 @@ __global__ __launch_bounds__(64 * WR * WC)
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int cs_all = p.cin / DT::kChunk;  // 64-byte chunks of the channel dimension
-  const int cbase = __builtin_amdgcn_readfirstlane(sid * p.cps);
-  const int cs = p.splitk > 1 ? (cbase + p.cps < cs_all ? p.cps : cs_all - cbase) : cs_all;  // ... this workgroup walks
+  const int cbase = SK ? __builtin_amdgcn_readfirstlane(sid * p.cps) : 0;
+  const int cs = SK ? (cbase + p.cps < cs_all ? p.cps : cs_all - cbase) : cs_all;  // ... this workgroup walks
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
   auto issue_a = [&](int chunk, unsigned slot) {
-    if (ABL >= 3 && ABL != 6) return;
+    if (ABL >= 3 && ABL <= 5) return;
     const unsigned dst = wave_lds + A_BASE + slot * A_SLOT;
     static_for(
         [&](auto jc) {
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64 * WR * WC)
         std::make_integer_sequence<int, kLpaMax>{});
   };
   auto issue_b = [&](int chunk, int tap, unsigned ring) {
-    if (ABL >= 3 && ABL != 6) return;
+    if (ABL >= 3 && ABL <= 5) return;
     const unsigned soff = ((unsigned)tap * (unsigned)cs_all + (unsigned)(cbase + chunk)) * (unsigned)p.cout * 64u;
 #pragma unroll
     for (int j = 0; j < LPB; ++j) dma1(v_b[j], rsrc_b, soff, wave_lds + ring * B_SLOT + (unsigned)j * (NW * 1024u));
@@ -218,7 +225,9 @@ __global__ __launch_bounds__(64 * WR * WC)
       default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPB + 7) : "memory"); break;
     }
   };
-  constexpr bool NODMA = ABL >= 3 && ABL != 6;
+  constexpr bool NODMA = ABL >= 3 && ABL <= 5;  // (the stamp instances 9 / 10 and the out-of-range ablations 7 / 8 do issue their DMAs:
+  // until round 3 this read `ABL != 6`, so the round-2 stamp instance ran without loads - its 1033 cycles / stage were a
+  // no-DMA number, see profiles/r03_kernel_evolution.md)
 
   frag afr[NSET][2][MT], bfr[NSET][2][NT];
   if (ABL == 4 || ABL == 5) {  // ablation: the fragments never change - give them ordinary values
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(64 * WR * WC)
     return;
   }
 
-  if (ABL == 0 && p.splitk > 1) {  // K split: raw accumulators to this piece's slab; the launcher's reduce pass finishes the tile
+  if constexpr (ABL == 0 && SK) {  // K split: raw accumulators to this piece's slab; the launcher's reduce pass finishes the tile
     float* slab = reinterpret_cast<float*>(p.partial) + (long long)piece * (BM * BN);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(64 * WR * WC)
           o.y = DT::pack2(v[2], v[3]);
           o.z = DT::pack2(v[4], v[5]);
           o.w = DT::pack2(v[6], v[7]);
-          *reinterpret_cast<uint4*>(yb + m * p.y_pitch + cb + c8) = o;
+          store16(yb + m * p.y_pitch + cb + c8, o, p.store_mode);
         }
       }
     };

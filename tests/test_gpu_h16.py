@@ -450,6 +450,59 @@ def test_conv_p8_k_split(hip_lib, tile, half):
             and float(wide[..., 16 + cout:].abs().max()) == 0, f"{name}: pitched output through the reduce pass"
 
 
+WS_PAIRS = [(64, 32), (128, 64), (128, 128), (256, 128), (256, 256), (384, 128), (512, 256), (512, 512), (768, 256)]
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout", WS_PAIRS)
+def test_conv1x1_weight_stationary_tile(hip_lib, cin, cout, half):
+    """Tile id 50 (csrc/conv1x1_ws_h16.hip): the streaming 1x1 kernel - weights in registers, activations through an LDS ring
+    filled by swizzled-source LDS-DMA, persistent grid - on every built (cin, cout) pair: against the fp32 CPU convolution
+    under the bar of the other 16-bit tiles; row counts that are not a multiple of the tile (1, 31, 33 rows and a few thousand:
+    zero fill by the descriptor range, guarded stores), more tiles than workgroups (the ring wraps), input read from a channel
+    slice of a wider buffer, output written into a slice, leaky and linear, bit-identical to the per-tap kernel's fp32-exact
+    cases being out of scope (accumulation order differs), deterministic."""
+    from millieye_amd import hip
+    half = HALVES[half]
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    wgt = _bf(torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5, half)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+    sc, sh = scale.cuda(), shift.cuda()
+    shapes = [(1, 1, 1), (1, 1, 31), (1, 3, 11), (2, 13, 13), (3, 52, 52)]
+    if cin <= 128:
+        shapes.append((2, 104, 208))   # 43 264 rows: several tiles per workgroup of the 256-workgroup grid
+    for case, (n, h, w) in enumerate(shapes):
+        act = case % 2
+        x = _bf(torch.randn((n, h, w, cin), generator=g), half)
+        ref = _ref(x, wgt, scale, shift, 1, 1, 0, act)
+        xs = x.cuda()
+        y = hip.conv2d_h16(xs, packed, sc, sh, 1, 1, 0, act, tile=50, split_k=1)
+        _check_bf16(y, ref, f"{cin}->{cout} {n}x{h}x{w} act {act} tile 50")
+        assert torch.equal(y, hip.conv2d_h16(xs, packed, sc, sh, 1, 1, 0, act, tile=50, split_k=1)), "not deterministic"
+        if case in (3, 4):
+            xw = torch.zeros((n, h, w, cin + 40), dtype=half).cuda()
+            xw[..., 8:8 + cin] = xs
+            wide = torch.zeros((n, h, w, cout + 48), dtype=half).cuda()
+            hip.conv2d_h16(xw[..., 8:8 + cin], packed, sc, sh, 1, 1, 0, act, out=wide[..., 16:16 + cout], tile=50, split_k=1)
+            assert torch.equal(wide[..., 16:16 + cout], y), "pitched input / output"
+            assert float(wide[..., :16].abs().max()) == 0 and float(wide[..., 16 + cout:].abs().max()) == 0
+
+
+def test_conv1x1_weight_stationary_refuses(hip_lib):
+    from millieye_amd import hip
+    x = torch.zeros((1, 8, 8, 256), dtype=torch.bfloat16).cuda()
+    w = torch.zeros((128, 1, 1, 256), dtype=torch.bfloat16).cuda()
+    one = torch.ones(128).cuda()
+    res = torch.zeros((1, 8, 8, 128), dtype=torch.bfloat16).cuda()
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(x, w, one, one, 1, 1, 0, 1, residual=res, tile=50)       # residual
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(x, w, one, one, 1, 1, 0, 1, y_f32=True, tile=50)         # fp32 output
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(x, w[:96], one[:96], one[:96], 1, 1, 0, 1, tile=50)      # no instance for 256 -> 96
+
+
 def test_conv_p8_refuses_what_it_cannot_do(hip_lib):
     from millieye_amd import hip
     x = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16).cuda()
