@@ -152,14 +152,19 @@ __global__ __launch_bounds__(64 * WN * WM) void conv1x1_ws_kernel(K1Args a) {
       issue(t + (NSLOT - 1) * G, ps);
     }
     const unsigned char* At = smem1 + (unsigned)slot * TILEB + a_base;
-    f32x16 acc;
+    f32x16 acc, acc1;  // two accumulation chains (even / odd k-steps): a lone wave per SIMD is bound by the dependent-MFMA
+                       // latency, not by the issue rate
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = acc1[e] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const v8 af = *reinterpret_cast<const v8*>(At + (((unsigned)(ks * 32)) ^ g16));
-      acc = H16<F16>::mfma(af, wf[ks], acc);
+    for (int ks = 0; ks < KS; ks += 2) {
+      const v8 af0 = *reinterpret_cast<const v8*>(At + (((unsigned)(ks * 32)) ^ g16));
+      const v8 af1 = *reinterpret_cast<const v8*>(At + (((unsigned)((ks + 1) * 32)) ^ g16));
+      acc = H16<F16>::mfma(af0, wf[ks], acc);
+      acc1 = H16<F16>::mfma(af1, wf[ks + 1], acc1);
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
     // ---- epilogue of this wave's 32 x 32 block ----------------------------------------------------------------------------------
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -204,11 +209,15 @@ int launch_ws(const Conv16P& p, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  int per_n = cus / tiles_n;           // one workgroup per CU in total
-  if (per_n < 1) per_n = 1;
-  a.grid_m = a.tiles_m < per_n ? a.tiles_m : per_n;
   const size_t lds = (size_t)NSLOT * BMT * CIN * 2 + (size_t)NW * 32 * 36 * sizeof(float);
   ME_REQUIRE(lds <= 160 * 1024, ME_E_TOOBIG, "me_conv2d_h16: tile 50 needs %zu bytes of LDS", lds);
+  int per_cu = (int)(160 * 1024 / lds);   // resident workgroups per CU by LDS (registers: cin / 4 + ~40 VGPRs per wave)
+  const int by_regs = 8 / (NW / 4) / (CIN >= 512 ? 4 : CIN >= 384 ? 3 : CIN >= 256 ? 2 : 1);
+  if (per_cu > by_regs) per_cu = by_regs;
+  if (per_cu < 1) per_cu = 1;
+  int per_n = cus * per_cu / tiles_n;
+  if (per_n < 1) per_n = 1;
+  a.grid_m = a.tiles_m < per_n ? a.tiles_m : per_n;
   const dim3 grid((unsigned)(a.grid_m * tiles_n)), block(64 * NW);
   if (p.f16) {
     auto kern = conv1x1_ws_kernel<CIN, WN, WM, NSLOT, 1>;
@@ -250,6 +259,26 @@ int launch_ws1x1(const Conv16P& p, hipStream_t stream) {
              "me_conv2d_h16: tile 50 (weight-stationary 1x1) needs a 1x1 / stride 1 layer without residual / upsampling / fp32 "
              "output, 16-byte aligned operands and one of the built (cin, cout) pairs; got %d -> %d", p.cin, p.cout);
   const int c = p.cin, o = p.cout;
+  static const int variant = [] {
+    const char* e = getenv("MILLIEYE_WS_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  if (variant && c == 256 && o == 128) {   // tuning: occupancy / ring-depth variants of the 256 -> 128 instance
+    switch (variant) {
+      case 1: return launch_ws<256, 4, 1, 3>(p, stream);   // 66 KB: two workgroups per CU
+      case 2: return launch_ws<256, 4, 1, 2>(p, stream);   // 50 KB: three workgroups per CU
+      case 3: return launch_ws<256, 4, 2, 3>(p, stream);   // 8 waves, 64-row tiles, one workgroup per CU
+      case 4: return launch_ws<256, 4, 2, 2>(p, stream);
+      case 5: return launch_ws<256, 4, 1, 4>(p, stream);   // 82 KB: one per CU with a shorter ring
+      default: break;
+    }
+  }
+  if (variant && c == 512 && o == 256) {
+    switch (variant) {
+      case 1: return launch_ws<512, 8, 1, 2>(p, stream);
+      default: break;
+    }
+  }
   //                           CIN  WN WM NSLOT        LDS: NSLOT * 32 WM * CIN * 2 + patches
   if (c == 64 && o == 32) return launch_ws<64, 1, 4, 8>(p, stream);      // 8 x 16 KB + 18 KB
   if (c == 128 && o == 64) return launch_ws<128, 2, 2, 8>(p, stream);    // 8 x 16 KB

@@ -6,7 +6,21 @@
 // arithmetic below uses the same operation order with FP contraction off, comparisons are
 // written as the C++ std::max / std::min the CPU kernel uses (NaN behaviour included).
 //
-// Pipeline per call (three launches + one 4*n byte memset):
+// Round 3: up to MATN (4096) candidates per image the selection is no longer one workgroup's serial argmax loop but the
+// whole chip's work (BASELINE north_star: "wavefront ballot / reduce for NMS"):
+//   nms_rank    sorts an image's candidates by key (rank = number of larger keys, 256 candidates per workgroup) and writes
+//               the sorted offset boxes (boxes + label * (max + 1); the maximum comes from nms_prep's atomics);
+//   nms_matrix  persistent grid over every (image, 64 x 64 block) of the upper-triangular suppression bit matrix: a wave
+//               per block, lane = row, 64 IoU tests per lane against the column boxes (readlane broadcast), one 64-bit
+//               word per lane;
+//   nms_scan    one workgroup per image walks the sorted list 64 candidates at a time: the block's 64 matrix rows are
+//               staged in LDS (the next block's rows are already in flight in registers), wave 0 resolves the block with
+//               scalar bit operations on the diagonal word (find-first-set over the not-yet-removed candidates, OR the
+//               winner's word in) and ORs the winners' rows into the removed mask (lane = 64-candidate word); stops at
+//               max_det winners.  Same visiting order and the same IoU test as before: bit-identical results.
+// More candidates than MATN (conf_thresh near 0): the single-workgroup kernel below, unchanged (MILLIEYE_NMS_LEGACY=1 forces it).
+//
+// Pipeline per call (launches + one 12*n byte memset):
 //   nms_prep    one thread per prediction row: conf >= thr filter, xywh->xyxy, class
 //               max/argmax, append candidate {raw box, key, label, cls_conf} (wave-aggregated
 //               atomic append; order does not matter, the key carries the row index).
@@ -27,26 +41,40 @@ constexpr int MAX_ROWS = 32768;  // 32 candidates per thread
 constexpr int LDS_CANDS = 4096;  // candidates per image kept in LDS by nms_select (96 KiB)
 constexpr int MAT_CANDS = 768;   // ... up to this many are resolved through a suppression bit matrix in LDS (108 KiB)
 
+constexpr int MATN = 4096;       // candidates per image the matrix path handles (64 words of 64 bits: one per lane)
+
 struct NmsWs {
   float4* raw;               // [n][cap] raw xyxy
-  float4* off;               // [n][cap] boxes + label*(max+1)
+  float4* off;               // [n][cap] boxes + label*(max+1) (matrix path: in sorted order)
   unsigned long long* key;   // [n][cap] (sortable(score) << 32) | ~row
   float* label;              // [n][cap]
   float* clsconf;            // [n][cap]
   int* keep_slot;            // [n][cap_keep] candidate slot of every winner
-  int* cand_count;           // [n]
-  int cap;
+  int* sslot;                // [n][cap] matrix path: candidate slot of sorted position
+  unsigned long long* mat;   // [n][matn][matn / 64] suppression bits of the sorted candidates (upper triangle)
+  int* cand_count;           // [n]   } one memset
+  unsigned* maxbits;         // [n]   } sortable() bits of the largest coordinate among the candidates
+  int* nanflag;              // [n]   } a candidate coordinate is NaN
+  int cap, matn, wc;         // wc = matn / 64 words per matrix row
+  int legacy;                // force the single-workgroup kernel
 };
 
 __host__ __device__ inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
 
+inline int matn_of(int rows) {
+  const int r = (rows + 63) & ~63;
+  return r < MATN ? r : MATN;
+}
+
 inline long long ws_bytes(int n, int rows) {
   const long long cap = rows;
+  const long long matn = matn_of(rows);
   long long b = 0;
   b += align_up((long long)n * cap * 16, 256) * 2;  // raw, off
   b += align_up((long long)n * cap * 8, 256);       // key
-  b += align_up((long long)n * cap * 4, 256) * 3;   // label, clsconf, keep_slot
-  b += align_up((long long)n * 4, 256);             // cand_count
+  b += align_up((long long)n * cap * 4, 256) * 4;   // label, clsconf, keep_slot, sslot
+  b += align_up((long long)n * matn * (matn / 64) * 8, 256);  // mat
+  b += align_up((long long)n * 12, 256);            // cand_count, maxbits, nanflag
   return b;
 }
 
@@ -61,7 +89,18 @@ inline NmsWs carve(void* base, int n, int rows) {
   w.label = reinterpret_cast<float*>(p); p += align_up((long long)n * cap * 4, 256);
   w.clsconf = reinterpret_cast<float*>(p); p += align_up((long long)n * cap * 4, 256);
   w.keep_slot = reinterpret_cast<int*>(p); p += align_up((long long)n * cap * 4, 256);
+  w.sslot = reinterpret_cast<int*>(p); p += align_up((long long)n * cap * 4, 256);
+  w.matn = matn_of(rows);
+  w.wc = w.matn / 64;
+  w.mat = reinterpret_cast<unsigned long long*>(p); p += align_up((long long)n * w.matn * w.wc * 8, 256);
   w.cand_count = reinterpret_cast<int*>(p);
+  w.maxbits = reinterpret_cast<unsigned*>(p) + n;
+  w.nanflag = reinterpret_cast<int*>(p) + 2 * n;
+  static const int legacy = [] {
+    const char* e = getenv("MILLIEYE_NMS_LEGACY");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  w.legacy = legacy;
   return w;
 }
 
@@ -72,6 +111,18 @@ __device__ __forceinline__ unsigned sortable(float f) {
 
 __device__ __forceinline__ unsigned long long make_key(float score, int row) {
   return ((unsigned long long)sortable(score) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)row);
+}
+
+// boxes.max() of batched_nms's offset trick, gathered while the candidates are appended: the largest non-NaN coordinate as
+// sortable bits (atomicMax; 0 = "none yet" sorts below every float) and a flag for NaN coordinates (torch's max is NaN then)
+__device__ __forceinline__ void note_max_coord(const NmsWs& w, int img, float x1, float y1, float x2, float y2) {
+  if ((x1 != x1) | (y1 != y1) | (x2 != x2) | (y2 != y2)) atomicOr(&w.nanflag[img], 1);
+  const float m = fmaxf(fmaxf(x1, y1), fmaxf(x2, y2));
+  if (m == m) atomicMax(&w.maxbits[img], sortable(m));
+}
+
+__device__ __forceinline__ float unsortable(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
 // ---- prep -------------------------------------------------------------------------------------
@@ -109,6 +160,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(float* pred, int rows, in
   w.key[o] = make_key(conf, row);
   w.label[o] = (float)arg;
   w.clsconf[o] = best;
+  note_max_coord(w, img, x1, y1, x2, y2);
 }
 
 // explicit boxes (box_ops.nms / batched_nms): every box is a candidate, img = 0
@@ -121,6 +173,7 @@ __global__ __launch_bounds__(256) void nms_prep_boxes_kernel(const float* boxes,
   w.label[row] = labels ? labels[row] : 0.f;
   w.clsconf[row] = 0.f;
   if (row == 0) w.cand_count[0] = m;
+  note_max_coord(w, 0, boxes[4 * row], boxes[4 * row + 1], boxes[4 * row + 2], boxes[4 * row + 3]);
 }
 
 // ---- select -----------------------------------------------------------------------------------
@@ -189,6 +242,7 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     if (t == 0) out_count[img] = 0;
     return;
   }
+  if (!w.legacy && cnt <= w.matn) return;  // the matrix path (nms_rank / nms_matrix / nms_scan) owns this image
   const long long base = (long long)img * w.cap;
   // Only as many waves as the candidate count deserves take part (surplus waves exit before the first barrier;
   // s_barrier only counts live waves).  Up to 2048 candidates every thread owns <= 2 of them and the greedy loop
@@ -479,6 +533,189 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
   if (t == 0) out_count[img] = kept;
 }
 
+
+// ---- matrix path -------------------------------------------------------------------------------
+// rank: sorted position of every candidate = number of larger keys (keys are unique: they embed the row).  256 candidates
+// per workgroup; the image's keys go through LDS in tiles of 2048, two keys per ds_read_b128.
+constexpr int RANK_TILE = 2048;
+__global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w, int use_offsets) {
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) unsigned long long s_keys[RANK_TILE];
+  const int img = blockIdx.y;
+  const int cnt = w.cand_count[img];
+  if (w.legacy || cnt > w.matn || (int)blockIdx.x * 256 >= cnt) return;
+  const long long base = (long long)img * w.cap;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long mine = j < cnt ? w.key[base + j] : ~0ull;
+  int rank = 0;
+  for (int t0 = 0; t0 < cnt; t0 += RANK_TILE) {
+    const int len = cnt - t0 < RANK_TILE ? cnt - t0 : RANK_TILE;
+    __syncthreads();
+    for (int i = threadIdx.x; i < RANK_TILE; i += 256) s_keys[i] = i < len ? w.key[base + t0 + i] : 0ull;  // 0 < every key
+    __syncthreads();
+    const int len2 = (len + 1) & ~1;
+    for (int i = 0; i < len2; i += 2) {
+      const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(&s_keys[i]);
+      rank += (k2.x > mine ? 1 : 0) + (k2.y > mine ? 1 : 0);
+    }
+  }
+  if (j >= cnt) return;
+  float4 bb = w.raw[base + j];
+  if (use_offsets) {
+    const float maxc = w.nanflag[img] ? NAN : unsortable(w.maxbits[img]);
+    const float o = w.label[base + j] * (maxc + 1.f);
+    bb.x = bb.x + o; bb.y = bb.y + o; bb.z = bb.z + o; bb.w = bb.w + o;
+  }
+  w.off[base + rank] = bb;
+  w.sslot[base + rank] = j;
+}
+
+// matrix: item = (image, block row bi, block column bj >= bi) of 64 x 64 candidates; persistent grid, one wave per item.
+// Lane i owns sorted candidate bi * 64 + i and tests it against the 64 column candidates (broadcast by readlane).
+__global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float iou_thresh) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  // items of image g: W_g * W_g (the lower-triangular ones are skipped), W_g = blocks of 64 candidates
+  int img = 0, first = 0;  // first item index of image img
+  int W = 0;
+  auto blocks_of = [&](int g) {
+    const int c = w.cand_count[g];
+    return (w.legacy || c > w.matn) ? 0 : (c + 63) >> 6;
+  };
+  W = blocks_of(0);
+  for (int q = wave_global;; q += nwaves) {
+    while (img < n && q >= first + W * W) {
+      first += W * W;
+      ++img;
+      W = img < n ? blocks_of(img) : 0;
+    }
+    if (img >= n) return;
+    const int r = q - first;
+    const int bi = r / W, bj = r - bi * W;
+    if (bj < bi) continue;
+    const int cnt = w.cand_count[img];
+    const long long base = (long long)img * w.cap;
+    const int row = bi * 64 + lane, col = bj * 64 + lane;
+    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f), cb = rb;
+    if (row < cnt) rb = w.off[base + row];
+    if (col < cnt) cb = w.off[base + col];
+    const float ra = box_area(rb), ca = box_area(cb);
+    unsigned long long bits = 0ull;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+      float4 bjx;
+      bjx.x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.x), b));
+      bjx.y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.y), b));
+      bjx.z = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.z), b));
+      bjx.w = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.w), b));
+      const float ja = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(ca), b));
+      const int j = bj * 64 + b;
+      if (j > row && j < cnt && iou_exceeds(rb, ra, bjx, ja, iou_thresh)) bits |= 1ull << b;
+    }
+    if (row < cnt) w.mat[((long long)img * w.matn + row) * w.wc + bj] = bits;
+  }
+}
+
+// scan: one workgroup per image.  Block b's 64 matrix rows (64 x wc words) sit in LDS; the rows of block b + 1 are loaded
+// into registers before wave 0 resolves block b, and stored to the other LDS buffer afterwards.
+__global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int* out_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
+  const int img = blockIdx.x;
+  const int cnt = w.cand_count[img];
+  if (cnt == 0 || w.legacy || cnt > w.matn) return;  // (cnt == 0: the legacy kernel writes the zero count)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wc = w.wc;                                   // words per matrix row (<= 64)
+  const int nblk = (cnt + 63) >> 6;
+  unsigned long long* buf[2] = {reinterpret_cast<unsigned long long*>(scan_lds),
+                                reinterpret_cast<unsigned long long*>(scan_lds) + 64 * wc};
+  int* s_keep = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(scan_lds) + 128 * wc);  // [max_det] sorted positions
+  __shared__ int s_stop, s_kept;
+  const unsigned long long* mat = w.mat + (long long)img * w.matn * wc;
+  // a block = 64 rows x wc words = 64 * wc * 8 bytes; thread t moves pieces t, t + 256, ... of 16 bytes (wc * 4 pieces per row pair)
+  const int pieces = 64 * wc / 2;          // 16-byte pieces per block
+  constexpr int PMAX = 8;                  // 64 * 64 / 2 / 256
+  ulonglong2 stage[PMAX];
+  auto fetch = [&](int blk) {
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+      const int pc = t + k * 256;
+      stage[k] = make_ulonglong2(0ull, 0ull);
+      if (pc < pieces) {
+        const int row = blk * 64 + (pc * 2) / wc;
+        if (row < cnt) stage[k] = *reinterpret_cast<const ulonglong2*>(mat + (long long)blk * 64 * wc + pc * 2);
+      }
+    }
+  };
+  auto put = [&](int which) {
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+      const int pc = t + k * 256;
+      if (pc < pieces) *reinterpret_cast<ulonglong2*>(buf[which] + pc * 2) = stage[k];
+    }
+  };
+  if (t == 0) {
+    s_stop = 0;
+    s_kept = 0;
+  }
+  fetch(0);
+  put(0);
+  __syncthreads();
+  unsigned long long rem = 0ull;  // wave 0: lane l = removed bits of candidates 64 l .. 64 l + 63
+  int kept = 0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int cur = blk & 1;
+    const bool more = blk + 1 < nblk;
+    if (more) fetch(blk + 1);  // in flight while wave 0 works
+    if (wv == 0) {
+      const unsigned long long* B = buf[cur];
+      // diagonal word of this lane's row (lower-triangular / stale words are never read: word index >= block index)
+      const unsigned long long diag = B[lane * wc + blk];
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rem, blk);
+      const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), blk);
+      unsigned long long curbits = ((unsigned long long)rhi << 32) | rlo;
+      const int last = cnt - (blk << 6);
+      const unsigned long long valid = last >= 64 ? ~0ull : ((1ull << last) - 1ull);
+      unsigned long long avail = ~curbits & valid;
+      unsigned long long keptmask = 0ull;
+      while (avail != 0ull && kept < max_det) {
+        const int i = __builtin_ctzll(avail);
+        keptmask |= 1ull << i;
+        if (lane == 0) s_keep[kept] = (blk << 6) + i;
+        ++kept;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+        curbits |= ((unsigned long long)hi << 32) | lo;
+        avail = ~curbits & valid & (i == 63 ? 0ull : (~0ull << (i + 1)));
+      }
+      // the winners' rows into the removed mask: lane = word
+      if (lane < wc) {
+        unsigned long long km = keptmask;
+        while (km != 0ull) {
+          const int i = __builtin_ctzll(km);
+          km &= km - 1ull;
+          rem |= B[i * wc + lane];
+        }
+      }
+      if (lane == 0) {
+        s_kept = kept;
+        if (kept >= max_det) s_stop = 1;
+      }
+    }
+    __syncthreads();             // wave 0 is done with buf[cur]; s_stop visible
+    if (s_stop) break;
+    if (more) put(cur ^ 1);
+    __syncthreads();
+  }
+  __syncthreads();
+  const int total = s_kept;
+  const long long base = (long long)img * w.cap;
+  for (int q = t; q < total; q += 256) w.keep_slot[base + q] = w.sslot[base + s_keep[q]];
+  if (t == 0) out_count[img] = total;
+}
+
 constexpr size_t kSelectLds = 112 * 1024;  // max(LDS_CANDS * 24, matrix mode: keys + boxes + sorted copies + 768 x 12 x 8 B bits)
 
 inline hipError_t select_lds_attr() {  // > 64 KiB of dynamic LDS needs the opt-in, once per process
@@ -522,6 +759,29 @@ __global__ __launch_bounds__(256) void nms_emit_indices_kernel(NmsWs w, const in
   keep[k] = (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
 }
 
+// the three launches of the matrix path (every kernel returns at once for images it does not own)
+inline int launch_matrix_path(const NmsWs& w, int n, int use_offsets, float iou_thresh, int max_det, int* out_count,
+                              hipStream_t stream) {
+  if (w.legacy) return 0;
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((w.matn + 255) / 256, n), dim3(256), 0, stream, w, use_offsets);
+  int rc = me::check_launch("nms_rank_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_matrix_kernel, dim3(1024), dim3(256), 0, stream, w, n, iou_thresh);
+  rc = me::check_launch("nms_matrix_kernel");
+  if (rc) return rc;
+  const int keep_cap = max_det < w.matn ? max_det : w.matn;  // an image of this path has at most matn candidates
+  const size_t lds = (size_t)128 * w.wc * 8 + (size_t)keep_cap * 4;
+  static bool attr = false;
+  if (!attr) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               96 * 1024));  // two 64 x 64-word buffers + <= 4096 winners = 80 KB at most
+    attr = true;
+  }
+  ME_REQUIRE(lds <= 96 * 1024, ME_E_TOOBIG, "me_nms: max_det %d too large for the scan kernel's LDS", max_det);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), lds, stream, w, max_det, out_count);
+  return me::check_launch("nms_scan_kernel");
+}
+
 }  // namespace
 
 extern "C" {
@@ -541,12 +801,14 @@ int me_nms_batched_f32(const me_nms_desc* d, void* stream_) {
   ME_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 255u) == 0, ME_E_ALIGN,
              "me_nms_batched_f32: workspace not 256-byte aligned");
   NmsWs w = carve(d->workspace, d->n, d->rows);
-  ME_HIP(hipMemsetAsync(w.cand_count, 0, sizeof(int) * d->n, stream));
+  ME_HIP(hipMemsetAsync(w.cand_count, 0, 3 * sizeof(int) * d->n, stream));  // counts, max-coordinate bits, NaN flags
   hipLaunchKernelGGL(nms_prep_kernel, dim3((d->rows + 255) / 256, d->n), dim3(256), 0, stream, d->pred, d->rows,
                      d->num_classes, d->conf_thresh, d->writeback_xyxy, w);
   int rc = me::check_launch("nms_prep_kernel");
   if (rc) return rc;
   const int max_det = d->max_det < d->rows ? d->max_det : d->rows;
+  rc = launch_matrix_path(w, d->n, 1, d->iou_thresh, max_det, d->count, stream);
+  if (rc) return rc;
   ME_HIP(select_lds_attr());
   hipLaunchKernelGGL(nms_select_kernel, dim3(d->n), dim3(SEL_THREADS), kSelectLds, stream, w, 1, d->iou_thresh, max_det,
                      d->count);
@@ -570,8 +832,11 @@ int me_nms_boxes_f32(const float* boxes, const float* scores, const float* label
   ME_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, ME_E_ALIGN,
              "me_nms_boxes_f32: workspace not 256-byte aligned");
   NmsWs w = carve(workspace, 1, m);
+  ME_HIP(hipMemsetAsync(w.cand_count, 0, 3 * sizeof(int), stream));
   hipLaunchKernelGGL(nms_prep_boxes_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, boxes, scores, labels, m, w);
   int rc = me::check_launch("nms_prep_boxes_kernel");
+  if (rc) return rc;
+  rc = launch_matrix_path(w, 1, labels ? 1 : 0, iou_thresh, m, keep_count, stream);
   if (rc) return rc;
   ME_HIP(select_lds_attr());
   hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_THREADS), kSelectLds, stream, w, labels ? 1 : 0, iou_thresh, m,
