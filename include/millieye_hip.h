@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 5
+#define ME_ABI_VERSION 6
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -392,6 +392,21 @@ int64_t me_conv_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t
 int me_conv_wgrad_mfma_f32(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n,
                            int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
                            void* workspace, int64_t workspace_bytes, void* stream);
+/* the same, with dW written in the parameter's own layout [cout][cin][k][k] (what autograd hands to the optimizer): the
+ * slab reduction does the transposition.  workspace: max(me_conv_wgrad_workspace_bytes(...), cout*k*k*cin*4) bytes for k > 1. */
+int me_conv_wgrad_mfma_oihw_f32(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n,
+                                int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
+                                void* workspace, int64_t workspace_bytes, void* stream);
+/* me_pack_conv_f32 - one launch from a conv block's parameters (nn.Conv2d weight [cout][cin][k][k] + bias, optional
+ * nn.BatchNorm2d gamma / beta / running mean / running var, reference yolov3/models.py:22-41) to every packed copy the fp32
+ * kernels read: ohwi [cout][k][k][cin] (me_conv_desc.wgt), tiled [k*k][cin/16][cout][16] (wgt_tiled; NULL or cin % 16 == 0),
+ * rot [cin][k][k][cout] = the data gradient's weights (180-degree rotation, channels transposed; NULL = skip) with its tiled
+ * copy rot_tiled [k*k][cout/16][cin][16] (NULL or cout % 16 == 0), and the folded (scale, shift) [cout] computed in double:
+ * scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ bias * scale); gamma == NULL: scale = 1, shift = bias or 0.
+ * Replaces ~25 torch launches per layer and training step (millieye_amd/engine.py:ConvWeights.refresh). */
+int me_pack_conv_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t ksize, const float* bias, const float* gamma,
+                     const float* beta, const float* mean, const float* var, float eps, float* ohwi, float* tiled,
+                     float* rot, float* rot_tiled, float* scale, float* shift, void* stream);
 /* RoI pooling backward: grad_out [k,c_out,7,7] scattered (atomicAdd) into the zero-filled NHWC grad_map */
 int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
                          int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch, void* stream);

@@ -41,7 +41,9 @@ constexpr int MAX_ROWS = 32768;  // 32 candidates per thread
 constexpr int LDS_CANDS = 4096;  // candidates per image kept in LDS by nms_select (96 KiB)
 constexpr int MAT_CANDS = 768;   // ... up to this many are resolved through a suppression bit matrix in LDS (108 KiB)
 
-constexpr int MATN = 4096;       // candidates per image the matrix path handles (64 words of 64 bits: one per lane)
+constexpr int MATN = 1024;       // sorted candidates per image the matrix path looks at: the greedy walk stops at max_det winners,
+                                 // and 200 winners almost always sit among the 1024 best-scored candidates; an image that needs
+                                 // more (nms_scan sets its fallback flag) is redone by the single-workgroup kernel
 
 struct NmsWs {
   float4* raw;               // [n][cap] raw xyxy
@@ -55,6 +57,7 @@ struct NmsWs {
   int* cand_count;           // [n]   } one memset
   unsigned* maxbits;         // [n]   } sortable() bits of the largest coordinate among the candidates
   int* nanflag;              // [n]   } a candidate coordinate is NaN
+  int* fallback;             // [n]   } nms_scan: the capped matrix did not reach max_det winners - nms_select redoes the image
   int cap, matn, wc;         // wc = matn / 64 words per matrix row
   int legacy;                // force the single-workgroup kernel
 };
@@ -74,7 +77,7 @@ inline long long ws_bytes(int n, int rows) {
   b += align_up((long long)n * cap * 8, 256);       // key
   b += align_up((long long)n * cap * 4, 256) * 4;   // label, clsconf, keep_slot, sslot
   b += align_up((long long)n * matn * (matn / 64) * 8, 256);  // mat
-  b += align_up((long long)n * 12, 256);            // cand_count, maxbits, nanflag
+  b += align_up((long long)n * 16, 256);            // cand_count, maxbits, nanflag, fallback
   return b;
 }
 
@@ -96,6 +99,7 @@ inline NmsWs carve(void* base, int n, int rows) {
   w.cand_count = reinterpret_cast<int*>(p);
   w.maxbits = reinterpret_cast<unsigned*>(p) + n;
   w.nanflag = reinterpret_cast<int*>(p) + 2 * n;
+  w.fallback = reinterpret_cast<int*>(p) + 3 * n;
   static const int legacy = [] {
     const char* e = getenv("MILLIEYE_NMS_LEGACY");
     return (e && e[0] == '1') ? 1 : 0;
@@ -126,41 +130,98 @@ __device__ __forceinline__ float unsortable(unsigned u) {
 }
 
 // ---- prep -------------------------------------------------------------------------------------
+// class max / argmax of one row by a group of 16 lanes: torch.max(1) semantics = the sequential scan "replace when v > best,
+// or when v is NaN and best is not" - i.e. the order: any NaN beats every number (first NaN wins), otherwise the larger
+// value, ties to the lower index - which is associative, so a shuffle tree gives the same answer.
+__device__ __forceinline__ bool cls_beats(float v, int i, float bv, int bi) {
+  const bool vn = v != v, bn = bv != bv;
+  if (vn != bn) return vn;
+  if (vn) return i < bi;
+  return v > bv || (v == bv && i < bi);
+}
+
 __global__ __launch_bounds__(256) void nms_prep_kernel(float* pred, int rows, int num_classes, float conf_thresh,
                                                        int writeback, NmsWs w) {
 #pragma clang fp contract(off)
+  __shared__ int s_rows[256];
+  __shared__ int s_n, s_base, s_nan;
+  __shared__ unsigned s_max;
   const int img = blockIdx.y;
   const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= rows) return;
   const int per = 5 + num_classes;
-  float* p = pred + ((long long)img * rows + row) * per;
-  const float cx = p[0], cy = p[1], bw = p[2], bh = p[3], conf = p[4];
-  // xywh2xyxy (utils.py:68-74): half extents as w / 2
-  const float x1 = cx - bw / 2, y1 = cy - bh / 2, x2 = cx + bw / 2, y2 = cy + bh / 2;
-  if (writeback) {
-    p[0] = x1; p[1] = y1; p[2] = x2; p[3] = y2;
+  if (threadIdx.x == 0) {
+    s_n = 0;
+    s_nan = 0;
+    s_max = 0u;
   }
-  if (!(conf >= conf_thresh)) return;
-  // torch.max(1): first index of the maximum
-  float best = -INFINITY;
-  int arg = 0;
-  if (num_classes > 0) {
-    best = p[5];
-    for (int c = 1; c < num_classes; ++c) {
+  __syncthreads();
+  if (row < rows) {
+    float* p = pred + ((long long)img * rows + row) * per;
+    const float conf = p[4];
+    if (writeback) {  // xywh2xyxy (utils.py:68-74) in place on every row: half extents as w / 2
+      const float cx = p[0], cy = p[1], bw = p[2], bh = p[3];
+      p[0] = cx - bw / 2; p[1] = cy - bh / 2; p[2] = cx + bw / 2; p[3] = cy + bh / 2;
+    }
+    if (conf >= conf_thresh) s_rows[atomicAdd(&s_n, 1)] = row;  // order is irrelevant: the key carries the row index
+  }
+  __syncthreads();
+  // the (few) rows that pass: 16 lanes per row read its class scores in 64-byte pieces - the one-thread-per-row loop of
+  // rounds 1-2 walked 80 dependent 4-byte loads per passing row while the other lanes of its wave waited (78 us at batch 32)
+  const int npass = s_n;
+  if (npass == 0) return;
+  // ONE global atomic per block for the slots, one for the maximum: thousands of same-address atomics per image serialise in
+  // the L2 (2500 candidates per image: 59 us with one atomicAdd per candidate, 78 us with the atomicMax beside it)
+  if (threadIdx.x == 0) s_base = atomicAdd(&w.cand_count[img], npass);
+  __syncthreads();
+  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+  for (int q = grp; q < npass; q += 16) {
+    const int r = s_rows[q];
+    const float* p = pred + ((long long)img * rows + r) * per;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = gl; c < num_classes; c += 16) {
       const float v = p[5 + c];
-      if (v > best || (v != v && best == best)) {  // NaN propagates like torch.max
+      if (arg == 0x7fffffff || cls_beats(v, c, best, arg)) {
         best = v;
         arg = c;
       }
     }
+#pragma unroll
+    for (int sft = 8; sft >= 1; sft >>= 1) {
+      const float ov = __shfl_xor(best, sft, 16);
+      const int oi = __shfl_xor(arg, sft, 16);
+      if (oi != 0x7fffffff && (arg == 0x7fffffff || cls_beats(ov, oi, best, arg))) {
+        best = ov;
+        arg = oi;
+      }
+    }
+    if (gl == 0) {
+      if (num_classes <= 0) {
+        best = -INFINITY;
+        arg = 0;
+      }
+      float x1, y1, x2, y2;
+      if (writeback) {  // already converted above (same thread block, behind the barrier)
+        x1 = p[0]; y1 = p[1]; x2 = p[2]; y2 = p[3];
+      } else {
+        const float cx = p[0], cy = p[1], bw = p[2], bh = p[3];
+        x1 = cx - bw / 2; y1 = cy - bh / 2; x2 = cx + bw / 2; y2 = cy + bh / 2;
+      }
+      const long long o = (long long)img * w.cap + s_base + q;
+      w.raw[o] = make_float4(x1, y1, x2, y2);
+      w.key[o] = make_key(p[4], r);
+      w.label[o] = (float)arg;
+      w.clsconf[o] = best;
+      if ((x1 != x1) | (y1 != y1) | (x2 != x2) | (y2 != y2)) atomicOr(&s_nan, 1);
+      const float m = fmaxf(fmaxf(x1, y1), fmaxf(x2, y2));
+      if (m == m) atomicMax(&s_max, sortable(m));
+    }
   }
-  const int slot = atomicAdd(&w.cand_count[img], 1);
-  const long long o = (long long)img * w.cap + slot;
-  w.raw[o] = make_float4(x1, y1, x2, y2);
-  w.key[o] = make_key(conf, row);
-  w.label[o] = (float)arg;
-  w.clsconf[o] = best;
-  note_max_coord(w, img, x1, y1, x2, y2);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_nan) atomicOr(&w.nanflag[img], 1);
+    if (s_max) atomicMax(&w.maxbits[img], s_max);
+  }
 }
 
 // explicit boxes (box_ops.nms / batched_nms): every box is a candidate, img = 0
@@ -242,7 +303,7 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(NmsWs w, int us
     if (t == 0) out_count[img] = 0;
     return;
   }
-  if (!w.legacy && cnt <= w.matn) return;  // the matrix path (nms_rank / nms_matrix / nms_scan) owns this image
+  if (!w.legacy && !w.fallback[img]) return;  // the matrix path (nms_rank / nms_matrix / nms_scan) has done this image
   const long long base = (long long)img * w.cap;
   // Only as many waves as the candidate count deserves take part (surplus waves exit before the first barrier;
   // s_barrier only counts live waves).  Up to 2048 candidates every thread owns <= 2 of them and the greedy loop
@@ -543,7 +604,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w, int use_offsets)
   __shared__ __attribute__((aligned(16))) unsigned long long s_keys[RANK_TILE];
   const int img = blockIdx.y;
   const int cnt = w.cand_count[img];
-  if (w.legacy || cnt > w.matn || (int)blockIdx.x * 256 >= cnt) return;
+  if (w.legacy || (int)blockIdx.x * 256 >= cnt) return;
   const long long base = (long long)img * w.cap;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const unsigned long long mine = j < cnt ? w.key[base + j] : ~0ull;
@@ -559,7 +620,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w, int use_offsets)
       rank += (k2.x > mine ? 1 : 0) + (k2.y > mine ? 1 : 0);
     }
   }
-  if (j >= cnt) return;
+  if (j >= cnt || rank >= w.matn) return;  // only the matn best-scored candidates enter the matrix
   float4 bb = w.raw[base + j];
   if (use_offsets) {
     const float maxc = w.nanflag[img] ? NAN : unsortable(w.maxbits[img]);
@@ -581,8 +642,8 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
   int img = 0, first = 0;  // first item index of image img
   int W = 0;
   auto blocks_of = [&](int g) {
-    const int c = w.cand_count[g];
-    return (w.legacy || c > w.matn) ? 0 : (c + 63) >> 6;
+    const int c = w.cand_count[g] < w.matn ? w.cand_count[g] : w.matn;
+    return w.legacy ? 0 : (c + 63) >> 6;
   };
   W = blocks_of(0);
   for (int q = wave_global;; q += nwaves) {
@@ -595,7 +656,7 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
     const int r = q - first;
     const int bi = r / W, bj = r - bi * W;
     if (bj < bi) continue;
-    const int cnt = w.cand_count[img];
+    const int cnt = w.cand_count[img] < w.matn ? w.cand_count[img] : w.matn;
     const long long base = (long long)img * w.cap;
     const int row = bi * 64 + lane, col = bj * 64 + lane;
     float4 rb = make_float4(0.f, 0.f, 0.f, 0.f), cb = rb;
@@ -612,7 +673,18 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
       bjx.w = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.w), b));
       const float ja = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(ca), b));
       const int j = bj * 64 + b;
-      if (j > row && j < cnt && iou_exceeds(rb, ra, bjx, ja, iou_thresh)) bits |= 1ull << b;
+      const bool live = j > row && j < cnt;
+      if (iou_thresh >= 0.f) {
+        // boxes that do not overlap have inter = 0: 0 / union is 0 (or NaN) and never exceeds a non-negative threshold; when
+        // no row of the wave overlaps column b - the common case with class offsets - the division is skipped (uniform branch)
+        const float xx1 = (rb.x < bjx.x) ? bjx.x : rb.x, yy1 = (rb.y < bjx.y) ? bjx.y : rb.y;
+        const float xx2 = (bjx.z < rb.z) ? bjx.z : rb.z, yy2 = (bjx.w < rb.w) ? bjx.w : rb.w;
+        const bool pos = live && (0.f < xx2 - xx1) && (0.f < yy2 - yy1);
+        if (__builtin_amdgcn_ballot_w64(pos) == 0ull) continue;
+        if (pos && iou_exceeds(rb, ra, bjx, ja, iou_thresh)) bits |= 1ull << b;
+      } else if (live && iou_exceeds(rb, ra, bjx, ja, iou_thresh)) {
+        bits |= 1ull << b;
+      }
     }
     if (row < cnt) w.mat[((long long)img * w.matn + row) * w.wc + bj] = bits;
   }
@@ -623,8 +695,9 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
 __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int* out_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
   const int img = blockIdx.x;
-  const int cnt = w.cand_count[img];
-  if (cnt == 0 || w.legacy || cnt > w.matn) return;  // (cnt == 0: the legacy kernel writes the zero count)
+  const int cnt_all = w.cand_count[img];
+  if (cnt_all == 0 || w.legacy) return;  // (cnt == 0: the legacy kernel writes the zero count)
+  const int cnt = cnt_all < w.matn ? cnt_all : w.matn;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int wc = w.wc;                                   // words per matrix row (<= 64)
   const int nblk = (cnt + 63) >> 6;
@@ -635,7 +708,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int
   const unsigned long long* mat = w.mat + (long long)img * w.matn * wc;
   // a block = 64 rows x wc words = 64 * wc * 8 bytes; thread t moves pieces t, t + 256, ... of 16 bytes (wc * 4 pieces per row pair)
   const int pieces = 64 * wc / 2;          // 16-byte pieces per block
-  constexpr int PMAX = 8;                  // 64 * 64 / 2 / 256
+  constexpr int PMAX = MATN / 64 * 64 / 2 / 256;   // 16-byte pieces per thread and block
   ulonglong2 stage[PMAX];
   auto fetch = [&](int blk) {
 #pragma unroll
@@ -711,6 +784,10 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int
   }
   __syncthreads();
   const int total = s_kept;
+  if (total < max_det && cnt_all > cnt) {  // the walk ran off the capped list: the single-workgroup kernel redoes this image
+    if (t == 0) w.fallback[img] = 1;
+    return;
+  }
   const long long base = (long long)img * w.cap;
   for (int q = t; q < total; q += 256) w.keep_slot[base + q] = w.sslot[base + s_keep[q]];
   if (t == 0) out_count[img] = total;
@@ -763,7 +840,7 @@ __global__ __launch_bounds__(256) void nms_emit_indices_kernel(NmsWs w, const in
 inline int launch_matrix_path(const NmsWs& w, int n, int use_offsets, float iou_thresh, int max_det, int* out_count,
                               hipStream_t stream) {
   if (w.legacy) return 0;
-  hipLaunchKernelGGL(nms_rank_kernel, dim3((w.matn + 255) / 256, n), dim3(256), 0, stream, w, use_offsets);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((w.cap + 255) / 256, n), dim3(256), 0, stream, w, use_offsets);
   int rc = me::check_launch("nms_rank_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(nms_matrix_kernel, dim3(1024), dim3(256), 0, stream, w, n, iou_thresh);
@@ -801,7 +878,7 @@ int me_nms_batched_f32(const me_nms_desc* d, void* stream_) {
   ME_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 255u) == 0, ME_E_ALIGN,
              "me_nms_batched_f32: workspace not 256-byte aligned");
   NmsWs w = carve(d->workspace, d->n, d->rows);
-  ME_HIP(hipMemsetAsync(w.cand_count, 0, 3 * sizeof(int) * d->n, stream));  // counts, max-coordinate bits, NaN flags
+  ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * d->n, stream));  // counts, max-coordinate bits, NaN / fallback flags
   hipLaunchKernelGGL(nms_prep_kernel, dim3((d->rows + 255) / 256, d->n), dim3(256), 0, stream, d->pred, d->rows,
                      d->num_classes, d->conf_thresh, d->writeback_xyxy, w);
   int rc = me::check_launch("nms_prep_kernel");
@@ -832,7 +909,7 @@ int me_nms_boxes_f32(const float* boxes, const float* scores, const float* label
   ME_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, ME_E_ALIGN,
              "me_nms_boxes_f32: workspace not 256-byte aligned");
   NmsWs w = carve(workspace, 1, m);
-  ME_HIP(hipMemsetAsync(w.cand_count, 0, 3 * sizeof(int), stream));
+  ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int), stream));
   hipLaunchKernelGGL(nms_prep_boxes_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, boxes, scores, labels, m, w);
   int rc = me::check_launch("nms_prep_boxes_kernel");
   if (rc) return rc;

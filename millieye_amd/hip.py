@@ -198,6 +198,10 @@ SIGNATURES = {
     "me_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int32] * 6),
     "me_conv_wgrad_mfma_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
                                + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_conv_wgrad_mfma_oihw_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
+                                    + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_pack_conv_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_float]
+                         + [C.c_void_p] * 7),
     "me_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "me_ps_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -233,8 +237,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 5:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 5")
+    if lib_.me_abi_version() != 6:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 6")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
@@ -604,19 +608,23 @@ def ps_roi_align(map_nhwc, rois, pooled=7, spatial_scale=1.0 / 16):
     return _roi("me_ps_roi_align_f32", map_nhwc, rois, pooled, spatial_scale, True)
 
 
-def conv_wgrad(x_nhwc, dy_nhwc, ksize, stride, pad):
-    """dW [cout, k, k, cin] (the packed layout of me_conv2d_f32) of y = conv(x, W) given dy, on the matrix pipe
-    (me_conv_wgrad_mfma_f32; slices of the pixel reduction go through a workspace and are added in a fixed order)."""
+def conv_wgrad(x_nhwc, dy_nhwc, ksize, stride, pad, oihw=False):
+    """dW of y = conv(x, W) given dy, on the matrix pipe (me_conv_wgrad_mfma_f32; slices of the pixel reduction go through a
+    workspace and are added in a fixed order): [cout, k, k, cin] (the packed layout of me_conv2d_f32), or - ``oihw`` - the
+    parameter's own [cout, cin, k, k] (me_conv_wgrad_mfma_oihw_f32: the slab reduction transposes, no extra launch)."""
     _require_cuda_f32(x_nhwc, "x")
     _require_cuda_f32(dy_nhwc, "dy")
     n, h, w, cin = x_nhwc.shape
     _, ho, wo, cout = dy_nhwc.shape
-    dw = torch.empty((cout, ksize, ksize, cin), device=x_nhwc.device, dtype=torch.float32)
+    shape = (cout, cin, ksize, ksize) if oihw else (cout, ksize, ksize, cin)
+    dw = torch.empty(shape, device=x_nhwc.device, dtype=torch.float32)
     need = lib().me_conv_wgrad_workspace_bytes(n, ho, wo, cin, cout, ksize)
+    if oihw and ksize > 1:
+        need = max(need, 4 * cout * cin * ksize * ksize)
     ws_ptr, keep = (None, None)
     if need > 0:
         ws_ptr, keep = _workspace(need, x_nhwc.device, slot="wgrad")
-    check(lib().me_conv_wgrad_mfma_f32(x_nhwc.data_ptr(), x_nhwc.stride(2), dy_nhwc.data_ptr(), dy_nhwc.stride(2),
-                                       dw.data_ptr(), n, h, w, cin, cout, ksize, stride, pad, ws_ptr, need, stream_ptr()),
-          "me_conv_wgrad_mfma_f32")
+    fn = lib().me_conv_wgrad_mfma_oihw_f32 if oihw else lib().me_conv_wgrad_mfma_f32
+    check(fn(x_nhwc.data_ptr(), x_nhwc.stride(2), dy_nhwc.data_ptr(), dy_nhwc.stride(2), dw.data_ptr(), n, h, w, cin, cout,
+             ksize, stride, pad, ws_ptr, need, stream_ptr()), "me_conv_wgrad_mfma_f32")
     return dw

@@ -59,6 +59,35 @@ def test_nms_matches_oracle_bitexact(hip_lib, n, rows, nc, thr):
             assert torch.equal(det[i, :cnt[i]].cpu(), ref[i]), f"image {i}: kept rows differ"
 
 
+def test_nms_capped_matrix_falls_back_when_it_runs_out(hip_lib):
+    """The multi-workgroup path looks at the 1024 best-scored candidates of an image; when those do not yield max_det
+    winners and more candidates exist (here: 3000 candidates in 60 tight clusters - every cluster keeps one box, so the walk
+    has to visit all of them), the image is redone by the single-workgroup kernel.  Both images of the batch must equal the
+    oracle bit for bit: image 0 takes the fallback, image 1 (300 well separated boxes) does not."""
+    from millieye_amd import hip
+    n, rows, nc = 2, 3200, 4
+    g = np.random.RandomState(5)
+    pred = np.zeros((n, rows, 5 + nc), dtype=np.float32)
+    centres = g.uniform(40, 380, size=(60, 2)).astype(np.float32)
+    which = g.randint(0, 60, size=rows)
+    pred[0, :, 0:2] = centres[which] + g.uniform(-1.5, 1.5, size=(rows, 2)).astype(np.float32)
+    pred[0, :, 2:4] = 60.0
+    pred[0, :, 4] = g.uniform(0.05, 1.0, size=rows)
+    pred[0, :, 5] = 0.9
+    pred[1, :, 0:2] = g.uniform(0, 416, size=(rows, 2))
+    pred[1, :, 2:4] = g.uniform(4, 12, size=(rows, 2))
+    pred[1, :, 4] = np.where(np.arange(rows) < 300, g.uniform(0.5, 1.0, size=rows), 0.01)
+    pred[1, :, 5:] = g.uniform(0, 1, size=(rows, nc))
+    pred = torch.from_numpy(pred)
+    ref, _ = _oracle_nms_cpp(pred, 0.1)
+    det, cnt = hip.nms_batched(pred.cuda(), 0.1, 0.5, 200, writeback_xyxy=False)
+    cnt = cnt.cpu().tolist()
+    assert ref[0].shape[0] < 200 and int((pred[0, :, 4] >= 0.1).sum()) > 1024, "image 0 must exhaust the capped list"
+    for i in range(n):
+        assert cnt[i] == ref[i].shape[0], f"image {i}: kept {cnt[i]} vs oracle {ref[i].shape[0]}"
+        assert torch.equal(det[i, :cnt[i]].cpu(), ref[i]), f"image {i}: kept rows differ"
+
+
 def test_nms_properties_and_edges(hip_lib):
     from millieye_amd import hip
     from millieye_amd.utils.utils import non_max_suppression_cpp, box_ops
