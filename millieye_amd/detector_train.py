@@ -66,6 +66,7 @@ class DetectorTrainer:
             t = d["type"]
             if t == "convolutional":
                 cw = eng._conv_weights(i)
+                cw.want_rot = i > 0  # the data gradient's weights come out of the same pack launch
                 cw.refresh(x.device)
                 k, s = int(d["size"]), int(d["stride"])
                 act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
@@ -77,13 +78,15 @@ class DetectorTrainer:
                     if cout > 2048:
                         raise hip.MeError("train-mode BatchNorm: more than 2048 channels")
                     ones, zeros = _const_vectors(cout, x.device)
-                    c_raw = hip.conv2d(src, cw.wgt, ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, x_nchw=(i == 0))
+                    c_raw = hip.conv2d_auto(src, cw.wgt, ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, x_nchw=(i == 0),
+                                            wgt_tiled=cw.wgt_tiled)
                     y = torch.empty_like(c_raw)
                     rows = c_raw.numel() // cout
                     st_bn = _bn_fwd(c_raw, cout, rows, cout, bn, act, y, cout, ws)
                     bn_state[i] = (c_raw, st_bn)
                 else:
-                    y = hip.conv2d(src, cw.wgt, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0))
+                    y = hip.conv2d_auto(src, cw.wgt, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0),
+                                        wgt_tiled=cw.wgt_tiled)
             elif t == "maxpool":
                 k, s = int(d["size"]), int(d["stride"])
                 y = hip.maxpool(outs[i - 1], k, s, zero_ext=(k == 2 and s == 1))
@@ -124,26 +127,52 @@ class DetectorTrainer:
         defs, outs, x = m.module_defs, st.outs, st.x
         dev = x.device
         L = len(defs)
+        # Gradient slots: dout[i] = (tensor, owned).  The first contribution to a slot is taken as it is - a fresh tensor is
+        # owned, an alias of somebody else's gradient (a [shortcut] hands its dy to both inputs) is not - and only a second
+        # contribution adds: in place when the slot owns its tensor, into a fresh sum otherwise.  Rounds 1-2 zero-filled a
+        # buffer per module and added every contribution into it: ~150 fill + add launches per step that moved ~5 GB.
         dout = [None] * L
         grads = {}
         stream = hip.stream_ptr
 
-        def grad_buf(i):
-            if dout[i] is None:
-                dout[i] = torch.zeros_like(outs[i])
-            return dout[i]
+        def add_out(a_t, b_t, out_t):
+            c = a_t.shape[-1]
+            hip.check(lib.me_add_f32(a_t.data_ptr(), a_t.stride(-2), b_t.data_ptr(), b_t.stride(-2), out_t.data_ptr(),
+                                     out_t.stride(-2), a_t.numel() // c, c, stream()), "me_add_f32")
+
+        def contribute(i, g, fresh):
+            """``g``: a gradient w.r.t. module i's output (NHWC, dense or a channel slice); ``fresh``: nobody else holds it."""
+            cur = dout[i]
+            if cur is None:
+                if fresh and g.is_contiguous():
+                    dout[i] = (g, True)
+                elif g.is_contiguous():
+                    dout[i] = (g, False)
+                else:  # a channel slice of a wider gradient ([route]): densify once
+                    dense = torch.empty(g.shape, device=dev, dtype=torch.float32)
+                    c = g.shape[-1]
+                    hip.check(lib.me_copy_f32(g.data_ptr(), g.stride(-2), dense.data_ptr(), c, g.numel() // c, c, stream()),
+                              "me_copy_f32")
+                    dout[i] = (dense, True)
+                return
+            t_cur, owned = cur
+            if owned:
+                add_out(t_cur, g, t_cur)
+            else:
+                total = torch.empty_like(t_cur)
+                add_out(t_cur, g, total)
+                dout[i] = (total, True)
 
         x_nhwc = None
         for i in reversed(range(L)):
             d = defs[i]
             t = d["type"]
             if t == "yolo":
-                g = draws[i]
-                _add_into(grad_buf(i - 1), g.data_ptr(), g.shape[-1], g.numel() // g.shape[-1], g.shape[-1])
+                contribute(i - 1, draws[i], True)
                 continue
-            dy = dout[i]
-            if dy is None:
+            if dout[i] is None:
                 continue
+            dy, dy_owned = dout[i]
             if t == "convolutional":
                 seq = m.module_list[i]
                 conv = seq[0]
@@ -155,7 +184,8 @@ class DetectorTrainer:
                 y = outs[i]
                 n, ho, wo, cout = y.shape
                 rows = n * ho * wo
-                dc = torch.empty_like(y)
+                # eval-mode BatchNorm: dc = dy * act'(y) * scale is element-wise - in place when this slot owns its gradient
+                dc = dy if (dy_owned and i not in st.bn_state) else torch.empty_like(y)
                 if i in st.bn_state:  # train-mode BatchNorm: gradient through the batch statistics
                     from .train_path import _bn_bwd
                     c_raw, st_bn = st.bn_state[i]
@@ -166,8 +196,8 @@ class DetectorTrainer:
                     dshift = torch.empty(cout, device=dev)
                     dgamma = torch.empty(cout, device=dev) if bn is not None else None
                     ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
-                    gam = bn.weight.detach().to(dev, torch.float32).contiguous() if bn is not None else None
-                    bet = bn.bias.detach().to(dev, torch.float32).contiguous() if bn is not None else None
+                    gam = bn.weight.detach() if bn is not None else None
+                    bet = bn.bias.detach() if bn is not None else None
                     hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
                                                         cw.scale.data_ptr() if bn is not None else None, _ptr(gam),
                                                         _ptr(bet), act, dc.data_ptr(), cout, dshift.data_ptr(),
@@ -177,7 +207,7 @@ class DetectorTrainer:
                     grads[f"module_list.{i}.batch_norm_{i}.bias"] = dshift
                 else:
                     grads[f"module_list.{i}.conv_{i}.bias"] = dshift
-                # weight gradient
+                # weight gradient, written in the parameter's own OIHW layout by the slab reduction
                 if i == 0:
                     if x_nhwc is None:
                         x_nhwc = x.permute(0, 2, 3, 1).contiguous()
@@ -185,8 +215,8 @@ class DetectorTrainer:
                 else:
                     xin = outs[i - 1]
                 _, h, w, cin = xin.shape
-                dw = hip.conv_wgrad(xin, dc, k, s, pad)  # MFMA weight gradient
-                grads[f"module_list.{i}.conv_{i}.weight"] = dw.permute(0, 3, 1, 2).contiguous()
+                grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
+                dout[i] = None
                 if i == 0:
                     continue
                 # data gradient
@@ -196,48 +226,66 @@ class DetectorTrainer:
                     dx = torch.empty((n, h, w, cin), device=dev, dtype=torch.float32)
                     hip.check(lib.me_gemm_f32(0, 0, rows, cin, cout, 1.0, dc.data_ptr(), cout, cw.wgt.data_ptr(), cin, 0.0,
                                               dx.data_ptr(), cin, stream()), "me_gemm_f32")
+                    contribute(i - 1, dx, True)
                 else:
-                    wt = cw.wgt.flip(1, 2).permute(3, 1, 2, 0).contiguous()  # [cin][k][k][cout], rotated 180 degrees
+                    if cw.rot is not None:  # [cin][k][k][cout] rotated 180 degrees, from the step's pack launch
+                        wt, wt_tiled = cw.rot, cw.rot_tiled
+                    else:
+                        wt, wt_tiled = cw.wgt.flip(1, 2).permute(3, 1, 2, 0).contiguous(), None
                     ones, zeros = _const_vectors(cin, dev)
+                    # a gradient already waiting in the consumer's slot rides in as the conv's residual: dx + existing in one
+                    # launch (in place when the slot owns its tensor: every element is read, then written, by one lane)
+                    prev = dout[i - 1]
+                    res = prev[0] if prev is not None and prev[0].is_contiguous() else None
+                    out_t = res if (prev is not None and prev[1] and res is not None) else None
                     if s == 1:
-                        dx = hip.conv2d(dc, wt, ones, zeros, k, 1, k - 1 - pad, hip.ACT_LINEAR)
+                        dx = hip.conv2d_auto(dc, wt, ones, zeros, k, 1, k - 1 - pad, hip.ACT_LINEAR, residual=res, out=out_t,
+                                             wgt_tiled=wt_tiled)
                     else:
                         # transposed convolution = stride-1 correlation over the zero-interleaved gradient
                         pp = k - 1 - pad
                         z = torch.zeros((n, h + k - 1, w + k - 1, cout), device=dev, dtype=torch.float32)
                         z[:, pp:pp + s * ho:s, pp:pp + s * wo:s, :] = dc
-                        dx = hip.conv2d(z, wt, ones, zeros, k, 1, 0, hip.ACT_LINEAR)
-                _add_into(grad_buf(i - 1), dx.data_ptr(), cin, n * h * w, cin)
+                        dx = hip.conv2d_auto(z, wt, ones, zeros, k, 1, 0, hip.ACT_LINEAR, residual=res, out=out_t,
+                                             wgt_tiled=wt_tiled)
+                    if res is not None:
+                        dout[i - 1] = (dx, True)
+                    else:
+                        contribute(i - 1, dx, True)
+                continue
             elif t == "shortcut":
-                c = dy.shape[-1]
-                px = dy.numel() // c
-                _add_into(grad_buf(i - 1), dy.data_ptr(), c, px, c)
-                _add_into(grad_buf(_resolve(d["from"], i)), dy.data_ptr(), c, px, c)
+                # both inputs receive dy itself; two slots now alias one tensor, so NEITHER may write into it (the conv in
+                # front of the shortcut is visited before the block's input and would otherwise run its backward in place)
+                contribute(i - 1, dy, False)
+                contribute(_resolve(d["from"], i), dy, False)
             elif t == "route":
                 srcs = [_resolve(v, i) for v in d["layers"].split(",")]
                 if len(srcs) == 1:
-                    c = dy.shape[-1]
-                    _add_into(grad_buf(srcs[0]), dy.data_ptr(), c, dy.numel() // c, c)
+                    contribute(srcs[0], dy, dy_owned)
                 else:
-                    ct, off = dy.shape[-1], 0
+                    off = 0
                     for sidx in srcs:
                         c = outs[sidx].shape[-1]
-                        _add_into(grad_buf(sidx), dy.data_ptr() + 4 * off, ct, dy.numel() // ct, c)
+                        contribute(sidx, dy[..., off:off + c], False)
                         off += c
             elif t == "upsample":
                 if int(d["stride"]) != 2:
                     raise NotImplementedError("upsample backward: stride 2 only")
                 n, h, w, c = outs[i - 1].shape
-                hip.check(lib.me_upsample2_bwd_f32(dy.data_ptr(), c, grad_buf(i - 1).data_ptr(), c, n, h, w, c, stream()),
+                g = torch.zeros((n, h, w, c), device=dev, dtype=torch.float32)
+                hip.check(lib.me_upsample2_bwd_f32(dy.data_ptr(), c, g.data_ptr(), c, n, h, w, c, stream()),
                           "me_upsample2_bwd_f32")
+                contribute(i - 1, g, True)
             elif t == "maxpool":
                 k, s = int(d["size"]), int(d["stride"])
                 zero_ext = 1 if (k == 2 and s == 1) else 0
                 xin = outs[i - 1]
                 n, h, w, c = xin.shape
-                hip.check(lib.me_maxpool_bwd_f32(xin.data_ptr(), c, dy.data_ptr(), c, grad_buf(i - 1).data_ptr(), c, n, h, w,
+                g = torch.zeros((n, h, w, c), device=dev, dtype=torch.float32)
+                hip.check(lib.me_maxpool_bwd_f32(xin.data_ptr(), c, dy.data_ptr(), c, g.data_ptr(), c, n, h, w,
                                                  c, k, s, 0 if zero_ext else (k - 1) // 2, zero_ext, stream()),
                           "me_maxpool_bwd_f32")
+                contribute(i - 1, g, True)
             dout[i] = None  # free as we go
         return grads
 

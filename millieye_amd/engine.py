@@ -91,6 +91,11 @@ class ConvWeights:
         self.dtype, self.cin_pad, self.cout_pad = dtype, cin_pad, cout_pad
         self.wgt = self.scale = self.shift = None
         self.wgt_tiled = None  # second packing [taps][cin/32][cout][32] (16-bit 3x3 layers) / [taps][cin/16][cout][16] (fp32)
+        # data-gradient weights (fp32 only, built on demand by ``want_rot``): [cin][k][k][cout] rotated by 180 degrees with the
+        # channels transposed, and their tiled copy [k*k][cout/16][cin][16] - the detector's training step runs the data
+        # gradient as me_conv2d_f32 on these (millieye_amd/detector_train.py)
+        self.want_rot = False
+        self.rot = self.rot_tiled = None
         self._stamp = None
 
     def _sources(self):
@@ -104,10 +109,51 @@ class ConvWeights:
     def stamp(self):
         return tuple((t.data_ptr(), t._version) for t in self._sources()) + (_EPOCH[0],)
 
+    def _refresh_packed_f32(self, device):
+        """fp32, parameters already on ``device``: ONE launch of ``me_pack_conv_f32`` writes every packed copy into the
+        stable buffers (a training step re-packs every layer: through torch that was ~25 launches per layer)."""
+        conv, bn = self.conv, self.bn
+        w = conv.weight
+        cout, cin, k, k2 = w.shape
+        if k != k2:
+            return None
+        srcs = [w] + [t for t in ((conv.bias,) if conv.bias is not None else ())]
+        if bn is not None:
+            srcs += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        if not all(t.device == device and t.dtype == torch.float32 and t.is_contiguous() for t in srcs):
+            return None
+        f32 = dict(device=device, dtype=torch.float32)
+        realloc = self.wgt is None or self.wgt.device != device or tuple(self.wgt.shape) != (cout, k, k, cin) \
+            or self.wgt.dtype != torch.float32
+        if realloc:
+            self.wgt = torch.empty((cout, k, k, cin), **f32)
+            self.scale, self.shift = torch.empty(cout, **f32), torch.empty(cout, **f32)
+            self.wgt_tiled = torch.empty((k * k, cin // 16, cout, 16), **f32) if cin % 16 == 0 else None
+            self.rot = self.rot_tiled = None
+        if self.want_rot and self.rot is None:
+            self.rot = torch.empty((cin, k, k, cout), **f32)
+            self.rot_tiled = torch.empty((k * k, cout // 16, cin, 16), **f32) if cout % 16 == 0 else None
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        hip.check(hip.lib().me_pack_conv_f32(
+            w.data_ptr(), cout, cin, k, ptr(conv.bias), ptr(bn.weight if bn is not None else None),
+            ptr(bn.bias if bn is not None else None), ptr(bn.running_mean if bn is not None else None),
+            ptr(bn.running_var if bn is not None else None), float(bn.eps) if bn is not None else 0.0, self.wgt.data_ptr(),
+            ptr(self.wgt_tiled), ptr(self.rot if self.want_rot else None), ptr(self.rot_tiled if self.want_rot else None),
+            self.scale.data_ptr(), self.shift.data_ptr(), hip.stream_ptr()), "me_pack_conv_f32")
+        return "realloc" if realloc else True
+
     def refresh(self, device):
-        stamp = self.stamp()
+        stamp = self.stamp() + (self.want_rot,)
         if stamp == self._stamp and self.wgt is not None and self.wgt.device == device:
             return False
+        dev = torch.device(device)
+        if self.dtype == "f32" and not self.cin_pad and not self.cout_pad and dev.type == "cuda":
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            done = self._refresh_packed_f32(dev)
+            if done is not None:
+                self._stamp = stamp
+                return done
         with torch.no_grad():
             w = self.conv.weight.detach().to(device=device, dtype=torch.float32)
             packed = w.permute(0, 2, 3, 1).contiguous()

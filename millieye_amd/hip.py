@@ -343,6 +343,51 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     return out
 
 
+_CONV_AUTO = {}
+
+
+def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, out=None, x_nchw=False,
+                wgt_tiled=None):
+    """:func:`conv2d` with the (tile, split_k) pair measured on this GPU the first time a layer shape is seen (the training
+    path's convolutions - forward and data gradient - have no engine plan whose autotuner would do it; the library's cold-start
+    guess took 128 x 64 tiles for every data gradient: 7.5 ms of a 42 ms Darknet-53 step where the tuned forward needs 5).
+    The candidates are timed into a scratch output, so an ``out`` that aliases ``residual`` (gradient accumulation in place)
+    is only written once, by the final call."""
+    if x_nchw or wgt_packed.shape[3] <= 4:
+        return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, x_nchw=x_nchw,
+                      wgt_tiled=wgt_tiled)
+    key = (tuple(x_nhwc.shape), x_nhwc.stride(2), wgt_packed.shape[0], ksize, stride, pad, residual is not None,
+           wgt_tiled is not None)
+    hit = _CONV_AUTO.get(key)
+    if hit is None:
+        cin = wgt_packed.shape[3]
+        cands = [(0, 0)] + [(t, sp) for t in (1, 2, 3, 4, 5) for sp in (1, 2, 4)]
+        if cin % 16 == 0:
+            cands += [(t, sp) for t in (41, 42, 43) for sp in (2, 4)]
+        scratch = None
+        best = (float("inf"), 0, 0)
+        for tile, split in cands:
+            try:
+                for _ in range(2):
+                    scratch = conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch,
+                                     tile=tile, split_k=split, wgt_tiled=wgt_tiled)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch, tile=tile,
+                           split_k=split, wgt_tiled=wgt_tiled)
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 3
+            except MeError:
+                continue
+            if ms < best[0]:
+                best = (ms, tile, split)
+        hit = _CONV_AUTO[key] = (best[1], best[2])
+    return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, tile=hit[0],
+                  split_k=hit[1], wgt_tiled=wgt_tiled)
+
+
 def tile_weights_f32(wgt_packed):
     """Second packing of fp32 OHWI weights for the patch-resident kernels (tile ids >= 100): ``[k*k][cin/16][cout][16]`` -
     every (tap, 16-channel chunk) slab of cout rows x 64 bytes contiguous (``me_conv_desc.wgt_tiled``)."""
