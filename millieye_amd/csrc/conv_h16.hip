@@ -33,6 +33,8 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream);
 long long p8_workspace_bytes(const Conv16P& p, int tile, int split);
 bool ws1x1_eligible(const Conv16P& p);      // conv1x1_ws_h16.hip: tile id 50, weight-stationary streaming 1x1
 int launch_ws1x1(const Conv16P& p, hipStream_t stream);
+bool ws3x3_eligible(const Conv16P& p);      // conv3x3_ws_h16.hip: tile id 60, weight-stationary 3x3 for cin 32 / 64
+int launch_ws3x3(const Conv16P& p, hipStream_t stream);
 bool stem_mfma_eligible(const Conv16P& p);  // stem_mfma_h16.hip
 int launch_stem_mfma(const Conv16P& p, hipStream_t stream);
 }  // namespace me16
@@ -728,6 +730,7 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   p.partial = reinterpret_cast<float*>(d->workspace);
   if (tile >= 100) return me16::launch_p8_tile(p, tile, stream);
   if (tile == 50) return me16::launch_ws1x1(p, stream);
+  if (tile == 60) return me16::launch_ws3x3(p, stream);
   const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows
   if (p.f16) {
     switch (tile) {

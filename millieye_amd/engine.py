@@ -773,7 +773,9 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128), 301: (128, 128), 311: (192, 128),
                      321: (256, 128), 331: (256, 128),
                      # weight-stationary streaming 1x1 (csrc/conv1x1_ws_h16.hip): persistent grid, 32-row tiles, no split-K
-                     50: (32, 256)}
+                     50: (32, 256),
+                     # weight-stationary 3x3 for cin 32 / 64 (csrc/conv3x3_ws_h16.hip): 2-D tiles, persistent grid, no split-K
+                     60: (256, 128)}
 _TUNE_TILES_TAIL = (41, 42, 43, 44, 45)  # fp32: tiles 1-5 with the last partial round of tiles cut split_k ways along K
 _TUNE_TILES_P8_F32 = (201, 221)  # fp32 is matrix-pipe bound: the big tiles' pad positions / quantisation cost more than
 # their traffic saves (tools/p8_bench_f32.py: only the 2-workgroup tiles come close to the 64x64 per-tap tile)
@@ -791,7 +793,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v10.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v11.json")  # bump with every kernel generation
 
 
 def _tune_load():
@@ -920,6 +922,8 @@ def _autotune(plan, lib):
                 tiles = tiles + _TUNE_TILES_P8  # the library refuses the ones that do not apply (cout % width, LDS)
             if d.ksize == 1 and d.stride == 1 and d.upsample == 1 and not d.y_f32 and not d.res:
                 tiles = tiles + (50,)  # refused by the library unless one of its (cin, cout) instances fits
+            if d.ksize == 3 and d.cin <= 64 and d.upsample == 1 and not d.y_f32:
+                tiles = tiles + (60,)
         else:
             if d.cin % 16 == 0 and os.environ.get("MILLIEYE_TUNE_TAIL", "1") != "0":
                 tiles = tiles + _TUNE_TILES_TAIL
@@ -935,7 +939,7 @@ def _autotune(plan, lib):
             # (patch tiles can be cut along K - split_k > 1, compact fp32 slabs + a reduce launch - but the slabs are twice the
             #  fp32 size of the layer's output: 60 -> 76 us at 13x13, tools/p8_bench.py 32 121,121/2; not offered to the tuner)
             p8_split = False
-            for split in (_TUNE_SPLITS[1:] if tail else (1,) if tile == 50 else _TUNE_SPLITS if tile < 100
+            for split in (_TUNE_SPLITS[1:] if tail else (1,) if tile in (50, 60) else _TUNE_SPLITS if tile < 100
                           else (1, 2, 3, 4) if p8_split else (1,)):
                 d.tile, d.split_k = tile, split
                 if tail or (tile >= 100 and split > 1):

@@ -344,6 +344,41 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
 
 
 _CONV_AUTO = {}
+_CONV_AUTO_LOADED = [False]
+
+
+def _conv_auto_file():
+    base = os.environ.get("MILLIEYE_TUNE_CACHE")
+    if base:
+        return base + ".train"
+    root = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
+    return os.path.join(root, "millieye_amd", "conv_auto_v1.json")
+
+
+def _conv_auto_load():
+    if _CONV_AUTO_LOADED[0]:
+        return
+    _CONV_AUTO_LOADED[0] = True
+    try:
+        import json
+        with open(_conv_auto_file()) as fh:
+            for k, v in json.load(fh).items():
+                _CONV_AUTO[k] = (int(v[0]), int(v[1]))
+    except (OSError, ValueError):
+        pass
+
+
+def _conv_auto_save():
+    try:
+        import json
+        path = _conv_auto_file()
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as fh:
+            json.dump({k: list(v) for k, v in _CONV_AUTO.items()}, fh)
+        os.replace(tmp, path)
+    except OSError:
+        pass  # an optimisation only
 
 
 def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, out=None, x_nchw=False,
@@ -356,8 +391,9 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
     if x_nchw or wgt_packed.shape[3] <= 4:
         return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, x_nchw=x_nchw,
                       wgt_tiled=wgt_tiled)
-    key = (tuple(x_nhwc.shape), x_nhwc.stride(2), wgt_packed.shape[0], ksize, stride, pad, residual is not None,
-           wgt_tiled is not None)
+    _conv_auto_load()
+    key = repr((tuple(x_nhwc.shape), x_nhwc.stride(2), wgt_packed.shape[0], ksize, stride, pad, residual is not None,
+                wgt_tiled is not None))
     hit = _CONV_AUTO.get(key)
     if hit is None:
         cin = wgt_packed.shape[3]
@@ -384,6 +420,7 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
             if ms < best[0]:
                 best = (ms, tile, split)
         hit = _CONV_AUTO[key] = (best[1], best[2])
+        _conv_auto_save()
     return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, tile=hit[0],
                   split_k=hit[1], wgt_tiled=wgt_tiled)
 

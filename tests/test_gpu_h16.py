@@ -489,6 +489,51 @@ def test_conv1x1_weight_stationary_tile(hip_lib, cin, cout, half):
             assert float(wide[..., :16].abs().max()) == 0 and float(wide[..., 16 + cout:].abs().max()) == 0
 
 
+WS3_CASES = [
+    # cin, cout, stride, n, h, w, res
+    (32, 64, 1, 2, 16, 16, True), (32, 64, 1, 1, 37, 21, False), (32, 64, 1, 3, 48, 40, True),
+    (32, 64, 2, 2, 32, 32, False), (32, 64, 2, 1, 45, 27, False), (32, 64, 2, 2, 64, 96, False),
+    (64, 128, 1, 2, 8, 16, True), (64, 128, 1, 1, 29, 19, True), (64, 128, 1, 2, 40, 56, False),
+    (64, 128, 2, 2, 16, 32, False), (64, 128, 2, 1, 37, 53, False), (64, 128, 2, 2, 48, 80, False),
+]
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,stride,n,h,w,with_res", WS3_CASES)
+def test_conv3x3_weight_stationary_tile(hip_lib, cin, cout, stride, n, h, w, with_res, half):
+    """Tile id 60 (csrc/conv3x3_ws_h16.hip): 3x3 layers with 32 / 64 input channels - the whole filter in registers, 2-D input
+    patches through an LDS ring, zero padding and ragged tiles by out-of-range DMA lanes - stride 1 and 2, with and without the
+    fused shortcut, odd image sizes (tiles that hang over every border), more tiles than workgroups, pitched input / output /
+    residual, against the fp32 CPU convolution under the bar of the other 16-bit tiles; deterministic."""
+    from millieye_amd import hip
+    half = HALVES[half]
+    g = torch.Generator().manual_seed(cin + 3 * h + w + stride)
+    x = _bf(torch.randn((n, h, w, cin), generator=g), half)
+    wgt = _bf(torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5, half)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    res = _bf(torch.randn((n, ho, wo, cout), generator=g), half) if with_res else None
+    act = 1 if (h + w) % 2 == 0 else 0
+    ref = _ref(x, wgt, scale, shift, 3, stride, 1, act, res, 1)
+    packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+    xs, sc, sh = x.cuda(), scale.cuda(), shift.cuda()
+    rs = res.cuda() if res is not None else None
+    y = hip.conv2d_h16(xs, packed, sc, sh, 3, stride, 1, act, residual=rs, tile=60, split_k=1)
+    _check_bf16(y, ref, f"{cin}->{cout} s{stride} {n}x{h}x{w} res{int(with_res)} tile 60")
+    assert torch.equal(y, hip.conv2d_h16(xs, packed, sc, sh, 3, stride, 1, act, residual=rs, tile=60, split_k=1))
+    xw = torch.zeros((n, h, w, cin + 24), dtype=half).cuda()
+    xw[..., 16:16 + cin] = xs
+    wide = torch.zeros((n, ho, wo, cout + 48), dtype=half).cuda()
+    rw = None
+    if rs is not None:
+        rw = torch.zeros((n, ho, wo, cout + 8), dtype=half).cuda()
+        rw[..., 8:] = rs
+    hip.conv2d_h16(xw[..., 16:16 + cin], packed, sc, sh, 3, stride, 1, act, residual=rw[..., 8:] if rw is not None else None,
+                   out=wide[..., 16:16 + cout], tile=60, split_k=1)
+    assert torch.equal(wide[..., 16:16 + cout], y), "pitched input / residual / output"
+    assert float(wide[..., :16].abs().max()) == 0 and float(wide[..., 16 + cout:].abs().max()) == 0
+
+
 def test_conv1x1_weight_stationary_refuses(hip_lib):
     from millieye_amd import hip
     x = torch.zeros((1, 8, 8, 256), dtype=torch.bfloat16).cuda()
