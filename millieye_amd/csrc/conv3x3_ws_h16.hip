@@ -13,8 +13,9 @@
 //     buffer_load ... lds straight from the NHWC frame: zero padding and ragged tiles are lanes whose offset is out of range;
 //   * one barrier per tile, NSLOT patches deep; the nine taps are LDS row shifts of the resident patch;
 //   * the XOR swizzle of the channel chunks sits on the DMA's source side (conv1x1_ws_h16.hip explains the scheme);
-//   * epilogue: affine + LeakyReLU, LDS transpose, fused shortcut (16-byte residual loads issued before the tile's MFMAs by
-//     inline asm so that their wait does not drain the patch DMAs), 16-byte stores.
+//   * epilogue: affine + LeakyReLU, LDS transpose, fused shortcut (16-byte residual loads requested before the tile's MFMAs; the
+//     patch refill of such layers is issued behind the epilogue so that the compiler's wait for them does not drain it),
+//     16-byte stores.
 #include <utility>
 
 #include "conv16_common.h"
@@ -53,7 +54,6 @@ __device__ __forceinline__ void wait_vm3() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-typedef unsigned r_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int CIN, int WN, int WM, int MBH, int MBW, int TMY, int TMX, int S, int NSLOT, int F16>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_ws_kernel(K3Args a) {
@@ -174,20 +174,21 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_ws_kernel(K3Args a) {
         const int oy = ty * TH + (mb / TMX) * MBH + q / MBW, ox = tx * TW + (mb % TMX) * MBW + q % MBW;
         mrow[j][pass] = (oy < a.ho && ox < a.wo) ? (nimg * a.ho + oy) * a.wo + ox : -1;
       }
-    // ---- shortcut operand: requested now (inline asm: the compiler's own wait for these loads would be vmcnt(0) and would
-    // drain the patch refill issued right behind them), waited for at the epilogue with the refill still in flight -----------
-    r_u32x4 rres[NR];
+    // ---- shortcut operand: plain loads requested before the tile's MFMAs (their latency hides behind them).  The compiler's
+    // wait for them counts only the loads it knows, i.e. it is a vmcnt(0) that would also drain a patch refill issued in front
+    // of it - so with a shortcut the refill is issued at the END of the iteration, behind the epilogue.  (A first version
+    // requested the pieces by inline asm and waited by hand; the compiler is free to copy such registers between the two asm
+    // statements - before the data has landed - and the detector's determinism stress test caught exactly that.)
+    uint4 rres[NR];
     if (a.res) {
 #pragma unroll
       for (int j = 0; j < MPW; ++j)
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           const long long m = mrow[j][pass] >= 0 ? mrow[j][pass] : 0;  // (pixels outside the map: any readable address)
-          const unsigned short* ptr = a.res + m * a.res_pitch + n0 + c8;
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[j * 2 + pass]) : "v"(ptr) : "memory");
+          rres[j * 2 + pass] = *reinterpret_cast<const uint4*>(a.res + m * a.res_pitch + n0 + c8);
         }
-    }
-    {
+    } else {
       const int ps = slot == 0 ? NSLOT - 1 : slot - 1;
       issue(t + (NSLOT - 1) * G, ps);
     }
@@ -215,20 +216,6 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_ws_kernel(K3Args a) {
         }
     }
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
-    if (a.res) {
-      // the residual pieces are older than this iteration's refill: leave exactly the refill in flight.  The registers pass
-      // through the asm so that no use of them can be scheduled above the wait.
-      if constexpr (NR == 2)
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rres[0]), "+v"(rres[1]) : "n"(ND) : "memory");
-      else if constexpr (NR == 4)
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rres[0]), "+v"(rres[1]), "+v"(rres[2]), "+v"(rres[3]) : "n"(ND) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%8)"
-                     : "+v"(rres[0]), "+v"(rres[1]), "+v"(rres[2]), "+v"(rres[3]), "+v"(rres[4 % NR]), "+v"(rres[5 % NR]),
-                       "+v"(rres[6 % NR]), "+v"(rres[7 % NR])
-                     : "n"(ND)
-                     : "memory");
-    }
 #pragma unroll
     for (int j = 0; j < MPW; ++j) {
 #pragma unroll
@@ -246,7 +233,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_ws_kernel(K3Args a) {
         if (m >= 0) {
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           if (a.res) {
-            const r_u32x4 r4 = rres[j * 2 + pass];
+            const uint4 r4 = rres[j * 2 + pass];
             const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -262,6 +249,10 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_ws_kernel(K3Args a) {
           me::store16(a.y + m * a.y_pitch + n0 + c8, o, a.store_mode);
         }
       }
+    }
+    if (a.res) {  // (see above: the refill of the slot tile t - G left, behind the shortcut's loads)
+      const int ps = slot == 0 ? NSLOT - 1 : slot - 1;
+      issue(t + (NSLOT - 1) * G, ps);
     }
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
   }

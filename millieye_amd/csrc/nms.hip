@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w, int use_offsets)
       rank += (k2.x > mine ? 1 : 0) + (k2.y > mine ? 1 : 0);
     }
   }
-  if (j >= cnt || rank >= w.matn) return;  // only the matn best-scored candidates enter the matrix
+  if (j >= cnt) return;  // (the matrix looks at the matn best-scored ones, the scan's continuation at the rest)
   float4 bb = w.raw[base + j];
   if (use_offsets) {
     const float maxc = w.nanflag[img] ? NAN : unsortable(w.maxbits[img]);
@@ -692,41 +692,39 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
 
 // scan: one workgroup per image.  Block b's 64 matrix rows (64 x wc words) sit in LDS; the rows of block b + 1 are loaded
 // into registers before wave 0 resolves block b, and stored to the other LDS buffer afterwards.
-__global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int* out_count) {
+constexpr int SCAN_THREADS = 1024;
+constexpr int CONT_KEEP = 1024;  // the continuation keeps the winners' boxes in LDS: max_det up to this (batched NMS: 200)
+
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(NmsWs w, int max_det, float iou_thresh, int* out_count) {
+#pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
   const int img = blockIdx.x;
   const int cnt_all = w.cand_count[img];
   if (cnt_all == 0 || w.legacy) return;  // (cnt == 0: the legacy kernel writes the zero count)
   const int cnt = cnt_all < w.matn ? cnt_all : w.matn;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int wc = w.wc;                                   // words per matrix row (<= 64)
+  constexpr int NWV = SCAN_THREADS / 64;
+  const int wc = w.wc;                                   // words per matrix row (<= 16)
   const int nblk = (cnt + 63) >> 6;
   unsigned long long* buf[2] = {reinterpret_cast<unsigned long long*>(scan_lds),
                                 reinterpret_cast<unsigned long long*>(scan_lds) + 64 * wc};
-  int* s_keep = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(scan_lds) + 128 * wc);  // [max_det] sorted positions
+  int* s_keep = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(scan_lds) + 128 * wc);  // [keep_cap] sorted positions
   __shared__ int s_stop, s_kept;
+  __shared__ unsigned long long s_mask[NWV], s_diag[64];
   const unsigned long long* mat = w.mat + (long long)img * w.matn * wc;
-  // a block = 64 rows x wc words = 64 * wc * 8 bytes; thread t moves pieces t, t + 256, ... of 16 bytes (wc * 4 pieces per row pair)
-  const int pieces = 64 * wc / 2;          // 16-byte pieces per block
-  constexpr int PMAX = MATN / 64 * 64 / 2 / 256;   // 16-byte pieces per thread and block
-  ulonglong2 stage[PMAX];
+  const long long base = (long long)img * w.cap;
+  // a block = 64 rows x wc words; thread t moves 16-byte piece t (64 * wc / 2 <= 512 pieces)
+  const int pieces = 64 * wc / 2;
+  ulonglong2 stage = make_ulonglong2(0ull, 0ull);
   auto fetch = [&](int blk) {
-#pragma unroll
-    for (int k = 0; k < PMAX; ++k) {
-      const int pc = t + k * 256;
-      stage[k] = make_ulonglong2(0ull, 0ull);
-      if (pc < pieces) {
-        const int row = blk * 64 + (pc * 2) / wc;
-        if (row < cnt) stage[k] = *reinterpret_cast<const ulonglong2*>(mat + (long long)blk * 64 * wc + pc * 2);
-      }
+    stage = make_ulonglong2(0ull, 0ull);
+    if (t < pieces) {
+      const int row = blk * 64 + (t * 2) / wc;
+      if (row < cnt) stage = *reinterpret_cast<const ulonglong2*>(mat + (long long)blk * 64 * wc + t * 2);
     }
   };
   auto put = [&](int which) {
-#pragma unroll
-    for (int k = 0; k < PMAX; ++k) {
-      const int pc = t + k * 256;
-      if (pc < pieces) *reinterpret_cast<ulonglong2*>(buf[which] + pc * 2) = stage[k];
-    }
+    if (t < pieces) *reinterpret_cast<ulonglong2*>(buf[which] + t * 2) = stage;
   };
   if (t == 0) {
     s_stop = 0;
@@ -737,6 +735,23 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int
   __syncthreads();
   unsigned long long rem = 0ull;  // wave 0: lane l = removed bits of candidates 64 l .. 64 l + 63
   int kept = 0;
+  // the serial part of a block, shared by both phases: walk the not-yet-removed candidates of the 64-bit word in order, OR the
+  // diagonal word of every winner in (lane i holds row i's word in dlo / dhi); returns the winners' mask
+  auto resolve = [&](unsigned long long curbits, unsigned long long valid, unsigned dlo, unsigned dhi, int blk) {
+    unsigned long long avail = ~curbits & valid;
+    unsigned long long keptmask = 0ull;
+    while (avail != 0ull && kept < max_det) {
+      const int i = __builtin_ctzll(avail);
+      keptmask |= 1ull << i;
+      if (lane == 0) s_keep[kept] = (blk << 6) + i;
+      ++kept;
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+      curbits |= ((unsigned long long)hi << 32) | lo;
+      avail = ~curbits & valid & (i == 63 ? 0ull : (~0ull << (i + 1)));
+    }
+    return keptmask;
+  };
   for (int blk = 0; blk < nblk; ++blk) {
     const int cur = blk & 1;
     const bool more = blk + 1 < nblk;
@@ -745,24 +760,12 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int
       const unsigned long long* B = buf[cur];
       // diagonal word of this lane's row (lower-triangular / stale words are never read: word index >= block index)
       const unsigned long long diag = B[lane * wc + blk];
-      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
       const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rem, blk);
       const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), blk);
-      unsigned long long curbits = ((unsigned long long)rhi << 32) | rlo;
       const int last = cnt - (blk << 6);
       const unsigned long long valid = last >= 64 ? ~0ull : ((1ull << last) - 1ull);
-      unsigned long long avail = ~curbits & valid;
-      unsigned long long keptmask = 0ull;
-      while (avail != 0ull && kept < max_det) {
-        const int i = __builtin_ctzll(avail);
-        keptmask |= 1ull << i;
-        if (lane == 0) s_keep[kept] = (blk << 6) + i;
-        ++kept;
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
-        curbits |= ((unsigned long long)hi << 32) | lo;
-        avail = ~curbits & valid & (i == 63 ? 0ull : (~0ull << (i + 1)));
-      }
+      const unsigned long long keptmask =
+          resolve(((unsigned long long)rhi << 32) | rlo, valid, (unsigned)diag, (unsigned)(diag >> 32), blk);
       // the winners' rows into the removed mask: lane = word
       if (lane < wc) {
         unsigned long long km = keptmask;
@@ -783,13 +786,65 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs w, int max_det, int
     __syncthreads();
   }
   __syncthreads();
-  const int total = s_kept;
-  if (total < max_det && cnt_all > cnt) {  // the walk ran off the capped list: the single-workgroup kernel redoes this image
-    if (t == 0) w.fallback[img] = 1;
-    return;
+  int total = s_kept;
+  if (total < max_det && cnt_all > cnt) {
+    // ---- continuation behind the matrix: the walk ran off the matn best-scored candidates without max_det winners.  The rest of
+    // the sorted list is processed 64 candidates at a time with the IoU tests done on demand by this workgroup: (A) each block
+    // against the winners so far (their boxes sit in LDS; wave v takes winners v, v + 16, ...; lane = candidate; ballot),
+    // (B) the block's own 64 x 64 tests (wave v: rows v, v + 16, ...), (C) the same serial resolve.  Linear in the number of
+    // candidates - (winners + 64) tests each - where the matrix is quadratic.
+    if (max_det > CONT_KEEP) {  // (plain nms on thousands of boxes keeps everything: the single-workgroup kernel redoes it)
+      if (t == 0) w.fallback[img] = 1;
+      return;
+    }
+    float4* kbox = reinterpret_cast<float4*>(scan_lds);   // the matrix buffers are free now: [CONT_KEEP] boxes
+    __syncthreads();
+    for (int q = t; q < total; q += SCAN_THREADS) kbox[q] = w.off[base + s_keep[q]];
+    __syncthreads();
+    kept = total;  // (every wave tracks the count; wave 0's resolve is replayed by all through s_kept)
+    for (int blk = w.matn >> 6; (blk << 6) < cnt_all && kept < max_det; ++blk) {
+      const int j = (blk << 6) + lane;
+      float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < cnt_all) cb = w.off[base + j];
+      const float ca = box_area(cb);
+      bool sup = false;
+      for (int k = wv; k < kept; k += NWV) {
+        const float4 kb = kbox[k];
+        sup = sup || iou_exceeds(kb, box_area(kb), cb, ca, iou_thresh);
+      }
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(sup);
+      if (lane == 0) s_mask[wv] = m;
+      for (int i = wv; i < 64; i += NWV) {   // diagonal rows: row i against the columns j > i of the block
+        float4 rb;
+        rb.x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.x), i));
+        rb.y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.y), i));
+        rb.z = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.z), i));
+        rb.w = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.w), i));
+        const float ra = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(ca), i));
+        const bool hit = lane > i && j < cnt_all && iou_exceeds(rb, ra, cb, ca, iou_thresh);
+        const unsigned long long word = __builtin_amdgcn_ballot_w64(hit);
+        if (lane == 0) s_diag[i] = word;
+      }
+      __syncthreads();
+      if (wv == 0) {
+        unsigned long long removed = 0ull;
+        for (int v = 0; v < NWV; ++v) removed |= s_mask[v];
+        const unsigned long long diag = s_diag[lane];
+        const int last = cnt_all - (blk << 6);
+        const unsigned long long valid = last >= 64 ? ~0ull : ((1ull << last) - 1ull);
+        const int before = kept;
+        const unsigned long long keptmask = resolve(removed, valid, (unsigned)diag, (unsigned)(diag >> 32), blk);
+        if ((keptmask >> lane) & 1ull)  // winners append their boxes in order
+          kbox[before + __builtin_popcountll(keptmask & ((1ull << lane) - 1ull))] = cb;
+        if (lane == 0) s_kept = kept;
+      }
+      __syncthreads();
+      kept = s_kept;
+    }
+    total = kept;
   }
-  const long long base = (long long)img * w.cap;
-  for (int q = t; q < total; q += 256) w.keep_slot[base + q] = w.sslot[base + s_keep[q]];
+  __syncthreads();
+  for (int q = t; q < total; q += SCAN_THREADS) w.keep_slot[base + q] = w.sslot[base + s_keep[q]];
   if (t == 0) out_count[img] = total;
 }
 
@@ -846,16 +901,18 @@ inline int launch_matrix_path(const NmsWs& w, int n, int use_offsets, float iou_
   hipLaunchKernelGGL(nms_matrix_kernel, dim3(1024), dim3(256), 0, stream, w, n, iou_thresh);
   rc = me::check_launch("nms_matrix_kernel");
   if (rc) return rc;
-  const int keep_cap = max_det < w.matn ? max_det : w.matn;  // an image of this path has at most matn candidates
-  const size_t lds = (size_t)128 * w.wc * 8 + (size_t)keep_cap * 4;
+  const int keep_cap = max_det < w.cap ? max_det : w.cap;
+  size_t lds = (size_t)128 * w.wc * 8;                                       // two blocks of matrix rows ...
+  if (max_det <= CONT_KEEP && lds < (size_t)CONT_KEEP * 16) lds = (size_t)CONT_KEEP * 16;  // ... or the continuation's winner boxes
+  lds += (size_t)keep_cap * 4;
   static bool attr = false;
   if (!attr) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               96 * 1024));  // two 64 x 64-word buffers + <= 4096 winners = 80 KB at most
+                               150 * 1024));
     attr = true;
   }
-  ME_REQUIRE(lds <= 96 * 1024, ME_E_TOOBIG, "me_nms: max_det %d too large for the scan kernel's LDS", max_det);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), lds, stream, w, max_det, out_count);
+  ME_REQUIRE(lds <= 150 * 1024, ME_E_TOOBIG, "me_nms: max_det %d too large for the scan kernel's LDS", max_det);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(SCAN_THREADS), lds, stream, w, max_det, iou_thresh, out_count);
   return me::check_launch("nms_scan_kernel");
 }
 

@@ -920,9 +920,10 @@ def _autotune(plan, lib):
             tiles = _TUNE_TILES_BF16 if d.cin % 64 == 0 else _TUNE_TILES_BF16[:4] + (15,)
             if d.ksize == 3 and d.stride == 1 and d.upsample == 1 and d.wgt_tiled and not d.y_f32:
                 tiles = tiles + _TUNE_TILES_P8  # the library refuses the ones that do not apply (cout % width, LDS)
-            if d.ksize == 1 and d.stride == 1 and d.upsample == 1 and not d.y_f32 and not d.res:
+            no_ws = os.environ.get("MILLIEYE_NO_WS", "")  # A/B: "50", "60" or "50,60" keep the weight-stationary kernels out
+            if d.ksize == 1 and d.stride == 1 and d.upsample == 1 and not d.y_f32 and not d.res and "50" not in no_ws:
                 tiles = tiles + (50,)  # refused by the library unless one of its (cin, cout) instances fits
-            if d.ksize == 3 and d.cin <= 64 and d.upsample == 1 and not d.y_f32:
+            if d.ksize == 3 and d.cin <= 64 and d.upsample == 1 and not d.y_f32 and "60" not in no_ws:
                 tiles = tiles + (60,)
         else:
             if d.cin % 16 == 0 and os.environ.get("MILLIEYE_TUNE_TAIL", "1") != "0":
