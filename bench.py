@@ -207,7 +207,7 @@ def stage_roofline(model, net, x, step, rois, reps=5):
             for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
                 ms = e0.elapsed_time(e1)
                 if n1 == "nms":
-                    add("NMS (prep + greedy select + emit)", ms, bytes=4.0 * n * plan.rows * (5 + (plan.num_classes or 0)))
+                    add("NMS (prep + rank sort + chip-wide IoU bit matrix + scan + emit)", ms, bytes=4.0 * n * plan.rows * (5 + (plan.num_classes or 0)))
                 elif n1 == "proposals":
                     add("proposal assembly", ms)
                 elif n1 == "score_maps":
