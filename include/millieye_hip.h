@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 6
+#define ME_ABI_VERSION 7
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -178,6 +178,14 @@ typedef struct me_nms_desc {
 } me_nms_desc;
 int64_t me_nms_workspace_bytes(int32_t n, int32_t rows);
 int me_nms_batched_f32(const me_nms_desc* d, void* stream);
+/* The same split over the decode: me_yolo_decode_cand_f32 = me_yolo_decode_f32 of one [yolo] scale that also appends the rows
+ * with objectness >= conf_thresh to the NMS candidate lists in `nms_workspace` (me_nms_workspace_bytes(n, rows_total) bytes,
+ * 256-byte aligned; `first` != 0 on the first scale of a forward resets the lists) while the row is in registers - the
+ * confidence filter of non_max_suppression_cpp (utils/utils.py:351-366) without re-reading [n, rows, 5 + C].  5 + C <= 128.
+ * me_nms_batched_prepped_f32 then runs selection + emit on those lists (same desc as me_nms_batched_f32, same workspace,
+ * writeback_xyxy must be 0).  Results are identical to me_yolo_decode_f32 + me_nms_batched_f32. */
+int me_yolo_decode_cand_f32(const me_yolo_desc* y, float conf_thresh, void* nms_workspace, int32_t first, void* stream);
+int me_nms_batched_prepped_f32(const me_nms_desc* d, void* stream);
 
 /* plain torchvision-style nms / batched_nms on explicit boxes (box_ops.* re-export used by
  *   run_sp.py:214 / run_mp.py:320).  boxes [m,4] xyxy, scores [m], labels [m] (float class ids,

@@ -224,6 +224,125 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(float* pred, int rows, in
   }
 }
 
+
+// ---- YOLO decode with the candidate lists as a by-product ------------------------------------------------------------------
+// me_yolo_decode_cand_f32: the decode of one [yolo] scale (same arithmetic as csrc/elementwise.hip:yolo_decode_kernel, reference
+// yolov3/models.py:132-179) that ALSO does nms_prep's job for its rows while they are in registers: confidence filter, class
+// max / argmax, xywh -> xyxy, candidate append, maximum coordinate.  nms_prep re-read the 116 MB prediction tensor right behind the
+// decode that wrote it (78 - 100 us at batch 32, the largest part of the NMS stage after round 3's select rewrite).
+// One wave per row (5 + C <= 128 elements: lane k and k + 64), 64 rows per workgroup, one global atomic per workgroup.
+struct YoloCand {
+  me_yolo_desc y;
+  float conf_thresh;
+};
+
+__global__ __launch_bounds__(256) void yolo_decode_cand_kernel(YoloCand d, NmsWs w) {
+#pragma clang fp contract(off)
+  __shared__ float4 s_box[64];
+  __shared__ unsigned long long s_key[64];
+  __shared__ float s_lab[64], s_cls[64];
+  __shared__ int s_n, s_base, s_nan;
+  __shared__ unsigned s_max;
+  const me_yolo_desc& y = d.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int img = blockIdx.y;
+  const int per = y.num_classes + 5;
+  const int gg = y.g * y.g;
+  const int rows_scale = y.num_anchors * gg;
+  if (threadIdx.x == 0) {
+    s_n = 0;
+    s_nan = 0;
+    s_max = 0u;
+  }
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    const int rr = blockIdx.x * 64 + wv * 16 + i;  // row of this scale
+    if (rr >= rows_scale) break;                   // (uniform per wave)
+    const int a = rr / gg, pix = rr - a * gg;
+    const float* xin = y.x + ((long long)img * gg + pix) * y.x_pitch + a * per;
+    const int row = y.row_offset + rr;             // row of the prediction tensor
+    float* out = y.out + ((long long)img * y.rows_total + row) * per;
+    const float aw = y.anchors[2 * a], ah = y.anchors[2 * a + 1];
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const int k = lane + 64 * hlf;
+      if (k < per) {
+        const float t = xin[k];
+        float o;
+        if (k < 2) {
+          const float sg = 1.f / (1.f + expf(-t));
+          const float gxy = (k == 0) ? (float)(pix % y.g) : (float)(pix / y.g);
+          o = (sg + gxy) * y.stride;
+        } else if (k < 4) {
+          o = (expf(t) * (k == 2 ? aw : ah)) * y.stride;
+        } else {
+          o = 1.f / (1.f + expf(-t));
+        }
+        out[k] = o;
+        v[hlf] = o;
+      }
+    }
+    const float conf = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 4));
+    if (!(conf >= d.conf_thresh)) continue;  // uniform
+    // class max / argmax (torch.max(1) semantics, see cls_beats)
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    if (lane >= 5 && lane < per) {
+      best = v[0];
+      arg = lane - 5;
+    }
+    if (lane + 64 < per && (arg == 0x7fffffff || cls_beats(v[1], lane + 59, best, arg))) {
+      best = v[1];
+      arg = lane + 59;
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      const float ov = __shfl_xor(best, sft, 64);
+      const int oi = __shfl_xor(arg, sft, 64);
+      if (oi != 0x7fffffff && (arg == 0x7fffffff || cls_beats(ov, oi, best, arg))) {
+        best = ov;
+        arg = oi;
+      }
+    }
+    if (y.num_classes <= 0) {
+      best = -INFINITY;
+      arg = 0;
+    }
+    const float cx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 0));
+    const float cy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 1));
+    const float bw = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 2));
+    const float bh = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 3));
+    if (lane == 0) {
+      const float x1 = cx - bw / 2, y1 = cy - bh / 2, x2 = cx + bw / 2, y2 = cy + bh / 2;  // xywh2xyxy (utils.py:68-74)
+      const int q = atomicAdd(&s_n, 1);
+      s_box[q] = make_float4(x1, y1, x2, y2);
+      s_key[q] = make_key(conf, row);
+      s_lab[q] = (float)arg;
+      s_cls[q] = best;
+      if ((x1 != x1) | (y1 != y1) | (x2 != x2) | (y2 != y2)) atomicOr(&s_nan, 1);
+      const float m = fmaxf(fmaxf(x1, y1), fmaxf(x2, y2));
+      if (m == m) atomicMax(&s_max, sortable(m));
+    }
+  }
+  __syncthreads();
+  const int npass = s_n;
+  if (npass == 0) return;
+  if (threadIdx.x == 0) {
+    s_base = atomicAdd(&w.cand_count[img], npass);
+    if (s_nan) atomicOr(&w.nanflag[img], 1);
+    if (s_max) atomicMax(&w.maxbits[img], s_max);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < npass) {
+    const long long o = (long long)img * w.cap + s_base + threadIdx.x;
+    w.raw[o] = s_box[threadIdx.x];
+    w.key[o] = s_key[threadIdx.x];
+    w.label[o] = s_lab[threadIdx.x];
+    w.clsconf[o] = s_cls[threadIdx.x];
+  }
+}
+
 // explicit boxes (box_ops.nms / batched_nms): every box is a candidate, img = 0
 __global__ __launch_bounds__(256) void nms_prep_boxes_kernel(const float* boxes, const float* scores,
                                                              const float* labels, int m, NmsWs w) {
@@ -925,7 +1044,34 @@ int64_t me_nms_workspace_bytes(int32_t n, int32_t rows) {
   return ws_bytes(n, rows);
 }
 
-int me_nms_batched_f32(const me_nms_desc* d, void* stream_) {
+static int nms_batched(const me_nms_desc* d, void* stream_, int prepped);
+
+int me_nms_batched_f32(const me_nms_desc* d, void* stream) { return nms_batched(d, stream, 0); }
+
+/* the candidate lists are already in the workspace (me_yolo_decode_cand_f32 of every scale): select + emit only */
+int me_nms_batched_prepped_f32(const me_nms_desc* d, void* stream) { return nms_batched(d, stream, 1); }
+
+int me_yolo_decode_cand_f32(const me_yolo_desc* y, float conf_thresh, void* nms_workspace, int32_t first, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(y && y->x && y->out && nms_workspace, ME_E_NULLPTR, "me_yolo_decode_cand_f32: null pointer");
+  ME_REQUIRE(y->n > 0 && y->g > 0 && y->num_anchors > 0 && y->num_anchors <= 8 && y->num_classes >= 0 &&
+                 y->num_classes + 5 <= 128, ME_E_BADARG, "me_yolo_decode_cand_f32: bad dimensions (5 + classes <= 128)");
+  ME_REQUIRE(y->x_pitch >= y->num_anchors * (y->num_classes + 5), ME_E_BADARG, "me_yolo_decode_cand_f32: x_pitch too small");
+  ME_REQUIRE(y->row_offset >= 0 && y->row_offset + y->num_anchors * y->g * y->g <= y->rows_total && y->rows_total <= MAX_ROWS,
+             ME_E_BADARG, "me_yolo_decode_cand_f32: rows out of range");
+  ME_REQUIRE(y->n <= 65535 && y->stride > 0.f, ME_E_BADARG, "me_yolo_decode_cand_f32: bad batch / stride");
+  ME_REQUIRE((reinterpret_cast<uintptr_t>(nms_workspace) & 255u) == 0, ME_E_ALIGN, "me_yolo_decode_cand_f32: workspace alignment");
+  NmsWs w = carve(nms_workspace, y->n, y->rows_total);
+  if (first) ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * y->n, stream));
+  YoloCand d;
+  d.y = *y;
+  d.conf_thresh = conf_thresh;
+  const int rows_scale = y->num_anchors * y->g * y->g;
+  hipLaunchKernelGGL(yolo_decode_cand_kernel, dim3((rows_scale + 63) / 64, y->n), dim3(256), 0, stream, d, w);
+  return me::check_launch("yolo_decode_cand_kernel");
+}
+
+static int nms_batched(const me_nms_desc* d, void* stream_, int prepped) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ME_REQUIRE(d && d->pred && d->det && d->count && d->workspace, ME_E_NULLPTR, "me_nms_batched_f32: null pointer");
   ME_REQUIRE(d->n > 0 && d->rows > 0 && d->num_classes >= 0 && d->max_det > 0, ME_E_BADARG,
@@ -935,11 +1081,16 @@ int me_nms_batched_f32(const me_nms_desc* d, void* stream_) {
   ME_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 255u) == 0, ME_E_ALIGN,
              "me_nms_batched_f32: workspace not 256-byte aligned");
   NmsWs w = carve(d->workspace, d->n, d->rows);
-  ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * d->n, stream));  // counts, max-coordinate bits, NaN / fallback flags
-  hipLaunchKernelGGL(nms_prep_kernel, dim3((d->rows + 255) / 256, d->n), dim3(256), 0, stream, d->pred, d->rows,
-                     d->num_classes, d->conf_thresh, d->writeback_xyxy, w);
-  int rc = me::check_launch("nms_prep_kernel");
-  if (rc) return rc;
+  int rc = 0;
+  if (!prepped) {
+    ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * d->n, stream));  // counts, max-coordinate bits, NaN / fallback flags
+    hipLaunchKernelGGL(nms_prep_kernel, dim3((d->rows + 255) / 256, d->n), dim3(256), 0, stream, d->pred, d->rows,
+                       d->num_classes, d->conf_thresh, d->writeback_xyxy, w);
+    rc = me::check_launch("nms_prep_kernel");
+    if (rc) return rc;
+  } else {
+    ME_REQUIRE(!d->writeback_xyxy, ME_E_BADARG, "me_nms_batched_prepped_f32: the fused decode does not rewrite the rows as xyxy");
+  }
   const int max_det = d->max_det < d->rows ? d->max_det : d->rows;
   rc = launch_matrix_path(w, d->n, 1, d->iou_thresh, max_det, d->count, stream);
   if (rc) return rc;

@@ -691,9 +691,13 @@ class DarknetEngine:
         return plan
 
     # ---------------------------------------------------------------------------------- execution
-    def run(self, x, keep_raw=False):
+    def run(self, x, keep_raw=False, nms_conf=None):
         """x: CUDA fp32 NCHW [N,C,H,W].  Returns (plan, yolo_outputs [N,R,5+C]); the feature tap is
-        ``plan.tap`` (a view into the plan's arena, valid until the next ``run`` of that plan)."""
+        ``plan.tap`` (a view into the plan's arena, valid until the next ``run`` of that plan).
+        ``nms_conf``: the caller will run NMS on the rows at this confidence threshold next (Network.forward): every [yolo]
+        decode then also appends its passing rows to the candidate lists of the shared NMS workspace
+        (``me_yolo_decode_cand_f32``) and ``plan.nms_prepped`` is set to the threshold - ``hip.nms_batched(..., prepped=True)``
+        skips its own pass over the 5 + C columns of every row."""
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             raise hip.MeError("Darknet input must be a 4-D CUDA float32 tensor [N,C,H,W]; this path has no CPU "
                               "fallback (the CPU restatement is oracle/, test infrastructure only)")
@@ -701,15 +705,23 @@ class DarknetEngine:
         self.refresh_weights(x.device)
         plan = self.plan_for(x, keep_raw)
         if _graphs_enabled() and not torch.cuda.is_current_stream_capturing():
+            plan.nms_prepped = None
             return self._run_graph(plan, x)
         yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
                                device=x.device)
-        self._launch_all(plan, x, yolo_out)
+        cand = None
+        plan.nms_prepped = None
+        if nms_conf is not None and plan.yolo_descs and 5 + (plan.num_classes or 0) <= 128 and plan.rows <= 32768 \
+                and plan.n <= 65535:
+            ws_ptr, _keep = hip.nms_workspace(plan.n, plan.rows, x.device)
+            cand = (float(nms_conf), ws_ptr)
+            plan.nms_prepped = float(nms_conf)
+        self._launch_all(plan, x, yolo_out, cand)
         plan.last_input = x  # keep the caller's tensor alive until the stream has consumed it
         return plan, yolo_out
 
     @staticmethod
-    def _launch_all(plan, x, yolo_out):
+    def _launch_all(plan, x, yolo_out, cand=None):
         xp = x.data_ptr()
         for dsc in plan.input_descs:
             dsc.x = xp
@@ -717,8 +729,14 @@ class DarknetEngine:
         for dsc in plan.yolo_descs:
             dsc.out = yp
         stream = hip.stream_ptr()
+        first = 1
+        decode_cand = hip.lib().me_yolo_decode_cand_f32 if cand is not None else None
         for fn, args, _keep, name in plan.launches:
-            rc = fn(*args, stream)
+            if decode_cand is not None and name.startswith("yolo"):
+                rc = decode_cand(args[0], cand[0], cand[1], first, stream)
+                first = 0
+            else:
+                rc = fn(*args, stream)
             if rc != 0:
                 hip.check(rc, name)
 

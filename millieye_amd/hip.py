@@ -198,6 +198,8 @@ SIGNATURES = {
     "me_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int32] * 6),
     "me_conv_wgrad_mfma_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
                                + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_yolo_decode_cand_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
+    "me_nms_batched_prepped_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "me_conv_wgrad_mfma_oihw_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
                                     + [C.c_void_p, C.c_int64, C.c_void_p]),
     "me_pack_conv_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_float]
@@ -237,8 +239,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 6:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 6")
+    if lib_.me_abi_version() != 7:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 7")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
@@ -626,9 +628,15 @@ def _workspace(nbytes, device, slot="nms"):
     return ws.data_ptr() + off, ws
 
 
-def nms_batched(pred, conf_thresh, iou_thresh, max_det, writeback_xyxy=True):
+def nms_workspace(n, rows, device):
+    """The cached NMS workspace for ``[n, rows]`` predictions (the buffer :func:`nms_batched` uses): ``(ptr, keepalive)``."""
+    return _workspace(lib().me_nms_workspace_bytes(n, rows), device)
+
+
+def nms_batched(pred, conf_thresh, iou_thresh, max_det, writeback_xyxy=True, prepped=False):
     """pred [N,R,5+C] (modified in place when ``writeback_xyxy``) -> (det [N,max_det,7+C],
-    count int32 [N]) on the device; rows >= count are unspecified."""
+    count int32 [N]) on the device; rows >= count are unspecified.  ``prepped``: the candidate lists are already in the
+    workspace (the engine decoded with ``me_yolo_decode_cand_f32`` at this ``conf_thresh``): selection + emit only."""
     _require_cuda_f32(pred, "prediction")
     if not pred.is_contiguous():
         raise MeError("prediction must be contiguous")
@@ -644,7 +652,10 @@ def nms_batched(pred, conf_thresh, iou_thresh, max_det, writeback_xyxy=True):
     d.pred, d.det, d.count, d.workspace = pred.data_ptr(), det.data_ptr(), count.data_ptr(), ws_ptr
     d.n, d.rows, d.num_classes, d.max_det = n, rows, nc, max_det
     d.conf_thresh, d.iou_thresh, d.writeback_xyxy = conf_thresh, iou_thresh, 1 if writeback_xyxy else 0
-    check(lib().me_nms_batched_f32(C.byref(d), stream_ptr()), "me_nms_batched_f32")
+    if prepped:
+        check(lib().me_nms_batched_prepped_f32(C.byref(d), stream_ptr()), "me_nms_batched_prepped_f32")
+    else:
+        check(lib().me_nms_batched_f32(C.byref(d), stream_ptr()), "me_nms_batched_f32")
     return det, count
 
 

@@ -111,9 +111,9 @@ class Network(nn.Module):
         dev, n = images.device, images.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)
         lib = hip.lib()
-        plan, yolo_out = self.base_detector._run(images)
+        plan, yolo_out = self.base_detector._run(images, nms_conf=float(self.conf_thresh))
         det, cnt = hip.nms_batched(yolo_out, float(self.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
-                                   writeback_xyxy=False)
+                                   writeback_xyxy=False, prepped=plan.nms_prepped == float(self.conf_thresh))
         num_classes = yolo_out.shape[2] - 5
         if num_classes < self.class_num:
             raise hip.MeError(f"the detector has {num_classes} classes, module 2 needs {self.class_num}")

@@ -385,7 +385,7 @@ class Network(nn.Module):
         cb = getattr(self, "_stage_cb", None)
         mark = cb or (lambda _name: None)  # bench.py: per-stage HIP events
         mark("start")
-        plan, yolo_out = self.base_detector._run(images)
+        plan, yolo_out = self.base_detector._run(images, nms_conf=float(self.conf_thresh))  # the decode fills the NMS lists
         mark("detector")
         # The score maps (reference :486-487) only need the feature tap, NMS only the decoded rows: NMS keeps 32
         # workgroups busy for ~0.3 ms, so the score-map convolutions run beside it on a second stream (mode 0 / 2 / 3).
@@ -398,7 +398,7 @@ class Network(nn.Module):
             with torch.cuda.stream(side):
                 maps_job = self._score_maps(plan, maps, n, dev)
         det, cnt = hip.nms_batched(yolo_out, float(self.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
-                                   writeback_xyxy=False)
+                                   writeback_xyxy=False, prepped=plan.nms_prepped == float(self.conf_thresh))
         mark("nms")
         num_classes = yolo_out.shape[2] - 5
         cols = 8 + self.class_num

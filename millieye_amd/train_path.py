@@ -249,9 +249,9 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
     with torch.no_grad():
         # the detector is frozen here: it runs in whatever storage mode Darknet.compute_dtype names (fp32 by default;
         # "bf16" / "f16" = BASELINE configs[3]'s "bf16 compute" for the part of the step that is inference)
-        plan, yolo_out = net.base_detector._run(images)
+        plan, yolo_out = net.base_detector._run(images, nms_conf=float(net.conf_thresh))
         det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
-                                   writeback_xyxy=False)
+                                   writeback_xyxy=False, prepped=plan.nms_prepped == float(net.conf_thresh))
         num_classes = yolo_out.shape[2] - 5
         cols = 8 + net.class_num
         cap_img = n * _DETECTIONS_PER_IMG

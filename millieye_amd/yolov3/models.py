@@ -255,10 +255,11 @@ class Darknet(nn.Module):
             eng.tap_module = index
             eng._plans.clear()
 
-    def _run(self, x, keep_raw=False):
-        """Internal: (plan, yolo_outputs) without cloning the feature tap (used by Network)."""
+    def _run(self, x, keep_raw=False, nms_conf=None):
+        """Internal: (plan, yolo_outputs) without cloning the feature tap (used by Network).  ``nms_conf``: see
+        ``DarknetEngine.run`` (the decode fills the NMS candidate lists)."""
         eng = self.engine if keep_raw else self.engine_for(self.compute_dtype)
-        return eng.run(x, keep_raw)
+        return eng.run(x, keep_raw, nms_conf=nms_conf)
 
     def forward(self, x, targets=None):
         """``(featuremap, yolo_outputs)``, or with ``targets`` ``(loss, featuremap, yolo_outputs)`` where
