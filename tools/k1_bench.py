@@ -48,7 +48,7 @@ def main():
         old = min((v, t) for t, v in res.items() if t != 50)
         ws = res.get(50)
         print(f"{h:4d}^2 {cin:4d}->{cout:4d} batch {n}: {mb:6.1f} MB in+out = {mb / 8e3 * 1e3:5.1f} us at 8 TB/s | per-tap best "
-              f"{old[0]:6.1f} us (tile {old[1]}) | tile 50 {ws:6.1f} us = {mb / ws / 1e3:4.2f} TB/s" if ws else f"{h} {cin}->{cout}: no ws")
+              f"{old[0]:6.1f} us (tile {old[1]}) | tile 50 {ws:6.1f} us = {mb / ws:4.2f} TB/s" if ws else f"{h} {cin}->{cout}: no ws")
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@ def main():
                 pass
         old = min((v, t) for t, v in res.items() if t != 60)
         print(f"{name} {h}^2 {cin}->{cout} s{stride} batch {n}: {mb:6.1f} MB = {mb / 8e3 * 1e3:5.1f} us at 8 TB/s | best other "
-              f"{old[0]:6.1f} us (tile {old[1]}) | tile 60 {res.get(60, float('nan')):6.1f} us = {mb / res.get(60, 1e9) / 1e3:4.2f} TB/s")
+              f"{old[0]:6.1f} us (tile {old[1]}) | tile 60 {res.get(60, float('nan')):6.1f} us = {mb / res.get(60, 1e9):4.2f} TB/s")
 
 
 if __name__ == "__main__":
