@@ -337,15 +337,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const float* __res
   const int sw_cc = cc ^ ((pp & 1) << 5);  // swizzled LDS column
 
   float4 ry = make_float4(0.f, 0.f, 0.f, 0.f), rx = ry;
+  // pixel coordinates of this loader lane, advanced by 16 pixels per stage with carries (round 3: the two integer divisions per
+  // lane and stage that decoded p were ~100 vector instructions beside 8 MFMAs - with 8 waves per SIMD the kernel was bound
+  // by them, not by the matrix pipe)
+  int f_img, f_oy, f_ox;
+  {
+    const int p = p_begin + pp;
+    f_img = p / hw;
+    const int rem = p - f_img * hw;
+    f_oy = rem / wo;
+    f_ox = rem - f_oy * wo;
+  }
   auto fetch = [&](int p0) {
     const int p = p0 + pp;
     ry = make_float4(0.f, 0.f, 0.f, 0.f);
     rx = ry;
     if (p < p_end) {
       const float* yrow = DY + (long long)p * dyp + co0 + cc;
-      const int nimg = p / hw;
-      const int rem = p - nimg * hw;
-      const int oy = rem / wo, ox = rem - oy * wo;
+      const int nimg = f_img, oy = f_oy, ox = f_ox;
       const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
       const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
       const float* xrow = X + ((long long)(nimg * h + iy) * w + ix) * xp + ci0 + cc;
@@ -363,6 +372,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const float* __res
           if (ci0 + cc + 2 < cin) rx.z = xrow[2];
           if (ci0 + cc + 3 < cin) rx.w = xrow[3];
         }
+      }
+    }
+    f_ox += 16;  // the next stage's pixel
+    while (f_ox >= wo) {
+      f_ox -= wo;
+      if (++f_oy == ho) {
+        f_oy = 0;
+        ++f_img;
       }
     }
   };
