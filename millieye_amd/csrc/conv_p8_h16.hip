@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void conv3x3_p8_reduce_h16(P8Args a, int bm, i
   }
 }
 
-template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0>
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0, int TG = 1>
 int launch_p8(const Conv16P& p, hipStream_t stream) {
   constexpr int BM = 32 * MT * WR, BN = 32 * NT * WC;
   P8Args a = {};
@@ -131,13 +131,13 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   magic_u32((unsigned)a.Wp, &a.wp_m, &a.wp_s);
   a.c.tiles_m = (int)((a.Mp + BM - 1) / BM);
   a.c.tiles_n = p.cout / BN;
-  size_t lds = 3 * (size_t)BN * 64 + 2 * (size_t)a.lpa * NWAVES * 1024;
+  size_t lds = 3 * (size_t)TG * BN * 64 + 2 * (size_t)a.lpa * NWAVES * 1024;
   const size_t epi = NWAVES * 2 * 32 * 36 * sizeof(float);
   if (lds < epi) lds = epi;
   ME_REQUIRE(lds <= (MINB == 2 ? 80 : 160) * 1024, ME_E_TOOBIG,
              "me_conv2d_h16: this tile needs %zu bytes of LDS for a %d-wide map", lds, p.w);
-  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL, false>;
-  auto kern_sk = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL == 0 ? 0 : ABL, ABL == 0>;  // K-split instance
+  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL, false, TG>;
+  auto kern_sk = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL == 0 ? 0 : ABL, ABL == 0, TG>;  // K-split instance
   static bool attr_set = false;
   if (!attr_set) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -192,7 +192,8 @@ bool p8_eligible(const Conv16P& p, int tile) {
 void p8_tile_shape(int tile, int* bm, int* bn) {
   static const int ids[][3] = {{100, 128, 256}, {110, 192, 256}, {120, 256, 256}, {101, 128, 128}, {121, 256, 128},
                                {131, 384, 128}, {141, 512, 128}, {200, 128, 256}, {201, 128, 128}, {221, 256, 128},
-                               {301, 128, 128}, {311, 192, 128}, {321, 256, 128}, {331, 256, 128}};
+                               {301, 128, 128}, {311, 192, 128}, {321, 256, 128}, {331, 256, 128},
+                               {421, 256, 128}, {431, 384, 128}, {441, 512, 128}};
   *bm = *bn = 0;
   for (const auto& t : ids)
     if (t[0] == tile) {
@@ -236,6 +237,10 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 311: return ME_P8(2, 2, 3, 2, 1, 2);   // 192 x 128
     case 321: return ME_P8(2, 2, 4, 2, 1, 2);   // 256 x 128
     case 331: return ME_P8(4, 1, 2, 4, 1, 2);   // 256 x 128, wave tile 64 x 128
+    // tap groups (round 3): the one-workgroup tiles with a barrier per THREE taps (72 KB of weight slabs per chunk in LDS)
+    case 421: return p.f16 ? launch_p8<4, 2, 2, 2, 1, 1, 1, 0, 3>(p, stream) : launch_p8<4, 2, 2, 2, 1, 1, 0, 0, 3>(p, stream);
+    case 431: return p.f16 ? launch_p8<4, 2, 3, 2, 1, 1, 1, 0, 3>(p, stream) : launch_p8<4, 2, 3, 2, 1, 1, 0, 0, 3>(p, stream);
+    case 441: return p.f16 ? launch_p8<4, 2, 4, 2, 1, 1, 1, 0, 3>(p, stream) : launch_p8<4, 2, 4, 2, 1, 1, 0, 0, 3>(p, stream);
     default: break;
   }
   // Ablation / instrumented instances of the tuning tools (tools/p8_timeline.py, tools/p8_bench.py --ablate): they skip parts

@@ -73,7 +73,12 @@ constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 wave
 // SK: the instance with the K-split slab epilogue (p.splitk > 1).  It is a separate instance on purpose: merely containing
 // that path cost the whole-tile kernel 20 % (106 scalar registers + 24 spilled against 56, and a slower main loop: 58.9 vs
 // 46.6 us on the 52 x 52 128 -> 256 layer, measured with the stamp instance that never had it - profiles/r03_kernel_evolution.md)
-template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false>
+// TG = 3 (PIPE = 1 only, round 3): the weight slabs of a 64-byte channel chunk sit in LDS as three GROUPS of three taps (72 KB for
+// BN = 128) and the workgroup synchronises once per group - 6 * MT * NT MFMAs per wave between barriers instead of 2 * MT * NT.
+// With a barrier and a DMA wait per tap a stage of the one-workgroup-per-CU tiles took ~1270 cycles for 768 of MFMA issue
+// (tools/p8_wgmap.py); the per-stage overhead is now paid once per three taps.  Group g of the next chunk is fetched into slot
+// g right behind the barrier that ends the current chunk's group g.
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false, int TG = 1>
 __global__ __launch_bounds__(64 * WR * WC)
     __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
   using frag = typename DT::frag;
@@ -83,7 +88,9 @@ __global__ __launch_bounds__(64 * WR * WC)
   constexpr int TM = 32 * MT, TN = 32 * NT, BM = TM * WR, BN = TN * WC;
   constexpr int LPB = BN / 16 / NW;
   static_assert(LPB >= 1 && BN % 128 == 0, "BN must be a multiple of 128");
-  constexpr unsigned B_SLOT = BN * 64u;
+  static_assert(TG == 1 || (TG == 3 && PIPE == 1), "tap groups need the register-pipelined variant");
+  constexpr unsigned B_TAP = BN * 64u;            // one tap's weight slab of a chunk
+  constexpr unsigned B_SLOT = TG * B_TAP;         // a ring slot: one tap, or a group of three
   constexpr unsigned A_BASE = 3u * B_SLOT;
   constexpr int NSET = PIPE ? 2 : 1;
 
@@ -213,6 +220,33 @@ __global__ __launch_bounds__(64 * WR * WC)
 #pragma unroll
     for (int j = 0; j < LPB; ++j) dma1(v_b[j], rsrc_b, soff, wave_lds + ring * B_SLOT + (unsigned)j * (NW * 1024u));
   };
+  auto issue_bg = [&](int chunk, int grp) {   // TG = 3: the three taps of group grp into slot grp
+    if (ABL >= 3 && ABL <= 5) return;
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+      const unsigned soff = ((unsigned)(3 * grp + tt) * (unsigned)cs_all + (unsigned)(cbase + chunk)) * (unsigned)p.cout * 64u;
+#pragma unroll
+      for (int j = 0; j < LPB; ++j)
+        dma1(v_b[j], rsrc_b, soff, wave_lds + (unsigned)grp * B_SLOT + (unsigned)tt * B_TAP + (unsigned)j * (NW * 1024u));
+    }
+  };
+  // vmcnt(3 * LPB + extra) / vmcnt(extra) with a runtime (uniform) extra = patch pieces that may stay in flight
+  auto wait_g = [&](bool with_group, int extra) {
+    if (with_group) {
+      switch (extra) {
+        case 0: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB) : "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB + 1) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB + 2) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB + 3) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB + 4) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB + 5) : "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB + 6) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * LPB + 7) : "memory"); break;
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+  };
   // s_waitcnt takes an immediate: the runtime patch count goes through a uniform switch
   auto wait_b_plus_a = [&]() {
     switch (lpa) {
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(64 * WR * WC)
       return;
     }
     const unsigned char* Ab = smem16 + A_BASE + (unsigned)(chunk & 1) * A_SLOT;
-    const unsigned char* Bb = b_frag + (T % 3) * B_SLOT;
+    const unsigned char* Bb = b_frag + (TG == 3 ? T * B_TAP : (T % 3) * B_SLOT);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       unsigned rb0 = rowbase[i];
@@ -279,9 +313,20 @@ __global__ __launch_bounds__(64 * WR * WC)
   using Z = std::integral_constant<int, 0>;
 
   issue_a(0, 0);
+  if constexpr (TG == 3) {
+    issue_bg(0, 0);
+    issue_bg(0, 1);
+    issue_bg(0, 2);
+    if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(6 * LPB) : "memory");   // the patch and group 0 have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+  } else {
   issue_b(0, 0, 0);
   issue_b(0, 1, 1);
-  if constexpr (PIPE) {
+  }
+  if constexpr (PIPE && TG == 1) {
     // ---- software pipeline: iteration s (after its barrier): DMA(s + 3) -> ring slot of stage s; LDS -> registers for
     // stage s + 1 (fragment set P ^ 1); MFMAs of stage s from set P.  9 stages per chunk: the parity flips per chunk. ----
     issue_b(0, 2, 2);
@@ -299,8 +344,27 @@ __global__ __launch_bounds__(64 * WR * WC)
     const bool more_chunks = chunk + 1 < cs;
     if constexpr (PIPE) {
       const bool has_next = T < 8 || more_chunks;  // stage s + 1 exists
-      // stage s + 1's weights must have landed; younger loads: stage s + 2's weights, and - taps 1, 2 - the next patch
       stamp();
+      if constexpr (TG == 3) {
+        // a barrier only where the NEXT tap opens a new group (T = 2, 5, 8): that group's weights must have landed, and every
+        // wave is done reading this group (the fragments of its last tap were fetched during the tap before).  Loads younger
+        // than the next group's weights:  T = 2: group 2 of this chunk + the next patch;  T = 5: the next patch + the next
+        // chunk's group 0;  T = 8: the next chunk's group 1.
+        if constexpr (T % 3 == 2) {
+          if (has_next) {
+            if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (T == 2) wait_g(true, more_chunks ? lpa : 0);
+            else if (T == 5) wait_g(more_chunks, more_chunks ? lpa : 0);
+            else wait_g(true, 0);
+            stamp();
+            if (ABL != 5) {
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+            }
+          }
+        }
+      } else {
+      // stage s + 1's weights must have landed; younger loads: stage s + 2's weights, and - taps 1, 2 - the next patch
       if (NODMA) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if (T >= 7 && !more_chunks) {
@@ -315,6 +379,7 @@ __global__ __launch_bounds__(64 * WR * WC)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
+      }
       stamp();
       // The matrix pipe must not idle while this wave issues its DMAs and next-stage fragment reads: the stage is laid
       // out as 2 * MT groups of NT MFMAs with one slice of that work behind each group (scheduling barriers pin the order):
@@ -325,7 +390,7 @@ __global__ __launch_bounds__(64 * WR * WC)
       constexpr int TN1 = T < 8 ? T + 1 : 0;
       const int cn = T < 8 ? chunk : chunk + 1;
       const unsigned char* Ab = smem16 + A_BASE + (unsigned)(cn & 1) * A_SLOT;
-      const unsigned char* Bb = b_frag + (TN1 % 3) * B_SLOT;
+      const unsigned char* Bb = b_frag + (TG == 3 ? TN1 * B_TAP : (TN1 % 3) * B_SLOT);
       constexpr int NS = SET ^ 1;
       static_for(
           [&](auto gc) {
@@ -344,9 +409,16 @@ __global__ __launch_bounds__(64 * WR * WC)
               }
             }
             if constexpr (g == MT) {
-              constexpr int T3 = (T + 3) % 9;
-              const int c3 = chunk + (T + 3 >= 9 ? 1 : 0);
-              if (c3 < cs) issue_b(c3, T3, (unsigned)(T3 % 3));
+              if constexpr (TG == 3) {
+                // behind the barrier of T = 2 / 5 / 8 the slot of group T / 3 is free: the next chunk's group goes there
+                if constexpr (T % 3 == 2) {
+                  if (more_chunks) issue_bg(chunk + 1, T / 3);
+                }
+              } else {
+                constexpr int T3 = (T + 3) % 9;
+                const int c3 = chunk + (T + 3 >= 9 ? 1 : 0);
+                if (c3 < cs) issue_b(c3, T3, (unsigned)(T3 % 3));
+              }
               if (T == 0 && more_chunks) issue_a(chunk + 1, (unsigned)((chunk + 1) & 1));
             }
             if constexpr (g >= MT) {  // 2 * NT B-fragment reads over the MT groups MT .. 2 MT - 1

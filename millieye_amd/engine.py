@@ -789,7 +789,7 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      # CU with register-pipelined fragments, 2xx two workgroups per CU
                      100: (128, 256), 110: (192, 256), 120: (256, 256), 101: (128, 128), 121: (256, 128), 131: (384, 128),
                      141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128), 301: (128, 128), 311: (192, 128),
-                     321: (256, 128), 331: (256, 128),
+                     321: (256, 128), 331: (256, 128), 421: (256, 128), 431: (384, 128), 441: (512, 128),
                      # weight-stationary streaming 1x1 (csrc/conv1x1_ws_h16.hip): persistent grid, 32-row tiles, no split-K
                      50: (32, 256),
                      # weight-stationary 3x3 for cin 32 / 64 (csrc/conv3x3_ws_h16.hip): 2-D tiles, persistent grid, no split-K
@@ -797,7 +797,7 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
 _TUNE_TILES_TAIL = (41, 42, 43, 44, 45)  # fp32: tiles 1-5 with the last partial round of tiles cut split_k ways along K
 _TUNE_TILES_P8_F32 = (201, 221)  # fp32 is matrix-pipe bound: the big tiles' pad positions / quantisation cost more than
 # their traffic saves (tools/p8_bench_f32.py: only the 2-workgroup tiles come close to the 64x64 per-tap tile)
-_TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321)
+_TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321, 421, 431, 441)  # 4xx: a barrier per three taps
 
 
 def _autotune_enabled():
@@ -811,7 +811,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v11.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v12.json")  # bump with every kernel generation
 
 
 def _tune_load():
