@@ -288,6 +288,24 @@ def test_conv_random_shapes(hip_lib):
     assert done >= 45
 
 
+def test_conv_even_filter_with_explicit_pad(hip_lib):
+    """2x2 filters with pad 1 (output one larger than the input): the shape the stride-2 data gradient of
+    millieye_amd/detector_train.py runs as (four output-parity classes in one 2x2 convolution); through the automatic
+    plan and the per-shape tuner of the training path."""
+    from millieye_amd import hip
+    for tag, n, h, w, cin, cout in (("e0", 2, 13, 13, 64, 128), ("e1", 1, 26, 20, 128, 256), ("e2", 3, 7, 9, 24, 36)):
+        x = _t(tag + "x", (n, cin, h, w))
+        wgt = torch.from_numpy(synth.normal(tag + "w", (cout, cin, 2, 2), 0, (2.0 / (cin * 4)) ** 0.5))
+        ref = F.conv2d(x, wgt, None, 1, 1)
+        one, zero = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        for fn in (hip.conv2d, hip.conv2d_auto):
+            got = fn(xd, hip.pack_conv_weight(wgt).cuda(), one, zero, 2, 1, 1, hip.ACT_LINEAR)
+            torch.cuda.synchronize()
+            assert tuple(got.shape) == (n, h + 1, w + 1, cout)
+            assert_close(got.cpu().permute(0, 3, 1, 2), ref, TOL, tag + fn.__name__)
+
+
 P8_F32_TILES_128 = (121, 131, 201, 221, 311, 321)
 P8_F32_TILES_256 = (100, 110, 200)
 
