@@ -434,6 +434,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// Round 3: the two shapes that matter, without the per-element divisions and the 4-byte stride-k*k stores of the kernel
+// above (25 us per layer on average, 1.9 ms of a Darknet-53 step at batch 8 - a sixth of the weight gradient's time).
+// (1) flat sum, 16 bytes per lane, four slabs in flight (1x1 filters and the OHWI result);
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_v4_kernel(const float* __restrict__ slabs, float* DW, long long count4,
+                                                                   int splits) {
+  const float4* S = reinterpret_cast<const float4*>(slabs);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count4; i += (long long)gridDim.x * 256) {
+    float4 v = S[i];
+    int k = 1;
+    for (; k + 3 < splits; k += 4) {
+      const float4 a = S[(long long)k * count4 + i], b = S[(long long)(k + 1) * count4 + i],
+                   c = S[(long long)(k + 2) * count4 + i], d = S[(long long)(k + 3) * count4 + i];
+      v.x = (((v.x + a.x) + b.x) + c.x) + d.x;
+      v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+      v.z = (((v.z + a.z) + b.z) + c.z) + d.z;
+      v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; k < splits; ++k) {
+      const float4 a = S[(long long)k * count4 + i];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    reinterpret_cast<float4*>(DW)[i] = v;
+  }
+}
+
+// (2) OHWI slabs -> OIHW parameter layout: a block owns one output channel x 64 input channels x all taps; the slab reads
+// are runs of 64 floats per tap, the sums turn through LDS ([ci][tap], odd pitch) and leave as one contiguous run.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_oihw_kernel(const float* __restrict__ slabs, float* DW, long long count,
+                                                                     int splits, int kk, int cin) {
+  extern __shared__ float s_t[];  // [64][kk | 1]
+  const int pitch = kk | 1;
+  const int co = blockIdx.y, c0 = blockIdx.x * 64;
+  const int nc = cin - c0 < 64 ? cin - c0 : 64;
+  for (int i = threadIdx.x; i < kk * 64; i += 256) {
+    const int tap = i >> 6, cl = i & 63;
+    if (cl < nc) {
+      const long long idx = ((long long)co * kk + tap) * cin + c0 + cl;
+      float v = slabs[idx];
+      int k = 1;
+      for (; k + 3 < splits; k += 4) {
+        const float a = slabs[(long long)k * count + idx], b = slabs[(long long)(k + 1) * count + idx],
+                    c = slabs[(long long)(k + 2) * count + idx], d = slabs[(long long)(k + 3) * count + idx];
+        v = (((v + a) + b) + c) + d;
+      }
+      for (; k < splits; ++k) v += slabs[(long long)k * count + idx];
+      s_t[cl * pitch + tap] = v;
+    }
+  }
+  __syncthreads();
+  float* dst = DW + ((long long)co * cin + c0) * kk;
+  for (int i = threadIdx.x; i < nc * kk; i += 256) {
+    const int cl = i / kk;  // (kk is small: 9, 25, 49)
+    dst[i] = s_t[cl * pitch + (i - cl * kk)];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // RoI pooling backward (torchvision roi_align / ps_roi_align backward semantics, oracle/tv_ops.c):
 // every sample scatters grad * w / count to its four bilinear corners with atomicAdd.
@@ -549,6 +605,81 @@ __global__ __launch_bounds__(256) void affine_bwd_partial_kernel(const float* __
   if (rl == 0 && c < C) {
     p0[(long long)chunk * C + c] = (float)(((s0s[0][cl] + s0s[1][cl]) + s0s[2][cl]) + s0s[3][cl]);
     p1[(long long)chunk * C + c] = (float)(((s1s[0][cl] + s1s[1][cl]) + s1s[2][cl]) + s1s[3][cl]);
+  }
+}
+
+// The same pass with 16-byte accesses and four rows in flight per lane (round 3: the scalar kernel above ran one 4-byte
+// load pair per lane and iteration - 1.5 TB/s on the 4 GB the Darknet-53 step moves through it at batch 8).  A block owns
+// 64 channels x one row chunk; its 256 threads are 16 channel quads x 16 row lanes, each lane walks rows rl, rl + 16, ...
+// four at a time; the 16 row lanes of a channel are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void affine_bwd_partial_v4_kernel(const float* __restrict__ Y, long long ldy,
+                                                                    const float* __restrict__ G, long long ldg, int rows,
+                                                                    int C, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int act, float* p0,
+                                                                    float* p1, int chunks, const float* __restrict__ scale,
+                                                                    float* DC, long long lddc) {
+  __shared__ double s0s[16][64], s1s[16][64];
+  const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + q * 4;
+  const int chunk = blockIdx.y;
+  const int per = (rows + chunks - 1) / chunks;
+  const int r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C) {  // C % 4 == 0: the quad is all in or all out
+    float ga[4], be[4], inv_ga[4], scl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ga[j] = gamma ? gamma[c + j] : 1.f;
+      be[j] = beta ? beta[c + j] : 0.f;
+      inv_ga[j] = (gamma && ga[j] != 0.f) ? 1.f / ga[j] : 0.f;
+      scl[j] = scale ? scale[c + j] : 1.f;
+    }
+    auto one = [&](int r, float4 y4, float4 g4) {
+      float y[4] = {y4.x, y4.y, y4.z, y4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = y[j];
+        if (act == ME_ACT_LEAKY) {
+          g[j] = y[j] > 0.f ? g[j] : 0.1f * g[j];
+          z = y[j] > 0.f ? y[j] : y[j] * 10.f;
+        }
+        s0[j] += g[j];
+        s1[j] += (double)g[j] * ((z - be[j]) * inv_ga[j]);
+        d[j] = scale ? g[j] * scl[j] : g[j];
+      }
+      if (DC) *reinterpret_cast<float4*>(DC + (long long)r * lddc + c) = make_float4(d[0], d[1], d[2], d[3]);
+    };
+    int r = r0 + rl;
+    for (; r + 48 < r1; r += 64) {
+      float4 yv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        yv[u] = *reinterpret_cast<const float4*>(Y + (long long)(r + 16 * u) * ldy + c);
+        gv[u] = *reinterpret_cast<const float4*>(G + (long long)(r + 16 * u) * ldg + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(r + 16 * u, yv[u], gv[u]);
+    }
+    for (; r < r1; r += 16)
+      one(r, *reinterpret_cast<const float4*>(Y + (long long)r * ldy + c),
+          *reinterpret_cast<const float4*>(G + (long long)r * ldg + c));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s0s[rl][q * 4 + j] = s0[j];
+    s1s[rl][q * 4 + j] = s1[j];
+  }
+  __syncthreads();
+  const int cl = threadIdx.x;
+  if (cl < 64 && blockIdx.x * 64 + cl < C) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      a += s0s[k][cl];
+      b += s1s[k][cl];
+    }
+    p0[(long long)chunk * C + blockIdx.x * 64 + cl] = (float)a;
+    p1[(long long)chunk * C + blockIdx.x * 64 + cl] = (float)b;
   }
 }
 
@@ -856,8 +987,16 @@ int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t 
   const int chunks = affine_chunks(rows);
   float* p0 = reinterpret_cast<float*>(workspace);
   float* p1 = p0 + (long long)chunks * channels;
-  hipLaunchKernelGGL(affine_bwd_partial_kernel, dim3((channels + 63) / 64, chunks), dim3(256), 0, stream, y, (long long)ldy,
-                     dy, (long long)lddy, rows, channels, gamma, beta, act, p0, p1, chunks, scale, dc, (long long)lddc);
+  const bool v4 = channels % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && lddc % 4 == 0 && me::aligned16(y) &&
+                  me::aligned16(dy) && me::aligned16(dc);
+  if (v4)
+    hipLaunchKernelGGL(affine_bwd_partial_v4_kernel, dim3((channels + 63) / 64, chunks), dim3(256), 0, stream, y,
+                       (long long)ldy, dy, (long long)lddy, rows, channels, gamma, beta, act, p0, p1, chunks, scale, dc,
+                       (long long)lddc);
+  else
+    hipLaunchKernelGGL(affine_bwd_partial_kernel, dim3((channels + 63) / 64, chunks), dim3(256), 0, stream, y,
+                       (long long)ldy, dy, (long long)lddy, rows, channels, gamma, beta, act, p0, p1, chunks, scale, dc,
+                       (long long)lddc);
   hipLaunchKernelGGL(affine_bwd_reduce_kernel, dim3((channels + 63) / 64), dim3(1024), 0, stream, p0, p1, channels, chunks,
                      dshift, dgamma);
   return me::check_launch("affine_act_bwd");
@@ -927,11 +1066,22 @@ int me_conv_wgrad_f32(const float* x, int64_t x_pitch, const float* dy, int64_t 
   return me::check_launch("conv_wgrad_kernel");
 }
 
-// pixel slices so that the grid has ~2048 workgroups; each slice a multiple of 16 pixels
+// pixel slices so that the grid has ~2048 workgroups; each slice a multiple of 16 pixels and at least WGRAD_MIN_PX of them
+// (round 3: the 1x1 layers were cut into up to 256 slices of ~96 pixels - six pipeline stages per workgroup, then a reduction
+// over 256 slabs; MILLIEYE_WGRAD_MINPX is the tuning switch that found the floor)
+static int wgrad_min_px() {
+  static const int v = [] {
+    const char* e = getenv("MILLIEYE_WGRAD_MINPX");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 256;
+  }();
+  return v;
+}
+
 static int wgrad_splits(long long P, int cin, int cout, int ks) {
   const long long tiles = (long long)((cin + 63) / 64) * ((cout + 63) / 64) * ks * ks;
   long long s = (2048 + tiles - 1) / tiles;
-  const long long max_s = (P + 63) / 64;
+  const long long max_s = (P + wgrad_min_px() - 1) / wgrad_min_px();
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   if (s > 256) s = 256;
@@ -974,8 +1124,17 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
                        (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per);
   int rc = me::check_launch("conv_wgrad_mfma_kernel");
   if (rc || !via_ws) return rc;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid1d(count)), dim3(256), 0, stream,
-                     reinterpret_cast<const float*>(workspace), dw, count, splits, (oihw && ksize > 1) ? ksize * ksize : 0, cin);
+  const float* slabs = reinterpret_cast<const float*>(workspace);
+  if (oihw && ksize > 1 && cout < 65536) {
+    const int kk = ksize * ksize;
+    hipLaunchKernelGGL(conv_wgrad_reduce_oihw_kernel, dim3((cin + 63) / 64, cout), dim3(256), 64 * (kk | 1) * sizeof(float),
+                       stream, slabs, dw, count, splits, kk, cin);
+  } else if (!(oihw && ksize > 1) && count % 4 == 0 && me::aligned16(dw) && me::aligned16(workspace)) {
+    hipLaunchKernelGGL(conv_wgrad_reduce_v4_kernel, dim3(grid1d(count / 4)), dim3(256), 0, stream, slabs, dw, count / 4, splits);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid1d(count)), dim3(256), 0, stream, slabs, dw, count, splits,
+                       (oihw && ksize > 1) ? ksize * ksize : 0, cin);
+  }
   return me::check_launch("conv_wgrad_reduce_kernel");
 }
 
