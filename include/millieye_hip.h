@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 7
+#define ME_ABI_VERSION 8
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -415,6 +415,31 @@ int me_conv_wgrad_mfma_oihw_f32(const float* x, int64_t x_pitch, const float* dy
 int me_pack_conv_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t ksize, const float* bias, const float* gamma,
                      const float* beta, const float* mean, const float* var, float eps, float* ohwi, float* tiled,
                      float* rot, float* rot_tiled, float* scale, float* shift, void* stream);
+/* The same for a whole network in ONE launch (a training step re-packs every layer: 75 launches of a few microseconds of
+ * work each were ~1.4 ms of a Darknet-53 step).  The caller fills one me_pack_desc per conv block (same pointers and meaning as
+ * the arguments of me_pack_conv_f32), me_pack_conv_plan validates them and fills first_block / blocks_x and returns the
+ * grid size (< 0: error code), the table is copied to device memory once (the packed buffers and parameters of a module
+ * tree are stable) and me_pack_conv_batch_f32 runs it. */
+typedef struct me_pack_desc {
+  const float* w;      /* [cout][cin][k][k] */
+  const float* bias;   /* or NULL */
+  const float* gamma;  /* BatchNorm weight or NULL (then beta / mean / var are ignored) */
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float* ohwi;
+  float* tiled;        /* or NULL */
+  float* rot;          /* or NULL */
+  float* rot_tiled;    /* or NULL */
+  float* scale;
+  float* shift;
+  int32_t cout, cin, ksize;
+  float eps;
+  int32_t first_block, blocks_x;  /* filled by me_pack_conv_plan */
+} me_pack_desc;
+int64_t me_pack_conv_plan(me_pack_desc* descs_host, int32_t count);
+int me_pack_conv_batch_f32(const me_pack_desc* descs_device, int32_t count, int64_t total_blocks, int32_t max_ksize,
+                           void* stream);
 /* RoI pooling backward: grad_out [k,c_out,7,7] scattered (atomicAdd) into the zero-filled NHWC grad_map */
 int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
                          int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch, void* stream);

@@ -434,6 +434,98 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// Weight gradient of the network's first convolution (3 input channels, 3x3): on the 64x64 MFMA tile above 3 of 64 input
+// channels are real and the K loop is 1.4 M pixels long - 1.4 ms of a Darknet-53 step at batch 8 for 2.4 GFLOP.  Here a
+// lane owns 4 output channels x all 27 (tap, ci) products of one pixel lane: 256 threads = 8 channel groups x 32 pixel
+// lanes, 108 accumulators per lane, the pixel's 27 inputs and 4 gradients are loaded once per 108 FMAs.  Per block the 32
+// pixel lanes are summed through LDS in a fixed order; a second kernel adds the blocks' partials (fixed order too).
+constexpr int SW_BLOCKS = 768;
+
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ X, long long xp,
+                                                         const float* __restrict__ DY, long long dyp, float* PART, int n,
+                                                         int h, int w, int cout, int stride, int pad, int ho, int wo) {
+  __shared__ float s_r[32][8][28];
+  const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int co0 = blockIdx.y * 32 + cg * 4;
+  const bool live = co0 < cout;  // cout % 4 == 0
+  const long long P = (long long)n * ho * wo;
+  const int hw = ho * wo;
+  float acc[4][27];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[j][t] = 0.f;
+  if (live) {
+    for (long long p = (long long)blockIdx.x * 32 + pl; p < P; p += (long long)gridDim.x * 32) {
+      const int img = (int)(p / hw);
+      const int rem = (int)(p - (long long)img * hw);
+      const int oy = rem / wo, ox = rem - oy * wo;
+      const float4 g = *reinterpret_cast<const float4*>(DY + p * dyp + co0);
+      float xv[27];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * stride - pad + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ox * stride - pad + kx;
+          const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+          const float* px = X + ((long long)(img * h + iy) * w + ix) * xp;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) xv[(ky * 3 + kx) * 3 + ci] = inb ? px[ci] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        acc[0][t] += g.x * xv[t];
+        acc[1][t] += g.y * xv[t];
+        acc[2][t] += g.z * xv[t];
+        acc[3][t] += g.w * xv[t];
+      }
+    }
+  }
+  // partial of this block in OHWI order: [co][tap][ci] = co * 27 + t
+  float* out = PART + ((long long)blockIdx.x * cout) * 27;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 27; ++t) s_r[pl][cg][t] = acc[j][t];
+    __syncthreads();
+    if (threadIdx.x < 8 * 27) {
+      const int g2 = threadIdx.x / 27, t = threadIdx.x - g2 * 27;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) v += s_r[k][g2][t];
+      const int co = blockIdx.y * 32 + g2 * 4 + j;
+      if (co < cout) out[(long long)co * 27 + t] = v;
+    }
+  }
+}
+
+// sum of the stem partials: 16 outputs x 16 lanes per block; OHWI (oihw = 0) or OIHW result
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ PART, float* DW, int count, int nblk,
+                                                                int oihw) {
+  __shared__ float s_p[16][17];
+  const int ol = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + ol;
+  float v = 0.f;
+  if (o < count)
+    for (int k = part; k < nblk; k += 16) v += PART[(long long)k * count + o];
+  s_p[part][ol] = v;
+  __syncthreads();
+  if (part == 0 && o < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += s_p[k][ol];
+    int dst = o;
+    if (oihw) {  // o = (co * 9 + tap) * 3 + ci  ->  (co * 3 + ci) * 9 + tap
+      const int co = o / 27, r = o - co * 27, tap = r / 3, ci = r - tap * 3;
+      dst = (co * 3 + ci) * 9 + tap;
+    }
+    DW[dst] = t;
+  }
+}
+
 // Round 3: the two shapes that matter, without the per-element divisions and the 4-byte stride-k*k stores of the kernel
 // above (25 us per layer on average, 1.9 ms of a Darknet-53 step at batch 8 - a sixth of the weight gradient's time).
 // (1) flat sum, 16 bytes per lane, four slabs in flight (1x1 filters and the OHWI result);
@@ -1088,7 +1180,10 @@ static int wgrad_splits(long long P, int cin, int cout, int ks) {
   return (int)s;
 }
 
+static bool stem_wgrad_shape(int cin, int cout, int ksize) { return cin == 3 && ksize == 3 && cout % 4 == 0; }
+
 int64_t me_conv_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize) {
+  if (stem_wgrad_shape(cin, cout, ksize)) return (int64_t)SW_BLOCKS * cout * 27 * (int64_t)sizeof(float);
   const int s = wgrad_splits((long long)n * ho * wo, cin, cout, ksize);
   return s > 1 ? (int64_t)s * cout * ksize * ksize * cin * (int64_t)sizeof(float) : 0;
 }
@@ -1103,8 +1198,17 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
   const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
   const long long P = (long long)n * ho * wo;
   ME_REQUIRE(P < (1ll << 31), ME_E_TOOBIG, "me_conv_wgrad_mfma_f32: too many output pixels");
-  int splits = wgrad_splits(P, cin, cout, ksize);
   const long long count = (long long)cout * ksize * ksize * cin;
+  if (stem_wgrad_shape(cin, cout, ksize) && dy_pitch % 4 == 0 && me::aligned16(dy) && workspace &&
+      workspace_bytes >= (int64_t)SW_BLOCKS * count * (int64_t)sizeof(float) && (cout + 31) / 32 < 65536) {
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(SW_BLOCKS, (cout + 31) / 32), dim3(256), 0, stream, x, (long long)x_pitch, dy,
+                       (long long)dy_pitch, part, n, h, w, cout, stride, pad, ho, wo);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, stream, part, dw, (int)count,
+                       SW_BLOCKS, oihw);
+    return me::check_launch("stem_wgrad_kernel");
+  }
+  int splits = wgrad_splits(P, cin, cout, ksize);
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * count * (int64_t)sizeof(float))) splits = 1;
   ME_REQUIRE(!oihw || ksize == 1 || (workspace && workspace_bytes >= count * (int64_t)sizeof(float)), ME_E_BADARG,
              "me_conv_wgrad_mfma_oihw_f32: needs a workspace of at least one slab (%lld bytes)", count * 4ll);

@@ -62,11 +62,11 @@ class DetectorTrainer:
         outs, raws, bn_state = [], {}, {}
         ws_t = torch.empty(int(lib.me_bn_workspace_bytes(2048)) + 256, dtype=torch.uint8, device=x.device)
         ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256
+        eng.refresh_train_weights(x.device)
         for i, d in enumerate(defs):
             t = d["type"]
             if t == "convolutional":
-                cw = eng._conv_weights(i)
-                cw.want_rot = i > 0  # the data gradient's weights come out of the same pack launch
+                cw = eng._conv_weights(i)  # (packed by refresh_train_weights above; a no-op stamp check here)
                 cw.refresh(x.device)
                 k, s = int(d["size"]), int(d["stride"])
                 act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
@@ -228,7 +228,10 @@ class DetectorTrainer:
                                               dx.data_ptr(), cin, stream()), "me_gemm_f32")
                     contribute(i - 1, dx, True)
                 else:
-                    if cw.rot is not None:  # [cin][k][k][cout] rotated 180 degrees, from the step's pack launch
+                    parity = s == 2 and k == 3 and pad == 1 and h == 2 * ho and w == 2 * wo and cin % 4 == 0
+                    if parity:
+                        wt = wt_tiled = None
+                    elif cw.rot is not None:  # [cin][k][k][cout] rotated 180 degrees, from the step's pack launch
                         wt, wt_tiled = cw.rot, cw.rot_tiled
                     else:
                         wt, wt_tiled = cw.wgt.flip(1, 2).permute(3, 1, 2, 0).contiguous(), None
@@ -241,7 +244,7 @@ class DetectorTrainer:
                     if s == 1:
                         dx = hip.conv2d_auto(dc, wt, ones, zeros, k, 1, k - 1 - pad, hip.ACT_LINEAR, residual=res, out=out_t,
                                              wgt_tiled=wt_tiled)
-                    elif s == 2 and k == 3 and pad == 1 and h == 2 * ho and w == 2 * wo and cin % 4 == 0:
+                    elif parity:
                         # Stride-2 transposed convolution by output parity (round 3; it ran as a 3x3 correlation over the
                         # zero-interleaved gradient: 9 taps on 4x the pixels = 4x the forward FLOPs).  dx[2a+py, 2b+px] only
                         # sees the taps with ky = py + 1 (mod 2), kx = px + 1 (mod 2): per axis one tap (W[1], offset 0) for the

@@ -109,9 +109,9 @@ class ConvWeights:
     def stamp(self):
         return tuple((t.data_ptr(), t._version) for t in self._sources()) + (_EPOCH[0],)
 
-    def _refresh_packed_f32(self, device):
-        """fp32, parameters already on ``device``: ONE launch of ``me_pack_conv_f32`` writes every packed copy into the
-        stable buffers (a training step re-packs every layer: through torch that was ~25 launches per layer)."""
+    def _prepare_packed_f32(self, device):
+        """Eligibility + the stable destination buffers of the one-launch pack: None (not fp32 parameters on ``device``),
+        "realloc" (new buffers: descriptors holding the old pointers are stale) or True."""
         conv, bn = self.conv, self.bn
         w = conv.weight
         cout, cin, k, k2 = w.shape
@@ -133,14 +133,33 @@ class ConvWeights:
         if self.want_rot and self.rot is None:
             self.rot = torch.empty((cin, k, k, cout), **f32)
             self.rot_tiled = torch.empty((k * k, cout // 16, cin, 16), **f32) if cout % 16 == 0 else None
-        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        hip.check(hip.lib().me_pack_conv_f32(
-            w.data_ptr(), cout, cin, k, ptr(conv.bias), ptr(bn.weight if bn is not None else None),
-            ptr(bn.bias if bn is not None else None), ptr(bn.running_mean if bn is not None else None),
-            ptr(bn.running_var if bn is not None else None), float(bn.eps) if bn is not None else 0.0, self.wgt.data_ptr(),
-            ptr(self.wgt_tiled), ptr(self.rot if self.want_rot else None), ptr(self.rot_tiled if self.want_rot else None),
-            self.scale.data_ptr(), self.shift.data_ptr(), hip.stream_ptr()), "me_pack_conv_f32")
         return "realloc" if realloc else True
+
+    def _pack_desc(self, d):
+        """Fill one ``hip.PackDesc`` (me_pack_desc) from the module's parameters and the buffers of _prepare_packed_f32."""
+        conv, bn = self.conv, self.bn
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        cout, cin, k, _ = conv.weight.shape
+        d.w, d.bias = conv.weight.data_ptr(), ptr(conv.bias)
+        d.gamma, d.beta = ptr(bn.weight if bn is not None else None), ptr(bn.bias if bn is not None else None)
+        d.mean, d.var = ptr(bn.running_mean if bn is not None else None), ptr(bn.running_var if bn is not None else None)
+        d.ohwi, d.tiled = self.wgt.data_ptr(), ptr(self.wgt_tiled)
+        d.rot, d.rot_tiled = ptr(self.rot if self.want_rot else None), ptr(self.rot_tiled if self.want_rot else None)
+        d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
+        d.cout, d.cin, d.ksize, d.eps = cout, cin, k, float(bn.eps) if bn is not None else 0.0
+        return d
+
+    def _refresh_packed_f32(self, device):
+        """fp32, parameters already on ``device``: ONE launch of ``me_pack_conv_f32`` writes every packed copy into the
+        stable buffers (a training step re-packs every layer: through torch that was ~25 launches per layer)."""
+        done = self._prepare_packed_f32(device)
+        if done is None:
+            return None
+        d = self._pack_desc(hip.PackDesc())
+        hip.check(hip.lib().me_pack_conv_f32(d.w, d.cout, d.cin, d.ksize, d.bias, d.gamma, d.beta, d.mean, d.var, d.eps, d.ohwi,
+                                             d.tiled, d.rot, d.rot_tiled, d.scale, d.shift, hip.stream_ptr()),
+                  "me_pack_conv_f32")
+        return done
 
     def refresh(self, device):
         stamp = self.stamp() + (self.want_rot,)
@@ -268,6 +287,60 @@ class DarknetEngine:
             cw.cin_pad, cw.cout_pad = cin_pad, cout_pad
             cw._stamp = None
         return cw
+
+    def refresh_train_weights(self, device):
+        """Training step (millieye_amd/detector_train.py): every conv block's parameters changed, so all of them are packed
+        by ONE ``me_pack_conv_batch_f32`` launch from a descriptor table kept in device memory (parameters and packed buffers
+        of a module tree are stable, so the table is rebuilt only when a pointer moves).  The rotated copies for the data
+        gradient ride along, except for layer 0 (no data gradient) and the 3x3 / stride-2 layers (their data gradient is the
+        output-parity convolution built from the forward layout).  Falls back to the per-layer launches when a block is not
+        plain fp32 on ``device``."""
+        import ctypes as C
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        cws = []
+        for i, d in enumerate(self.model.module_defs):
+            if d["type"] != "convolutional":
+                continue
+            cw = self._conv_weights(i)
+            cw.want_rot = i > 0 and not (int(d["size"]) == 3 and int(d["stride"]) == 2)
+            cws.append(cw)
+        stale = []
+        for cw in cws:
+            stamp = cw.stamp() + (cw.want_rot,)
+            if not (stamp == cw._stamp and cw.wgt is not None and cw.wgt.device == dev):
+                stale.append((cw, stamp))
+        if not stale:
+            return
+        batch = self.dtype == "f32" and dev.type == "cuda" and len(stale) >= 2 and \
+            not any(cw.cin_pad or cw.cout_pad for cw, _ in stale)
+        if batch:
+            states = [cw._prepare_packed_f32(dev) for cw, _ in stale]
+            batch = all(st is not None for st in states)
+        if not batch:
+            for cw, _ in stale:
+                if cw.refresh(dev) == "realloc" and self._plans:
+                    self._plans.clear()
+            return
+        if "realloc" in states and self._plans:
+            self._plans.clear()
+        descs = (hip.PackDesc * len(stale))()
+        for d, (cw, _) in zip(descs, stale):
+            cw._pack_desc(d)
+        key = bytes(descs)
+        cached = self.__dict__.get("_pack_table")
+        if cached is None or cached[0] != key:
+            total = int(hip.lib().me_pack_conv_plan(descs, len(stale)))
+            if total <= 0:
+                raise hip.MeError("me_pack_conv_plan: " + hip.lib().me_last_error().decode("utf-8", "replace"))
+            table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+            cached = self._pack_table = (key, table, total, max(int(d.ksize) for d in descs))
+        _, table, total, max_k = cached
+        hip.check(hip.lib().me_pack_conv_batch_f32(table.data_ptr(), len(stale), total, max_k, hip.stream_ptr()),
+                  "me_pack_conv_batch_f32")
+        for cw, stamp in stale:
+            cw._stamp = stamp
 
     def refresh_weights(self, device):
         """Re-pack whatever parameter changed since the last run.  The fast path is one flat tuple of

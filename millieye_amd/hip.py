@@ -114,7 +114,19 @@ class HeadsDesc(C.Structure):
     ]
 
 
-_STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights, 6: Conv16Desc}
+class PackDesc(C.Structure):
+    """me_pack_desc: one conv block of a me_pack_conv_batch_f32 table."""
+    _fields_ = [
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p),
+        ("var", C.c_void_p),
+        ("ohwi", C.c_void_p), ("tiled", C.c_void_p), ("rot", C.c_void_p), ("rot_tiled", C.c_void_p), ("scale", C.c_void_p),
+        ("shift", C.c_void_p),
+        ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("eps", C.c_float),
+        ("first_block", C.c_int32), ("blocks_x", C.c_int32),
+    ]
+
+
+_STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights, 6: Conv16Desc, 7: PackDesc}
 
 # name -> (restype, argtypes); every symbol include/millieye_hip.h declares
 SIGNATURES = {
@@ -206,6 +218,8 @@ SIGNATURES = {
                          + [C.c_void_p] * 7),
     "me_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_pack_conv_plan": (C.c_int64, [C.POINTER(PackDesc), C.c_int32]),
+    "me_pack_conv_batch_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "me_ps_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "me_roi_align_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -239,8 +253,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 7:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 7")
+    if lib_.me_abi_version() != 8:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 8")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "

@@ -345,3 +345,66 @@ def test_conv_p8_f32_refuses_what_it_cannot_do(hip_lib):
         hip.conv2d(x, torch.zeros((72, 3, 3, 32)).cuda(), one[:72], one[:72], 3, 1, 1, 1, tile=221)  # cout % 128
     with pytest.raises(hip.MeError):
         hip.conv2d(x, torch.zeros((128, 3, 3, 32)).cuda(), one, one, 3, 2, 1, 1, tile=221)           # stride 2
+
+
+def test_pack_conv_single_and_batch(hip_lib):
+    """me_pack_conv_f32 / me_pack_conv_batch_f32: every packed copy against torch permutes of the OIHW parameter (ragged
+    channel counts, 1x1 / 3x3 / 5x5, with and without BatchNorm / bias / rotated copies), and the one-launch table gives the
+    same bytes as the per-layer launches."""
+    from millieye_amd import hip
+    lib = hip.lib()
+    shapes = [(32, 3, 3, True, False), (64, 32, 3, True, True), (51, 48, 1, False, True), (40, 80, 3, True, True),
+              (128, 256, 1, True, True), (16, 16, 3, True, True), (255, 1024, 1, False, False), (96, 36, 3, True, True)]
+    keep, descs, expect = [], (hip.PackDesc * len(shapes))(), []
+    for idx, (cout, cin, k, with_bn, with_rot) in enumerate(shapes):
+        tag = f"pk{idx}"
+        w = _t(tag + "w", (cout, cin, k, k)).cuda()
+        bias = None if with_bn else _t(tag + "b", (cout,)).cuda()
+        g, b, m = (_t(tag + c, (cout,)).cuda() for c in "gbm") if with_bn else (None, None, None)
+        v = _t(tag + "v", (cout,), 0.5, 1.5).cuda() if with_bn else None
+        outs = dict(ohwi=torch.zeros((cout, k, k, cin)), tiled=torch.zeros((k * k, cin // 16, cout, 16)) if cin % 16 == 0 else None,
+                    rot=torch.zeros((cin, k, k, cout)) if with_rot else None,
+                    rott=torch.zeros((k * k, cout // 16, cin, 16)) if with_rot and cout % 16 == 0 else None,
+                    scale=torch.zeros(cout), shift=torch.zeros(cout))
+        one = {n_: (t.cuda() if t is not None else None) for n_, t in outs.items()}
+        two = {n_: (t.cuda() if t is not None else None) for n_, t in outs.items()}
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        hip.check(lib.me_pack_conv_f32(w.data_ptr(), cout, cin, k, ptr(bias), ptr(g), ptr(b), ptr(m), ptr(v), 1e-5,
+                                       one["ohwi"].data_ptr(), ptr(one["tiled"]), ptr(one["rot"]), ptr(one["rott"]),
+                                       one["scale"].data_ptr(), one["shift"].data_ptr(), hip.stream_ptr()), "me_pack_conv_f32")
+        d = descs[idx]
+        d.w, d.bias, d.gamma, d.beta, d.mean, d.var = w.data_ptr(), ptr(bias), ptr(g), ptr(b), ptr(m), ptr(v)
+        d.ohwi, d.tiled, d.rot, d.rot_tiled = two["ohwi"].data_ptr(), ptr(two["tiled"]), ptr(two["rot"]), ptr(two["rott"])
+        d.scale, d.shift, d.cout, d.cin, d.ksize, d.eps = two["scale"].data_ptr(), two["shift"].data_ptr(), cout, cin, k, 1e-5
+        keep.append((w, bias, g, b, m, v))
+        # torch restatement
+        wc = w.cpu()
+        assert torch.equal(one["ohwi"].cpu(), wc.permute(0, 2, 3, 1).contiguous()), tag
+        if one["tiled"] is not None:
+            ref = wc.permute(2, 3, 1, 0).reshape(k * k, cin // 16, 16, cout).permute(0, 1, 3, 2).contiguous()
+            assert torch.equal(one["tiled"].cpu(), ref), tag
+        if one["rot"] is not None:
+            rot = wc.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+            assert torch.equal(one["rot"].cpu(), rot), tag
+            if one["rott"] is not None:
+                ref = rot.permute(1, 2, 3, 0).reshape(k * k, cout // 16, 16, cin).permute(0, 1, 3, 2).contiguous()
+                assert torch.equal(one["rott"].cpu(), ref), tag
+        if with_bn:
+            sc = g.cpu().double() / torch.sqrt(v.cpu().double() + 1e-5)
+            sh = b.cpu().double() - m.cpu().double() * sc
+        else:
+            sc, sh = torch.ones(cout, dtype=torch.float64), bias.cpu().double()
+        assert_close(one["scale"].cpu(), sc.float(), 1e-6, tag + "scale")
+        assert_close(one["shift"].cpu(), sh.float(), 1e-6, tag + "shift")
+        expect.append((one, two))
+    total = int(lib.me_pack_conv_plan(descs, len(shapes)))
+    assert total > 0
+    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).cuda()
+    hip.check(lib.me_pack_conv_batch_f32(table.data_ptr(), len(shapes), total, 3, hip.stream_ptr()), "me_pack_conv_batch_f32")
+    torch.cuda.synchronize()
+    for one, two in expect:
+        for n_ in one:
+            if one[n_] is not None:
+                assert torch.equal(one[n_], two[n_]), n_
+    bad = (hip.PackDesc * 1)()
+    assert int(lib.me_pack_conv_plan(bad, 1)) < 0

@@ -96,7 +96,8 @@ def test_conv_wgrad_and_dgrad(hip_lib, cin, cout, k):
 
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s", [(2, 10, 12, 32, 64, 3, 1), (3, 13, 13, 64, 255, 1, 1), (2, 16, 16, 3, 32, 3, 1),
                                                 (2, 20, 20, 32, 64, 3, 2), (1, 7, 7, 10, 10, 7, 1), (4, 26, 26, 128, 256, 3, 1),
-                                                (1, 5, 9, 48, 20, 3, 1)])
+                                                (1, 5, 9, 48, 20, 3, 1), (3, 33, 41, 3, 32, 3, 2), (2, 24, 24, 3, 72, 3, 1),
+                                                (1, 9, 9, 3, 30, 3, 1)])
 def test_conv_wgrad_mfma(hip_lib, n, h, w, cin, cout, k, s):
     """me_conv_wgrad_mfma_f32 (matrix-pipe weight gradient, sliced pixel reduction + ordered slab sum) against torch
     CPU autograd: stride 2, ragged / unaligned channel counts (cin 3, cout 255), 1x1 and 7x7 (pad 0), many slices."""
@@ -114,6 +115,8 @@ def test_conv_wgrad_mfma(hip_lib, n, h, w, cin, cout, k, s):
     dw2 = hip.conv_wgrad(xd, dyd, k, s, pad)
     assert torch.equal(dw, dw2), "the sliced reduction must be deterministic"
     assert _rel(dw.permute(0, 3, 1, 2), wt.grad) < 1e-4
+    # the parameter's own layout (the slab reduction transposes; cin = 3 with cout % 4 == 0 is the stem kernel)
+    assert torch.equal(hip.conv_wgrad(xd, dyd, k, s, pad, oihw=True), dw.permute(0, 3, 1, 2).contiguous())
 
 
 def test_roi_backward_vs_oracle(hip_lib):

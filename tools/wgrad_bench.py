@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from millieye_amd import hip  # noqa: E402
 
 # (count in the network, input h, cin, cout, k, stride)
-SHAPES = [(1, 416, 32, 64, 3, 2), (1, 208, 64, 32, 1, 1), (1, 208, 32, 64, 3, 1), (1, 208, 64, 128, 3, 2),
+SHAPES = [(1, 416, 3, 32, 3, 1), (1, 416, 32, 64, 3, 2), (1, 208, 64, 32, 1, 1), (1, 208, 32, 64, 3, 1), (1, 208, 64, 128, 3, 2),
           (2, 104, 128, 64, 1, 1), (2, 104, 64, 128, 3, 1), (1, 104, 128, 256, 3, 2), (8, 52, 256, 128, 1, 1),
           (8, 52, 128, 256, 3, 1), (1, 52, 256, 512, 3, 2), (8, 26, 512, 256, 1, 1), (8, 26, 256, 512, 3, 1),
           (1, 26, 512, 1024, 3, 2), (7, 13, 1024, 512, 1, 1), (7, 13, 512, 1024, 3, 1), (1, 13, 1024, 51, 1, 1),
