@@ -415,6 +415,118 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const float* __res
   }
 }
 
+// The same GEMM on larger tiles (round 3): TCO x TCI outputs per workgroup, each of the 4 waves (TCO/2) x (TCI/2) =
+// MT x NT accumulators of 32x32.  A 64x64 tile moves 8 KB of operands per 131 KFLOP (16 FLOP/B out of L2 - 5 TB/s of L2
+// traffic at the 83 TFLOP/s it reached on the 3x3 layers); 128x128 halves the bytes and the LDS reads per FLOP.  16-byte
+// loads only (the launcher keeps the 64x64 kernel above for ragged / unaligned operands).
+template <int TCO, int TCI>
+__global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const float* __restrict__ X, long long xp,
+                                                              const float* __restrict__ DY, long long dyp, float* OUT, int n,
+                                                              int h, int w, int cin, int cout, int ks, int stride, int pad,
+                                                              int ho, int wo, int splits, int px_per_split) {
+  constexpr int MT = TCO / 64, NT = TCI / 64;      // 32x32 blocks per wave
+  constexpr int YV = TCO / 64, XV = TCI / 64;      // float4 loads per lane and stage: 16 px x T/4 quads over 256 lanes
+  __shared__ __attribute__((aligned(16))) float Ys[2][16][TCO];
+  __shared__ __attribute__((aligned(16))) float Xs[2][16][TCI];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tap = blockIdx.z / splits, split = blockIdx.z - tap * splits;
+  const int ky = tap / ks, kx = tap - ky * ks;
+  const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
+  const int P = n * ho * wo;
+  const int p_begin = split * px_per_split;
+  const int p_end = (p_begin + px_per_split < P) ? p_begin + px_per_split : P;
+  const int hw = ho * wo;
+  // loader role: pixel row pp of the stage, channel quads cc + 64 * v
+  const int pp = tid >> 4, cc = (tid & 15) * 4;
+  const int sw = (pp & 1) << 5;
+
+  float4 ry[YV], rx[XV];
+  int f_img, f_oy, f_ox;
+  {
+    const int p = p_begin + pp;
+    f_img = p / hw;
+    const int rem = p - f_img * hw;
+    f_oy = rem / wo;
+    f_ox = rem - f_oy * wo;
+  }
+  auto fetch = [&](int p0) {
+    const int p = p0 + pp;
+#pragma unroll
+    for (int v = 0; v < YV; ++v) ry[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int v = 0; v < XV; ++v) rx[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < p_end) {
+      const float* yrow = DY + (long long)p * dyp + co0 + cc;
+      const int iy = f_oy * stride - pad + ky, ix = f_ox * stride - pad + kx;
+      const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+      const float* xrow = X + ((long long)(f_img * h + iy) * w + ix) * xp + ci0 + cc;
+#pragma unroll
+      for (int v = 0; v < YV; ++v)
+        if (co0 + cc + 64 * v < cout) ry[v] = *reinterpret_cast<const float4*>(yrow + 64 * v);
+      if (inb) {
+#pragma unroll
+        for (int v = 0; v < XV; ++v)
+          if (ci0 + cc + 64 * v < cin) rx[v] = *reinterpret_cast<const float4*>(xrow + 64 * v);
+      }
+    }
+    f_ox += 16;
+    while (f_ox >= wo) {
+      f_ox -= wo;
+      if (++f_oy == ho) {
+        f_oy = 0;
+        ++f_img;
+      }
+    }
+  };
+
+  wg_f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int i32 = lane & 31, kk = lane >> 5;
+  const int a_base = wr * (TCO / 2) + i32, b_base = wc * (TCI / 2) + i32, ksw = kk << 5;
+
+  fetch(p_begin);
+  int buf = 0;
+  for (int p0 = p_begin; p0 < p_end; p0 += 16) {
+#pragma unroll
+    for (int v = 0; v < YV; ++v) *reinterpret_cast<float4*>(&Ys[buf][pp][(cc + 64 * v) ^ sw]) = ry[v];
+#pragma unroll
+    for (int v = 0; v < XV; ++v) *reinterpret_cast<float4*>(&Xs[buf][pp][(cc + 64 * v) ^ sw]) = rx[v];
+    __syncthreads();
+    if (p0 + 16 < p_end) fetch(p0 + 16);  // in flight while the matrix pipe works
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = Ys[buf][2 * t + kk][(a_base + 32 * i) ^ ksw];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = Xs[buf][2 * t + kk][(b_base + 32 * j) ^ ksw];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+  float* out = OUT + (long long)split * cout * ks * ks * cin;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ci = ci0 + wc * (TCI / 2) + 32 * j + i32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wr * (TCO / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kk;
+        if (co < cout && ci < cin) out[((long long)co * ks * ks + tap) * cin + ci] = acc[i][j][e];
+      }
+    }
+}
+
 // kk_cin > 0: write the sum in the parameter's own OIHW layout (i indexes the OHWI slabs: co, tap, ci) - the autograd result of
 // the detector's training step without a permute + contiguous launch per layer
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* DW, long long count,
@@ -1170,9 +1282,40 @@ static int wgrad_min_px() {
   return v;
 }
 
+// tile choice (output channels x input channels per workgroup), measured on the Darknet-53 shapes at batch 8
+// (tools/wgrad_bench.py): 128 x 128 wins where the pixel reduction is long and both dimensions fill the tile (52^2 x 8:
+// 153 -> 136 us); on the shorter reductions (26^2, 13^2), the 1x1 filters and the half-wide tiles the fewer, fatter waves
+// lose more latency hiding than the halved L2 traffic buys.  MILLIEYE_WGRAD_TILE=64 / 128 forces one kernel (A/B switch).
+static void wgrad_tile(long long P, int cin, int cout, int ks, int& tco, int& tci) {
+  static const int force = [] {
+    const char* e = getenv("MILLIEYE_WGRAD_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  tco = tci = 64;
+  if (force == 64) return;
+  if (force == 128) {
+    tco = cout >= 128 ? 128 : 64;
+    tci = cin >= 128 ? 128 : 64;
+  } else if (ks >= 3 && P >= 16384 && cin >= 128 && cout >= 128) {
+    tco = tci = 128;
+  }
+}
+
+static int wgrad_target_wgs(int tco, int tci) {
+  static const int v = [] {
+    const char* e = getenv("MILLIEYE_WGRAD_WGS");
+    return e ? atoi(e) : 0;
+  }();
+  if (v > 0) return v;
+  return (tco == 128 && tci == 128) ? 1024 : 2048;
+}
+
 static int wgrad_splits(long long P, int cin, int cout, int ks) {
-  const long long tiles = (long long)((cin + 63) / 64) * ((cout + 63) / 64) * ks * ks;
-  long long s = (2048 + tiles - 1) / tiles;
+  int tco, tci;
+  wgrad_tile(P, cin, cout, ks, tco, tci);
+  const long long tiles = (long long)((cin + tci - 1) / tci) * ((cout + tco - 1) / tco) * ks * ks;
+  const int target = wgrad_target_wgs(tco, tci);
+  long long s = (target + tiles - 1) / tiles;
   const long long max_s = (P + wgrad_min_px() - 1) / wgrad_min_px();
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -1219,10 +1362,23 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
   float* out = via_ws ? reinterpret_cast<float*>(workspace) : dw;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (x_pitch % 4 == 0) && (dy_pitch % 4 == 0) && me::aligned16(x) &&
                    me::aligned16(dy);
-  dim3 grid((cin + 63) / 64, (cout + 63) / 64, ksize * ksize * splits);
-  if (vec)
+  int tco, tci;
+  wgrad_tile(P, cin, cout, ksize, tco, tci);
+  if (!vec) tco = tci = 64;  // (the split count was sized for the larger tile: correct, a few workgroups more)
+  dim3 grid((cin + tci - 1) / tci, (cout + tco - 1) / tco, ksize * ksize * splits);
+#define ME_WG_TILE(A, B)                                                                                              \
+  hipLaunchKernelGGL((conv_wgrad_tile_kernel<A, B>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,           \
+                     (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per)
+  if (vec && tco == 128 && tci == 128)
+    ME_WG_TILE(128, 128);
+  else if (vec && tco == 128)
+    ME_WG_TILE(128, 64);
+  else if (vec && tci == 128)
+    ME_WG_TILE(64, 128);
+  else if (vec)
     hipLaunchKernelGGL(conv_wgrad_mfma_kernel<true>, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,
                        (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per);
+#undef ME_WG_TILE
   else
     hipLaunchKernelGGL(conv_wgrad_mfma_kernel<false>, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,
                        (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per);

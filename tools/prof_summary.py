@@ -26,6 +26,16 @@ def main():
         for k, c, v, n, d in cur.execute(q):
             print(f"{short(k):90s} {c:28s} {v:16.1f} {n:5d} {d:12.0f}")
         return
+    if "--by-grid" in sys.argv:  # one line per (kernel, grid): the same kernel on different layer shapes
+        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        disp = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch"))
+        sym = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
+        q = (f"select s.kernel_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, count(*), avg(d.end - d.start), sum(d.end - d.start) "
+             f"from {disp} d join {sym} s on d.kernel_id = s.id group by 1, 2, 3, 4 order by 7 desc limit 60")
+        print(f"# per (kernel, grid) - {db}")
+        for k, gx, gy, gz, n, avg, tot in cur.execute(q):
+            print(f"{short(k)[:70]:70s} grid {gx:8d} {gy:5d} {gz:4d} calls {n:5d} avg {avg / 1e3:8.1f} us total {tot / 1e3:10.1f} us")
+        return
     print(f"# kernel-trace --stats summary - {db}")
     print(f"{'kernel':90s} {'calls':>7s} {'total us':>12s} {'avg us':>10s} {'%':>7s}")
     for name, calls, total, avg, pct in cur.execute("select * from top_kernels"):

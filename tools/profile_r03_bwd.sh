@@ -4,7 +4,7 @@ TAG=${TAG:-r03}; R=$PWD; OUT=$R/gpurun_out/prof; mkdir -p $OUT; export TMPDIR=/t
 export MILLIEYE_TUNE_CACHE=/tmp/tune_$TAG.json
 python bench.py --workload detector_train --no-cpu-baseline --steps 10 --warmup 3 > $OUT/${TAG}_bench_detector_train_b8.json 2> $OUT/${TAG}_bench_detector_train_b8.err
 cd /tmp   # (the bench run above measured and cached the training path's conv tiles: the profiled run is steady state)
-rocprofv3 --kernel-trace --stats -d /tmp/ktb_$TAG -o k -- python $R/bench.py --workload detector_train --no-cpu-baseline --steps 3 --warmup 1 > /tmp/ktb.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/ktb_$TAG -o k -- python $R/bench.py --workload detector_train --no-cpu-baseline --steps 12 --warmup 2 > /tmp/ktb.log 2>&1
 python $R/tools/prof_summary.py /tmp/ktb_$TAG/k_results.db > $OUT/${TAG}_bench_detector_train_b8_kernel_stats.txt 2>&1
 cat $OUT/${TAG}_bench_detector_train_b8.json
 head -40 $OUT/${TAG}_bench_detector_train_b8_kernel_stats.txt
