@@ -466,6 +466,10 @@ int me_ps_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, i
  *   ToTensor().float() (:267), pad_to_square (:270), F.interpolate(bilinear, align_corners=True) to
  *   [3,map_size,map_size] (collate_fn :318-321).  out [n,3,map_size,map_size]. */
 int me_image_pad_resize_u8_f32(const uint8_t* src, int32_t h, int32_t w, float* dst, int32_t size, void* stream);
+/* the same with the stage-2 augmentation (module2_mixed/utils/datasets.py:143-146, utils/augmentations.py:6-9): flip != 0
+ * mirrors the PADDED square left-right (horisontal_flip runs between pad_to_square and collate_fn's resize). */
+int me_image_pad_resize_flip_u8_f32(const uint8_t* src, int32_t h, int32_t w, float* dst, int32_t size, int32_t flip,
+                                    void* stream);
 int me_radar_heatmap_f32(const double* points, const int32_t* offsets, const int32_t* sizes, int32_t n,
                          int32_t radar_maps_size, float* out, int32_t map_size, void* stream);
 

@@ -16,8 +16,10 @@
 namespace {
 
 // ---- image: u8 HWC -> padded square -> nearest resize -> f32 CHW -------------------------------------------
+// flip: the padded square is mirrored left-right before the resize (module2_mixed/utils/datasets.py:143-146,
+// utils/augmentations.py: horisontal_flip runs on the padded tensor, the resize in collate_fn afterwards)
 __global__ __launch_bounds__(256) void image_pad_resize_kernel(const unsigned char* __restrict__ src, int h, int w,
-                                                               float* __restrict__ dst, int S) {
+                                                               float* __restrict__ dst, int S, int flip) {
   const int P = h > w ? h : w;                 // padded side
   const int diff = h > w ? h - w : w - h;
   const int pad1 = diff / 2;                   // upper / left padding (datasets.py:20)
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void image_pad_resize_kernel(const unsigned ch
     int px = P == S ? x : (int)floorf((float)x * scale);
     py = py < P - 1 ? py : P - 1;
     px = px < P - 1 ? px : P - 1;
+    if (flip) px = P - 1 - px;
     const int sy = py - pad_top, sx = px - pad_left;
     float r = 0.f, g = 0.f, b = 0.f;  // pad_value 0 (datasets.py:211)
     if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) {
@@ -150,7 +153,19 @@ int me_image_pad_resize_u8_f32(const uint8_t* src, int32_t h, int32_t w, float* 
   ME_REQUIRE((long long)size * size < (1ll << 30), ME_E_TOOBIG, "me_image_pad_resize_u8_f32: output too large");
   int blocks = (int)me::ceil_div((int64_t)size * size, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(image_pad_resize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, h, w, dst, size);
+  hipLaunchKernelGGL(image_pad_resize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, h, w, dst, size, 0);
+  return me::check_launch("image_pad_resize_kernel");
+}
+
+int me_image_pad_resize_flip_u8_f32(const uint8_t* src, int32_t h, int32_t w, float* dst, int32_t size, int32_t flip,
+                                    void* stream) {
+  ME_REQUIRE(src && dst, ME_E_NULLPTR, "me_image_pad_resize_flip_u8_f32: null pointer");
+  ME_REQUIRE(h > 0 && w > 0 && size > 0, ME_E_BADARG, "me_image_pad_resize_flip_u8_f32: non-positive size");
+  ME_REQUIRE((long long)size * size < (1ll << 30), ME_E_TOOBIG, "me_image_pad_resize_flip_u8_f32: output too large");
+  int blocks = (int)me::ceil_div((int64_t)size * size, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(image_pad_resize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, h, w, dst, size,
+                     flip ? 1 : 0);
   return me::check_launch("image_pad_resize_kernel");
 }
 

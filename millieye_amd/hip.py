@@ -137,6 +137,8 @@ SIGNATURES = {
     "me_batch_statistics_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                           C.c_void_p, C.c_void_p]),
     "me_image_pad_resize_u8_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "me_image_pad_resize_flip_u8_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                                  C.c_void_p]),
     "me_radar_heatmap_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_void_p]),
     "me_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

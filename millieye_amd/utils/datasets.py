@@ -54,8 +54,10 @@ def _pad_amounts(h, w):
 class StagedImages:
     """A batch of decoded frames waiting for ``.to(device)``: uint8 HWC tensors + the target side."""
 
-    def __init__(self, frames, size):
+    def __init__(self, frames, size, flips=None):
         self.frames, self.size = list(frames), int(size)
+        # stage-2 augmentation (module2_mixed/utils/datasets.py:143-146): mirror the padded square before the resize
+        self.flips = [bool(f) for f in flips] if flips is not None else [False] * len(self.frames)
         self.shape = torch.Size((len(self.frames), 3, self.size, self.size))
         self.dtype = torch.float32
 
@@ -77,8 +79,8 @@ class StagedImages:
             if c != 3 or frame.dtype != torch.uint8:
                 raise hip.MeError(f"frame {i}: expected uint8 [h,w,3], got {frame.dtype} {tuple(frame.shape)}")
             d = frame.contiguous().to(device, non_blocking=True)
-            hip.check(lib.me_image_pad_resize_u8_f32(d.data_ptr(), h, w, out[i].data_ptr(), self.size, stream),
-                      "me_image_pad_resize_u8_f32")
+            hip.check(lib.me_image_pad_resize_flip_u8_f32(d.data_ptr(), h, w, out[i].data_ptr(), self.size,
+                                                          int(self.flips[i]), stream), "me_image_pad_resize_flip_u8_f32")
         return out
 
 

@@ -119,10 +119,11 @@ def _progress(iterable, desc):
     return tqdm.tqdm(iterable, desc=desc)
 
 
-def ap_per_class(tp, conf, pred_cls, target_cls):
+def ap_per_class(tp, conf, pred_cls, target_cls, with_conf=False):
     """Per-class AP + pooled PR curve, reference :77-154.
 
-    Returns ``(p, r, ap, f1, classes_int32, (precision_curve, recall_curve))``."""
+    Returns ``(p, r, ap, f1, classes_int32, (precision_curve, recall_curve))``; ``with_conf`` = the stage-2 tree's variant
+    (module2_mixed/utils/utils.py:219-295), whose curve tuple carries the sorted confidences as a third entry."""
     order = np.argsort(-conf)
     tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
     unique_classes = np.unique(target_cls)
@@ -161,6 +162,8 @@ def ap_per_class(tp, conf, pred_cls, target_cls):
         tpc = (tp).cumsum()
         recall_curve = tpc / (n_gt + 1e-16)
         precision_curve = tpc / (tpc + fpc)
+    if with_conf:
+        return p, r, ap, f1, unique_classes.astype("int32"), (precision_curve, recall_curve, conf)
     return p, r, ap, f1, unique_classes.astype("int32"), (precision_curve, recall_curve)
 
 

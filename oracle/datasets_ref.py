@@ -105,3 +105,46 @@ def collate(items, img_size, map_size):
     radar_maps = torch.stack([F.interpolate(m.unsqueeze(0), map_size, mode="bilinear", align_corners=True).squeeze(0)
                               for m in radar_maps])
     return imgs, targets, radar_boxes, radar_maps
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stage 2: ListDataset of module2_mixed/utils/datasets.py:75-166 (pinned by tests/golden/m2_listdataset.npz: outputs of the
+# real class on generated PNGs, tests/golden/make_golden.py --module2-loops)
+# ---------------------------------------------------------------------------------------------------------------------
+def list_item(img_path, label_path, flip):
+    """``ListDataset.__getitem__`` (:93-148) with the augmentation draw made by the caller: ToTensor(convert('RGB')),
+    pad_to_square, label arithmetic in float64 then float32 targets, horisontal_flip (utils/augmentations.py:6-9) on the
+    PADDED image.  Returns (img [3,P,P], targets [k,6] | None)."""
+    from PIL import Image
+    img = to_tensor(np.asarray(Image.open(img_path).convert("RGB")))
+    _, h, w = img.shape
+    img, pad = pad_to_square(img, 0)
+    _, padded_h, padded_w = img.shape
+    targets = None
+    if os.path.exists(label_path):
+        boxes = torch.from_numpy(np.loadtxt(label_path).reshape(-1, 5))
+        x1 = w * (boxes[:, 1] - boxes[:, 3] / 2) + pad[0]
+        y1 = h * (boxes[:, 2] - boxes[:, 4] / 2) + pad[2]
+        x2 = w * (boxes[:, 1] + boxes[:, 3] / 2) + pad[1]
+        y2 = h * (boxes[:, 2] + boxes[:, 4] / 2) + pad[3]
+        boxes[:, 1] = ((x1 + x2) / 2) / padded_w
+        boxes[:, 2] = ((y1 + y2) / 2) / padded_h
+        boxes[:, 3] *= w / padded_w
+        boxes[:, 4] *= h / padded_h
+        targets = torch.zeros((len(boxes), 6))
+        targets[:, 1:] = boxes
+    if flip:
+        img = torch.flip(img, [-1])
+        targets[:, 2] = 1 - targets[:, 2]
+    return img, targets
+
+
+def list_collate(items, img_size):
+    """``ListDataset.collate_fn`` (:150-163) without the multiscale draw: the sample index counts the items that HAVE
+    targets (an unlabelled frame shifts the following indices - kept as in the reference)."""
+    imgs, targets = list(zip(*items))
+    targets = [b for b in targets if b is not None]
+    for i, b in enumerate(targets):
+        b[:, 0] = i
+    targets = torch.cat(targets, 0)
+    return torch.stack([resize(img, img_size) for img in imgs]), targets
