@@ -11,7 +11,8 @@ pipeline as stage 3 (``millieye_amd/my_models.py``) minus the radar branch, plus
 The module tree carries the reference's parameter names (``fcn_layers.net.conv_0.weight``, ``refinement_head.net0.0.weight``,
 ``ensemble_head.fc2.0.weight`` ...) so stage-2 checkpoints load unchanged and ``train.load_pretrained_module2`` can hand them
 to stage 3.  With ``targets`` the call returns ``(output, loss, metric)`` and ``loss.backward()`` runs the HIP backward of
-``millieye_amd/module2/train_path.py`` (focal + confidence + category + SmoothL1 box losses, reference :366-459).
+``millieye_amd/module2/train_path.py`` (focal + confidence + category + SmoothL1 box losses, reference :366-459); in
+``train()`` mode without targets it returns the rows of the train-mode forward (batch-statistics BatchNorm, Dropout).
 """
 import ctypes as C
 
@@ -101,13 +102,13 @@ class Network(nn.Module):
         object.__setattr__(self, "_packs", None)
 
     def forward(self, images, targets=None):
-        if targets is not None:  # training call: (output, loss, metric), reference :366-461
+        if targets is not None or self.fcn_layers.net[1].training or self.refinement_head.training:
+            # training call: (output, loss, metric), reference :366-461; without targets in train() mode: the output rows of
+            # the train-mode forward (batch-statistics BatchNorm, active Dropout)
             from .train_path import forward_train
             return forward_train(self, images, targets)
         if not images.is_cuda:
             raise hip.MeError("Network.forward needs CUDA tensors (MI355X); there is no CPU fallback")
-        if self.fcn_layers.net[1].training:
-            raise NotImplementedError("module-2 Network.forward in train() mode is not built; call model.eval()")
         dev, n = images.device, images.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)
         lib = hip.lib()

@@ -71,8 +71,8 @@ def forward_train(net, images, targets):
         raise hip.MeError("Network.forward needs CUDA tensors (MI355X); there is no CPU fallback")
     bn = net.fcn_layers.net[1]
     if not (bn.training and net.refinement_head.training):
-        raise NotImplementedError("module-2 Network.forward(images, targets) needs the heads in train() mode, as "
-                                  "module2_mixed/train.py:127 sets them")
+        raise NotImplementedError("module-2 Network.forward in a mixed mode (fcn_layers and refinement_head must both be in "
+                                  "train(), as module2_mixed/train.py:127 sets them, or both in eval())")
     dev, n, size = images.device, images.shape[0], images.shape[-1]
     lib = hip.lib()
     f32 = dict(device=dev, dtype=torch.float32)
@@ -143,6 +143,11 @@ def forward_train(net, images, targets):
         output = torch.stack((bx[:, 0], nx - nw / 2, ny - nh / 2, nx + nw / 2, ny + nh / 2, masks[positive, 1], bx[:, 6],
                               bx[:, 7]), 1)
         output = output[torch.sort(output[:, 5], descending=True, stable=True).indices].cpu()
+        if targets is None:
+            # train() mode without targets (reference :299-364 in train mode): batch statistics in fcn_layers (running
+            # statistics updated above), Dropout active, no loss
+            net._last_train = dict(k=k, refine=refine, masks=masks, boxes=boxes)
+            return output
 
         # labels + sampling on the host (reference :369-420)
         targets[:, 2:] = xywh2xyxy(targets[:, 2:])

@@ -95,6 +95,41 @@ def test_module2_training_step_vs_oracle_and_reference(hip_lib):
             assert np.allclose(sd[key[4:]].cpu().numpy(), g[key], rtol=1e-3, atol=1e-5), key
 
 
+def test_module2_train_mode_forward_without_targets(hip_lib):
+    """``model.train(); model.base_detector.eval(); model(images)`` (no targets): the rows of the train-mode forward - batch
+    statistics in fcn_layers (running statistics move), Dropout active (mask from torch's CPU generator, like aten's CPU
+    path) - equal the ``output`` of the training step of the real reference run / the oracle under the same seed (the
+    output does not depend on the targets), and the buffers move exactly as in that step.  Mixed modes still raise."""
+    import random
+    from millieye_amd.module2.my_models import Network, define_yolo
+    from tests.golden.make_golden import M2_TRAIN_CASE, m2_train_fill_
+    name, cfg, n, s, conf, seed = M2_TRAIN_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    net = m2_train_fill_(Network(define_yolo(cfg_path(cfg)), conf), name)
+    net = net.to(net.device).train()
+    net.base_detector.eval()
+    before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k and not k.startswith("base_detector.")}
+    random.seed(seed)
+    torch.manual_seed(seed)
+    out = net(x.cuda())
+    assert torch.is_tensor(out) and out.device.type == "cpu" and out.shape[1] == 8
+    assert_close(out, torch.from_numpy(g["output"]), 1e-3, "train-mode rows vs the reference's training-step output")
+    sd = net.state_dict()
+    for key in g.files:
+        if key.startswith("buf/"):
+            assert np.allclose(sd[key[4:]].cpu().numpy(), g[key], rtol=1e-3, atol=1e-5), key
+            assert not torch.equal(sd[key[4:]], before[key[4:]]), key
+    net.eval()
+    eval_rows = net(x.cuda())
+    assert eval_rows.shape[0] > 0 and not (eval_rows.shape == out.shape and torch.allclose(eval_rows, out, atol=1e-4))
+    net.train()
+    net.base_detector.eval()
+    net.refinement_head.eval()
+    with pytest.raises(NotImplementedError):
+        net(x.cuda())
+
+
 @pytest.mark.parametrize("dtype,px,tol,share", [("bf16", 4.0, 0.1, 0.75), ("f16", 2.0, 0.02, 0.95)])
 def test_module2_forward_in_16bit_storage_modes(hip_lib, dtype, px, tol, share):
     """BASELINE configs[2] literally ("module2 ... bf16 inference"): the stage-2 network with the detector in a 16-bit
