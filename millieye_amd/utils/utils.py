@@ -317,8 +317,10 @@ def build_targets(pred_boxes, pred_cls, target, anchors, ignore_thres):
 
     obj_mask[owner] = 1
     noobj_mask[owner] = 0
-    for t_idx in range(shape_iou.shape[1]):  # other anchors that fit well are neither object nor background
-        noobj_mask[image_of[t_idx], shape_iou[:, t_idx] > ignore_thres, gj[t_idx], gi[t_idx]] = 0
+    # other anchors that fit well are neither object nor background (reference: a python loop over the targets, one masked
+    # assignment each; zeros are written, so one scatter over every (anchor, target) pair above the threshold is the same)
+    a_fit, t_fit = torch.nonzero(shape_iou > ignore_thres, as_tuple=True)
+    noobj_mask[image_of[t_fit], a_fit, gj[t_fit], gi[t_fit]] = 0
 
     tx[owner] = centre[:, 0] - centre[:, 0].floor()
     ty[owner] = centre[:, 1] - centre[:, 1].floor()

@@ -114,35 +114,41 @@ class YOLOLayer(nn.Module):
                 pred_boxes=pred_boxes, pred_cls=pred_cls, target=targets, anchors=scaled_anchors,
                 ignore_thres=self.ignore_thres)
             obj_mask, noobj_mask = obj_mask.bool(), noobj_mask.bool()
-            loss_x = self.mse_loss(x[obj_mask], tx[obj_mask])
-            loss_y = self.mse_loss(y[obj_mask], ty[obj_mask])
-            loss_w = self.mse_loss(w[obj_mask], tw[obj_mask])
-            loss_h = self.mse_loss(h[obj_mask], th[obj_mask])
-            loss_conf_obj = self.bce_loss(pred_conf[obj_mask], tconf[obj_mask])
-            loss_conf_noobj = self.bce_loss(pred_conf[noobj_mask], tconf[noobj_mask])
+            # x[obj_mask] == x[obj_idx] (boolean indexing IS nonzero order): the cell lists are computed once instead of
+            # once per term (a nonzero + host sync each)
+            obj_idx, noobj_idx = obj_mask.nonzero(as_tuple=True), noobj_mask.nonzero(as_tuple=True)
+            loss_x = self.mse_loss(x[obj_idx], tx[obj_idx])
+            loss_y = self.mse_loss(y[obj_idx], ty[obj_idx])
+            loss_w = self.mse_loss(w[obj_idx], tw[obj_idx])
+            loss_h = self.mse_loss(h[obj_idx], th[obj_idx])
+            conf_at_obj, conf_at_noobj = pred_conf[obj_idx], pred_conf[noobj_idx]
+            loss_conf_obj = self.bce_loss(conf_at_obj, tconf[obj_idx])
+            loss_conf_noobj = self.bce_loss(conf_at_noobj, tconf[noobj_idx])
             loss_conf = self.obj_scale * loss_conf_obj + self.noobj_scale * loss_conf_noobj
-            loss_cls = self.bce_loss(pred_cls[obj_mask], tcls[obj_mask])
+            loss_cls = self.bce_loss(pred_cls[obj_idx], tcls[obj_idx])
             total_loss = loss_x + loss_y + loss_w + loss_h + loss_conf + loss_cls
             conf50 = (pred_conf > 0.5).float()
             iou50 = (iou_scores > 0.5).float()
             iou75 = (iou_scores > 0.75).float()
             detected_mask = conf50 * class_mask * tconf
-            self.metrics = {
-                "loss": to_cpu(total_loss).item(), "x": to_cpu(loss_x).item(), "y": to_cpu(loss_y).item(),
-                "w": to_cpu(loss_w).item(), "h": to_cpu(loss_h).item(), "conf": to_cpu(loss_conf).item(),
-                "cls": to_cpu(loss_cls).item(), "cls_acc": to_cpu(100 * class_mask[obj_mask].mean()).item(),
-                "recall50": to_cpu(torch.sum(iou50 * detected_mask) / (obj_mask.sum() + 1e-16)).item(),
-                "recall75": to_cpu(torch.sum(iou75 * detected_mask) / (obj_mask.sum() + 1e-16)).item(),
-                "precision": to_cpu(torch.sum(iou50 * detected_mask) / (conf50.sum() + 1e-16)).item(),
-                "conf_obj": to_cpu(pred_conf[obj_mask].mean()).item(),
-                "conf_noobj": to_cpu(pred_conf[noobj_mask].mean()).item(), "grid_size": g,
-            }
+            n_obj_t, n_noobj_t = obj_mask.sum(), noobj_mask.sum()
+            # the thirteen scalars of the reference's metrics dict, read back in ONE transfer (it reads them one .item() at a
+            # time); all are float32 scalars, so the values are the same floats
+            scalars = torch.stack([
+                total_loss, loss_x, loss_y, loss_w, loss_h, loss_conf, loss_cls, 100 * class_mask[obj_idx].mean(),
+                torch.sum(iou50 * detected_mask) / (n_obj_t + 1e-16), torch.sum(iou75 * detected_mask) / (n_obj_t + 1e-16),
+                torch.sum(iou50 * detected_mask) / (conf50.sum() + 1e-16), conf_at_obj.mean(), conf_at_noobj.mean(),
+                n_obj_t.float(), n_noobj_t.float()]).tolist()
+            keys = ("loss", "x", "y", "w", "h", "conf", "cls", "cls_acc", "recall50", "recall75", "precision", "conf_obj",
+                    "conf_noobj")
+            self.metrics = dict(zip(keys, scalars[:13]))
+            self.metrics["grid_size"] = g
         if return_targets:  # what me_yolo_loss_bwd_f32 needs (detector backward, millieye_amd/detector_train.py)
             f = dict(device=dev, dtype=torch.float32)
             bt = dict(obj=obj_mask.to(torch.uint8).contiguous(), noobj=noobj_mask.to(torch.uint8).contiguous(),
                       tx=tx.to(**f).contiguous(), ty=ty.to(**f).contiguous(), tw=tw.to(**f).contiguous(),
                       th=th.to(**f).contiguous(), tcls=tcls.to(**f).contiguous(), tconf=tconf.to(**f).contiguous(),
-                      n_obj=int(obj_mask.sum()), n_noobj=int(noobj_mask.sum()))
+                      n_obj=int(scalars[13]), n_noobj=int(scalars[14]))
             return total_loss, bt
         return total_loss
 
