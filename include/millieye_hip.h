@@ -440,6 +440,22 @@ typedef struct me_pack_desc {
 int64_t me_pack_conv_plan(me_pack_desc* descs_host, int32_t count);
 int me_pack_conv_batch_f32(const me_pack_desc* descs_device, int32_t count, int64_t total_blocks, int32_t max_ksize,
                            void* stream);
+/* me_yolo_loss_fwd_f32 - the YOLO loss of one detection scale (module3_our_dataset/yolov3/models.py:181-232 with
+ * utils/utils.py:381-440 build_targets) in three launches and one read-back: the dense build_targets tensors
+ * (obj / noobj masks uint8 [N,A,G,G], tx / ty / tw / th / tconf / class_mask / iou_scores float [N,A,G,G], tcls
+ * [N,A,G,G,C] - what me_yolo_loss_bwd_f32 takes) from targets [m,6] = (image, class, cx, cy, w, h) in [0,1] (device),
+ * and result[16] (device floats): total loss, x, y, w, h, conf, cls, cls_acc, recall50, recall75, precision, conf_obj,
+ * conf_noobj (the reference's metrics dict), n_obj, n_noobj, and a flag (1 = a target outside the batch / grid / class
+ * range: the reference raises IndexError there).  scaled_anchors_host: 2 * num_anchors floats (anchor / stride), host
+ * memory, num_anchors <= 16.  Two targets owning the same cell: the later one wins (the reference's CPU index_put_
+ * order).  workspace: me_yolo_loss_workspace_bytes() bytes, 16-byte aligned, ZERO on first use (the call leaves its
+ * ticket words zero again).  Sums in double, added in a fixed order: deterministic. */
+int64_t me_yolo_loss_workspace_bytes(void);
+int me_yolo_loss_fwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                         const float* scaled_anchors_host, const float* targets, int32_t m, float ignore_thres, float obj_scale,
+                         float noobj_scale, uint8_t* obj_mask, uint8_t* noobj_mask, float* tx, float* ty, float* tw, float* th,
+                         float* tcls, float* tconf, float* class_mask, float* iou_scores, void* workspace, float* result,
+                         void* stream);
 /* RoI pooling backward: grad_out [k,c_out,7,7] scattered (atomicAdd) into the zero-filled NHWC grad_map */
 int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
                          int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch, void* stream);

@@ -220,6 +220,9 @@ SIGNATURES = {
                          + [C.c_void_p] * 7),
     "me_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_yolo_loss_workspace_bytes": (C.c_int64, []),
+    "me_yolo_loss_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                                       C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 13),
     "me_pack_conv_plan": (C.c_int64, [C.POINTER(PackDesc), C.c_int32]),
     "me_pack_conv_batch_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "me_ps_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

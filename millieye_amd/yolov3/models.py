@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import hip
 from ..engine import DarknetEngine
 from ..utils.parse_config import parse_model_config, parse_data_config  # noqa: F401 (re-export)
 from ..utils.utils import build_targets, to_cpu  # noqa: F401 (re-export, reference :9-10)
@@ -92,6 +93,8 @@ class YOLOLayer(nn.Module):
         path and its backward is not built."""
         n, g = raw_nhwc.shape[0], raw_nhwc.shape[1]
         dev = raw_nhwc.device
+        if raw_nhwc.is_cuda:
+            return self._loss_from_raw_hip(raw_nhwc, targets, return_targets)
         with torch.no_grad():
             pred = raw_nhwc.reshape(n, g, g, self.num_anchors, self.num_classes + 5).permute(0, 3, 1, 2, 4)
             x = torch.sigmoid(pred[..., 0])
@@ -152,7 +155,59 @@ class YOLOLayer(nn.Module):
             return total_loss, bt
         return total_loss
 
+    def _loss_from_raw_hip(self, raw_nhwc, targets, return_targets):
+        """The same loss + metrics on the device: ``me_yolo_loss_fwd_f32`` (csrc/yolo_loss.hip) - target assignment, the six
+        terms and the metric sums in three launches and one read-back instead of ~200 torch ops and ~15 host syncs per scale."""
+        import ctypes as C
+        n, g = raw_nhwc.shape[0], raw_nhwc.shape[1]
+        dev, na, nc = raw_nhwc.device, self.num_anchors, self.num_classes
+        raw = raw_nhwc
+        if raw.dtype != torch.float32 or raw.stride(3) != 1 or raw.stride(1) != g * raw.stride(2) or \
+                raw.stride(0) != g * g * raw.stride(2):
+            raw = raw.float().contiguous()
+        stride = self.img_dim / g
+        scaled = [v for aw, ah in self.anchors for v in (aw / stride, ah / stride)]
+        self.scaled_anchors = torch.tensor(scaled, dtype=torch.float32).view(na, 2)  # (host copy; the kernel takes the floats)
+        tg = targets.to(device=dev, dtype=torch.float32).contiguous()
+        cells = (n, na, g, g)
+        f32 = dict(device=dev, dtype=torch.float32)
+        obj, noobj = torch.empty(cells, device=dev, dtype=torch.uint8), torch.empty(cells, device=dev, dtype=torch.uint8)
+        tx, ty, tw, th, tconf, cmask, ious = (torch.empty(cells, **f32) for _ in range(7))
+        tcls = torch.empty(cells + (nc,), **f32)
+        result = torch.empty(16, **f32)
+        anchors_c = (C.c_float * len(scaled))(*[float(torch.tensor(v, dtype=torch.float32)) for v in scaled])
+        ws = _yolo_loss_workspace(dev)
+        hip.check(hip.lib().me_yolo_loss_fwd_f32(
+            raw.data_ptr(), raw.stride(2), n, g, na, nc, anchors_c, tg.data_ptr(), tg.shape[0], float(self.ignore_thres),
+            float(self.obj_scale), float(self.noobj_scale), obj.data_ptr(), noobj.data_ptr(), tx.data_ptr(), ty.data_ptr(),
+            tw.data_ptr(), th.data_ptr(), tcls.data_ptr(), tconf.data_ptr(), cmask.data_ptr(), ious.data_ptr(), ws.data_ptr(),
+            result.data_ptr(), hip.stream_ptr()), "me_yolo_loss_fwd_f32")
+        scalars = result.tolist()  # the one host read of this scale
+        if scalars[15] != 0.0:
+            raise IndexError("YOLO loss: a target lies outside the batch, the grid (cx / cy must be < 1) or the class range")
+        keys = ("loss", "x", "y", "w", "h", "conf", "cls", "cls_acc", "recall50", "recall75", "precision", "conf_obj",
+                "conf_noobj")
+        self.metrics = dict(zip(keys, scalars[:13]))
+        self.metrics["grid_size"] = g
+        total_loss = result[0].clone()
+        if return_targets:
+            bt = dict(obj=obj, noobj=noobj, tx=tx, ty=ty, tw=tw, th=th, tcls=tcls, tconf=tconf, n_obj=int(scalars[13]),
+                      n_noobj=int(scalars[14]))
+            return total_loss, bt
+        return total_loss
 
+
+
+
+_LOSS_WS = {}
+
+
+def _yolo_loss_workspace(dev):
+    """Zeroed once per device; the kernel leaves its ticket words zero again (me_yolo_loss_fwd_f32)."""
+    ws = _LOSS_WS.get(str(dev))
+    if ws is None:
+        ws = _LOSS_WS[str(dev)] = torch.zeros(int(hip.lib().me_yolo_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+    return ws
 
 
 def _conv_block(index, spec, in_channels):

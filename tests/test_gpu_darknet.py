@@ -1,6 +1,7 @@
 """-m gpu: whole-detector parity - Darknet(cfg).forward on the HIP engine vs the CPU oracle
 (oracle/darknet_ref.py, itself pinned to the reference by tests/golden) on identical seeded
 weights and frames.  Bar: 1e-3 (allclose rtol=atol) on featuremap and every yolo_outputs row."""
+import numpy as np
 import pytest
 import torch
 
@@ -199,3 +200,49 @@ def test_frames_are_independent_across_batch_sizes(hip_lib):
             ref = big[b0:b0 + 8]
             err = (small - ref).abs() / ref.abs().clamp(min=1.0)
             assert float(err.max()) <= 1e-4, (b0, float(err.max()))
+
+
+@pytest.mark.parametrize("n,g,nc,m", [(2, 13, 12, 9), (3, 26, 80, 40), (1, 7, 3, 1), (2, 10, 12, 0)])
+def test_yolo_loss_kernel_vs_the_torch_restatement(hip_lib, n, g, nc, m):
+    """me_yolo_loss_fwd_f32 (target assignment + six loss terms + metrics of one scale on the device) against the torch-op
+    restatement of the same reference code (``YOLOLayer.loss_from_raw`` on CPU tensors - pinned to the reference's numbers by
+    tests/test_train_cpu.py / test_yolo_loss_value_vs_reference_golden): every dense build_targets tensor exactly, loss terms and
+    metrics to 1e-5; two targets in one cell (the later one wins, both class labels stay), targets on cell borders, no target
+    at all (NaN means, like the reference); a target outside the grid raises IndexError like the reference's index_put_."""
+    from millieye_amd.yolov3.models import YOLOLayer
+    rng = np.random.RandomState(100 * g + m)
+    anchors = [(10, 13), (33, 23), (62, 45)]
+    layer = YOLOLayer(anchors, nc, img_dim=32 * g)
+    raw = torch.from_numpy(rng.normal(0, 1.5, (n, g, g, 3 * (5 + nc))).astype(np.float32))
+    tg = np.zeros((m, 6), np.float32)
+    if m:
+        tg[:, 0] = rng.randint(0, n, m)
+        tg[:, 1] = rng.randint(0, nc, m)
+        tg[:, 2:4] = rng.uniform(0.02, 0.98, (m, 2))
+        tg[:, 4:6] = rng.uniform(0.03, 0.5, (m, 2))
+    if m >= 9:
+        tg[3] = tg[1]          # same cell, same anchor: the later target's regression values win ...
+        tg[3, 1] = (tg[1, 1] + 1) % nc   # ... and both labels are set
+        tg[3, 2] += 0.2 / g
+        tg[5, 2:4] = (np.floor(tg[5, 2:4] * g) + 0.0) / g   # exactly on a cell border
+    targets = torch.from_numpy(tg)
+    ref_loss, ref_bt = layer.loss_from_raw(raw, targets.clone(), return_targets=True)
+    ref_metrics = dict(layer.metrics)
+    got_loss, bt = layer.loss_from_raw(raw.cuda(), targets.clone(), return_targets=True)
+    for k in ("obj", "noobj", "tx", "ty", "tw", "th", "tcls", "tconf"):
+        a, b = bt[k].cpu().float(), ref_bt[k].cpu().float()
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=0, atol=1e-6), k
+    assert bt["n_obj"] == ref_bt["n_obj"] and bt["n_noobj"] == ref_bt["n_noobj"]
+    for k, v in ref_metrics.items():
+        w = layer.metrics[k]
+        assert (np.isnan(v) and np.isnan(w)) or abs(v - w) <= 1e-5 * max(1.0, abs(v)), (k, v, w)
+    assert (np.isnan(float(ref_loss)) and np.isnan(float(got_loss))) or \
+        abs(float(got_loss) - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss)))
+    again, _ = layer.loss_from_raw(raw.cuda(), targets.clone(), return_targets=True)
+    assert torch.equal(again, got_loss) or (torch.isnan(again) and torch.isnan(got_loss)), "fixed-order sums: deterministic"
+    if m:
+        bad = targets.clone()
+        bad[0, 2] = 1.0  # cx == 1 -> cell index g
+        with pytest.raises(IndexError):
+            layer.loss_from_raw(raw.cuda(), bad)
+        layer.loss_from_raw(raw.cuda(), targets.clone())  # the flag word was reset
