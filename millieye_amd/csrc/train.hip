@@ -316,7 +316,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool VEC>
+// ABL (tuning only, MILLIEYE_ABLATION=1 + MILLIEYE_WGRAD_ABL): 1 = global loads only for the first stage (matrix pipe + LDS +
+// barriers), 2 = no MFMAs (memory side + LDS).  26^2 x 8, 256 -> 512, 3x3 (12.8 GFLOP = 81 us of matrix pipe): 142 us as
+// built (15 of them the slab sum), 121 without the loads, 70 without the MFMAs; a second stage of loads in flight changed
+// nothing (146 us) - the loop is bound by neither load latency nor L2 bytes, it loses ~25 us to LDS issue + barriers and ~22 us
+// to imperfect overlap of the loads.
+template <bool VEC, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const float* __restrict__ X, long long xp,
                                                               const float* __restrict__ DY, long long dyp, float* OUT,
                                                               int n, int h, int w, int cin, int cout, int ks, int stride,
@@ -396,12 +401,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const float* __res
     *reinterpret_cast<float4*>(&Ys[buf][pp][sw_cc]) = ry;
     *reinterpret_cast<float4*>(&Xs[buf][pp][sw_cc]) = rx;
     __syncthreads();
-    if (p0 + 16 < p_end) fetch(p0 + 16);  // in flight while the matrix pipe works
+    if (p0 + 16 < p_end && (ABL != 1 || p0 == p_begin)) fetch(p0 + 16);  // in flight while the matrix pipe works
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const float a = Ys[buf][2 * t + kk][a_col];
       const float b = Xs[buf][2 * t + kk][b_col];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      if (ABL != 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      else acc[t] += a * b;
     }
     buf ^= 1;
   }
@@ -1375,9 +1381,20 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
     ME_WG_TILE(128, 64);
   else if (vec && tci == 128)
     ME_WG_TILE(64, 128);
-  else if (vec)
-    hipLaunchKernelGGL(conv_wgrad_mfma_kernel<true>, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,
-                       (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per);
+  else if (vec) {
+    static const int abl = [] {
+      const char* on = getenv("MILLIEYE_ABLATION");
+      const char* e = getenv("MILLIEYE_WGRAD_ABL");
+      return (on && on[0] == '1' && e) ? atoi(e) : 0;
+    }();
+#define ME_WG_ABL(A)                                                                                                   \
+  hipLaunchKernelGGL((conv_wgrad_mfma_kernel<true, A>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,          \
+                     (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per)
+    if (abl == 1) ME_WG_ABL(1);
+    else if (abl == 2) ME_WG_ABL(2);
+    else ME_WG_ABL(0);
+#undef ME_WG_ABL
+  }
 #undef ME_WG_TILE
   else
     hipLaunchKernelGGL(conv_wgrad_mfma_kernel<false>, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,

@@ -214,10 +214,21 @@ __global__ __launch_bounds__(256) void yolo_loss_reduce_kernel(YoloLossArgs a) {
   if (!s_last) return;
   __threadfence();
   // the last block adds the partials in block order and forms the reference's scalars in float32
+  // (16 lanes per sum, each over the blocks lane, lane + 16, ..., then the lanes in order: one thread per sum walked up to
+  //  256 dependent loads - 54 us per scale)
+  __shared__ double s_lane[16][YL_SUMS];
   __shared__ double s_tot[YL_SUMS];
+  {
+    const int k = threadIdx.x & 15, ln = threadIdx.x >> 4;
+    double v = 0.0;
+    for (unsigned b = ln; b < gridDim.x; b += 16) v += a.partials[(long long)b * YL_SUMS + k];
+    s_lane[ln][k] = v;
+  }
+  __syncthreads();
   if (threadIdx.x < YL_SUMS) {
     double v = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b) v += a.partials[(long long)b * YL_SUMS + threadIdx.x];
+#pragma unroll
+    for (int ln = 0; ln < 16; ++ln) v += s_lane[ln][threadIdx.x];
     s_tot[threadIdx.x] = v;
   }
   __syncthreads();
