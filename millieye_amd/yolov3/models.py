@@ -166,7 +166,7 @@ class YOLOLayer(nn.Module):
                 raw.stride(0) != g * g * raw.stride(2):
             raw = raw.float().contiguous()
         stride = self.img_dim / g
-        scaled = [v for aw, ah in self.anchors for v in (aw / stride, ah / stride)]
+        scaled = [float(np.float32(v)) for aw, ah in self.anchors for v in (aw / stride, ah / stride)]  # float32 like the reference's tensor
         self.scaled_anchors = torch.tensor(scaled, dtype=torch.float32).view(na, 2)  # (host copy; the kernel takes the floats)
         tg = targets.to(device=dev, dtype=torch.float32).contiguous()
         cells = (n, na, g, g)
@@ -175,7 +175,7 @@ class YOLOLayer(nn.Module):
         tx, ty, tw, th, tconf, cmask, ious = (torch.empty(cells, **f32) for _ in range(7))
         tcls = torch.empty(cells + (nc,), **f32)
         result = torch.empty(16, **f32)
-        anchors_c = (C.c_float * len(scaled))(*[float(torch.tensor(v, dtype=torch.float32)) for v in scaled])
+        anchors_c = (C.c_float * len(scaled))(*scaled)
         ws = _yolo_loss_workspace(dev)
         hip.check(hip.lib().me_yolo_loss_fwd_f32(
             raw.data_ptr(), raw.stride(2), n, g, na, nc, anchors_c, tg.data_ptr(), tg.shape[0], float(self.ignore_thres),
