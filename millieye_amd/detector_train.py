@@ -20,6 +20,8 @@ backward  ``me_yolo_loss_bwd_f32`` seeds the raw detection maps; modules are wal
           ``me_gemm_f32``), ``me_upsample2_bwd_f32``, ``me_maxpool_bwd_f32``, ``me_add_f32`` for fan-out accumulation.
 
 """
+import os
+
 import torch
 
 from . import hip
@@ -164,6 +166,8 @@ class DetectorTrainer:
                 dout[i] = (total, True)
 
         x_nhwc = None
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0" else None
         for i in reversed(range(L)):
             d = defs[i]
             t = d["type"]
@@ -215,7 +219,16 @@ class DetectorTrainer:
                 else:
                     xin = outs[i - 1]
                 _, h, w, cin = xin.shape
-                grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
+                if side is not None:
+                    # the weight gradient only feeds the optimizer: it runs on a second stream beside the data gradient of the
+                    # same layer (both read dc), so the tails / slab sums of one fill the other's idle CUs
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
+                    dc.record_stream(side)
+                    xin.record_stream(side)
+                else:
+                    grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
                 dout[i] = None
                 if i == 0:
                     continue
@@ -302,7 +315,19 @@ class DetectorTrainer:
                           "me_maxpool_bwd_f32")
                 contribute(i - 1, g, True)
             dout[i] = None  # free as we go
+        if side is not None:
+            main.wait_stream(side)
         return grads
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 _PARITY_IDX = {}
