@@ -433,6 +433,10 @@ typedef struct me_pack_desc {
   float* rot_tiled;    /* or NULL */
   float* scale;
   float* shift;
+  float* parity;       /* or NULL; 3x3 only: [4*cin][2][2][cout], the weights of the 2x2 convolution that computes the four
+                        * output-parity classes of a stride-2 / pad-1 layer's data gradient at once (class = 2*py + px, channel
+                        * class*cin + c; tap (i, j) of class (py, px) = W[ky(py,i)][kx(px,j)], ky(0,0)=1, ky(0,1)=none (zero),
+                        * ky(1,0)=2, ky(1,1)=0) - millieye_amd/detector_train.py */
   int32_t cout, cin, ksize;
   float eps;
   int32_t first_block, blocks_x;  /* filled by me_pack_conv_plan */

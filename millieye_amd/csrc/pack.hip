@@ -89,6 +89,16 @@ __device__ __forceinline__ void pack_block(const PackArgs& a, int bx, int by, fl
             s_w[(och * 16 + l) * pitch + c * kk + tap];
     }
   }
+  if (a.parity && kk == 9) {  // parity[(cls * cin + c) * 4 + ij][o]: one (cls, ij, c) row of no floats per group step
+    for (int r = grp; r < 16 * nc; r += 8) {
+      const int c = r % nc, q = r / nc;  // q = cls * 4 + ij
+      const int py = q >> 3, px = (q >> 2) & 1, i = (q >> 1) & 1, j = q & 1;
+      const int ky = py ? (i ? 0 : 2) : (i ? -1 : 1), kx = px ? (j ? 0 : 2) : (j ? -1 : 1);
+      const float v = (ky < 0 || kx < 0 || lane >= no) ? 0.f : s_w[lane * pitch + c * kk + ky * 3 + kx];
+      if (lane < no)
+        a.parity[(((long long)(q >> 2) * a.cin + c0 + c) * 4 + (q & 3)) * a.cout + o0 + lane] = v;
+    }
+  }
   if (bx == 0 && t < no) {  // the fold, in double like ConvWeights.refresh did on the host side of torch
     const int o = o0 + t;
     double sc = 1.0, sh = 0.0;
@@ -138,7 +148,7 @@ int me_pack_conv_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t ksi
   ME_REQUIRE(!rot_tiled || (cout % 16 == 0 && rot), ME_E_BADARG, "me_pack_conv_f32: the rotated tiled copy needs cout %% 16 == 0");
   PackArgs a;
   a.w = w_oihw; a.bias = bias; a.gamma = gamma; a.beta = beta; a.mean = mean; a.var = var;
-  a.ohwi = ohwi; a.tiled = tiled; a.rot = rot; a.rot_tiled = rot_tiled; a.scale = scale; a.shift = shift;
+  a.ohwi = ohwi; a.tiled = tiled; a.rot = rot; a.rot_tiled = rot_tiled; a.scale = scale; a.shift = shift; a.parity = nullptr;
   a.cout = cout; a.cin = cin; a.ksize = ksize; a.eps = eps; a.first_block = 0; a.blocks_x = (cin + PC - 1) / PC;
   const size_t lds = (size_t)PO * (PC * ksize * ksize + 1) * sizeof(float);
   ME_REQUIRE(lds <= 64 * 1024, ME_E_TOOBIG, "me_pack_conv_f32: filter too large");
@@ -156,7 +166,7 @@ int64_t me_pack_conv_plan(me_pack_desc* d, int32_t count) {
     const bool ok = a.w && a.ohwi && a.scale && a.shift && a.cout > 0 && a.cin > 0 && a.ksize >= 1 &&
                     (size_t)PO * (PC * a.ksize * a.ksize + 1) * sizeof(float) <= 64 * 1024 &&
                     (!a.gamma || (a.beta && a.mean && a.var)) && (!a.tiled || a.cin % 16 == 0) &&
-                    (!a.rot_tiled || (a.cout % 16 == 0 && a.rot));
+                    (!a.rot_tiled || (a.cout % 16 == 0 && a.rot)) && (!a.parity || a.ksize == 3);
     if (!ok) { me::set_error("me_pack_conv_plan: descriptor %d is not valid (see me_pack_conv_f32)", i); return ME_E_BADARG; }
     a.first_block = (int32_t)blocks;
     a.blocks_x = (a.cin + PC - 1) / PC;

@@ -96,6 +96,8 @@ class ConvWeights:
         # gradient as me_conv2d_f32 on these (millieye_amd/detector_train.py)
         self.want_rot = False
         self.rot = self.rot_tiled = None
+        # weights of the stride-2 layers' output-parity data gradient ([4*cin][2][2][cout]); written by the whole-network pack
+        self.want_parity, self.parity, self.parity_stamp = False, None, None
         self._stamp = None
 
     def _sources(self):
@@ -133,6 +135,10 @@ class ConvWeights:
         if self.want_rot and self.rot is None:
             self.rot = torch.empty((cin, k, k, cout), **f32)
             self.rot_tiled = torch.empty((k * k, cout // 16, cin, 16), **f32) if cout % 16 == 0 else None
+        if realloc:
+            self.parity = None
+        if getattr(self, "want_parity", False) and k == 3 and getattr(self, "parity", None) is None:
+            self.parity = torch.empty((4 * cin, 2, 2, cout), **f32)
         return "realloc" if realloc else True
 
     def _pack_desc(self, d):
@@ -146,6 +152,7 @@ class ConvWeights:
         d.ohwi, d.tiled = self.wgt.data_ptr(), ptr(self.wgt_tiled)
         d.rot, d.rot_tiled = ptr(self.rot if self.want_rot else None), ptr(self.rot_tiled if self.want_rot else None)
         d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
+        d.parity = ptr(getattr(self, "parity", None) if getattr(self, "want_parity", False) else None)
         d.cout, d.cin, d.ksize, d.eps = cout, cin, k, float(bn.eps) if bn is not None else 0.0
         return d
 
@@ -155,6 +162,7 @@ class ConvWeights:
         done = self._prepare_packed_f32(device)
         if done is None:
             return None
+        self.parity_stamp = None  # (the per-layer entry point has no parity output)
         d = self._pack_desc(hip.PackDesc())
         hip.check(hip.lib().me_pack_conv_f32(d.w, d.cout, d.cin, d.ksize, d.bias, d.gamma, d.beta, d.mean, d.var, d.eps, d.ohwi,
                                              d.tiled, d.rot, d.rot_tiled, d.scale, d.shift, hip.stream_ptr()),
@@ -304,7 +312,9 @@ class DarknetEngine:
             if d["type"] != "convolutional":
                 continue
             cw = self._conv_weights(i)
-            cw.want_rot = i > 0 and not (int(d["size"]) == 3 and int(d["stride"]) == 2)
+            s2 = int(d["size"]) == 3 and int(d["stride"]) == 2
+            cw.want_rot = i > 0 and not s2
+            cw.want_parity = i > 0 and s2  # (only the batch launch writes it; the data gradient builds it itself otherwise)
             cws.append(cw)
         stale = []
         for cw in cws:
@@ -341,6 +351,7 @@ class DarknetEngine:
                   "me_pack_conv_batch_f32")
         for cw, stamp in stale:
             cw._stamp = stamp
+            cw.parity_stamp = stamp if getattr(cw, "parity", None) is not None else None
 
     def refresh_weights(self, device):
         """Re-pack whatever parameter changed since the last run.  The fast path is one flat tuple of

@@ -120,7 +120,7 @@ class PackDesc(C.Structure):
         ("w", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p),
         ("var", C.c_void_p),
         ("ohwi", C.c_void_p), ("tiled", C.c_void_p), ("rot", C.c_void_p), ("rot_tiled", C.c_void_p), ("scale", C.c_void_p),
-        ("shift", C.c_void_p),
+        ("shift", C.c_void_p), ("parity", C.c_void_p),
         ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("eps", C.c_float),
         ("first_block", C.c_int32), ("blocks_x", C.c_int32),
     ]

@@ -397,6 +397,13 @@ def test_pack_conv_single_and_batch(hip_lib):
         assert_close(one["scale"].cpu(), sc.float(), 1e-6, tag + "scale")
         assert_close(one["shift"].cpu(), sh.float(), 1e-6, tag + "shift")
         expect.append((one, two))
+    # the stride-2 layers' parity weights ride in the whole-network launch (3x3 only)
+    from millieye_amd.detector_train import _parity_weights
+    par = {}
+    for idx, (cout, cin, k, _bn, _rot) in enumerate(shapes):
+        if k == 3 and cin > 4:
+            par[idx] = torch.zeros((4 * cin, 2, 2, cout), device="cuda")
+            descs[idx].parity = par[idx].data_ptr()
     total = int(lib.me_pack_conv_plan(descs, len(shapes)))
     assert total > 0
     table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).cuda()
@@ -406,5 +413,7 @@ def test_pack_conv_single_and_batch(hip_lib):
         for n_ in one:
             if one[n_] is not None:
                 assert torch.equal(one[n_], two[n_]), n_
+    for idx, t in par.items():
+        assert torch.equal(t, _parity_weights(expect[idx][1]["ohwi"])), f"parity weights of shape {shapes[idx]}"
     bad = (hip.PackDesc * 1)()
     assert int(lib.me_pack_conv_plan(bad, 1)) < 0
