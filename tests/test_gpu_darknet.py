@@ -246,3 +246,37 @@ def test_yolo_loss_kernel_vs_the_torch_restatement(hip_lib, n, g, nc, m):
         with pytest.raises(IndexError):
             layer.loss_from_raw(raw.cuda(), bad)
         layer.loss_from_raw(raw.cuda(), targets.clone())  # the flag word was reset
+
+
+def test_detector_backward_stream_overlap_is_bit_stable(hip_lib, monkeypatch):
+    """The weight gradients run on a second HIP stream beside the data gradients (millieye_amd/detector_train.py): with memory
+    churn between the steps (the caching allocator hands freed blocks straight back) ten repeated Darknet-53 steps must give
+    the SAME bits for every gradient, and the same bits as the single-stream run - a read of a buffer the main stream has
+    already recycled, or an optimizer reading a gradient still being written, would show up here."""
+    from millieye_amd import synth
+    model = ph.make_darknet("yolov3", tag="ovl").cuda()
+    n, s = 4, 160
+    x = torch.from_numpy(synth.uniform("ovl/x", (n, 3, s, s))).cuda()
+    rng = np.random.RandomState(7)
+    tg = np.zeros((9, 6), np.float32)
+    tg[:, 0] = rng.randint(0, n, 9)
+    tg[:, 1] = rng.randint(0, 80, 9)
+    tg[:, 2:4] = rng.uniform(0.1, 0.9, (9, 2))
+    tg[:, 4:6] = rng.uniform(0.05, 0.4, (9, 2))
+    targets = torch.from_numpy(tg)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, _, _ = model(x, targets.clone())
+        loss.backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    monkeypatch.setenv("MILLIEYE_WGRAD_STREAM", "0")
+    single = step()
+    monkeypatch.setenv("MILLIEYE_WGRAD_STREAM", "1")
+    for rep in range(10):
+        junk = [torch.empty(int(rng.randint(1, 64)) * 1024 * 256, device="cuda").fill_(float("nan")) for _ in range(4)]
+        got = step()
+        del junk
+        for k, g in got.items():
+            assert torch.equal(g, single[k]), (rep, k)
