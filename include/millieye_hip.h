@@ -270,6 +270,11 @@ typedef struct me_heads_desc {
   float* save_feat_rad;
   float* save_hidden;
   float* save_small;
+  /* optional scratch [n_img_cap + n_radar, 980] floats: when given, the RoI pooling runs as its own launch (one workgroup per
+   * RoI - 8 RoIs' 7840 bilinear samples per workgroup were two thirds of the fused launch, which has less than one workgroup
+   * per CU to hide them behind) and the heads kernel reads the pooled features back; same samples, same arithmetic.  NULL =
+   * the single fused launch. */
+  float* pool_scratch;
 } me_heads_desc;
 int me_roi_heads_f32(const me_heads_desc* d, void* stream);
 /* me_compact_sort_rows_f32 - the tail of Network.forward (my_models.py:517-539): keep the rows whose `keep` byte is set

@@ -259,8 +259,32 @@ __device__ void tail_one(const me_heads_desc& d, const float* sm, const float* r
   o[0] = roi[0]; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = p; o[6] = c6; o[7] = c7;
 }
 
+// RoI pooling of one RoI per workgroup into d.pool_scratch [cap][2 * FEAT] (see me_heads_desc.pool_scratch)
+__global__ __launch_bounds__(256) void roi_pool_kernel(me_heads_desc d) {
+  __shared__ float s_box[5];
+  const int t = threadIdx.x;
+  const int n_img = *d.n_img;
+  const int k = blockIdx.x;
+  if (k >= n_img + d.n_radar) return;
+  if (t < 5) s_box[t] = (k < n_img) ? d.img_boxes[(long long)k * d.box_cols + t] : d.radar_boxes[(long long)(k - n_img) * 5 + t];
+  __syncthreads();
+  float* out = d.pool_scratch + (long long)k * 2 * FEAT;
+  for (int f = t; f < 2 * FEAT; f += 256) {
+    float v;
+    if (f < FEAT) {
+      const int pw = f % P, ph = (f / P) % P;
+      v = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_box, d.spatial_scale, f, ph, pw);
+    } else {
+      const int g = f - FEAT;
+      const int pw = g % P, ph = (g / P) % P, c = g / PP;
+      v = roi_sample(d.radar_map, d.radar_pitch, d.rh, d.rw, s_box, d.spatial_scale, c, ph, pw);
+    }
+    out[f] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
-  __shared__ float s_feat[RPB][2 * FEAT];  // [r][0:490] image (PS-RoIAlign), [490:980] radar (RoIAlign)
+  __shared__ __attribute__((aligned(16))) float s_feat[RPB][2 * FEAT];  // [r][0:490] image (PS-RoIAlign), [490:980] radar (RoIAlign)
   __shared__ float s_hid[RPB][HID];
   __shared__ float s_small[RPB][16];       // 0-3 reg, 4-5 cls logits(0,1), 6-15 radar conv
   __shared__ float s_roi[RPB][5];
@@ -283,7 +307,26 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
   }
   __syncthreads();
 
-  // phase A: pooled features
+  // phase A: pooled features (sampled here, or read back from the pooling launch)
+  if (d.pool_scratch) {
+    // the nr rows are contiguous on both sides (2 * FEAT = 1960 floats = 490 float4 per RoI); four loads in flight per lane
+    const float4* src = reinterpret_cast<const float4*>(d.pool_scratch + (long long)k0 * 2 * FEAT);
+    float4* dst = reinterpret_cast<float4*>(&s_feat[0][0]);
+    const int n4 = nr * (2 * FEAT / 4);
+    for (int i0 = 0; i0 < n4; i0 += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + t;
+        v[u] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + t;
+        if (i < n4) dst[i] = v[u];
+      }
+    }
+  } else
   for (int idx = t; idx < nr * 2 * FEAT; idx += 256) {
     const int r = idx / (2 * FEAT), f = idx % (2 * FEAT);
     float v;
@@ -653,6 +696,11 @@ int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
              "me_roi_heads_f32: training mode needs all four save_* pointers and wts.rb");
   const int cap = d->n_img_cap + d->n_radar;
   if (cap == 0) return 0;
+  if (d->pool_scratch) {
+    hipLaunchKernelGGL(roi_pool_kernel, dim3(cap), dim3(256), 0, stream, *d);
+    const int rc = me::check_launch("roi_pool_kernel");
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(roi_heads_kernel, dim3((cap + RPB - 1) / RPB), dim3(256), 0, stream, *d);
   return me::check_launch("roi_heads_kernel");
 }

@@ -111,6 +111,7 @@ class HeadsDesc(C.Structure):
         ("out_rows", C.c_void_p), ("keep", C.c_void_p), ("sort_key", C.c_void_p),
         ("save_feat_img", C.c_void_p), ("save_feat_rad", C.c_void_p), ("save_hidden", C.c_void_p),
         ("save_small", C.c_void_p),
+        ("pool_scratch", C.c_void_p),
     ]
 
 
