@@ -21,7 +21,11 @@ rocprofv3 --kernel-trace --stats -d /tmp/ktb8_$TAG -o k -- python $R/bench.py --
 rocprofv3 --kernel-trace --stats -d /tmp/ktb_$TAG -o k -- python $R/bench.py --workload detector_train --no-cpu-baseline --steps 26 --warmup 2 > /tmp/ktb.log 2>&1
 python $R/tools/prof_summary.py /tmp/ktb_$TAG/k_results.db > $OUT/${TAG}_bench_detector_train_b8_kernel_stats.txt 2>&1
 python $R/tools/prof_summary.py /tmp/ktb_$TAG/k_results.db --by-grid > $OUT/${TAG}_bench_detector_train_b8_by_grid.txt 2>&1
-(cd $R/tools; python prof_diff.py /tmp/ktb8_$TAG/k_results.db /tmp/ktb_$TAG/k_results.db pack_conv_batch_kernel) > $OUT/${TAG}_bench_detector_train_b8_per_step.txt 2>&1
+(cd $R/tools; python prof_diff.py /tmp/ktb8_$TAG/k_results.db /tmp/ktb_$TAG/k_results.db pack_conv_batch_kernel) > $OUT/${TAG}_bench_detector_train_b8_per_step_overlap.txt 2>&1
+# the same with the weight gradients on the main stream: a kernel's duration is its own (the per-kernel rooflines of DESIGN section 3)
+MILLIEYE_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/kts8_$TAG -o k -- python $R/bench.py --workload detector_train --no-cpu-baseline --steps 6 --warmup 2 > /tmp/kts8.log 2>&1
+MILLIEYE_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/kts_$TAG -o k -- python $R/bench.py --workload detector_train --no-cpu-baseline --steps 26 --warmup 2 > /tmp/kts.log 2>&1
+(cd $R/tools; python prof_diff.py /tmp/kts8_$TAG/k_results.db /tmp/kts_$TAG/k_results.db pack_conv_batch_kernel) > $OUT/${TAG}_bench_detector_train_b8_per_step.txt 2>&1
 (cd $R; python tools/wgrad_bench.py 8; python tools/dgrad_bench.py 8; python tools/pack_bench.py) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_backward_microbench.txt
 # HBM traffic: FETCH_SIZE / WRITE_SIZE need separate passes; one pair per storage mode, every forward of the pass at batch 32
 C32="$CMD --no-bf16-line --prewarm-seconds 0.3"
