@@ -86,78 +86,14 @@ class YOLOLayer(nn.Module):
         return output, self.loss_from_raw(nhwc, targets)
 
     def loss_from_raw(self, raw_nhwc, targets, return_targets=False):
-        """YOLO loss + metrics of this scale (reference :181-232) from the raw detection map
-        ``raw_nhwc`` [N, G, G, A*(5+C)] (any strides) and ``targets`` [m,6] = (image_i, class, cx, cy, w, h)
-        normalised to [0,1].  Device-side torch ops (anchor matching is index bookkeeping,
-        ``utils.utils.build_targets``); the value carries no gradient - the detector is frozen on this
-        path and its backward is not built."""
-        n, g = raw_nhwc.shape[0], raw_nhwc.shape[1]
-        dev = raw_nhwc.device
-        if raw_nhwc.is_cuda:
-            return self._loss_from_raw_hip(raw_nhwc, targets, return_targets)
-        with torch.no_grad():
-            pred = raw_nhwc.reshape(n, g, g, self.num_anchors, self.num_classes + 5).permute(0, 3, 1, 2, 4)
-            x = torch.sigmoid(pred[..., 0])
-            y = torch.sigmoid(pred[..., 1])
-            w = pred[..., 2]
-            h = pred[..., 3]
-            pred_conf = torch.sigmoid(pred[..., 4])
-            pred_cls = torch.sigmoid(pred[..., 5:])
-            stride = self.img_dim / g
-            grid_x = torch.arange(g, device=dev).repeat(g, 1).view(1, 1, g, g).float()
-            grid_y = torch.arange(g, device=dev).repeat(g, 1).t().view(1, 1, g, g).float()
-            scaled_anchors = torch.tensor([(aw / stride, ah / stride) for aw, ah in self.anchors],
-                                          dtype=torch.float32, device=dev)
-            self.scaled_anchors = scaled_anchors
-            anchor_w = scaled_anchors[:, 0:1].view(1, self.num_anchors, 1, 1)
-            anchor_h = scaled_anchors[:, 1:2].view(1, self.num_anchors, 1, 1)
-            pred_boxes = torch.stack((x + grid_x, y + grid_y, torch.exp(w) * anchor_w, torch.exp(h) * anchor_h), -1)
-            targets = targets.to(dev)
-            iou_scores, class_mask, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf = build_targets(
-                pred_boxes=pred_boxes, pred_cls=pred_cls, target=targets, anchors=scaled_anchors,
-                ignore_thres=self.ignore_thres)
-            obj_mask, noobj_mask = obj_mask.bool(), noobj_mask.bool()
-            # x[obj_mask] == x[obj_idx] (boolean indexing IS nonzero order): the cell lists are computed once instead of
-            # once per term (a nonzero + host sync each)
-            obj_idx, noobj_idx = obj_mask.nonzero(as_tuple=True), noobj_mask.nonzero(as_tuple=True)
-            loss_x = self.mse_loss(x[obj_idx], tx[obj_idx])
-            loss_y = self.mse_loss(y[obj_idx], ty[obj_idx])
-            loss_w = self.mse_loss(w[obj_idx], tw[obj_idx])
-            loss_h = self.mse_loss(h[obj_idx], th[obj_idx])
-            conf_at_obj, conf_at_noobj = pred_conf[obj_idx], pred_conf[noobj_idx]
-            loss_conf_obj = self.bce_loss(conf_at_obj, tconf[obj_idx])
-            loss_conf_noobj = self.bce_loss(conf_at_noobj, tconf[noobj_idx])
-            loss_conf = self.obj_scale * loss_conf_obj + self.noobj_scale * loss_conf_noobj
-            loss_cls = self.bce_loss(pred_cls[obj_idx], tcls[obj_idx])
-            total_loss = loss_x + loss_y + loss_w + loss_h + loss_conf + loss_cls
-            conf50 = (pred_conf > 0.5).float()
-            iou50 = (iou_scores > 0.5).float()
-            iou75 = (iou_scores > 0.75).float()
-            detected_mask = conf50 * class_mask * tconf
-            n_obj_t, n_noobj_t = obj_mask.sum(), noobj_mask.sum()
-            # the thirteen scalars of the reference's metrics dict, read back in ONE transfer (it reads them one .item() at a
-            # time); all are float32 scalars, so the values are the same floats
-            scalars = torch.stack([
-                total_loss, loss_x, loss_y, loss_w, loss_h, loss_conf, loss_cls, 100 * class_mask[obj_idx].mean(),
-                torch.sum(iou50 * detected_mask) / (n_obj_t + 1e-16), torch.sum(iou75 * detected_mask) / (n_obj_t + 1e-16),
-                torch.sum(iou50 * detected_mask) / (conf50.sum() + 1e-16), conf_at_obj.mean(), conf_at_noobj.mean(),
-                n_obj_t.float(), n_noobj_t.float()]).tolist()
-            keys = ("loss", "x", "y", "w", "h", "conf", "cls", "cls_acc", "recall50", "recall75", "precision", "conf_obj",
-                    "conf_noobj")
-            self.metrics = dict(zip(keys, scalars[:13]))
-            self.metrics["grid_size"] = g
-        if return_targets:  # what me_yolo_loss_bwd_f32 needs (detector backward, millieye_amd/detector_train.py)
-            f = dict(device=dev, dtype=torch.float32)
-            bt = dict(obj=obj_mask.to(torch.uint8).contiguous(), noobj=noobj_mask.to(torch.uint8).contiguous(),
-                      tx=tx.to(**f).contiguous(), ty=ty.to(**f).contiguous(), tw=tw.to(**f).contiguous(),
-                      th=th.to(**f).contiguous(), tcls=tcls.to(**f).contiguous(), tconf=tconf.to(**f).contiguous(),
-                      n_obj=int(scalars[13]), n_noobj=int(scalars[14]))
-            return total_loss, bt
-        return total_loss
-
-    def _loss_from_raw_hip(self, raw_nhwc, targets, return_targets):
-        """The same loss + metrics on the device: ``me_yolo_loss_fwd_f32`` (csrc/yolo_loss.hip) - target assignment, the six
-        terms and the metric sums in three launches and one read-back instead of ~200 torch ops and ~15 host syncs per scale."""
+        """YOLO loss + metrics of this scale (reference :181-232 with ``utils.build_targets`` :381-440) from the raw detection
+        map ``raw_nhwc`` [N, G, G, A*(5+C)] (CUDA) and ``targets`` [m,6] = (image_i, class, cx, cy, w, h) normalised to [0,1]:
+        ``me_yolo_loss_fwd_f32`` (csrc/yolo_loss.hip) - target assignment, the six terms and the metric sums in three launches
+        and one read-back (the reference runs ~200 torch ops and ~15 host reads per scale).  Sets ``self.metrics`` like the
+        reference; ``return_targets`` adds the dense build_targets tensors ``me_yolo_loss_bwd_f32`` takes.  There is no CPU
+        path (the torch-op restatement the tests compare with is ``oracle/darknet_ref.py:yolo_loss_terms``)."""
+        if not raw_nhwc.is_cuda:
+            raise hip.MeError("YOLOLayer.loss_from_raw needs CUDA tensors (MI355X); there is no CPU fallback")
         import ctypes as C
         n, g = raw_nhwc.shape[0], raw_nhwc.shape[1]
         dev, na, nc = raw_nhwc.device, self.num_anchors, self.num_classes

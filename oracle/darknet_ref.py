@@ -209,6 +209,76 @@ def yolo_loss(raw, anchors, num_classes, img_dim, targets, ignore_thres=0.5, obj
     return loss
 
 
+def yolo_loss_terms(raw_nhwc, anchors, num_classes, img_dim, targets, ignore_thres=0.5, obj_scale=1, noobj_scale=100):
+    """Everything ``YOLOLayer.forward`` computes besides the decoded rows when it is given targets (models.py:181-232 with
+    build_targets, utils/utils.py:381-440), from the raw map ``raw_nhwc`` [N, G, G, A*(5+C)]: ``(total_loss, metrics,
+    dense)`` - the reference's metrics dict and the dense build_targets tensors (obj / noobj masks, tx, ty, tw, th, tcls,
+    tconf, class_mask, iou_scores).  The reference's own statements, one torch op each (its per-target python loop included);
+    the checker of ``me_yolo_loss_fwd_f32``.  Loss and gradients of the same code are pinned by ``yolo_loss`` above against
+    tests/golden/yololoss_*.npz, the metrics by the GPU test against the same fixtures."""
+    n, g, na = raw_nhwc.shape[0], raw_nhwc.shape[1], len(anchors)
+    with torch.no_grad():
+        pred = raw_nhwc.reshape(n, g, g, na, num_classes + 5).permute(0, 3, 1, 2, 4)
+        x, y = torch.sigmoid(pred[..., 0]), torch.sigmoid(pred[..., 1])
+        w, h = pred[..., 2], pred[..., 3]
+        pred_conf, pred_cls = torch.sigmoid(pred[..., 4]), torch.sigmoid(pred[..., 5:])
+        stride = img_dim / g
+        grid_x = torch.arange(g).repeat(g, 1).view(1, 1, g, g).float()
+        grid_y = torch.arange(g).repeat(g, 1).t().view(1, 1, g, g).float()
+        sa = torch.tensor([(aw / stride, ah / stride) for aw, ah in anchors], dtype=torch.float32)
+        pred_boxes = torch.stack((x + grid_x, y + grid_y, torch.exp(w) * sa[:, 0].view(1, na, 1, 1),
+                                  torch.exp(h) * sa[:, 1].view(1, na, 1, 1)), -1)
+        cells = (n, na, g, g)
+        obj = torch.zeros(cells, dtype=torch.bool)
+        noobj = torch.ones(cells, dtype=torch.bool)
+        class_mask, iou_scores, tx, ty, tw, th = (torch.zeros(cells) for _ in range(6))
+        tcls = torch.zeros(cells + (num_classes,))
+        if targets.shape[0]:
+            tb = targets[:, 2:6] * g
+            gxy, gwh = tb[:, :2], tb[:, 2:]
+            ious = torch.stack([_wh_iou(a, gwh) for a in sa])
+            best_n = ious.max(0)[1]
+            b, labels = targets[:, :2].long().t()
+            gi, gj = gxy.long().t()
+            obj[b, best_n, gj, gi] = True
+            noobj[b, best_n, gj, gi] = False
+            for k, a_ious in enumerate(ious.t()):
+                noobj[b[k], a_ious > ignore_thres, gj[k], gi[k]] = False
+            tx[b, best_n, gj, gi] = gxy[:, 0] - gxy[:, 0].floor()
+            ty[b, best_n, gj, gi] = gxy[:, 1] - gxy[:, 1].floor()
+            tw[b, best_n, gj, gi] = torch.log(gwh[:, 0] / sa[best_n][:, 0] + 1e-16)
+            th[b, best_n, gj, gi] = torch.log(gwh[:, 1] / sa[best_n][:, 1] + 1e-16)
+            tcls[b, best_n, gj, gi, labels] = 1
+            class_mask[b, best_n, gj, gi] = (pred_cls[b, best_n, gj, gi].argmax(-1) == labels).float()
+            pb = pred_boxes[b, best_n, gj, gi]                                 # bbox_iou(..., x1y1x2y2=False), utils.py:173-200
+            b1x1, b1x2 = pb[:, 0] - pb[:, 2] / 2, pb[:, 0] + pb[:, 2] / 2
+            b1y1, b1y2 = pb[:, 1] - pb[:, 3] / 2, pb[:, 1] + pb[:, 3] / 2
+            b2x1, b2x2 = tb[:, 0] - tb[:, 2] / 2, tb[:, 0] + tb[:, 2] / 2
+            b2y1, b2y2 = tb[:, 1] - tb[:, 3] / 2, tb[:, 1] + tb[:, 3] / 2
+            inter = torch.clamp(torch.min(b1x2, b2x2) - torch.max(b1x1, b2x1) + 1, min=0) * \
+                torch.clamp(torch.min(b1y2, b2y2) - torch.max(b1y1, b2y1) + 1, min=0)
+            a1, a2 = (b1x2 - b1x1 + 1) * (b1y2 - b1y1 + 1), (b2x2 - b2x1 + 1) * (b2y2 - b2y1 + 1)
+            iou_scores[b, best_n, gj, gi] = inter / (a1 + a2 - inter + 1e-16)
+        tconf = obj.float()
+        mse, bce = F.mse_loss, F.binary_cross_entropy
+        loss_x, loss_y = mse(x[obj], tx[obj]), mse(y[obj], ty[obj])
+        loss_w, loss_h = mse(w[obj], tw[obj]), mse(h[obj], th[obj])
+        loss_conf = obj_scale * bce(pred_conf[obj], tconf[obj]) + noobj_scale * bce(pred_conf[noobj], tconf[noobj])
+        loss_cls = bce(pred_cls[obj], tcls[obj])
+        total = loss_x + loss_y + loss_w + loss_h + loss_conf + loss_cls
+        conf50, iou50, iou75 = (pred_conf > 0.5).float(), (iou_scores > 0.5).float(), (iou_scores > 0.75).float()
+        detected = conf50 * class_mask * tconf
+        metrics = {"loss": total.item(), "x": loss_x.item(), "y": loss_y.item(), "w": loss_w.item(), "h": loss_h.item(),
+                   "conf": loss_conf.item(), "cls": loss_cls.item(), "cls_acc": (100 * class_mask[obj].mean()).item(),
+                   "recall50": (torch.sum(iou50 * detected) / (obj.sum() + 1e-16)).item(),
+                   "recall75": (torch.sum(iou75 * detected) / (obj.sum() + 1e-16)).item(),
+                   "precision": (torch.sum(iou50 * detected) / (conf50.sum() + 1e-16)).item(),
+                   "conf_obj": pred_conf[obj].mean().item(), "conf_noobj": pred_conf[noobj].mean().item(), "grid_size": g}
+        dense = dict(obj=obj, noobj=noobj, tx=tx, ty=ty, tw=tw, th=th, tcls=tcls, tconf=tconf, class_mask=class_mask,
+                     iou_scores=iou_scores, n_obj=int(obj.sum()), n_noobj=int(noobj.sum()))
+    return total, metrics, dense
+
+
 def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list.", training=False):
     """Summed YOLO loss of every scale + its gradient w.r.t. every detector parameter.  ``training`` selects the
     BatchNorm mode (False: running statistics, what every reference script uses; True: batch statistics, momentum 0.9).

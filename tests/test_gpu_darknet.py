@@ -204,11 +204,12 @@ def test_frames_are_independent_across_batch_sizes(hip_lib):
 
 @pytest.mark.parametrize("n,g,nc,m", [(2, 13, 12, 9), (3, 26, 80, 40), (1, 7, 3, 1), (2, 10, 12, 0)])
 def test_yolo_loss_kernel_vs_the_torch_restatement(hip_lib, n, g, nc, m):
-    """me_yolo_loss_fwd_f32 (target assignment + six loss terms + metrics of one scale on the device) against the torch-op
-    restatement of the same reference code (``YOLOLayer.loss_from_raw`` on CPU tensors - pinned to the reference's numbers by
-    tests/test_train_cpu.py / test_yolo_loss_value_vs_reference_golden): every dense build_targets tensor exactly, loss terms and
-    metrics to 1e-5; two targets in one cell (the later one wins, both class labels stay), targets on cell borders, no target
-    at all (NaN means, like the reference); a target outside the grid raises IndexError like the reference's index_put_."""
+    """me_yolo_loss_fwd_f32 (target assignment + six loss terms + metrics of one scale on the device) against the oracle's
+    torch-op restatement of the reference code (``oracle/darknet_ref.py:yolo_loss_terms``): every dense build_targets tensor
+    exactly, loss terms and metrics to 1e-5; two targets in one cell (the later one wins, both class labels stay), targets
+    on cell borders, no target at all (NaN means, like the reference); a target outside the grid raises IndexError like the
+    reference's index_put_; CPU tensors are refused (no fallback)."""
+    from oracle import darknet_ref
     from millieye_amd.yolov3.models import YOLOLayer
     rng = np.random.RandomState(100 * g + m)
     anchors = [(10, 13), (33, 23), (62, 45)]
@@ -226,8 +227,9 @@ def test_yolo_loss_kernel_vs_the_torch_restatement(hip_lib, n, g, nc, m):
         tg[3, 2] += 0.2 / g
         tg[5, 2:4] = (np.floor(tg[5, 2:4] * g) + 0.0) / g   # exactly on a cell border
     targets = torch.from_numpy(tg)
-    ref_loss, ref_bt = layer.loss_from_raw(raw, targets.clone(), return_targets=True)
-    ref_metrics = dict(layer.metrics)
+    ref_loss, ref_metrics, ref_bt = darknet_ref.yolo_loss_terms(raw, anchors, nc, 32 * g, targets.clone())
+    with pytest.raises(Exception):
+        layer.loss_from_raw(raw, targets.clone())
     got_loss, bt = layer.loss_from_raw(raw.cuda(), targets.clone(), return_targets=True)
     for k in ("obj", "noobj", "tx", "ty", "tw", "th", "tcls", "tconf"):
         a, b = bt[k].cpu().float(), ref_bt[k].cpu().float()

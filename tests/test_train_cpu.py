@@ -128,6 +128,36 @@ def test_oracle_detector_training_step_matches_reference():
     assert checked == 37
 
 
+def test_oracle_yolo_loss_terms_match_the_reference_metrics():
+    """oracle/darknet_ref.yolo_loss_terms (the checker of the device loss kernel me_yolo_loss_fwd_f32: loss terms, the
+    reference's metrics dict, dense build_targets tensors) on the oracle's own raw detection maps against the numbers the real
+    reference's YOLO layers reported (tests/golden/yololoss_tiny12_s96_n2.npz: total loss and m{i}/{metric} per scale)."""
+    from oracle import darknet_ref
+    from tests.golden.make_golden import YOLO_LOSS_CASE
+    from tests.parity_helpers import make_darknet
+    name, cfg, n, s = YOLO_LOSS_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    model = make_darknet(cfg, name)
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    text = cfgs.KNOWN[cfg]()
+    _, _, outs = darknet_ref.darknet_forward(text, model.state_dict(), x, return_layers=True)
+    blocks = darknet_ref.parse_cfg_text(text)[1:]
+    targets = torch.from_numpy(g["targets"])
+    total, scale = 0.0, 0
+    for i, b in enumerate(blocks):
+        if b["type"] != "yolo":
+            continue
+        raw = outs[i - 1].permute(0, 2, 3, 1).contiguous()  # the detection conv's output, NHWC
+        loss, metrics, dense = darknet_ref.yolo_loss_terms(raw, darknet_ref._anchors_of(b), int(b["classes"]), s, targets.clone())
+        for k, v in metrics.items():
+            ref = float(g[f"m{scale}/{k}"])
+            assert abs(float(v) - ref) <= 1e-5 * max(1.0, abs(ref)), (scale, k, v, ref)
+        assert dense["n_obj"] > 0 and dense["tcls"].sum() >= dense["n_obj"]
+        total += float(loss)
+        scale += 1
+    assert scale == 2 and abs(total - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+
+
 def test_oracle_detector_training_step_train_mode_bn_matches_reference():
     """Same with the detector in train() mode: batch-statistics BatchNorm (momentum 0.9), loss, gradients and the
     updated running statistics against the reference's own run (yololoss_tiny12_s96_n2_bntrain.npz)."""
