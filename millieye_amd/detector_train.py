@@ -11,13 +11,15 @@ The graph is static, so forward and backward are explicit launch sequences over 
 one :class:`torch.autograd.Function` whose inputs are the detector parameters:
 
 forward   every module output is kept (NHWC): ``me_conv2d_f32`` (folded BN + LeakyReLU epilogue), ``me_maxpool_f32``,
-          ``me_upsample_f32``, ``me_add_f32`` (shortcut), ``me_copy_f32`` (route concat); the YOLO loss value and the
-          ``build_targets`` masks come from ``YOLOLayer.loss_from_raw`` (index bookkeeping, as in the reference).
+          ``me_upsample_f32``, ``me_add_f32`` (shortcut), ``me_copy_f32`` (route concat); every layer's packed weights come
+          from ONE ``me_pack_conv_batch_f32`` launch (``DarknetEngine.refresh_train_weights``); the YOLO loss value, the
+          metrics and the dense ``build_targets`` tensors come from ``YOLOLayer.loss_from_raw`` = ``me_yolo_loss_fwd_f32``.
 backward  ``me_yolo_loss_bwd_f32`` seeds the raw detection maps; modules are walked in reverse:
           ``me_affine_act_bwd_f32`` (activation + BN-affine backward, d gamma / d beta / d bias),
-          ``me_conv_wgrad_mfma_f32`` (weight gradient on the matrix pipe), the data gradient as ``me_conv2d_f32`` on the 180-degree rotated,
-          transposed weights (stride 2: on the zero-interleaved gradient; the 255 / 51-channel detection convs:
-          ``me_gemm_f32``), ``me_upsample2_bwd_f32``, ``me_maxpool_bwd_f32``, ``me_add_f32`` for fan-out accumulation.
+          ``me_conv_wgrad_mfma_oihw_f32`` (weight gradient on the matrix pipe, on a second HIP stream beside the data
+          gradient), the data gradient as ``me_conv2d_f32`` on the 180-degree rotated, transposed weights (3x3 / stride 2: one
+          2x2 convolution for the four output-parity classes + a pixel shuffle; the 255 / 51-channel detection convs:
+          ``me_gemm_f32``), ``me_upsample2_bwd_f32``, ``me_maxpool_bwd_f32``; gradients accumulate in slots with ownership.
 
 """
 import os
