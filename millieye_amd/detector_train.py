@@ -266,7 +266,7 @@ class DetectorTrainer:
                         # even positions, two (W[2] at offset 0, W[0] at offset +1) for the odd ones.  All four parity classes
                         # come out of ONE 2x2 convolution of dc (pad 1) with 4 * cin output channels - 16 tap-units per
                         # gradient pixel instead of 36 - followed by a pixel shuffle of the cropped result.
-                        fresh = getattr(cw, "parity", None) is not None and getattr(cw, "parity_stamp", None) == cw._stamp
+                        fresh = cw.parity is not None and cw.parity_stamp == cw._stamp
                         pw = cw.parity if fresh else _parity_weights(cw.wgt)  # (from the step's pack launch when it ran)
                         dx4 = hip.conv2d_auto(dc, pw, _const_vectors(4 * cin, dev)[0],
                                               _const_vectors(4 * cin, dev)[1], 2, 1, 1, hip.ACT_LINEAR)

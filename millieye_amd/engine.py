@@ -137,7 +137,7 @@ class ConvWeights:
             self.rot_tiled = torch.empty((k * k, cout // 16, cin, 16), **f32) if cout % 16 == 0 else None
         if realloc:
             self.parity = None
-        if getattr(self, "want_parity", False) and k == 3 and getattr(self, "parity", None) is None:
+        if self.want_parity and k == 3 and self.parity is None:
             self.parity = torch.empty((4 * cin, 2, 2, cout), **f32)
         return "realloc" if realloc else True
 
@@ -152,7 +152,7 @@ class ConvWeights:
         d.ohwi, d.tiled = self.wgt.data_ptr(), ptr(self.wgt_tiled)
         d.rot, d.rot_tiled = ptr(self.rot if self.want_rot else None), ptr(self.rot_tiled if self.want_rot else None)
         d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
-        d.parity = ptr(getattr(self, "parity", None) if getattr(self, "want_parity", False) else None)
+        d.parity = ptr(self.parity if self.want_parity else None)
         d.cout, d.cin, d.ksize, d.eps = cout, cin, k, float(bn.eps) if bn is not None else 0.0
         return d
 
@@ -351,7 +351,7 @@ class DarknetEngine:
                   "me_pack_conv_batch_f32")
         for cw, stamp in stale:
             cw._stamp = stamp
-            cw.parity_stamp = stamp if getattr(cw, "parity", None) is not None else None
+            cw.parity_stamp = stamp if cw.parity is not None else None
 
     def refresh_weights(self, device):
         """Re-pack whatever parameter changed since the last run.  The fast path is one flat tuple of
