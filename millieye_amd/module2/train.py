@@ -17,7 +17,8 @@ batches.  Kept line by line:
 
 The TensorBoard scalars (loss, "precesion" = tp / positive, recall = tp / true) go to an optional ``writer``; a zero
 denominator skips the scalar instead of raising.  With ``torch.distributed`` initialised every rank runs the loop on its own
-batches and the gradients are SUM-all-reduced in one bucket before the step (``millieye_amd/parallel.py``).
+batches, the gradients are SUM-all-reduced in one bucket before the step (``millieye_amd/parallel.py``) and the head
+BatchNorm's running statistics are averaged over the ranks once per epoch.
 """
 import argparse
 import datetime
@@ -82,6 +83,11 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
                     writer.add_scalar("recall", metric["tp"] / metric["true"], global_step=batches_done)
             model.seen += imgs.size(0)
 
+        if distributed:
+            # identical parameters on every rank after the summed-gradient steps; the fcn_layers BatchNorm's running statistics
+            # are not (each rank normalises its own batches): average them once per epoch, like the stage-3 loop does
+            from ..train import sync_batchnorm_buffers
+            sync_batchnorm_buffers(model)
         evaluating = epoch % evaluation_interval == 0 and evaluate_fn is not None
         if evaluating and rank == 0:
             log("\n---- Evaluating Model ----")

@@ -83,3 +83,66 @@ def test_m2_train_loop_harness_matches_reference_script(tmp_path):
     net = ml.prepare(ml.OracleBackedM2Network)
     hist = ml.run(net, tmp_path)
     ml.check(net, hist, tmp_path, loss_tol=1e-5, param_atol=2e-5, sum_tol=1e-6, ap_tol=1e-6)
+
+
+def _m2_dp_worker(rank, world, port, q, ckpt_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from millieye_amd.module2.train import train_loop
+    c, g = mg.M2_LOOP_CASE, ml.golden()
+    targets = {k[len("targets/"):]: g[k] for k in g.files if k.startswith("targets/")}
+    net = ml.prepare(ml.OracleBackedM2Network)
+
+    class Shard:  # rank r trains on batches r, r + 1 of the stand-in set: different data, equal counts
+        def __len__(self):
+            return 2
+
+        def __iter__(self):
+            b = mg.m2_loop_batches(c["name"], "train", c["train_batches"], c["batch"], c["size"], targets)
+            return iter(b[rank:rank + 2])
+
+    random.seed(c["seed"] + rank)
+    torch.manual_seed(c["seed"] + rank)
+    hist = train_loop(net, Shard(), epochs=2, gradient_accumulations=1, evaluate_fn=None,
+                      checkpoint_dir=os.path.join(ckpt_dir, f"r{rank}"), log=lambda *_: None)
+    heads = {k: v.detach().clone() for k, v in net.named_parameters() if not k.startswith("base_detector.")}
+    heads.update({"buf/" + k: v.detach().clone().float() for k, v in net.named_buffers()
+                  if "running_" in k and not k.startswith("base_detector.")})
+    q.put((rank, hist["steps"], hist["losses"], {k: v.numpy() for k, v in heads.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_m2_train_loop_data_parallel_replicas_stay_identical(tmp_path):
+    """``module2/train.py:train_loop`` under ``torch.distributed`` (gloo, world size 2): each rank trains on its own batches,
+    the gradients are SUM-all-reduced in one bucket before every AdamW step - the replicas' head parameters stay bit-identical
+    although their losses differ, they move away from the start, and only rank 0 writes checkpoints."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_m2_dp_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, steps, losses, heads = q.get(timeout=600)
+        got[rank] = (steps, losses, heads)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] == [0, 1, 2, 3]
+    assert got[0][1] != got[1][1], "the ranks saw different batches"
+    start = dict(ml.prepare(ml.OracleBackedM2Network).named_parameters())
+    moved = 0
+    for k, v in got[0][2].items():
+        assert np.array_equal(v, got[1][2][k]), k   # parameters AND the averaged BatchNorm running statistics
+        if not k.startswith("buf/"):
+            moved += int(not np.array_equal(v, start[k].detach().numpy()))
+    assert moved >= 10
+    assert sorted(os.listdir(tmp_path / "r0" )) == ["ckpt_0.pth", "ckpt_1.pth"] and not os.path.exists(tmp_path / "r1" / "ckpt_0.pth")
