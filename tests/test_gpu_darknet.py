@@ -242,6 +242,11 @@ def test_yolo_loss_kernel_vs_the_torch_restatement(hip_lib, n, g, nc, m):
         abs(float(got_loss) - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss)))
     again, _ = layer.loss_from_raw(raw.cuda(), targets.clone(), return_targets=True)
     assert torch.equal(again, got_loss) or (torch.isnan(again) and torch.isnan(got_loss)), "fixed-order sums: deterministic"
+    # the raw map as a channel slice of a wider buffer (pitch > A * (5 + C)): same bits
+    wide = torch.full((n, g, g, raw.shape[-1] + 7), 9.0, device="cuda")
+    wide[..., 3:3 + raw.shape[-1]] = raw.cuda()
+    sliced, _ = layer.loss_from_raw(wide[..., 3:3 + raw.shape[-1]], targets.clone(), return_targets=True)
+    assert torch.equal(sliced, got_loss) or (torch.isnan(sliced) and torch.isnan(got_loss))
     if m:
         bad = targets.clone()
         bad[0, 2] = 1.0  # cx == 1 -> cell index g

@@ -462,3 +462,23 @@ def test_iou_labels_kernel_is_bit_identical_with_the_host_restatement(hip_lib):
     assert float(out[:, 0].abs().max()) == 0
     hip.check(hip.lib().me_iou_labels_f32(None, 0, cols, None, 0, tgd.data_ptr(), q, refine.data_ptr(), mask1.data_ptr(),
                                           keep.data_ptr(), out.data_ptr(), hip.stream_ptr()), "no proposals")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k", [(2, 18, 22, 3, 32, 3), (8, 48, 48, 128, 128, 3), (2, 12, 12, 64, 96, 1)])
+def test_conv_wgrad_pitched_operands(hip_lib, n, h, w, cin, cout, k):
+    """x and dy as channel slices of wider NHWC buffers (pitch > channels): the stem kernel (cin 3), the 128x128-tile kernel and
+    the 64x64 one must honour the pitches (16-byte alignment kept by slicing at multiples of 4 channels)."""
+    from millieye_amd import hip
+    pad = (k - 1) // 2
+    tag = f"wp{n}{h}{cin}{cout}{k}"
+    x = _t(tag + "x", (n, cin, h, w))
+    wt = _t(tag + "w", (cout, cin, k, k), -0.2, 0.2).requires_grad_(True)
+    y = F.conv2d(x, wt, None, 1, pad)
+    dy = _t(tag + "dy", tuple(y.shape))
+    y.backward(dy)
+    xw = torch.full((n, h, w, cin + 8), 3.0, device="cuda")
+    xw[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    dw_ = torch.full((n, h, w, cout + 12), -2.0, device="cuda")
+    dw_[..., 8:8 + cout] = dy.permute(0, 2, 3, 1).cuda()
+    got = hip.conv_wgrad(xw[..., 4:4 + cin], dw_[..., 8:8 + cout], k, 1, pad, oihw=True)
+    assert _rel(got, wt.grad) < 1e-4
