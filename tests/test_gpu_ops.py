@@ -417,3 +417,26 @@ def test_pack_conv_single_and_batch(hip_lib):
         assert torch.equal(t, _parity_weights(expect[idx][1]["ohwi"])), f"parity weights of shape {shapes[idx]}"
     bad = (hip.PackDesc * 1)()
     assert int(lib.me_pack_conv_plan(bad, 1)) < 0
+
+
+def test_round3_entry_points_refuse_bad_arguments(hip_lib):
+    """me_yolo_loss_fwd_f32 / me_pack_conv_batch_f32 / me_image_pad_resize_flip_u8_f32: null pointers and impossible sizes
+    come back as negative ME_E_* codes with a message, nothing is launched."""
+    import ctypes as C
+    from millieye_amd import hip
+    lib = hip.lib()
+    buf = torch.zeros(4096, device="cuda")
+    ws = torch.zeros(int(lib.me_yolo_loss_workspace_bytes()), dtype=torch.uint8, device="cuda")
+    anchors = (C.c_float * 64)(*([1.0] * 64))
+    p = buf.data_ptr()
+    args = lambda na, raw=p, wsp=ws.data_ptr(): (raw, 3 * 17, 1, 2, na, 12, anchors, p, 1, 0.5, 1.0, 100.0, p, p, p, p, p, p, p, p,  # noqa: E731
+                                                p, p, wsp, p, hip.stream_ptr())
+    assert lib.me_yolo_loss_fwd_f32(*args(3, raw=None)) < 0 and b"null" in lib.me_last_error()
+    assert lib.me_yolo_loss_fwd_f32(*args(17)) < 0 and b"16 anchors" in lib.me_last_error()
+    assert lib.me_yolo_loss_fwd_f32(*args(3, wsp=ws.data_ptr() + 4)) < 0
+    assert lib.me_pack_conv_batch_f32(None, 1, 1, 3, hip.stream_ptr()) < 0
+    assert lib.me_pack_conv_batch_f32(p, 1, 0, 3, hip.stream_ptr()) < 0
+    assert lib.me_pack_conv_batch_f32(p, 1, 1, 7, hip.stream_ptr()) < 0 and b"too large" in lib.me_last_error()
+    assert lib.me_image_pad_resize_flip_u8_f32(None, 4, 4, p, 8, 1, hip.stream_ptr()) < 0
+    assert lib.me_image_pad_resize_flip_u8_f32(p, 0, 4, p, 8, 1, hip.stream_ptr()) < 0
+    torch.cuda.synchronize()
