@@ -152,3 +152,29 @@ def test_product_path_has_no_cpu_fallback():
             if f.endswith(".py"):
                 src += open(os.path.join(root, f)).read()
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_dropin_directories_export_the_reference_import_names():
+    """``millieye_amd/dropin`` (module3_our_dataset) and ``millieye_amd/dropin_m2`` (module2_mixed) carry the top-level module
+    names the reference's scripts import (INTEGRATION.md level 1): in a fresh interpreter started in each directory the names
+    resolve to this package's classes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    checks = {
+        "dropin": "from my_models import Network, define_yolo, init_yolo; from test_fusion import evaluate; "
+                  "from utils.datasets import MyDataset; from utils.utils import non_max_suppression_cpp, ap_per_class; "
+                  "from utils.parse_config import parse_model_config; from yolov3.models import Darknet; "
+                  "print(Network.__module__, MyDataset.__module__)",
+        "dropin_m2": "from my_models import Network, define_yolo, init_yolo; from test_module2 import evaluate; "
+                     "from utils.datasets import ListDataset; from utils.utils import ap_per_class, load_classes; "
+                     "from utils.parse_config import parse_data_config; from yolov3.models import Darknet; "
+                     "print(Network.__module__, ListDataset.__module__)",
+    }
+    expect = {"dropin": "millieye_amd.my_models millieye_amd.utils.datasets",
+              "dropin_m2": "millieye_amd.module2.my_models millieye_amd.module2.datasets"}
+    for d, code in checks.items():
+        out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(root, "millieye_amd", d), capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1] == expect[d], out.stdout
