@@ -292,10 +292,12 @@ int me_compact_sort_rows_f32(const float* rows, const uint8_t* keep, const float
  * (image_i, x1,y1,x2,y2, obj, cls_conf, cls_pred, class scores...), *n_boxes of them valid (device scalar).
  * Weights: w0t [490,256] (transposed), b0, w1 [4,256], b1, w2 [class_num+1,256], b2, e1w [32,2], e1b, e2w
  * [2,32*(class_num+1)], e2b of me_heads_weights; the radar fields are ignored. */
+/* pool_scratch (round 3): optional [boxes_cap, 490] floats, 16-byte aligned - the PS-RoIAlign then runs as its own launch (one
+ * workgroup per box), like me_heads_desc.pool_scratch; NULL = the single fused launch. */
 int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t fh, int32_t fw, float spatial_scale,
                     const float* boxes, const int32_t* n_boxes, int32_t boxes_cap, int32_t box_cols, int32_t class_num,
                     const me_heads_weights* w, float refine_threshold, float* regress_out, float* refine_out,
-                    float* mask_out, float* out_rows, uint8_t* keep, float* sort_key, void* stream);
+                    float* mask_out, float* out_rows, uint8_t* keep, float* sort_key, float* pool_scratch, void* stream);
 
 /* ---- stage-2 training building blocks (module2_mixed/my_models.py:96-164 heads, :366-459 objective) ------------------
  * me_linear_f32: y [rows,out] = act(x [rows,in] . w[out,in]^T + bias) (nn.Linear + Linear / LeakyReLU / Sigmoid).

@@ -409,10 +409,25 @@ struct M2Desc {
   const float *w0t, *b0, *w1, *b1, *w2, *b2, *e1w, *e1b, *e2w, *e2b;
   float thr;
   float *regress_out, *refine_out, *mask_out, *out_rows, *sort_key; unsigned char* keep;
+  float* pool_scratch;  // [boxes_cap][FEAT] or NULL (see me_heads_desc.pool_scratch)
 };
 
+// PS-RoIAlign of one box per workgroup into d.pool_scratch
+__global__ __launch_bounds__(256) void m2_pool_kernel(M2Desc d) {
+  __shared__ float s_box[5];
+  const int t = threadIdx.x, k = blockIdx.x;
+  if (k >= *d.n_boxes) return;
+  if (t < 5) s_box[t] = d.boxes[(long long)k * d.box_cols + t];
+  __syncthreads();
+  float* out = d.pool_scratch + (long long)k * FEAT;
+  for (int f = t; f < FEAT; f += 256) {
+    const int pw = f % P, ph = (f / P) % P;
+    out[f] = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_box, d.spatial_scale, f, ph, pw);
+  }
+}
+
 __global__ __launch_bounds__(256) void m2_heads_kernel(M2Desc d) {
-  __shared__ float s_feat[RPB][FEAT];
+  __shared__ __attribute__((aligned(16))) float s_feat[RPB][FEAT];
   __shared__ float s_hid[RPB][HID];
   __shared__ float s_small[RPB][4 + M2_MAXC];  // 0-3 reg, 4.. class logits
   __shared__ float s_roi[RPB][5];
@@ -426,6 +441,24 @@ __global__ __launch_bounds__(256) void m2_heads_kernel(M2Desc d) {
     s_roi[r][c] = (r < nr) ? d.boxes[(long long)(k0 + r) * d.box_cols + c] : 0.f;
   }
   __syncthreads();
+  if (d.pool_scratch) {  // pooled by m2_pool_kernel: nr rows of FEAT floats, contiguous on both sides (FEAT * 4 = 1960 bytes)
+    const float2* src = reinterpret_cast<const float2*>(d.pool_scratch + (long long)k0 * FEAT);
+    float2* dst = reinterpret_cast<float2*>(&s_feat[0][0]);
+    const int n2 = nr * (FEAT / 2);
+    for (int i0 = 0; i0 < n2; i0 += 1024) {
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + t;
+        v[u] = i < n2 ? src[i] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + t;
+        if (i < n2) dst[i] = v[u];
+      }
+    }
+  } else
   for (int idx = t; idx < nr * FEAT; idx += 256) {
     const int r = idx / FEAT, f = idx % FEAT;
     const int pw = f % P, ph = (f / P) % P;
@@ -659,7 +692,7 @@ int me_gather_class_boxes_f32(const float* det, const int32_t* count, int32_t n,
 int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t fh, int32_t fw, float spatial_scale,
                     const float* boxes, const int32_t* n_boxes, int32_t boxes_cap, int32_t box_cols, int32_t class_num,
                     const me_heads_weights* w, float refine_threshold, float* regress_out, float* refine_out,
-                    float* mask_out, float* out_rows, uint8_t* keep, float* sort_key, void* stream_) {
+                    float* mask_out, float* out_rows, uint8_t* keep, float* sort_key, float* pool_scratch, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (boxes_cap == 0) return 0;
   ME_REQUIRE(img_map && boxes && n_boxes && w && regress_out && refine_out && mask_out && out_rows && keep && sort_key,
@@ -670,8 +703,14 @@ int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t 
              "me_m2_heads_f32: null weight pointer");
   M2Desc d{img_map, img_pitch, n, fh, fw, spatial_scale, boxes, n_boxes, box_cols, class_num + 1,
            w->w0t, w->b0, w->w1, w->b1, w->w2, w->b2, w->e1w, w->e1b, w->e2w, w->e2b, refine_threshold,
-           regress_out, refine_out, mask_out, out_rows, sort_key, keep};
+           regress_out, refine_out, mask_out, out_rows, sort_key, keep, pool_scratch};
   const int blocks = (boxes_cap + RPB - 1) / RPB;
+  if (pool_scratch) {
+    ME_REQUIRE(me::aligned16(pool_scratch), ME_E_ALIGN, "me_m2_heads_f32: pool_scratch must be 16-byte aligned");
+    hipLaunchKernelGGL(m2_pool_kernel, dim3(boxes_cap), dim3(256), 0, stream, d);
+    const int rc = me::check_launch("m2_pool_kernel");
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(m2_heads_kernel, dim3(blocks), dim3(256), 0, stream, d);
   return me::check_launch("m2_heads_kernel");
 }

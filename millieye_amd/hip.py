@@ -179,7 +179,8 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "me_m2_heads_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(HeadsWeights), C.c_float,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "me_heads_tail_f32": (C.c_int, [C.POINTER(HeadsDesc), C.c_void_p, C.c_int32, C.c_void_p]),
     "me_iou_labels_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -151,10 +151,11 @@ class Network(nn.Module):
         rows = torch.empty((cap, 8), **f32)
         keep = torch.zeros((cap,), device=dev, dtype=torch.uint8)
         key = torch.empty((cap,), **f32)
+        pooled = torch.empty((cap, 490), **f32)  # the PS-RoIAlign as its own launch (one workgroup per box)
         hip.check(lib.me_m2_heads_f32(score_map.data_ptr(), 490, n, fh, fw, 1.0 / 16, boxes.data_ptr(), n_dev.data_ptr(),
                                       cap, cols, self.class_num, C.byref(w), float(self.refine_threshold),
                                       regress.data_ptr(), refine.data_ptr(), mask.data_ptr(), rows.data_ptr(),
-                                      keep.data_ptr(), key.data_ptr(), hip.stream_ptr()), "me_m2_heads_f32")
+                                      keep.data_ptr(), key.data_ptr(), pooled.data_ptr(), hip.stream_ptr()), "me_m2_heads_f32")
         ordered = torch.empty((cap, 8), **f32)
         n_out = torch.empty((1,), device=dev, dtype=torch.int32)
         hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
