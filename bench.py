@@ -710,6 +710,7 @@ def main():
         if args.workload == "detector_train":
             out["config"]["grad_bucket_bytes"] = int(last.get("bucket_bytes", 0))
             out["config"]["loss_last_step"] = round(float(last["loss"]), 5)
+            out["config"]["wgrad_stream"] = os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0"  # weight gradients beside the data gradients
             out["config"]["workload"] = out["config"]["workload"].replace(
                 "fp32 inference", "fp32 detector training step (forward + HIP backward of every layer, eval-mode BN, "
                 "full-gradient all-reduce, SGD)")
