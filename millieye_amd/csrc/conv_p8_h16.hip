@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void conv3x3_p8_reduce_h16(P8Args a, int bm, i
   }
 }
 
-template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0, int TG = 1>
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0, int TG = 1, int DS = 0>
 int launch_p8(const Conv16P& p, hipStream_t stream) {
   constexpr int BM = 32 * MT * WR, BN = 32 * NT * WC;
   P8Args a = {};
@@ -124,20 +124,21 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   a.Mp = (long long)p.n * a.Ip;
   a.rows = BM + 2 * a.halo;
   constexpr int NWAVES = WR * WC;
-  a.lpa = ((a.rows + 15) / 16 + NWAVES - 1) / NWAVES;
+  constexpr int NWA = DS ? NWAVES / 2 : NWAVES;   // waves that fetch the patch (DS: the upper half, see conv_p8_impl.h)
+  a.lpa = ((a.rows + 15) / 16 + NWA - 1) / NWA;
   ME_REQUIRE(a.lpa <= kLpaMax, ME_E_TOOBIG, "me_conv2d_h16: patch of %d rows does not fit (map too wide for this tile)", a.rows);
   ME_REQUIRE(a.Mp < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: too many padded positions");
   magic_u32((unsigned)a.Ip, &a.ip_m, &a.ip_s);
   magic_u32((unsigned)a.Wp, &a.wp_m, &a.wp_s);
   a.c.tiles_m = (int)((a.Mp + BM - 1) / BM);
   a.c.tiles_n = p.cout / BN;
-  size_t lds = 3 * (size_t)TG * BN * 64 + 2 * (size_t)a.lpa * NWAVES * 1024;
+  size_t lds = 3 * (size_t)TG * BN * 64 + 2 * (size_t)a.lpa * NWA * 1024;
   const size_t epi = NWAVES * 2 * 32 * 36 * sizeof(float);
   if (lds < epi) lds = epi;
   ME_REQUIRE(lds <= (MINB == 2 ? 80 : 160) * 1024, ME_E_TOOBIG,
              "me_conv2d_h16: this tile needs %zu bytes of LDS for a %d-wide map", lds, p.w);
-  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL, false, TG>;
-  auto kern_sk = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL == 0 ? 0 : ABL, ABL == 0, TG>;  // K-split instance
+  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL, false, TG, DS>;
+  auto kern_sk = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL == 0 ? 0 : ABL, ABL == 0, TG, DS>;  // K-split instance
   static bool attr_set = false;
   if (!attr_set) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -193,7 +194,9 @@ void p8_tile_shape(int tile, int* bm, int* bn) {
   static const int ids[][3] = {{100, 128, 256}, {110, 192, 256}, {120, 256, 256}, {101, 128, 128}, {121, 256, 128},
                                {131, 384, 128}, {141, 512, 128}, {200, 128, 256}, {201, 128, 128}, {221, 256, 128},
                                {301, 128, 128}, {311, 192, 128}, {321, 256, 128}, {331, 256, 128},
-                               {421, 256, 128}, {431, 384, 128}, {441, 512, 128}};
+                               {421, 256, 128}, {431, 384, 128}, {441, 512, 128},
+                               {521, 256, 128}, {531, 384, 128}, {600, 128, 256}, {601, 128, 128}, {621, 256, 128},
+                               {721, 256, 128}, {731, 384, 128}};
   *bm = *bn = 0;
   for (const auto& t : ids)
     if (t[0] == tile) {
@@ -241,6 +244,17 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 421: return p.f16 ? launch_p8<4, 2, 2, 2, 1, 1, 1, 0, 3>(p, stream) : launch_p8<4, 2, 2, 2, 1, 1, 0, 0, 3>(p, stream);
     case 431: return p.f16 ? launch_p8<4, 2, 3, 2, 1, 1, 1, 0, 3>(p, stream) : launch_p8<4, 2, 3, 2, 1, 1, 0, 0, 3>(p, stream);
     case 441: return p.f16 ? launch_p8<4, 2, 4, 2, 1, 1, 1, 0, 3>(p, stream) : launch_p8<4, 2, 4, 2, 1, 1, 0, 0, 3>(p, stream);
+    // DMA duty split (round 4): waves 0-3 fetch weight slabs only, waves 4-7 the patch only (conv_p8_impl.h, DS)
+#define ME_P8D(WR, WC, MT, NT, PIPE, MINB, TG) \
+  (p.f16 ? launch_p8<WR, WC, MT, NT, PIPE, MINB, 1, 0, TG, 1>(p, stream) : launch_p8<WR, WC, MT, NT, PIPE, MINB, 0, 0, TG, 1>(p, stream))
+    case 521: return ME_P8D(4, 2, 2, 2, 1, 1, 1);   // 121
+    case 531: return ME_P8D(4, 2, 3, 2, 1, 1, 1);   // 131
+    case 600: return ME_P8D(2, 4, 2, 2, 0, 2, 1);   // 200
+    case 601: return ME_P8D(4, 2, 1, 2, 0, 2, 1);   // 201
+    case 621: return ME_P8D(4, 2, 2, 2, 0, 2, 1);   // 221
+    case 721: return ME_P8D(4, 2, 2, 2, 1, 1, 3);   // 421
+    case 731: return ME_P8D(4, 2, 3, 2, 1, 1, 3);   // 431
+#undef ME_P8D
     default: break;
   }
   // Ablation / instrumented instances of the tuning tools (tools/p8_timeline.py, tools/p8_bench.py --ablate): they skip parts
@@ -249,15 +263,15 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     const char* e = getenv("MILLIEYE_ABLATION");
     return e && e[0] == '1';
   }();
-  ME_REQUIRE(ablation_ok || !((tile >= 180 && tile <= 199) || (tile >= 280 && tile <= 299)), ME_E_BADARG,
+  ME_REQUIRE(ablation_ok || !((tile >= 180 && tile <= 199) || (tile >= 280 && tile <= 299) || (tile >= 680 && tile <= 699)), ME_E_BADARG,
              "me_conv2d_h16: tile id %d is an ablation instance with wrong results (tuning tools only: MILLIEYE_ABLATION=1)",
              tile);
   if (tile == 199 || tile == 299)  // 2048 x 8 bytes of time stamps go to the workspace
     ME_REQUIRE(p.partial && p.partial_bytes >= 16384, ME_E_BADARG,
                "me_conv2d_h16: the time-stamp instances need a workspace of at least 16384 bytes");
-  if (tile == 196 || tile == 296) {  // six 8-byte words per workgroup
+  if (tile == 196 || tile == 296 || tile == 696) {  // six 8-byte words per workgroup
     int bm, bn;
-    p8_tile_shape(tile == 196 ? 131 : 221, &bm, &bn);
+    p8_tile_shape(tile == 196 ? 131 : 221, &bm, &bn);  // (696: same tile shape as 296)
     const long long mp = (long long)p.n * (p.h + 1) * (p.w + 1);
     const long long need = ((mp + bm - 1) / bm) * (p.cout / bn) * 48;
     ME_REQUIRE(p.partial && p.partial_bytes >= need, ME_E_BADARG,
@@ -278,6 +292,7 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 196: return launch_p8<4, 2, 3, 2, 1, 1, 0, 10>(p, stream);  // 131 with per-workgroup stamps
     case 297: return launch_p8<4, 2, 2, 2, 0, 2, 0, 7>(p, stream);
     case 298: return launch_p8<4, 2, 2, 2, 0, 2, 0, 8>(p, stream);
+    case 696: return launch_p8<4, 2, 2, 2, 0, 2, 0, 10, 1, 1>(p, stream);  // 621 with per-workgroup stamps
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown patch tile id %d", tile);
   }
 #undef ME_P8

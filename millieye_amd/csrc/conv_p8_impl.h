@@ -78,7 +78,13 @@ constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 wave
 // With a barrier and a DMA wait per tap a stage of the one-workgroup-per-CU tiles took ~1270 cycles for 768 of MFMA issue
 // (tools/p8_wgmap.py); the per-stage overhead is now paid once per three taps.  Group g of the next chunk is fetched into slot
 // g right behind the barrier that ends the current chunk's group g.
-template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false, int TG = 1>
+// DS = 1 (round 4): DMA duty split.  A wave's loads return IN ORDER (vmcnt retires oldest first), so when every wave issues
+// both streams, a weight slab requested behind the next chunk's patch (an HBM / MALL miss, >= 2 us under load) cannot land
+// before that patch does: with the per-tap ring the patch has to be complete within three stages of its issue, and the
+// stamps show the waits exactly there.  With DS the lower half of the waves issues ONLY weight slabs (L2 hits, needed soon),
+// the upper half ONLY the patch (needed at the next chunk): the weight queue never waits behind a miss, and the patch has
+// the whole chunk to arrive.
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false, int TG = 1, int DS = 0>
 __global__ __launch_bounds__(64 * WR * WC)
     __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
   using frag = typename DT::frag;
@@ -86,7 +92,9 @@ __global__ __launch_bounds__(64 * WR * WC)
   constexpr int NW = WR * WC;
   static_assert(NW == 8 || NW == 4, "8 waves, or 4 (two independent 4-wave workgroups per CU: their barriers interleave)");
   constexpr int TM = 32 * MT, TN = 32 * NT, BM = TM * WR, BN = TN * WC;
-  constexpr int LPB = BN / 16 / NW;
+  constexpr int NWB = DS ? NW / 2 : NW;  // waves that issue weight slabs (the first NWB)
+  constexpr int NWA = DS ? NW / 2 : NW;  // waves that issue the patch (the last NWA)
+  constexpr int LPB = BN / 16 / NWB;
   static_assert(LPB >= 1 && BN % 128 == 0, "BN must be a multiple of 128");
   static_assert(TG == 1 || (TG == 3 && PIPE == 1), "tap groups need the register-pipelined variant");
   constexpr unsigned B_TAP = BN * 64u;            // one tap's weight slab of a chunk
@@ -117,7 +125,10 @@ __global__ __launch_bounds__(64 * WR * WC)
   const long long q0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
   const int lpa = a.lpa;
-  const unsigned A_SLOT = (unsigned)lpa * (NW * 1024u);
+  const unsigned A_SLOT = (unsigned)lpa * (NWA * 1024u);
+  const bool is_b = !DS || wave < NWB;        // wave-uniform roles
+  const bool is_a = !DS || wave >= NW - NWA;
+  const int wa = wave - (NW - NWA);           // patch-wave index (meaningful when is_a)
 
   // first image the patch can touch: descriptor base, so that per-lane offsets stay small and non-negative
   const long long pq0 = q0 - a.halo;
@@ -128,11 +139,11 @@ __global__ __launch_bounds__(64 * WR * WC)
   unsigned v_a[kLpaMax], v_b[LPB];
   auto setup_a = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const int r = (wave + NW * j) * 16 + (lane >> 2);
+    const int r = (wa + NWA * j) * 16 + (lane >> 2);
     const int qd = (lane & 3) ^ ((r >> 2) & 3);
     const long long pq = pq0 + r;
     unsigned off = kOobOffset;
-    if (ABL != 1 && ABL != 8 && j < lpa && r < a.rows && pq >= 0 && pq < a.Mp) {
+    if (ABL != 1 && ABL != 8 && is_a && j < lpa && r < a.rows && pq >= 0 && pq < a.Mp) {
       const unsigned u = (unsigned)pq;
       const unsigned n = udiv_magic(u, a.ip_m, a.ip_s);
       const unsigned rem = u - n * (unsigned)a.Ip;
@@ -146,9 +157,9 @@ __global__ __launch_bounds__(64 * WR * WC)
   static_for(setup_a, std::make_integer_sequence<int, kLpaMax>{});
   auto setup_b = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const int row = (wave + NW * j) * 16 + (lane >> 2);
+    const int row = (wave + NWB * j) * 16 + (lane >> 2);
     const int qd = (lane & 3) ^ ((row >> 2) & 3);
-    v_b[j] = (ABL != 1 && ABL != 7) ? (unsigned)(n0 + row) * 64u + 16u * qd : kOobOffset;  // cout % BN == 0: always in range
+    v_b[j] = (ABL != 1 && ABL != 7 && is_b) ? (unsigned)(n0 + row) * 64u + 16u * qd : kOobOffset;  // cout % BN == 0: always in range
   };
   static_for(setup_b, std::make_integer_sequence<int, LPB>{});
 
@@ -204,32 +215,49 @@ __global__ __launch_bounds__(64 * WR * WC)
   const int cbase = SK ? __builtin_amdgcn_readfirstlane(sid * p.cps) : 0;
   const int cs = SK ? (cbase + p.cps < cs_all ? p.cps : cs_all - cbase) : cs_all;  // ... this workgroup walks
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+  const unsigned wave_lds_a = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wa < 0 ? 0 : wa) * 1024u);
   auto issue_a = [&](int chunk, unsigned slot) {
     if (ABL >= 3 && ABL <= 5) return;
-    const unsigned dst = wave_lds + A_BASE + slot * A_SLOT;
+    if (DS && !is_a) return;
+    const unsigned dst = wave_lds_a + A_BASE + slot * A_SLOT;
     static_for(
         [&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          if (j < lpa) dma1(v_a[j], rsrc_a, (unsigned)(cbase + chunk) * 64u, dst + (unsigned)j * (NW * 1024u));
+          if (j < lpa) dma1(v_a[j], rsrc_a, (unsigned)(cbase + chunk) * 64u, dst + (unsigned)j * (NWA * 1024u));
         },
         std::make_integer_sequence<int, kLpaMax>{});
   };
   auto issue_b = [&](int chunk, int tap, unsigned ring) {
     if (ABL >= 3 && ABL <= 5) return;
+    if (DS && !is_b) return;
     const unsigned soff = ((unsigned)tap * (unsigned)cs_all + (unsigned)(cbase + chunk)) * (unsigned)p.cout * 64u;
 #pragma unroll
-    for (int j = 0; j < LPB; ++j) dma1(v_b[j], rsrc_b, soff, wave_lds + ring * B_SLOT + (unsigned)j * (NW * 1024u));
+    for (int j = 0; j < LPB; ++j) dma1(v_b[j], rsrc_b, soff, wave_lds + ring * B_SLOT + (unsigned)j * (NWB * 1024u));
   };
   auto issue_bg = [&](int chunk, int grp) {   // TG = 3: the three taps of group grp into slot grp
     if (ABL >= 3 && ABL <= 5) return;
+    if (DS && !is_b) return;
 #pragma unroll
     for (int tt = 0; tt < 3; ++tt) {
       const unsigned soff = ((unsigned)(3 * grp + tt) * (unsigned)cs_all + (unsigned)(cbase + chunk)) * (unsigned)p.cout * 64u;
 #pragma unroll
       for (int j = 0; j < LPB; ++j)
-        dma1(v_b[j], rsrc_b, soff, wave_lds + (unsigned)grp * B_SLOT + (unsigned)tt * B_TAP + (unsigned)j * (NW * 1024u));
+        dma1(v_b[j], rsrc_b, soff, wave_lds + (unsigned)grp * B_SLOT + (unsigned)tt * B_TAP + (unsigned)j * (NWB * 1024u));
     }
   };
+  // DS: the two roles wait for different things.  Weight waves count weight pieces only; patch waves wait for the whole
+  // patch (vmcnt(0)) at the stage whose barrier opens the next chunk, and for nothing but their LDS reads elsewhere.
+  auto ds_wait = [&](auto nc, bool patch_due) {   // nc = weight pieces that may stay in flight (compile-time)
+    constexpr int N = decltype(nc)::value;
+    if (is_b) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    else if (patch_due) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  using V0 = std::integral_constant<int, 0>;
+  using V1 = std::integral_constant<int, LPB>;
+  using V2 = std::integral_constant<int, 2 * LPB>;
+  using V3 = std::integral_constant<int, 3 * LPB>;
+  using V6 = std::integral_constant<int, 6 * LPB>;
   // vmcnt(3 * LPB + extra) / vmcnt(extra) with a runtime (uniform) extra = patch pieces that may stay in flight
   auto wait_g = [&](bool with_group, int extra) {
     if (with_group) {
@@ -318,6 +346,7 @@ __global__ __launch_bounds__(64 * WR * WC)
     issue_bg(0, 1);
     issue_bg(0, 2);
     if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (DS) ds_wait(V6{}, true);
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(6 * LPB) : "memory");   // the patch and group 0 have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -331,6 +360,7 @@ __global__ __launch_bounds__(64 * WR * WC)
     // stage s + 1 (fragment set P ^ 1); MFMAs of stage s from set P.  9 stages per chunk: the parity flips per chunk. ----
     issue_b(0, 2, 2);
     if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (DS) ds_wait(V2{}, true);
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPB) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -353,6 +383,12 @@ __global__ __launch_bounds__(64 * WR * WC)
         if constexpr (T % 3 == 2) {
           if (has_next) {
             if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (DS) {
+              // weight waves: T = 2: group 2 may fly; T = 5: the next chunk's group 0 (if any); T = 8: its group 1.
+              // patch waves: the next chunk's patch must be in LDS behind the barrier of T = 8
+              if (T == 5 && !more_chunks) ds_wait(V0{}, false);
+              else ds_wait(V3{}, T == 8);
+            }
             else if (T == 2) wait_g(true, more_chunks ? lpa : 0);
             else if (T == 5) wait_g(more_chunks, more_chunks ? lpa : 0);
             else wait_g(true, 0);
@@ -367,6 +403,9 @@ __global__ __launch_bounds__(64 * WR * WC)
       // stage s + 1's weights must have landed; younger loads: stage s + 2's weights, and - taps 1, 2 - the next patch
       if (NODMA) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if (DS) {
+        if (T >= 7 && !more_chunks) ds_wait(V0{}, false);
+        else ds_wait(V1{}, T == 8);   // patch waves: the next chunk's patch is read from stage 8 on
       } else if (T >= 7 && !more_chunks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else if ((T == 1 || T == 2) && more_chunks) {
@@ -440,6 +479,9 @@ __global__ __launch_bounds__(64 * WR * WC)
       stamp();
       if (NODMA) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if (DS) {
+        if (T == 8 && !more_chunks) ds_wait(V0{}, false);
+        else ds_wait(V1{}, T == 0);   // patch waves: this chunk's patch (requested at tap 0 of the previous chunk)
       } else if (T == 8 && !more_chunks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else if ((T == 1 || T == 2) && more_chunks) {

@@ -874,6 +874,9 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      100: (128, 256), 110: (192, 256), 120: (256, 256), 101: (128, 128), 121: (256, 128), 131: (384, 128),
                      141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128), 301: (128, 128), 311: (192, 128),
                      321: (256, 128), 331: (256, 128), 421: (256, 128), 431: (384, 128), 441: (512, 128),
+                     # 5xx / 6xx / 7xx: the 1xx / 2xx / 4xx tiles with the DMA duty split (weights by waves 0-3, patch by waves 4-7)
+                     521: (256, 128), 531: (384, 128), 600: (128, 256), 601: (128, 128), 621: (256, 128), 721: (256, 128),
+                     731: (384, 128),
                      # weight-stationary streaming 1x1 (csrc/conv1x1_ws_h16.hip): persistent grid, 32-row tiles, no split-K
                      50: (32, 256),
                      # weight-stationary 3x3 for cin 32 / 64 (csrc/conv3x3_ws_h16.hip): 2-D tiles, persistent grid, no split-K

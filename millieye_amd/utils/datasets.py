@@ -51,6 +51,42 @@ def _pad_amounts(h, w):
     return (0, 0, pad1, pad2) if h <= w else (pad1, pad2, 0, 0)
 
 
+def read_label_rows(label_path):
+    """A YOLO label file as a float64 ``[k,5]`` tensor ``(class, cx, cy, w, h)`` (``np.loadtxt``, like the reference)."""
+    return torch.from_numpy(np.loadtxt(label_path).reshape(-1, 5))
+
+
+def letterbox_labels(lab, scale_hw, pad, padded_hw):
+    """Label geometry shared by both producers (stage 3 ``MyDataset``, stage 2 ``module2.ListDataset``).
+
+    ``lab``: float64 ``[k,5]`` rows ``(class, cx, cy, w, h)``; ``scale_hw = (sy, sx)`` turns its coordinates into pixels of
+    the *unpadded* frame (the frame's height / width for normalised labels, ``(1, 1)`` for pixel labels); ``pad`` is
+    ``_pad_amounts`` of that frame, ``padded_hw`` the padded size.  Returns float32 ``[k,6]`` rows ``(0, class, cx, cy, w, h)``
+    relative to the padded square.  float64 arithmetic in the reference's order (module3 ``datasets.py:224-245``, module2
+    ``utils/datasets.py:111-135``): corners in pixels, each shifted by the padding on its side, centre back to [0,1];
+    extents scaled by one python-float ratio."""
+    sy, sx = scale_hw
+    padded_h, padded_w = padded_hw
+    half_w, half_h = lab[:, 3] / 2, lab[:, 4] / 2
+    left = (lab[:, 1] - half_w) * sx + pad[0]
+    right = (lab[:, 1] + half_w) * sx + pad[1]
+    top = (lab[:, 2] - half_h) * sy + pad[2]
+    bottom = (lab[:, 2] + half_h) * sy + pad[3]
+    out = torch.zeros((len(lab), 6))
+    out[:, 1] = lab[:, 0]
+    out[:, 2] = ((left + right) / 2) / padded_w
+    out[:, 3] = ((top + bottom) / 2) / padded_h
+    out[:, 4] = lab[:, 3] * (sx / padded_w)
+    out[:, 5] = lab[:, 4] * (sy / padded_h)
+    return out
+
+
+def decode_rgb_u8(img_path):
+    """PIL decode -> uint8 ``[h,w,3]`` tensor (the only image work left on the host)."""
+    from PIL import Image
+    return torch.from_numpy(np.array(Image.open(img_path).convert("RGB"), dtype=np.uint8))
+
+
 class StagedImages:
     """A batch of decoded frames waiting for ``.to(device)``: uint8 HWC tensors + the target side."""
 
@@ -181,26 +217,10 @@ class MyDataset(Dataset):
 
     @staticmethod
     def _load_targets(label_path, hw, pad, padded_hw):
-        """YOLO label file (class, cx, cy, w, h relative to the *unpadded* frame) -> ``[k,6]`` rows
-        ``(0, class, cx, cy, w, h)`` relative to the padded square, or ``None`` without a file.  float64 arithmetic in
-        the reference's order (datasets.py:224-245): corners in pixels, shift by the padding, centre back to [0,1]."""
+        """``[k,6]`` target rows of one frame (``letterbox_labels``), or ``None`` without a label file."""
         if not os.path.exists(label_path):
             return None
-        h, w = hw
-        padded_h, padded_w = padded_hw
-        lab = torch.from_numpy(np.loadtxt(label_path).reshape(-1, 5))
-        half_w, half_h = lab[:, 3] / 2, lab[:, 4] / 2
-        left = (lab[:, 1] - half_w) * w + pad[0]
-        right = (lab[:, 1] + half_w) * w + pad[1]
-        top = (lab[:, 2] - half_h) * h + pad[2]
-        bottom = (lab[:, 2] + half_h) * h + pad[3]
-        out = torch.zeros((len(lab), 6))
-        out[:, 1] = lab[:, 0]
-        out[:, 2] = ((left + right) / 2) / padded_w
-        out[:, 3] = ((top + bottom) / 2) / padded_h
-        out[:, 4] = lab[:, 3] * (w / padded_w)
-        out[:, 5] = lab[:, 4] * (h / padded_h)
-        return out
+        return letterbox_labels(read_label_rows(label_path), hw, pad, padded_hw)
 
     @staticmethod
     def _load_radar_boxes(box_path, pad, padded_side):

@@ -359,8 +359,9 @@ def test_detector_16bit_608_batch16(hip_lib, dtype):
     assert e_batch <= bound, f"{dtype}: mean relative error vs fp32 {e_batch:.2e}"
 
 
-P8_TILES_256 = (100, 110, 120, 200)
-P8_TILES_128 = (101, 121, 131, 141, 201, 221, 301, 311, 321, 331, 421, 431, 441)
+P8_TILES_256 = (100, 110, 120, 200, 600)
+P8_TILES_128 = (101, 121, 131, 141, 201, 221, 301, 311, 321, 331, 421, 431, 441,
+                521, 531, 601, 621, 721, 731)   # 5xx / 6xx / 7xx: DMA duty split (round 4)
 P8_CASES = [
     # name, n, h, w, cin, cout, act, res
     ("13x13 two images per tile", 5, 13, 13, 64, 256, 1, True),
@@ -417,7 +418,7 @@ def test_conv_p8_patch_resident_tiles(hip_lib, case, half):
 
 
 @pytest.mark.parametrize("half", ["bf16", "f16"])
-@pytest.mark.parametrize("tile", [121, 221, 201, 100, 131, 431])
+@pytest.mark.parametrize("tile", [121, 221, 201, 100, 131, 431, 621, 731])
 def test_conv_p8_k_split(hip_lib, tile, half):
     """Patch tiles with split_k > 1: every tile is cut along the 32-channel chunks into split_k workgroups (compact fp32
     slabs), conv3x3_p8_reduce_h16 sums them in a fixed order and applies the epilogue - same bar against the fp32 CPU
