@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void conv3x3_p8_reduce_h16(P8Args a, int bm, i
   }
 }
 
-template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0, int TG = 1, int DS = 0>
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, int F16, int ABL = 0, int TG = 1, int DS = 0, int RB = 3>
 int launch_p8(const Conv16P& p, hipStream_t stream) {
   constexpr int BM = 32 * MT * WR, BN = 32 * NT * WC;
   P8Args a = {};
@@ -132,13 +132,13 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   magic_u32((unsigned)a.Wp, &a.wp_m, &a.wp_s);
   a.c.tiles_m = (int)((a.Mp + BM - 1) / BM);
   a.c.tiles_n = p.cout / BN;
-  size_t lds = 3 * (size_t)TG * BN * 64 + 2 * (size_t)a.lpa * NWA * 1024;
+  size_t lds = (size_t)RB * TG * BN * 64 + 2 * (size_t)a.lpa * NWA * 1024;
   const size_t epi = NWAVES * 2 * 32 * 36 * sizeof(float);
   if (lds < epi) lds = epi;
   ME_REQUIRE(lds <= (MINB == 2 ? 80 : 160) * 1024, ME_E_TOOBIG,
              "me_conv2d_h16: this tile needs %zu bytes of LDS for a %d-wide map", lds, p.w);
-  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL, false, TG, DS>;
-  auto kern_sk = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL == 0 ? 0 : ABL, ABL == 0, TG, DS>;  // K-split instance
+  auto kern = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL, false, TG, DS, RB>;
+  auto kern_sk = conv3x3_p8_kernel<WR, WC, MT, NT, PIPE, MINB, DT16<F16>, ABL == 0 ? 0 : ABL, ABL == 0, TG, DS, RB>;  // K-split instance
   static bool attr_set = false;
   if (!attr_set) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -149,6 +149,10 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   // count leaves CUs idle or with a lone workgroup (13x13: 176 tiles of 256 x 128); slabs + a second launch
   const int cs = p.cin / 32;
   a.c.store_mode = me::store_mode();
+  if (ABL == 9) {
+    const char* e = getenv("MILLIEYE_STAMP_WAVE");
+    a.stamp_wave = e ? atoi(e) : 0;
+  }
   a.c.splitk = p.splitk > cs ? cs : (p.splitk < 1 ? 1 : p.splitk);
   a.c.cps = (cs + a.c.splitk - 1) / a.c.splitk;
   while (a.c.splitk > 1 && (a.c.splitk - 1) * a.c.cps >= cs) --a.c.splitk;
@@ -160,9 +164,18 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
     ME_REQUIRE(ABL == 0 && p.partial && p.partial_bytes >= need, ME_E_BADARG,
                "me_conv2d_h16: tile with split_k=%d needs a workspace of %lld bytes", a.c.splitk, need);
   }
+  static const int nmap_env = [] {
+    const char* e = getenv("MILLIEYE_P8_NMAP");
+    return e ? atoi(e) : 0;
+  }();
+  a.c.nmap = (nmap_env && a.c.splitk == 1 && a.c.tiles_n <= 8 && 8 % a.c.tiles_n == 0) ? 1 : 0;
   if (a.c.splitk > 1)
     hipLaunchKernelGGL(kern_sk, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
-  else
+  else if (a.c.nmap) {
+    const int G = 8 / a.c.tiles_n;
+    const unsigned per_xcd = (unsigned)((a.c.tiles_m + G - 1) / G);
+    hipLaunchKernelGGL(kern, dim3(8u * per_xcd), dim3(64 * NWAVES), lds, stream, a);
+  } else
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
   int rc = me::check_launch("conv3x3_p8_h16");
   if (rc || a.c.splitk == 1) return rc;
@@ -195,8 +208,10 @@ void p8_tile_shape(int tile, int* bm, int* bn) {
                                {131, 384, 128}, {141, 512, 128}, {200, 128, 256}, {201, 128, 128}, {221, 256, 128},
                                {301, 128, 128}, {311, 192, 128}, {321, 256, 128}, {331, 256, 128},
                                {421, 256, 128}, {431, 384, 128}, {441, 512, 128},
-                               {521, 256, 128}, {531, 384, 128}, {600, 128, 256}, {601, 128, 128}, {621, 256, 128},
-                               {721, 256, 128}, {731, 384, 128}};
+                               {621, 256, 128},
+                               {721, 256, 128}, {731, 384, 128},
+                               {810, 192, 256}, {820, 256, 256}, {821, 256, 128}, {831, 384, 128},
+                               {841, 512, 128}};
   *bm = *bn = 0;
   for (const auto& t : ids)
     if (t[0] == tile) {
@@ -247,14 +262,19 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     // DMA duty split (round 4): waves 0-3 fetch weight slabs only, waves 4-7 the patch only (conv_p8_impl.h, DS)
 #define ME_P8D(WR, WC, MT, NT, PIPE, MINB, TG) \
   (p.f16 ? launch_p8<WR, WC, MT, NT, PIPE, MINB, 1, 0, TG, 1>(p, stream) : launch_p8<WR, WC, MT, NT, PIPE, MINB, 0, 0, TG, 1>(p, stream))
-    case 521: return ME_P8D(4, 2, 2, 2, 1, 1, 1);   // 121
-    case 531: return ME_P8D(4, 2, 3, 2, 1, 1, 1);   // 131
-    case 600: return ME_P8D(2, 4, 2, 2, 0, 2, 1);   // 200
-    case 601: return ME_P8D(4, 2, 1, 2, 0, 2, 1);   // 201
     case 621: return ME_P8D(4, 2, 2, 2, 0, 2, 1);   // 221
     case 721: return ME_P8D(4, 2, 2, 2, 1, 1, 3);   // 421
     case 731: return ME_P8D(4, 2, 3, 2, 1, 1, 3);   // 431
 #undef ME_P8D
+    // ping-pong (round 4, PIPE = 2): one 8-wave workgroup per CU whose halves run half a stage apart (conv_p8_impl.h)
+#define ME_P8R(WR, WC, MT, NT, RB) \
+  (p.f16 ? launch_p8<WR, WC, MT, NT, 2, 1, 1, 0, 1, 0, RB>(p, stream) : launch_p8<WR, WC, MT, NT, 2, 1, 0, 0, 1, 0, RB>(p, stream))
+    case 810: return ME_P8R(2, 4, 3, 2, 3);   // 192 x 256
+    case 820: return ME_P8R(2, 4, 4, 2, 3);   // 256 x 256
+    case 821: return ME_P8R(4, 2, 2, 2, 3);   // 256 x 128
+    case 831: return ME_P8R(4, 2, 3, 2, 3);   // 384 x 128
+    case 841: return ME_P8R(4, 2, 4, 2, 3);   // 512 x 128
+#undef ME_P8R
     default: break;
   }
   // Ablation / instrumented instances of the tuning tools (tools/p8_timeline.py, tools/p8_bench.py --ablate): they skip parts
@@ -263,15 +283,15 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     const char* e = getenv("MILLIEYE_ABLATION");
     return e && e[0] == '1';
   }();
-  ME_REQUIRE(ablation_ok || !((tile >= 180 && tile <= 199) || (tile >= 280 && tile <= 299) || (tile >= 680 && tile <= 699)), ME_E_BADARG,
+  ME_REQUIRE(ablation_ok || !((tile >= 180 && tile <= 199) || (tile >= 280 && tile <= 299) || (tile >= 680 && tile <= 699) || (tile >= 880 && tile <= 899) || (tile >= 1080 && tile <= 1099)), ME_E_BADARG,
              "me_conv2d_h16: tile id %d is an ablation instance with wrong results (tuning tools only: MILLIEYE_ABLATION=1)",
              tile);
-  if (tile == 199 || tile == 299)  // 2048 x 8 bytes of time stamps go to the workspace
+  if (tile == 199 || tile == 299 || tile == 899)  // 2048 x 8 bytes of time stamps go to the workspace
     ME_REQUIRE(p.partial && p.partial_bytes >= 16384, ME_E_BADARG,
                "me_conv2d_h16: the time-stamp instances need a workspace of at least 16384 bytes");
-  if (tile == 196 || tile == 296 || tile == 696) {  // six 8-byte words per workgroup
+  if (tile == 196 || tile == 296 || tile == 696 || tile == 896) {  // six 8-byte words per workgroup
     int bm, bn;
-    p8_tile_shape(tile == 196 ? 131 : 221, &bm, &bn);  // (696: same tile shape as 296)
+    p8_tile_shape(tile == 196 || tile == 896 ? 131 : 221, &bm, &bn);  // (696: same tile shape as 296)
     const long long mp = (long long)p.n * (p.h + 1) * (p.w + 1);
     const long long need = ((mp + bm - 1) / bm) * (p.cout / bn) * 48;
     ME_REQUIRE(p.partial && p.partial_bytes >= need, ME_E_BADARG,
@@ -293,6 +313,13 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 297: return launch_p8<4, 2, 2, 2, 0, 2, 0, 7>(p, stream);
     case 298: return launch_p8<4, 2, 2, 2, 0, 2, 0, 8>(p, stream);
     case 696: return launch_p8<4, 2, 2, 2, 0, 2, 0, 10, 1, 1>(p, stream);  // 621 with per-workgroup stamps
+    case 896: return launch_p8<4, 2, 3, 2, 2, 1, 0, 10>(p, stream);        // 831 with per-workgroup stamps
+    case 899: return launch_p8<4, 2, 3, 2, 2, 1, 0, 9>(p, stream);         // 831 with time stamps
+    case 881: return launch_p8<4, 2, 3, 2, 2, 1, 0, 1>(p, stream);         // 831, every DMA lane out of range
+    case 887: return launch_p8<4, 2, 3, 2, 2, 1, 0, 7>(p, stream);         // 831, weights out of range
+    case 888: return launch_p8<4, 2, 3, 2, 2, 1, 0, 8>(p, stream);         // 831, patch out of range
+    case 890: return launch_p8<4, 2, 3, 2, 2, 1, 0, 3>(p, stream);         // 831 without DMA
+    case 893: return launch_p8<4, 2, 3, 2, 2, 1, 0, 6>(p, stream);         // 831 without epilogue
     default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: unknown patch tile id %d", tile);
   }
 #undef ME_P8

@@ -31,6 +31,9 @@ struct P8Conv {
   void* partial;  // K split: fp32 slabs [tile][split][BM][BN] of raw accumulators; instrumented builds: time stamps
   int splitk;     // workgroups per tile (each takes `cps` 64-byte chunks of the channel dimension), 1 = whole tiles
   int cps;
+  int nmap;        // 1: every XCD owns ONE column of tiles (tile_n = xcd % tiles_n; tiles_n divides 8) and every tiles_n-th..
+                   // row of them: its slice of the weights (1 / tiles_n of them) stays in its own 4 MB L2 however far the
+                   // workgroups drift apart along K; the grid is 8 x the largest per-XCD count, surplus workgroups exit
   int store_mode;  // epilogue stores: 0 plain, 1 nt (streaming), 2 sc1 (write-through: the line leaves the XCD's L2 at once
                    // instead of waiting dirty for the end-of-kernel release)
 };
@@ -45,6 +48,7 @@ struct P8Args {
   unsigned wp_m, wp_s;    // magic division by Wp
   int lpa;                // patch DMA instructions per wave and chunk = ceil(ceil(rows / 16) / 8)
   int rows;               // BM + 2 * halo
+  int stamp_wave;         // instrumented instances (ABL = 9): the wave of workgroup 0 whose s_memtime stamps are recorded
 };
 
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) { return (__umulhi(n, m) + n) >> s; }
@@ -84,7 +88,8 @@ constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 wave
 // stamps show the waits exactly there.  With DS the lower half of the waves issues ONLY weight slabs (L2 hits, needed soon),
 // the upper half ONLY the patch (needed at the next chunk): the weight queue never waits behind a miss, and the patch has
 // the whole chunk to arrive.
-template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false, int TG = 1, int DS = 0>
+// RB (PIPE = 2 only): slots of the weight ring; a slab is requested RB - 1 stages before its stage.
+template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false, int TG = 1, int DS = 0, int RB = 3>
 __global__ __launch_bounds__(64 * WR * WC)
     __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
   using frag = typename DT::frag;
@@ -97,10 +102,13 @@ __global__ __launch_bounds__(64 * WR * WC)
   constexpr int LPB = BN / 16 / NWB;
   static_assert(LPB >= 1 && BN % 128 == 0, "BN must be a multiple of 128");
   static_assert(TG == 1 || (TG == 3 && PIPE == 1), "tap groups need the register-pipelined variant");
+  static_assert(PIPE != 2 || (NW == 8 && MINB == 1 && TG == 1 && (DS == 0 || DS == 2)), "ping-pong: one 8-wave workgroup per CU");
+  static_assert(DS != 2 || PIPE == 2, "the spread duty split belongs to the ping-pong variant");
   constexpr unsigned B_TAP = BN * 64u;            // one tap's weight slab of a chunk
   constexpr unsigned B_SLOT = TG * B_TAP;         // a ring slot: one tap, or a group of three
-  constexpr unsigned A_BASE = 3u * B_SLOT;
-  constexpr int NSET = PIPE ? 2 : 1;
+  static_assert(RB == 3 || (PIPE == 2 && RB >= 3 && RB <= 9), "deeper rings: ping-pong variant only");
+  constexpr unsigned A_BASE = (unsigned)RB * B_SLOT;
+  constexpr int NSET = PIPE == 1 ? 2 : 1;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
   const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem16;
@@ -120,15 +128,25 @@ __global__ __launch_bounds__(64 * WR * WC)
     sid = SK ? piece - wg * p.splitk : 0;  // K split: this workgroup multiplies chunks [sid * cps, (sid + 1) * cps) of the tile
     tile_n = wg % p.tiles_n;
     tile_m = wg / p.tiles_n;
+    if (!SK && p.nmap) {
+      const int G = 8 / p.tiles_n;          // XCDs that share a column
+      tile_n = xcd % p.tiles_n;
+      tile_m = idx * G + xcd / p.tiles_n;
+      piece = tile_m * p.tiles_n + tile_n;
+      if (tile_m >= p.tiles_m) return;
+    }
   }
   const int W = p.w, H = p.h;
   const long long q0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
   const int lpa = a.lpa;
   const unsigned A_SLOT = (unsigned)lpa * (NWA * 1024u);
-  const bool is_b = !DS || wave < NWB;        // wave-uniform roles
-  const bool is_a = !DS || wave >= NW - NWA;
-  const int wa = wave - (NW - NWA);           // patch-wave index (meaningful when is_a)
+  // wave-uniform roles.  DS = 1: waves 0-3 weights, 4-7 patch.  DS = 2 (ping-pong): waves 0, 1 of each half fetch weights,
+  // waves 2, 3 of each half the patch - and they spread it over the taps (below)
+  const bool is_b = DS == 2 ? ((wave >> 1) & 1) == 0 : (!DS || wave < NWB);
+  const bool is_a = DS == 2 ? ((wave >> 1) & 1) == 1 : (!DS || wave >= NW - NWA);
+  const int wa = DS == 2 ? (wave & 1) + 2 * (wave >> 2) : wave - (NW - NWA);   // patch-wave index (meaningful when is_a)
+  const int wbi = DS == 2 ? (wave & 1) + 2 * (wave >> 2) : wave;               // weight-wave index (meaningful when is_b)
 
   // first image the patch can touch: descriptor base, so that per-lane offsets stay small and non-negative
   const long long pq0 = q0 - a.halo;
@@ -157,7 +175,7 @@ __global__ __launch_bounds__(64 * WR * WC)
   static_for(setup_a, std::make_integer_sequence<int, kLpaMax>{});
   auto setup_b = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const int row = (wave + NWB * j) * 16 + (lane >> 2);
+    const int row = (wbi + NWB * j) * 16 + (lane >> 2);
     const int qd = (lane & 3) ^ ((row >> 2) & 3);
     v_b[j] = (ABL != 1 && ABL != 7 && is_b) ? (unsigned)(n0 + row) * 64u + 16u * qd : kOobOffset;  // cout % BN == 0: always in range
   };
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(64 * WR * WC)
   int dbg_n = 0;
   auto stamp = [&]() {
     if constexpr (ABL == 9) {
-      if (blockIdx.x == 0 && wave == 0 && dbg && dbg_n < 2040) {
+      if (blockIdx.x == 0 && wave == a.stamp_wave && dbg && dbg_n < 2040) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         if (lane == 0) dbg[dbg_n] = t;
         ++dbg_n;
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(64 * WR * WC)
   const int cs_all = p.cin / DT::kChunk;  // 64-byte chunks of the channel dimension
   const int cbase = SK ? __builtin_amdgcn_readfirstlane(sid * p.cps) : 0;
   const int cs = SK ? (cbase + p.cps < cs_all ? p.cps : cs_all - cbase) : cs_all;  // ... this workgroup walks
-  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wbi * 1024u);
   const unsigned wave_lds_a = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wa < 0 ? 0 : wa) * 1024u);
   auto issue_a = [&](int chunk, unsigned slot) {
     if (ABL >= 3 && ABL <= 5) return;
@@ -226,6 +244,12 @@ __global__ __launch_bounds__(64 * WR * WC)
           if (j < lpa) dma1(v_a[j], rsrc_a, (unsigned)(cbase + chunk) * 64u, dst + (unsigned)j * (NWA * 1024u));
         },
         std::make_integer_sequence<int, kLpaMax>{});
+  };
+  auto issue_a_piece = [&](int chunk, unsigned slot, auto jc) {   // one patch piece of this wave (DS = 2: spread over the taps)
+    constexpr int j = decltype(jc)::value;
+    if (ABL >= 3 && ABL <= 5) return;
+    if (!is_a || j >= lpa) return;
+    dma1(v_a[j], rsrc_a, (unsigned)(cbase + chunk) * 64u, wave_lds_a + A_BASE + slot * A_SLOT + (unsigned)j * (NWA * 1024u));
   };
   auto issue_b = [&](int chunk, int tap, unsigned ring) {
     if (ABL >= 3 && ABL <= 5) return;
@@ -305,7 +329,7 @@ __global__ __launch_bounds__(64 * WR * WC)
           bfr[s2][ks][j] = DT::fill(0.02f * (float)(lane - j));
       }
   }
-  auto load_frags = [&](auto setc, auto tc, int chunk) {
+  auto load_frags = [&](auto setc, auto tc, int chunk, int bslot = -1) {   // bslot >= 0: runtime ring slot (PIPE = 2)
     constexpr int SET = decltype(setc)::value, T = decltype(tc)::value;
     if (ABL == 4 || ABL == 5) {
 #pragma unroll
@@ -313,7 +337,7 @@ __global__ __launch_bounds__(64 * WR * WC)
       return;
     }
     const unsigned char* Ab = smem16 + A_BASE + (unsigned)(chunk & 1) * A_SLOT;
-    const unsigned char* Bb = b_frag + (TG == 3 ? T * B_TAP : (T % 3) * B_SLOT);
+    const unsigned char* Bb = b_frag + (bslot >= 0 ? (unsigned)bslot * B_SLOT : (TG == 3 ? T * B_TAP : (T % 3) * B_SLOT));
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       unsigned rb0 = rowbase[i];
@@ -351,11 +375,13 @@ __global__ __launch_bounds__(64 * WR * WC)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+  } else if constexpr (PIPE == 2) {
+    static_for([&](auto sc) { issue_b(0, decltype(sc)::value, (unsigned)decltype(sc)::value); }, std::make_integer_sequence<int, RB - 1>{});
   } else {
   issue_b(0, 0, 0);
   issue_b(0, 1, 1);
   }
-  if constexpr (PIPE && TG == 1) {
+  if constexpr (PIPE == 1 && TG == 1) {
     // ---- software pipeline: iteration s (after its barrier): DMA(s + 3) -> ring slot of stage s; LDS -> registers for
     // stage s + 1 (fragment set P ^ 1); MFMAs of stage s from set P.  9 stages per chunk: the parity flips per chunk. ----
     issue_b(0, 2, 2);
@@ -507,6 +533,116 @@ __global__ __launch_bounds__(64 * WR * WC)
       stamp();
     }
   };
+  // ---- PIPE = 2 (round 4): ping-pong.  The counters of the lockstep variants (profiles/r04_p8_*_sq.txt) show waves stalled on
+  // the matrix pipe 37-44 % of their life while that pipe is busy 36-42 % of the time: the two waves of a SIMD want it in the
+  // same phase and leave it idle together (DMA issue, fragment reads, waits) in the other.  Here the workgroup's two halves
+  // (waves 0-3 / 4-7: one wave per SIMD each) run HALF A STAGE APART: a stage is a load segment L (weight DMA of stage s + 2,
+  // this stage's fragment reads) and a compute segment C (its MFMAs, back to back at raised priority) with a barrier behind
+  // each; the second half enters one barrier late, so that its L(s) runs beside the first half's C(s) and its C(s) beside
+  // the first half's L(s + 1).  One fragment set; time slot 2s: G0 L(s); slot 2s + 1: G0 C(s) | G1 L(s); slot 2s + 2: G1 C(s).
+  //   RAW: a wave waits for ITS pieces of slab s + 1 before the barrier that ends slot 2s + 1 (G0 behind C(s), G1 behind L(s)).
+  //   WAR: slab s + 2 goes to the ring slot of slab s - 1, last read by G1 in slot 2s - 1; G0 issues it in slot 2s.
+  if constexpr (PIPE == 2) {
+    constexpr int D = RB - 1;   // prefetch distance in stages
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    auto wait_vm = [&](auto nc, bool plus_patch) {   // vmcnt(N [+ lpa]); s_waitcnt takes an immediate
+      constexpr int N = decltype(nc)::value;
+      if (!plus_patch) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); return; }
+      switch (lpa) {
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 1) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 2) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 3) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 4) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 5) : "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 6) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 7) : "memory"); break;
+      }
+    };
+    if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (DS == 2 && is_a) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * LPB) : "memory");   // patch 0 and slab 0 have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp == 1) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    int rs = 0;   // ring slot of the current stage; the slab D stages ahead goes to the slot of the stage before this one
+    auto stage_pp = [&](auto tc, int chunk) {
+      constexpr int T = decltype(tc)::value;
+      const bool more_chunks = chunk + 1 < cs;
+      // my pieces of the next stage's slab must have landed.  Loads retire in order: younger than that slab are the D - 1
+      // slabs behind it (fewer at the very end) and - when it was requested before this chunk's tap-0 patch burst, i.e. for
+      // T < D - the next chunk's patch.  Entering a chunk (T = 8) its patch is older than the slab, so it has landed too.
+      auto wait_next = [&]() {
+        if (NODMA) return;
+        if constexpr (DS == 2) {
+          // weight waves never queue behind a patch piece; patch waves: everything of the next chunk by the end of tap 8
+          if (is_a) {
+            if (T == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+          }
+          if (!more_chunks) {
+            if constexpr (T < 8) wait_vm(std::integral_constant<int, (D - 1 < 7 - T ? D - 1 : 7 - T) * LPB>{}, false);
+          } else {
+            wait_vm(std::integral_constant<int, (D - 1) * LPB>{}, false);
+          }
+          return;
+        }
+        if (!more_chunks) {
+          if constexpr (T < 8) wait_vm(std::integral_constant<int, (D - 1 < 7 - T ? D - 1 : 7 - T) * LPB>{}, false);
+        } else {
+          wait_vm(std::integral_constant<int, (D - 1) * LPB>{}, T < D);
+        }
+      };
+      stamp();
+      {
+        constexpr int T2 = (T + D) % 9;
+        const int c2 = chunk + (T + D >= 9 ? 1 : 0);
+        if (c2 < cs) issue_b(c2, T2, (unsigned)(rs == 0 ? RB - 1 : rs - 1));
+      }
+      if constexpr (DS == 2) {
+        // the next chunk's patch leaves in small steps (two pieces at tap 0, one per tap after): a burst of up to 28 KB of
+        // misses in front of the weight slabs was what made the two streams cost more together than the sum of each alone
+        if (more_chunks) {
+          const unsigned sl = (unsigned)((chunk + 1) & 1);
+          if constexpr (T == 0) {
+            issue_a_piece(chunk + 1, sl, std::integral_constant<int, 0>{});
+            issue_a_piece(chunk + 1, sl, std::integral_constant<int, 1>{});
+          } else if constexpr (T <= 5) {
+            issue_a_piece(chunk + 1, sl, std::integral_constant<int, T + 1>{});
+          }
+        }
+      } else {
+        if (T == 0 && more_chunks) issue_a(chunk + 1, (unsigned)((chunk + 1) & 1));
+      }
+      load_frags(Z{}, tc, chunk, rs);
+      if (grp == 1) wait_next();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();
+      if (ABL != 5) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();
+      __builtin_amdgcn_s_setprio(1);
+      mfmas(Z{});
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 0) wait_next();
+      stamp();
+      if (ABL != 5) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      rs = rs + 1 == RB ? 0 : rs + 1;
+    };
+    for (int chunk = 0; chunk < cs; ++chunk)
+      static_for([&](auto tc) { stage_pp(tc, chunk); }, std::make_integer_sequence<int, 9>{});
+    if (grp == 0 && ABL != 5) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  } else
   {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -684,7 +820,7 @@ __global__ __launch_bounds__(64 * WR * WC)
   if constexpr (ABL == 9) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp();
-    if (blockIdx.x == 0 && wave == 0 && lane == 0 && dbg) dbg[2047] = (unsigned long long)dbg_n;
+    if (blockIdx.x == 0 && wave == a.stamp_wave && lane == 0 && dbg) dbg[2047] = (unsigned long long)dbg_n;
   }
 }
 

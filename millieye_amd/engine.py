@@ -874,9 +874,10 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      100: (128, 256), 110: (192, 256), 120: (256, 256), 101: (128, 128), 121: (256, 128), 131: (384, 128),
                      141: (512, 128), 200: (128, 256), 201: (128, 128), 221: (256, 128), 301: (128, 128), 311: (192, 128),
                      321: (256, 128), 331: (256, 128), 421: (256, 128), 431: (384, 128), 441: (512, 128),
-                     # 5xx / 6xx / 7xx: the 1xx / 2xx / 4xx tiles with the DMA duty split (weights by waves 0-3, patch by waves 4-7)
-                     521: (256, 128), 531: (384, 128), 600: (128, 256), 601: (128, 128), 621: (256, 128), 721: (256, 128),
-                     731: (384, 128),
+                     # round 4: 6xx / 7xx = 221 / 421 / 431 with the DMA duty split (weights by waves 0-3, patch by waves 4-7);
+                     # 8xx = ping-pong halves (one workgroup per CU, its halves half a stage apart)
+                     621: (256, 128), 721: (256, 128), 731: (384, 128),
+                     810: (192, 256), 820: (256, 256), 821: (256, 128), 831: (384, 128), 841: (512, 128),
                      # weight-stationary streaming 1x1 (csrc/conv1x1_ws_h16.hip): persistent grid, 32-row tiles, no split-K
                      50: (32, 256),
                      # weight-stationary 3x3 for cin 32 / 64 (csrc/conv3x3_ws_h16.hip): 2-D tiles, persistent grid, no split-K
@@ -884,7 +885,8 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
 _TUNE_TILES_TAIL = (41, 42, 43, 44, 45)  # fp32: tiles 1-5 with the last partial round of tiles cut split_k ways along K
 _TUNE_TILES_P8_F32 = (201, 221)  # fp32 is matrix-pipe bound: the big tiles' pad positions / quantisation cost more than
 # their traffic saves (tools/p8_bench_f32.py: only the 2-workgroup tiles come close to the 64x64 per-tap tile)
-_TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321, 421, 431, 441)  # 4xx: a barrier per three taps
+_TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321, 421, 431, 441,   # 4xx: a barrier per three taps
+                  621, 721, 731, 810, 831)  # round 4: duty split, ping-pong
 
 
 def _autotune_enabled():
@@ -898,7 +900,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v12.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v13.json")  # bump with every kernel generation
 
 
 def _tune_load():
