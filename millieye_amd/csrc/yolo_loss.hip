@@ -288,6 +288,10 @@ int me_yolo_loss_fwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, 
   a.ticket = reinterpret_cast<unsigned int*>(a.partials + (size_t)YL_BLOCKS * YL_SUMS);
   a.bad = reinterpret_cast<int*>(a.ticket + 1);
   a.result = result;
+  // stream-ordered reset of the two words in front of every call: a launch that ever aborted half-way (some blocks had drawn
+  // their tickets) must not leave a counter behind that no later call can bring back to "last block" - the result would
+  // never be written again
+  ME_HIP(hipMemsetAsync(a.ticket, 0, 2 * sizeof(unsigned int), stream));
   const long long cells = (long long)n * num_anchors * g * g;
   long long ib = (cells * num_classes + 255) / 256;
   if (ib > 4096) ib = 4096;

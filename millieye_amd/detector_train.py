@@ -50,6 +50,42 @@ class _State:
     pass
 
 
+# Per-pass timing of one step (bench.py: the training line's own roofline).  While a dict sits in ``_TIMING[0]`` every
+# forward / data-gradient / weight-gradient convolution is bracketed by HIP events on the launch stream and the weight
+# gradients stay on that stream (a kernel's duration is then its own); outside it the brackets cost nothing.
+_TIMING = [None]
+
+
+class _timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if _TIMING[0] is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMING[0] is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _TIMING[0].setdefault(self.kind, []).append((self.a, b, self.flops))
+        return False
+
+
+def profile_step_passes(step_fn):
+    """Run ``step_fn()`` once with the brackets on: ``{"fwd" | "dgrad" | "wgrad": (milliseconds, flops, launches)}`` -
+    the convolution kernels of each pass of the detector training step, sequential on one stream."""
+    _TIMING[0] = {}
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b, _f in v), sum(f for _a, _b, f in v), len(v)) for k, v in _TIMING[0].items()}
+    finally:
+        _TIMING[0] = None
+
+
 class DetectorTrainer:
     def __init__(self, model):
         self.m = model
@@ -82,15 +118,17 @@ class DetectorTrainer:
                     if cout > 2048:
                         raise hip.MeError("train-mode BatchNorm: more than 2048 channels")
                     ones, zeros = _const_vectors(cout, x.device)
-                    c_raw = hip.conv2d_auto(src, cw.wgt, ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, x_nchw=(i == 0),
-                                            wgt_tiled=cw.wgt_tiled)
+                    with _timed("fwd", _conv_flops(src, cw.wgt, s, i == 0)):
+                        c_raw = hip.conv2d_auto(src, cw.wgt, ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, x_nchw=(i == 0),
+                                                wgt_tiled=cw.wgt_tiled)
                     y = torch.empty_like(c_raw)
                     rows = c_raw.numel() // cout
                     st_bn = _bn_fwd(c_raw, cout, rows, cout, bn, act, y, cout, ws)
                     bn_state[i] = (c_raw, st_bn)
                 else:
-                    y = hip.conv2d_auto(src, cw.wgt, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0),
-                                        wgt_tiled=cw.wgt_tiled)
+                    with _timed("fwd", _conv_flops(src, cw.wgt, s, i == 0)):
+                        y = hip.conv2d_auto(src, cw.wgt, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0),
+                                            wgt_tiled=cw.wgt_tiled)
             elif t == "maxpool":
                 k, s = int(d["size"]), int(d["stride"])
                 y = hip.maxpool(outs[i - 1], k, s, zero_ext=(k == 2 and s == 1))
@@ -124,8 +162,11 @@ class DetectorTrainer:
         return st
 
     # ------------------------------------------------------------------------------------------ backward
-    def backward(self, st, draws):
-        """``draws``: {yolo module index: d loss / d raw map [N,G,G,A*(5+C)]}.  Returns {parameter name: gradient}."""
+    def backward(self, st, draws, reducer=None):
+        """``draws``: {yolo module index: d loss / d raw map [N,G,G,A*(5+C)]}.  Returns {parameter name: gradient}.
+        ``reducer`` (``parallel.GradChunkReducer``): every gradient is handed over as soon as its kernels are enqueued, so
+        the data-parallel exchange of the deep layers runs beside the backward of the shallow ones; the caller collects
+        the reduced tensors with ``reducer.finish()``."""
         m, lib = self.m, hip.lib()
         eng = m.engine
         defs, outs, x = m.module_defs, st.outs, st.x
@@ -169,7 +210,7 @@ class DetectorTrainer:
 
         x_nhwc = None
         main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0" else None
+        side = _side_stream(dev) if os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0" and _TIMING[0] is None else None
         for i in reversed(range(L)):
             d = defs[i]
             t = d["type"]
@@ -213,6 +254,12 @@ class DetectorTrainer:
                     grads[f"module_list.{i}.batch_norm_{i}.bias"] = dshift
                 else:
                     grads[f"module_list.{i}.conv_{i}.bias"] = dshift
+                if reducer is not None:
+                    if bn is not None:
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.weight", dgamma, main)
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.bias", dshift, main)
+                    else:
+                        reducer.push(f"module_list.{i}.conv_{i}.bias", dshift, main)
                 # weight gradient, written in the parameter's own OIHW layout by the slab reduction
                 if i == 0:
                     if x_nhwc is None:
@@ -230,11 +277,16 @@ class DetectorTrainer:
                     dc.record_stream(side)
                     xin.record_stream(side)
                 else:
-                    grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
+                    with _timed("wgrad", 2.0 * rows * cout * k * k * cin):
+                        grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
+                if reducer is not None:
+                    reducer.push(f"module_list.{i}.conv_{i}.weight", grads[f"module_list.{i}.conv_{i}.weight"],
+                                 side if side is not None else main)
                 dout[i] = None
                 if i == 0:
                     continue
                 # data gradient
+                tm = _timed("dgrad", 2.0 * rows * cout * k * k * cin).__enter__()
                 if cout % 4 != 0:
                     if k != 1 or s != 1:
                         raise NotImplementedError(f"conv {i}: data gradient for cout={cout} (not a multiple of 4) needs k=1")
@@ -284,6 +336,7 @@ class DetectorTrainer:
                         dout[i - 1] = (dx, True)
                     else:
                         contribute(i - 1, dx, True)
+                tm.__exit__()
                 continue
             elif t == "shortcut":
                 # both inputs receive dy itself; two slots now alias one tensor, so NEITHER may write into it (the conv in
@@ -322,6 +375,14 @@ class DetectorTrainer:
         if side is not None:
             main.wait_stream(side)
         return grads
+
+
+def _conv_flops(src, wgt_ohwi, stride, nchw):
+    """2 * output pixels * cout * k * k * cin of one convolution (``src``: its input, NHWC - NCHW for the first layer)."""
+    n = src.shape[0]
+    h, w = (src.shape[2], src.shape[3]) if nchw else (src.shape[1], src.shape[2])
+    cout, k, _, cin = wgt_ohwi.shape
+    return 2.0 * n * (h // stride) * (w // stride) * cout * k * k * cin
 
 
 _SIDE = {}
@@ -408,7 +469,12 @@ class _DarknetLoss(torch.autograd.Function):
                                                float(bt["n_noobj"]), float(layer.obj_scale), float(layer.noobj_scale),
                                                gscale, draw.data_ptr(), ch, hip.stream_ptr()), "me_yolo_loss_bwd_f32")
             draws[idx] = draw
-        grads = ctx.trainer.backward(st, draws)
+        reducer = model.__dict__.get("_grad_reducer")  # parallel.overlap_detector_allreduce: exchange beside the backward
+        if reducer is not None:
+            reducer.begin(st.x.device)
+        grads = ctx.trainer.backward(st, draws, reducer)
+        if reducer is not None:
+            grads.update(reducer.finish())
         out = []
         for name, needs in zip(ctx.names, ctx.needs_input_grad[4:]):
             g = grads.get(name) if needs else None

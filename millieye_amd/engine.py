@@ -863,6 +863,7 @@ def _graphs_enabled():
 # ------------------------------------------------------------------------------------------ autotuner
 _TUNE_CACHE = {}
 _TUNE_FILE_LOADED = [False]
+_TUNE_STATS = {"measured": 0}  # layer shapes whose candidates were timed in this process (0 = every choice came from the file)
 _TUNE_TILES = (1, 2, 3, 4, 5)  # (7 / 47 = 64x64 with a 6 / 9-stage LDS ring: no gain at batch 1 / 8 - a lone wave per SIMD is bound by its
 # own MFMA chain, not by DMA latency - so they stay forced-only ids)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
@@ -977,6 +978,7 @@ def _autotune(plan, lib):
     def required():
         return max([scratch_of(d2) for _m2, d2 in plan.conv_descs if d2.cin > 4] + [0])
 
+    _TUNE_STATS["measured"] += len(todo)
     if not todo:
         ensure_workspace(required())  # cached choices may need more scratch than the analytic plan asked for
         return

@@ -375,7 +375,12 @@ def _conv_auto_file():
     if base:
         return base + ".train"
     root = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(root, "millieye_amd", "conv_auto_v1.json")
+    # the choices belong to one kernel generation (ABI version) on one GPU model: neither may leak into another
+    try:
+        gpu = torch.cuda.get_device_name(torch.cuda.current_device()).replace(" ", "_").replace("/", "_")
+    except Exception:
+        gpu = "unknown"
+    return os.path.join(root, "millieye_amd", f"conv_auto_v2_abi{int(lib().me_abi_version())}_{gpu}.json")
 
 
 def _conv_auto_load():
@@ -425,6 +430,7 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
             cands += [(t, sp) for t in (41, 42, 43) for sp in (2, 4)]
         scratch = None
         best = (float("inf"), 0, 0)
+        torch.cuda.synchronize()  # every stream idle (the weight-gradient stream too): the timings are the candidates' own
         for tile, split in cands:
             try:
                 for _ in range(2):
@@ -444,8 +450,14 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
                 best = (ms, tile, split)
         hit = _CONV_AUTO[key] = (best[1], best[2])
         _conv_auto_save()
-    return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, tile=hit[0],
-                  split_k=hit[1], wgt_tiled=wgt_tiled)
+    try:
+        return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, tile=hit[0],
+                      split_k=hit[1], wgt_tiled=wgt_tiled)
+    except MeError:
+        if hit == (0, 0):
+            raise
+        _CONV_AUTO[key] = (0, 0)  # a stale entry (a tile this library refuses for the shape): the planner's own choice
+        return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, wgt_tiled=wgt_tiled)
 
 
 def tile_weights_f32(wgt_packed):
@@ -640,10 +652,18 @@ def tile_counters(device, slot="conv"):
 
 
 def _workspace(nbytes, device, slot="nms"):
-    key = (slot, device.index if device.index is not None else torch.cuda.current_device())
+    """Cached scratch per (slot, device, STREAM): kernels on different streams never share a buffer (the weight gradients of
+    the detector step run on a side stream while the main stream's convolutions use theirs), and a buffer that is replaced
+    by a bigger one is handed back to the caching allocator only behind the work already queued on its stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(idx)
+    key = (slot, idx, cur.cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() - ((-ws.data_ptr()) % 256) < nbytes:  # usable bytes behind the aligned start
-        ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        if ws is not None:
+            ws.record_stream(cur)  # (allocated under this stream already; explicit for buffers adopted from older versions)
+        with torch.cuda.device(idx):
+            ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     off = (-ws.data_ptr()) % 256
     return ws.data_ptr() + off, ws

@@ -137,6 +137,17 @@ def main(argv=None):
     data_config = parse_data_config(opt.data_config)
     train_path, valid_path = data_config["train"], data_config["valid"]
     class_names = load_classes(opt.classes_path)
+    # data parallel (new in this build, as in millieye_amd/train.py main()): under ``python -m torch.distributed.run
+    # --nproc-per-node N -m millieye_amd.module2.train ...`` every process takes the GPU of its LOCAL_RANK and a 1 / N shard
+    # of each epoch; only rank 0 evaluates and writes checkpoints, the others wait in the loop's barrier
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                             timeout=datetime.timedelta(hours=4))  # rank 0's evaluation outlasts 10 min
     model = Network(define_yolo(opt.yolo_cfg), opt.conf_thresh)
     model = model.to(model.device)
     if opt.checkpoint:
@@ -144,9 +155,15 @@ def main(argv=None):
     else:
         model.apply(weights_init_normal)
         init_yolo(model=model.base_detector, weights_path=opt.yolo_weights)
+    if world > 1:  # the random initialisation drew from each process's own RNG: replicas start from rank 0's state
+        with torch.no_grad():
+            for t in model.state_dict().values():
+                torch.distributed.broadcast(t, 0)
+        model.base_detector.invalidate_weights()
     dataset = ListDataset(train_path, augment=True, multiscale=opt.multiscale_training)
-    dataloader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=True, num_workers=opt.n_cpu,
-                                             pin_memory=False, collate_fn=dataset.collate_fn)
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if world > 1 else None
+    dataloader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=sampler is None, sampler=sampler,
+                                             num_workers=opt.n_cpu, pin_memory=False, collate_fn=dataset.collate_fn)
     writer = None
     try:
         from torch.utils.tensorboard import SummaryWriter

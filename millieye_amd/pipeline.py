@@ -97,6 +97,22 @@ class FusionPipeline:
         self.ctx = mp.get_context(start_method)      # run_mp.py:287: spawn
         self.stats = {}
 
+    @staticmethod
+    def _next_payload(q, proc, poll_s=0.5):
+        """``q.get()`` that notices a producer killed hard (OOM killer, a segfault in the decode / radar code): such a
+        process never posts its END payload, and a crash must not look like an endless wait."""
+        import queue as _queue
+        while True:
+            try:
+                return q.get(timeout=poll_s)
+            except _queue.Empty:
+                if not proc.is_alive():
+                    try:   # whatever it managed to queue before dying (END included) still counts
+                        return q.get(timeout=poll_s)
+                    except _queue.Empty:
+                        raise ProducerError(f"the producer process died without ending the stream (exit code "
+                                            f"{proc.exitcode})") from None
+
     def __iter__(self):
         ctx = self.ctx
         q = ctx.Queue(maxsize=QUEUE_SIZE)
@@ -108,7 +124,7 @@ class FusionPipeline:
         t0, frames, dropped = time.perf_counter(), 0, None
         try:
             while True:
-                payload = q.get()
+                payload = self._next_payload(q, proc)
                 if payload["frame_idx"] == _END:
                     dropped = payload["dropped"]
                     if payload.get("error"):

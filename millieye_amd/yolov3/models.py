@@ -110,7 +110,7 @@ class YOLOLayer(nn.Module):
         obj, noobj = torch.empty(cells, device=dev, dtype=torch.uint8), torch.empty(cells, device=dev, dtype=torch.uint8)
         tx, ty, tw, th, tconf, cmask, ious = (torch.empty(cells, **f32) for _ in range(7))
         tcls = torch.empty(cells + (nc,), **f32)
-        result = torch.empty(16, **f32)
+        result = torch.zeros(16, **f32)  # (never uninitialised memory as a loss, whatever happens to the launch)
         anchors_c = (C.c_float * len(scaled))(*scaled)
         ws = _yolo_loss_workspace(dev)
         hip.check(hip.lib().me_yolo_loss_fwd_f32(
@@ -139,10 +139,12 @@ _LOSS_WS = {}
 
 
 def _yolo_loss_workspace(dev):
-    """Zeroed once per device; the kernel leaves its ticket words zero again (me_yolo_loss_fwd_f32)."""
-    ws = _LOSS_WS.get(str(dev))
+    """One per (device, stream): two YOLO layers / models computing their loss on different streams never share the block
+    partials and the ticket.  Zeroed at creation; ``me_yolo_loss_fwd_f32`` resets its ticket words in front of every call."""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _LOSS_WS.get(key)
     if ws is None:
-        ws = _LOSS_WS[str(dev)] = torch.zeros(int(hip.lib().me_yolo_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+        ws = _LOSS_WS[key] = torch.zeros(int(hip.lib().me_yolo_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
     return ws
 
 

@@ -33,6 +33,21 @@ class BrokenSource:
         raise RuntimeError("camera unplugged")
 
 
+class KilledSource:
+    """Two frames, then the producer process dies the hard way (no exception, no END payload): what the OOM killer or a
+    segfault in the decode code looks like from the consumer's side."""
+
+    def __call__(self):
+        import os
+        from millieye_amd import synth
+        from tests.golden.make_golden import radar_points
+        frame = (synth.uniform("demo/frame", (480, 640, 3)) * 255 * 0.1).astype(np.uint8)
+        for f in range(2):
+            yield frame, [radar_points(f)]
+        time.sleep(0.3)   # let the queue's feeder thread flush what was queued
+        os._exit(7)
+
+
 class TaggedGenerator:
     """A caller-supplied generator (picklable): proposals that no default RadarProposalGenerator would produce."""
 

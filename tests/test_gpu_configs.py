@@ -9,6 +9,8 @@ size-independent property these tests lean on: the rows of frame f in a batch ru
 frame f - exactly in fp32 up to accumulation-order rounding (1e-3, north_star), and up to the storage error in the 16-bit
 modes (tile / split-K choices follow M, so a few roundings differ).  The fp32 runs are pinned to the CPU oracle on sampled
 frames (the oracle needs seconds per Darknet-53 frame)."""
+import os
+
 import pytest
 import torch
 
@@ -61,6 +63,34 @@ def test_module2_batch32_fp32_vs_oracle(hip_lib):
     assert total >= 6, "the sampled frames must carry detections"
 
 
+PLAN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plan_16bit_configs.json")
+
+
+def _pin_plan(monkeypatch, tmp_path):
+    """The tuned (tile, split_k) table of these configurations as tools/dump_plan.py measured it (tests/golden/
+    plan_16bit_configs.json) instead of whatever this box's autotuner would pick: the tests run the tiles the benchmark
+    runs, and the same arithmetic on every GPU box.  Returns a function that asserts nothing had to be measured."""
+    import shutil
+    from millieye_amd import engine
+    local = tmp_path / "plan.json"
+    shutil.copy(PLAN, local)
+    monkeypatch.setenv("MILLIEYE_TUNE_CACHE", str(local))
+    monkeypatch.setenv("MILLIEYE_AUTOTUNE", "1")
+    saved = dict(engine._TUNE_CACHE), engine._TUNE_FILE_LOADED[0]
+    engine._TUNE_CACHE.clear()
+    engine._TUNE_FILE_LOADED[0] = False
+    before = engine._TUNE_STATS["measured"]
+
+    def check():
+        measured = engine._TUNE_STATS["measured"] - before
+        engine._TUNE_CACHE.clear()
+        engine._TUNE_CACHE.update(saved[0])
+        engine._TUNE_FILE_LOADED[0] = saved[1]
+        assert measured == 0, (f"{measured} layer shapes were not in {PLAN}: regenerate it with tools/dump_plan.py "
+                               f"(the kernel generation or the planned shapes changed)")
+    return check
+
+
 def _match_share(ref, got, px, tol):
     """Share of ``ref`` rows with a ``got`` row of the same image and class within ``px`` pixels on every corner and
     ``tol`` on the refined confidence."""
@@ -77,19 +107,19 @@ def _match_share(ref, got, px, tol):
     return matched / ref.shape[0]
 
 
-@pytest.mark.parametrize("dtype,px,tol,bar", [("bf16", 4.0, 0.1, 0.8), ("f16", 2.0, 0.02, 0.9)])
-def test_module2_batch32_16bit(hip_lib, monkeypatch, dtype, px, tol, bar):
+@pytest.mark.parametrize("dtype,px,tol,bar", [("bf16", 4.0, 0.1, 0.9), ("f16", 2.0, 0.02, 0.9)])
+def test_module2_batch32_16bit(hip_lib, monkeypatch, tmp_path, dtype, px, tol, bar):
     """(The per-layer tile choice is normally MEASURED on the GPU box, so the roundings - and with them a handful of rows near the
-    confidence threshold - moved from box to box and this test's shares with them; here the autotuner is off: the library's
-    deterministic cold-start tiles, the same arithmetic on every box.  The tuned tiles are covered by the per-op and
-    whole-detector tests of test_gpu_h16.py.)
+    confidence threshold - moved from box to box and this test's shares with them; here the plan is PINNED to the tuned table
+    the benchmark configuration runs, ``_pin_plan``: the tiles under test are the ones bench.py times, and the arithmetic is
+    the same on every box.)
     configs[2] literally ("module2 ... 416x416 bf16 inference, batch=32"), and the IEEE-half mode: the batch-32 run in a
     16-bit storage mode is deterministic, its frames agree with the batch-1 runs of the same frames in the same mode
     (``bar`` of the rows of the four sampled frames within the storage error, no frame below ``bar - 0.15``; the tile choice is measured per GPU box, so the share moves by a few rows from box to box: the tile choice
     follows M, so accumulation order - hence a few roundings of the 8-bit mantissa, amplified by 75 random-weight layers and a
     confidence threshold - differs; measured 89 - 100 % per frame in bf16), and it is as close to the fp32 batch-32 run as the
     batch-1 runs are (share of fp32 rows with a counterpart, -10 points)."""
-    monkeypatch.setenv("MILLIEYE_AUTOTUNE", "0")
+    plan_check = _pin_plan(monkeypatch, tmp_path)
     name, n, s = "m2b32", 32, 416
     net = _m2_net(name)
     net = net.to(net.device)
@@ -108,13 +138,14 @@ def test_module2_batch32_16bit(hip_lib, monkeypatch, dtype, px, tol, bar):
         assert abs(mine.shape[0] - one.shape[0]) <= max(3, 0.2 * one.shape[0]), (f, mine.shape, one.shape)
         share = _match_share(one, mine, px, tol)
         print(f"[m2b32 {dtype}] frame {f}: {share:.1%} of {one.shape[0]} batch-1 rows found in the batch-32 run")
-        assert share >= bar - 0.15, f"{dtype}: frame {f}: {share:.0%} of the batch-1 rows found in the batch-32 run"
+        assert share >= bar - 0.1, f"{dtype}: frame {f}: {share:.0%} of the batch-1 rows found in the batch-32 run"
         found += share * one.shape[0]
         rows_total += one.shape[0]
         r32 = _frame_rows(ref32, f)
         s_batch, s_one = _match_share(r32, mine, px, tol), _match_share(r32, one, px, tol)
         assert s_batch >= s_one - 0.1, f"{dtype}: frame {f}: batch-32 {s_batch:.0%} vs batch-1 {s_one:.0%} of the fp32 rows"
     assert found >= bar * rows_total, f"{dtype}: {found / max(rows_total, 1):.0%} of the batch-1 rows found in the batch-32 run"
+    plan_check()
 
 
 def _net608(tag):
@@ -127,14 +158,14 @@ def _net608(tag):
     return net
 
 
-def test_full_pipeline_608_batch16_fp32_and_f16(hip_lib, monkeypatch):
+def test_full_pipeline_608_batch16_fp32_and_f16(hip_lib, monkeypatch, tmp_path):
     """configs[4] per-GPU shape end to end: Darknet-53 at 608x608, batch 16 (128 frames over 8 GPUs), detector -> NMS over
     22 743 rows per frame -> proposals -> score maps (38x38) -> RoI heads -> ordered rows.  (1) fp32: two frames against the
     CPU oracle (1e-3); (2) IEEE half: deterministic, the frames of the batch-16 run agree with their batch-1 runs in the same
     mode, and the batch run is as close to the fp32 rows as the batch-1 runs are."""
     from oracle import network_ref
     from tests.test_gpu_network import _cmp_rows_ties
-    monkeypatch.setenv("MILLIEYE_AUTOTUNE", "0")  # deterministic tiles: the same arithmetic on every GPU box (see the module-2 test)
+    plan_check = _pin_plan(monkeypatch, tmp_path)  # the benchmark's tuned tiles, the same on every GPU box (see the module-2 test)
     name, n, s = "full608", 16, 608
     net = _net608(name)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
@@ -182,6 +213,7 @@ def test_full_pipeline_608_batch16_fp32_and_f16(hip_lib, monkeypatch):
         r32 = _frame_rows(out32, f)
         assert _match_share(r32, mine, 2.0, 0.03) >= _match_share(r32, one, 2.0, 0.03) - 0.1, f"frame {f}: vs the fp32 rows"
     assert found >= 0.8 * rows_total, f"{found / max(rows_total, 1):.0%} of the f16 batch-1 rows found in the batch-16 run"
+    plan_check()
 
 
 def test_nms_608_batch16_bitexact(hip_lib):

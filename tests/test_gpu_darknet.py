@@ -2,6 +2,8 @@
 (oracle/darknet_ref.py, itself pinned to the reference by tests/golden) on identical seeded
 weights and frames.  Bar: 1e-3 (allclose rtol=atol) on featuremap and every yolo_outputs row."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -151,6 +153,38 @@ def test_detector_backward_darknet53_vs_oracle(hip_lib):
     loss.backward()
     for k, p in model.named_parameters():
         _grad_check(p.grad.cpu(), ref_grads[k], k, tol=5e-3)
+
+
+def test_detector_backward_darknet53_416_batch8_vs_oracle(hip_lib):
+    """The shape ``bench.py --workload detector_train`` times - Darknet-53, 416 x 416, batch 8, trained-like weights, the
+    bench's own targets - against the oracle's CPU autograd: the 128 x 128 weight-gradient tile (>= 16 384 reduced pixels),
+    the parity-split stride-2 data gradients, the autotuned forward / data-gradient tiles and the weight-gradient stream
+    are only reached at this size (the 64-px test above runs the small-map paths).  Loss to 1e-3; every parameter's
+    gradient by norm and on 64 samples to 5e-3 of its largest entry."""
+    from millieye_amd import cfgs, synth
+    from oracle import darknet_ref
+    name, n, s = "d53bwd416", 8, 416
+    cpu_model = ph.make_darknet("yolov3", tag=name, trained_like=True)
+    targets = torch.tensor([[i, (3 * i) % 80, 0.3 + 0.04 * (i % 8), 0.4 + 0.03 * (i % 5), 0.2, 0.3] for i in range(n)],
+                           dtype=torch.float32)
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    torch.set_num_threads(min(64, len(os.sched_getaffinity(0))))
+    ref_loss, ref_grads = darknet_ref.darknet_train_step(cfgs.KNOWN["yolov3"](), cpu_model.state_dict(), x, targets)
+    model = ph.make_darknet("yolov3", tag=name, trained_like=True).cuda().eval()
+    loss, _fm, _yo = model(x.cuda(), targets)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
+    loss.backward()
+    torch.cuda.synchronize()
+    seen = 0
+    for k, p in model.named_parameters():
+        got, ref = p.grad.cpu(), ref_grads[k]
+        scale = max(float(ref.abs().max()), 1e-12)
+        gn, rn = float(got.double().norm()), float(ref.double().norm())
+        assert abs(gn - rn) <= 5e-3 * max(rn, 1e-12), (k, gn, rn)
+        step = max(1, got.numel() // 64)
+        assert float((got.flatten()[::step] - ref.flatten()[::step]).abs().max()) <= 5e-3 * scale, k
+        seen += 1
+    assert seen == 222  # 75 conv weights + 72 x (BN weight, bias) + 3 detection biases
 
 
 def test_detector_backward_train_mode_batchnorm(hip_lib):

@@ -145,3 +145,103 @@ def test_dp_stage3_hip_step_two_ranks_equals_one_way(hip_lib):
         checked += p.grad is not None
     assert checked >= 20
     assert got[0][0] == got[1][0] == 4 * sum(p.numel() for p in head_parameters(net))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# detector training (row a6): the gradient stream of the HIP backward leaves in reverse-layer chunks through
+# parallel.GradChunkReducer while the backward is still running.  Two processes on the one leased GPU (gloo over CUDA tensors,
+# as above).  The YOLO loss terms are per-batch MEANS over the obj / noobj cells (reference yolov3/models.py:240-250), so
+# the sum of two shards' gradients is the gradient of loss(shard 0) + loss(shard 1), not of the 1-way loss: the reference
+# for the reduced gradients is therefore the sum of the two shards' steps computed one after the other in ONE process
+# without any reducer - same kernels, same shards, only the exchange differs.
+# ---------------------------------------------------------------------------------------------------------------------
+def _det_problem():
+    import torch
+    from millieye_amd import synth
+    from tests import parity_helpers as ph
+    model = ph.make_darknet("yolov3-tiny-12", tag="dp-det", trained_like=True)
+    x = torch.from_numpy(synth.uniform("dp-det/x", (4, 3, 96, 96)))
+    targets = torch.tensor([[i, (3 * i) % 12, 0.3 + 0.1 * (i % 3), 0.4 + 0.05 * i, 0.25, 0.3] for i in range(4)],
+                           dtype=torch.float32)
+    return model, x, targets
+
+
+def _det_shard_step(model, x, targets, lo, hi):
+    import torch
+    tg = targets[(targets[:, 0] >= lo) & (targets[:, 0] < hi)].clone()
+    tg[:, 0] -= lo
+    for p in model.parameters():
+        p.grad = None
+    loss, _fm, _yo = model(x[lo:hi].contiguous().cuda(), tg)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+def _det_dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, x, targets = _det_problem()
+    model = model.cuda().eval()
+    red = par.overlap_detector_allreduce(model, chunk_bytes=256 << 10)   # 8.7 M parameters -> dozens of chunks
+    assert red is not None
+    lo, hi = par.shard_range(x.shape[0], rank, world)
+    loss, grads = _det_shard_step(model, x, targets, lo, hi)
+    q.put((rank, loss, red.chunks_last, red.bytes_last, {k: v.cpu().numpy() for k, v in grads.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_detector_hip_step_chunked_allreduce_two_ranks(hip_lib):
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_det_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, loss, chunks, nbytes, grads = q.get(timeout=900)
+        got[rank] = (loss, chunks, nbytes, grads)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, x, targets = _det_problem()
+    model = model.cuda().eval()
+    l0, g0 = _det_shard_step(model, x, targets, 0, 2)
+    l1, g1 = _det_shard_step(model, x, targets, 2, 4)
+    assert got[0][0] == pytest.approx(l0, rel=1e-6) and got[1][0] == pytest.approx(l1, rel=1e-6)
+    n_param_bytes = 4 * sum(p.numel() for p in model.parameters())
+    checked = 0
+    for rank in (0, 1):
+        _loss, chunks, nbytes, grads = got[rank]
+        assert nbytes == n_param_bytes and chunks >= 8, (chunks, nbytes, n_param_bytes)
+        assert sorted(grads) == sorted(g0)
+        for name, want in g0.items():
+            want = (want + g1[name]).cpu()
+            mine = torch.from_numpy(grads[name])
+            scale = max(float(want.abs().max()), 1e-12)
+            # same kernels on the same shards; only atomics inside a shard's own kernels may reorder sums
+            assert float((mine - want).abs().max()) <= 1e-5 * scale, (name, rank)
+            checked += 1
+    assert checked >= 2 * 30
+
+
+def test_bench_allreduce_microbenchmark_runs_through_rccl(hip_lib):
+    """``bench.py --workload allreduce``: under a launcher RCCL exchanges the 247.8 MB bucket (world 1
+    on this lease); without one the line says that nothing was exchanged."""
+    out = _bench(["--workload", "allreduce", "--bytes", "33554432"], {"BENCH_FORCE_SPAWN": "1"})
+    assert out["config"]["rccl_ranks"] == 1 and out["config"]["bytes"] == 33554432 and out["config"]["chunks"] == 1
+    assert out["value"] > 0 and out["unit"] == "GB/s"
+    out = _bench(["--workload", "allreduce", "--bytes", "33554432"], {})
+    assert out["config"]["rccl_ranks"] == 0 and "nothing was exchanged" in out["config"]["workload"]

@@ -243,3 +243,68 @@ def test_dp_stage3_step_equals_one_way():
     assert n_checked >= 20
     assert got[0][0] == got[1][0] == 4 * sum(p.numel() for p in net.parameters()
                                             if p.requires_grad) - 4 * sum(p.numel() for p in net.base_detector.parameters())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GradChunkReducer (detector training, row a6 / e): gradients leave in production order, one collective per chunk
+# ---------------------------------------------------------------------------------------------------------------------
+def _chunk_worker(rank, world, port, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    shapes = [(7,), (3, 5), (64, 3, 3, 3), (1,), (300,), (2, 2)]
+    grads = [torch.randn(s, generator=g) for s in shapes]
+    red = par.GradChunkReducer(chunk_bytes=1024)
+    red.begin("cpu")
+    for i, t in enumerate(grads):
+        red.push(f"p{i}", t)
+    done = red.finish()
+    q.put((rank, red.chunks_last, red.bytes_last, {k: v.clone() for k, v in done.items()}, [t.clone() for t in grads]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_chunk_reducer_two_ranks_gloo():
+    """Two ranks push six gradients of uneven sizes with a 1 KB chunk limit: three collectives (the 6.9 KB conv weight closes
+    its chunk alone), every reduced tensor = the sum of the two ranks' tensors bit for bit, returned in the producer's shape,
+    names preserved, byte count = every gradient once."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, chunks, nbytes, done, mine = q.get(timeout=300)
+        got[rank] = (chunks, nbytes, done, mine)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = [a + b for a, b in zip(got[0][3], got[1][3])]
+    for rank in (0, 1):
+        chunks, nbytes, done, _mine = got[rank]
+        assert chunks == 3 and nbytes == 4 * sum(t.numel() for t in total)
+        assert sorted(done) == [f"p{i}" for i in range(6)]
+        for i, t in enumerate(total):
+            assert done[f"p{i}"].shape == t.shape and torch.equal(done[f"p{i}"], t), i
+
+
+def test_overlap_detector_allreduce_needs_a_process_group():
+    """Without a process group nothing is attached (bench.py then says "all-reduce skipped")."""
+    from millieye_amd import parallel as par
+
+    class M:
+        pass
+    m = M()
+    assert par.overlap_detector_allreduce(m) is None and "_grad_reducer" not in m.__dict__

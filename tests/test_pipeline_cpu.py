@@ -76,6 +76,21 @@ def test_producer_failure_is_reported_not_mistaken_for_the_end():
     assert got == list(range(len(got))) and pipe.stats["frames"] == len(got)
 
 
+def test_producer_killed_hard_raises_instead_of_hanging():
+    """a producer that dies without posting END (os._exit here; the OOM killer in production) ends the iteration
+    with ProducerError naming the exit code - the consumer's q.get() must not wait forever."""
+    import pytest
+    from millieye_amd.pipeline import ProducerError
+    from tests.pipeline_helpers import KilledSource
+    pipe = FusionPipeline(_fuser(), KilledSource(), infer=slow_infer, drop_oldest=False)
+    got = []
+    with pytest.raises(ProducerError) as err:
+        for rows, info in pipe:
+            got.append(info["frame_idx"])
+    assert "exit code 7" in str(err.value), str(err.value)
+    assert got == [0, 1]
+
+
 def test_custom_generator_reaches_the_producer_or_is_refused():
     import pytest
     fuser = FrameFuser(None, RADAR_CALIB, model_mode=0, generator=TaggedGenerator(RADAR_CALIB))
