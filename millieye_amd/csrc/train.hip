@@ -677,6 +677,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_oihw_kernel(const float
   const int pitch = kk | 1;
   const int co = blockIdx.y, c0 = blockIdx.x * 64;
   const int nc = cin - c0 < 64 ? cin - c0 : 64;
+  if ((cin & 3) == 0 && nc == 64) {
+    // 16-byte loads, eight slabs in flight per lane (round 4: the scalar loop below kept 4 KB per workgroup in flight and
+    // summed 38 MB of nine-tap slabs at 1.5 - 2.5 TB/s)
+    for (int i = threadIdx.x; i < kk * 16; i += 256) {
+      const int tap = i >> 4, q4 = (i & 15) * 4;
+      const long long idx = ((long long)co * kk + tap) * cin + c0 + q4;
+      float4 v = *reinterpret_cast<const float4*>(slabs + idx);
+      int k = 1;
+      for (; k + 7 < splits; k += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(slabs + (long long)(k + u) * count + idx);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w;
+        }
+      }
+      for (; k < splits; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(slabs + (long long)k * count + idx);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      s_t[(q4 + 0) * pitch + tap] = v.x;
+      s_t[(q4 + 1) * pitch + tap] = v.y;
+      s_t[(q4 + 2) * pitch + tap] = v.z;
+      s_t[(q4 + 3) * pitch + tap] = v.w;
+    }
+  } else
   for (int i = threadIdx.x; i < kk * 64; i += 256) {
     const int tap = i >> 6, cl = i & 63;
     if (cl < nc) {
@@ -1331,10 +1358,25 @@ static int wgrad_splits(long long P, int cin, int cout, int ks) {
 
 static bool stem_wgrad_shape(int cin, int cout, int ksize) { return cin == 3 && ksize == 3 && cout % 4 == 0; }
 
+extern "C++" {
+namespace me_wg9 {  // wgrad9.hip: all nine taps of a (cout, cin) tile per workgroup (3x3, stride 1, pad 1)
+bool shape(int cin, int cout, int ksize, int stride, int pad, int* tco, int* tci);
+int splits(int n, int h, int w, int cin, int cout, int* per);
+int launch(const float* x, long long xp, const float* dy, long long dyp, float* slabs, int n, int h, int w, int cin, int cout,
+           hipStream_t stream, int* splits_out);
+}  // namespace me_wg9
+}  // extern "C++"
+
 int64_t me_conv_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize) {
   if (stem_wgrad_shape(cin, cout, ksize)) return (int64_t)SW_BLOCKS * cout * 27 * (int64_t)sizeof(float);
   const int s = wgrad_splits((long long)n * ho * wo, cin, cout, ksize);
-  return s > 1 ? (int64_t)s * cout * ksize * ksize * cin * (int64_t)sizeof(float) : 0;
+  int64_t need = s > 1 ? (int64_t)s * cout * ksize * ksize * cin * (int64_t)sizeof(float) : 0;
+  if (ksize == 3) {  // the nine-tap kernel (stride 1: the input map is the output map) always goes through slabs
+    const int s9 = me_wg9::splits(n, ho, wo, cin, cout, nullptr);
+    const int64_t need9 = (int64_t)s9 * cout * 9 * cin * (int64_t)sizeof(float);
+    if (need9 > need) need = need9;
+  }
+  return need;
 }
 
 static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t dy_pitch, float* dw, int32_t n, int32_t h,
@@ -1358,13 +1400,29 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
     return me::check_launch("stem_wgrad_kernel");
   }
   int splits = wgrad_splits(P, cin, cout, ksize);
+  bool done9 = false;
+  {
+    int tco9, tci9;
+    if (me_wg9::shape(cin, cout, ksize, stride, pad, &tco9, &tci9) && h == ho && w == wo && workspace) {
+      const int s9 = me_wg9::splits(n, h, w, cin, cout, nullptr);
+      if (workspace_bytes >= (int64_t)s9 * count * (int64_t)sizeof(float)) {
+        int sp = 0;
+        const int rc9 = me_wg9::launch(x, x_pitch, dy, dy_pitch, reinterpret_cast<float*>(workspace), n, h, w, cin, cout, stream, &sp);
+        if (rc9 > 0) return rc9;
+        if (rc9 == 0) {
+          splits = sp;
+          done9 = true;
+        }
+      }
+    }
+  }
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * count * (int64_t)sizeof(float))) splits = 1;
   ME_REQUIRE(!oihw || ksize == 1 || (workspace && workspace_bytes >= count * (int64_t)sizeof(float)), ME_E_BADARG,
              "me_conv_wgrad_mfma_oihw_f32: needs a workspace of at least one slab (%lld bytes)", count * 4ll);
   int per = (int)((P + splits - 1) / splits);
   per = (per + 15) & ~15;
   ME_REQUIRE((long long)ksize * ksize * splits < 65536, ME_E_TOOBIG, "me_conv_wgrad_mfma_f32: grid too large");
-  const bool via_ws = splits > 1 || (oihw && ksize > 1);  // (a 1x1 filter's OHWI and OIHW layouts coincide)
+  const bool via_ws = done9 || splits > 1 || (oihw && ksize > 1);  // (a 1x1 filter's OHWI and OIHW layouts coincide)
   float* out = via_ws ? reinterpret_cast<float*>(workspace) : dw;
   const bool vec = (cin % 4 == 0) && (cout % 4 == 0) && (x_pitch % 4 == 0) && (dy_pitch % 4 == 0) && me::aligned16(x) &&
                    me::aligned16(dy);
@@ -1372,6 +1430,9 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
   wgrad_tile(P, cin, cout, ksize, tco, tci);
   if (!vec) tco = tci = 64;  // (the split count was sized for the larger tile: correct, a few workgroups more)
   dim3 grid((cin + tci - 1) / tci, (cout + tco - 1) / tco, ksize * ksize * splits);
+  if (done9) {
+    // (slabs written by the nine-tap kernel: straight to the reduction)
+  } else
 #define ME_WG_TILE(A, B)                                                                                              \
   hipLaunchKernelGGL((conv_wgrad_tile_kernel<A, B>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,           \
                      (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per)

@@ -327,20 +327,14 @@ class Network(nn.Module):
             object.__setattr__(self, "_side", st)
         return st
 
-    def _score_maps(self, plan, maps, n, dev):
-        """roi_score_map [n,fh,fw,490] (cnn_layers_1 on the feature tap) and radar_score_map [n,h,w,10 (pitch 12)]
-        (cnn_layers_3 on the radar maps) on the current stream; returns (roi_score_map, radar_score_map, fh, fw, mh, mw)."""
+    def _radar_score_map(self, maps, n, dev):
+        """radar_score_map [n,h,w,10 (pitch 12)] = cnn_layers_3 on the radar maps, on the current stream.  It depends on
+        nothing the detector computes, so ``forward`` starts it on the side stream BEFORE the detector (four small launches
+        that used to sit behind the detector on the critical path of the score-map branch)."""
         f32 = dict(device=dev, dtype=torch.float32)
         packs = self._get_packs()
-        tap16 = getattr(plan, "dtype", "f32") != "f32"
-        for key in (plan.dtype if tap16 else "img", "r1", "r2", "r3", "r4"):
+        for key in ("r1", "r2", "r3", "r4"):
             packs[key].refresh(dev)
-        fh, fw, fc = plan.tap_shape
-        roi_score_map = torch.empty((n, fh, fw, 490), **f32)
-        if tap16:
-            self._conv16(plan.tap_ptr, plan.tap_pitch, n, fh, fw, fc, packs[plan.dtype], 1, 0, hip.ACT_LEAKY, roi_score_map)
-        else:
-            self._conv(plan.tap_ptr, plan.tap_pitch, False, n, fh, fw, fc, packs["img"], 1, 0, hip.ACT_LEAKY, roi_score_map)
         maps = maps.contiguous()
         if not (maps.is_cuda and maps.dtype == torch.float32):
             raise hip.MeError("radar maps must be CUDA float32 [N,3,h,w]")
@@ -356,6 +350,26 @@ class Network(nn.Module):
         # the reference hands both maps to the RoI ops with the same spatial_scale; a radar map of another size (the
         # demos feed the raw 32 x 32 map, quirk q15) is legal there: the pooling kernel takes per-map sizes
         self._keep_side = (t1, t2, t3, maps)  # alive until the next forward: the side stream may still read them
+        return radar_score_map, mh, mw
+
+    def _roi_score_map(self, plan, n, dev):
+        """roi_score_map [n,fh,fw,490] = cnn_layers_1 on the detector's feature tap, on the current stream."""
+        packs = self._get_packs()
+        tap16 = getattr(plan, "dtype", "f32") != "f32"
+        packs[plan.dtype if tap16 else "img"].refresh(dev)
+        fh, fw, fc = plan.tap_shape
+        roi_score_map = torch.empty((n, fh, fw, 490), device=dev, dtype=torch.float32)
+        if tap16:
+            self._conv16(plan.tap_ptr, plan.tap_pitch, n, fh, fw, fc, packs[plan.dtype], 1, 0, hip.ACT_LEAKY, roi_score_map)
+        else:
+            self._conv(plan.tap_ptr, plan.tap_pitch, False, n, fh, fw, fc, packs["img"], 1, 0, hip.ACT_LEAKY, roi_score_map)
+        return roi_score_map, fh, fw
+
+    def _score_maps(self, plan, maps, n, dev, radar_job=None):
+        """Both score maps on the current stream (``radar_job``: the radar half was already started there); returns
+        (roi_score_map, radar_score_map, fh, fw, mh, mw)."""
+        roi_score_map, fh, fw = self._roi_score_map(plan, n, dev)
+        radar_score_map, mh, mw = radar_job if radar_job is not None else self._radar_score_map(maps, n, dev)
         return roi_score_map, radar_score_map, fh, fw, mh, mw
 
     # ---------------------------------------------------------------------------------- forward
@@ -385,6 +399,14 @@ class Network(nn.Module):
         cb = getattr(self, "_stage_cb", None)
         mark = cb or (lambda _name: None)  # bench.py: per-stage HIP events
         mark("start")
+        # the radar CNN needs nothing from the detector: it starts on the side stream now and runs beside it (mode 0 / 2 / 3)
+        radar_job = None
+        if cb is None and model_mode != 1:
+            self._check_eval()
+            side = self._side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                radar_job = self._radar_score_map(maps, n, dev)
         plan, yolo_out = self.base_detector._run(images, nms_conf=float(self.conf_thresh))  # the decode fills the NMS lists
         mark("detector")
         # The score maps (reference :486-487) only need the feature tap, NMS only the decoded rows: NMS keeps 32
@@ -396,7 +418,7 @@ class Network(nn.Module):
             side = self._side_stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                maps_job = self._score_maps(plan, maps, n, dev)
+                maps_job = self._score_maps(plan, maps, n, dev, radar_job)
         det, cnt = hip.nms_batched(yolo_out, float(self.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
                                    writeback_xyxy=False, prepped=plan.nms_prepped == float(self.conf_thresh))
         mark("nms")
