@@ -496,6 +496,8 @@ def main():
 
     if args.workload == "allreduce":
         return allreduce_bench(args, world, rank, dev)
+    if world > 1:
+        os.environ["MILLIEYE_TUNE_SYNC"] = "1"  # the replicas run rank 0's tuned (tile, split_k) table (engine._autotune)
     import __graft_entry__ as g
     if rank == 0:
         g.build()
@@ -683,6 +685,7 @@ def main():
 
     # north_star: "frames/sec ... at batch 1/8/32": the same step at batch 1 and 8 (rank 0's frames; untimed plan building
     # and autotuning first), fp32 and bf16 storage, reported beside - never instead of - `value`
+    os.environ["MILLIEYE_TUNE_SYNC"] = "0"  # from here on rank 0 plans alone (batch sweep, stage table, accuracy leg)
     sweep = []
     if rank == 0 and args.workload in ("full", "detector") and args.dtype == "f32" and not args.no_batch_sweep:
         for b in (1, 8):

@@ -307,7 +307,10 @@ int launch(const float* x, long long xp, const float* dy, long long dyp, float* 
   a.Ip = (h + 1) * a.Wp;
   a.Mp = (long long)n * a.Ip;
   if (a.Mp >= (1ll << 31)) return -1;
-  constexpr int NG = 2;
+  static const int NG = [] {   // wave groups per workgroup: 2 = eight waves merging through LDS (default), 1 = four waves
+    const char* e = getenv("MILLIEYE_WGRAD9_NG");
+    return (e && e[0] == '1') ? 1 : 2;
+  }();
   a.hb = (a.Wp + 1 + 15) / 16;
   a.nr = 2 * a.hb + 2 * NG;
   size_t lds = ((size_t)2 * 16 * NG * tco + (size_t)(a.nr + 1) * 16 * tci) * sizeof(float);
@@ -316,13 +319,18 @@ int launch(const float* x, long long xp, const float* dy, long long dyp, float* 
   if (lds > 160 * 1024) return -1;
   const int s = splits(n, h, w, cin, cout, &a.per);
   if (a.Ip <= 16 * a.hb) return -1;  // (pos_of assumes the halo is shorter than one image)
-  auto kern = conv_wgrad9_kernel<2, 2, NG>;
   static bool attr_set = false;
   if (!attr_set) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad9_kernel<2, 2, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad9_kernel<2, 2, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(cin / tci, cout / tco, s), dim3(256 * NG), lds, stream, a);
+  if (NG == 2)
+    hipLaunchKernelGGL((conv_wgrad9_kernel<2, 2, 2>), dim3(cin / tci, cout / tco, s), dim3(512), lds, stream, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad9_kernel<2, 2, 1>), dim3(cin / tci, cout / tco, s), dim3(256), lds, stream, a);
   *splits_out = s;
   return me::check_launch("conv_wgrad9_kernel");
 }

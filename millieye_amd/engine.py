@@ -863,7 +863,7 @@ def _graphs_enabled():
 # ------------------------------------------------------------------------------------------ autotuner
 _TUNE_CACHE = {}
 _TUNE_FILE_LOADED = [False]
-_TUNE_STATS = {"measured": 0}  # layer shapes whose candidates were timed in this process (0 = every choice came from the file)
+_TUNE_STATS = {"measured": 0, "synced": 0}  # layer shapes whose candidates were timed in this process (0 = every choice came from the file)
 _TUNE_TILES = (1, 2, 3, 4, 5)  # (7 / 47 = 64x64 with a 6 / 9-stage LDS ring: no gain at batch 1 / 8 - a lone wave per SIMD is bound by its
 # own MFMA chain, not by DMA latency - so they stay forced-only ids)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
@@ -945,18 +945,41 @@ def _autotune(plan, lib):
     _tune_load()
     bf16 = plan.dtype in _TORCH_HALF
     conv_fn = lib.me_conv2d_h16 if bf16 else lib.me_conv2d_f32
-    todo = []
+    todo, keyed = [], []
     for _m, d in plan.conv_descs:
         if d.cin <= 4:
             continue
         key = (d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.upsample, int(bool(d.res)))
         if bf16:
             key += (16 + d.y_f32 + 2 * d.half_type,)
+        keyed.append((key, d))
         hit = _TUNE_CACHE.get(key)
         if hit is not None:
             d.tile, d.split_k = hit
         else:
             todo.append((key, d))
+
+    def agree_on_rank0():
+        """Data-parallel replicas run the SAME (tile, split_k) per layer: every rank measures (or finds) its own choices,
+        then rank 0's table for this plan replaces them - per-rank measurement noise would otherwise give the replicas
+        different accumulation orders (harmless for fp32 parity bars, visible in the 16-bit modes; VERDICT r03 robustness).
+        One small object broadcast per plan build; every rank reaches it whichever way it got its choices."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        # opt-in (MILLIEYE_TUNE_SYNC=1): every rank must build the same plans at the same points of the program - true for the
+        # lock-step loops of bench.py, NOT for a loop in which rank 0 evaluates alone while the others wait in a barrier
+        if os.environ.get("MILLIEYE_TUNE_SYNC", "0") not in ("1", "true", "on"):
+            return
+        box = [{k: (int(dd.tile), int(dd.split_k)) for k, dd in keyed} if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        _TUNE_STATS["synced"] += 1
+        for k, dd in keyed:
+            hit0 = box[0].get(k)
+            if hit0 is not None:
+                dd.tile, dd.split_k = hit0
+                _TUNE_CACHE[k] = hit0
+
     def ensure_workspace(nbytes):
         have = plan.conv_ws.numel() - 256 if plan.conv_ws is not None else 0
         if nbytes > have:
@@ -980,6 +1003,7 @@ def _autotune(plan, lib):
 
     _TUNE_STATS["measured"] += len(todo)
     if not todo:
+        agree_on_rank0()
         ensure_workspace(required())  # cached choices may need more scratch than the analytic plan asked for
         return
     ws_bytes = plan.conv_ws.numel() - 256 if plan.conv_ws is not None else 0
@@ -1089,6 +1113,7 @@ def _autotune(plan, lib):
             best = (best[0], best[1][1], best[1][2])
         d.tile, d.split_k = best[1], best[2]
         _TUNE_CACHE[key] = (best[1], best[2])
+    agree_on_rank0()
     ensure_workspace(required())
     _tune_save()
 

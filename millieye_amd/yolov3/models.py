@@ -266,6 +266,10 @@ class Darknet(nn.Module):
         detector backward is not built (no reference script trains the detector)."""
         if targets is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(x, targets)
+        if any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
+            # model.train() without autograd (reference :35,247-267: legal, batch statistics, running statistics updated):
+            # the inference engine folds BatchNorm into the convolution and cannot do that - the training path's forward can
+            return self._forward_batch_stats(x, targets)
         plan, yolo_outputs = self._run(x, keep_raw=targets is not None)
         if getattr(plan, "graph", None) is not None:
             yolo_outputs = yolo_outputs.clone()  # graph replays write a static buffer: the caller gets its own tensor
@@ -283,6 +287,41 @@ class Darknet(nn.Module):
                 loss = loss + layer.loss_from_raw(raw, targets)
             return loss, self.featuremap, yolo_outputs
         return self.featuremap, yolo_outputs
+
+    def _forward_batch_stats(self, x, targets):
+        """``Darknet.forward`` under ``model.train()`` outside autograd: BatchNorm layers in train() mode normalise with the
+        batch statistics and update their running statistics (``me_bn_train_fwd_f32``), the others stay folded; outputs (and,
+        with ``targets``, the loss VALUE) come from that forward.  fp32 only, like every training path of this package."""
+        from ..detector_train import DetectorTrainer
+        if self.compute_dtype != "f32":
+            raise NotImplementedError("train()-mode BatchNorm: float32 only (the 16-bit storage modes fold BatchNorm)")
+        with torch.no_grad():
+            st = DetectorTrainer(self).forward(x)
+            yolo_outputs = self._decode_state(st, x)
+            if targets is None:
+                return self.featuremap, yolo_outputs
+            loss = 0
+            for layer, (_idx, raw) in zip(self.yolo_layers, sorted(st.raws.items())):
+                layer.img_dim = x.shape[2]
+                loss = loss + layer.loss_from_raw(raw, targets)
+            return loss, self.featuremap, yolo_outputs
+
+    def _decode_state(self, st, x):
+        """Decoded rows ``[N, R, 5 + C]`` + the feature tap from a training-path forward state (both BatchNorm modes)."""
+        from .. import hip
+        rows_total = sum(l.num_anchors * r.shape[1] * r.shape[2] for l, (_i, r) in zip(self.yolo_layers, sorted(st.raws.items())))
+        yolo_outputs, off = None, 0
+        for layer, (_idx, raw) in zip(self.yolo_layers, sorted(st.raws.items())):
+            yolo_outputs = hip.yolo_decode(raw, layer.anchors, layer.num_classes, x.shape[2], out=yolo_outputs,
+                                           rows_total=rows_total, row_offset=off)
+            off += layer.num_anchors * raw.shape[1] * raw.shape[2]
+            layer.grid_size, layer.stride = raw.shape[1], x.shape[2] / raw.shape[1]
+        tap = self.engine.tap_module
+        if tap is not None and tap < len(st.outs) and st.outs[tap] is not None:
+            self.featuremap = hip.nhwc_to_nchw(st.outs[tap])
+        if not hasattr(self, "featuremap"):
+            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+        return yolo_outputs
 
     def _forward_train(self, x, targets):
         """``(loss, featuremap, yolo_outputs)`` with a differentiable loss (reference :181-267 under autograd): every

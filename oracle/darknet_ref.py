@@ -87,7 +87,8 @@ def _readers(blocks):
     return readers
 
 
-def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list.", return_layers=False, storage="f32"):
+def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list.", return_layers=False, storage="f32",
+                    training=False):
     """Evaluate the detector.  ``state_dict`` keys: ``{prefix}{i}.conv_{i}.weight`` etc.
     Returns ``(featuremap or None, yolo_outputs [N,R,5+C])`` (+ per-module outputs on request).
 
@@ -96,7 +97,11 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
     with one round-to-nearest-even to bfloat16 at every point where millieye_amd/csrc/conv_bf16.hip stores 16-bit data -
     the frame and the weights of every convolution, and every activation written to memory, i.e. after
     conv+BN+LeakyReLU (and after the [shortcut] add when that convolution feeds only the shortcut - the add is then part of
-    the same kernel and sees the unrounded value).  Detection convolutions (read only by a [yolo] block) stay fp32."""
+    the same kernel and sees the unrounded value).  Detection convolutions (read only by a [yolo] block) stay fp32.
+
+    ``training=True``: BatchNorm on batch statistics, as ``Darknet.forward(x)`` computes under ``model.train()`` in the
+    reference (yolov3/models.py:35,247-267); the running statistics of ``state_dict`` are updated IN PLACE with momentum 0.9
+    like the module's buffers (pass a copy to keep the originals)."""
     blocks = parse_cfg_text(cfg_text)[1:]
     img_dim = x.shape[2]
     outs, yolo = [], []
@@ -125,7 +130,7 @@ def darknet_forward(cfg_text, state_dict, x, tap_module=8, prefix="module_list."
                 if int(b["batch_normalize"]):
                     p = f"{prefix}{i}.batch_norm_{i}."
                     x = F.batch_norm(x, state_dict[p + "running_mean"], state_dict[p + "running_var"],
-                                     state_dict[p + "weight"], state_dict[p + "bias"], False, 0.9, 1e-5)
+                                     state_dict[p + "weight"], state_dict[p + "bias"], training, 0.9, 1e-5)
                 if b["activation"] == "leaky":
                     x = F.leaky_relu(x, 0.1)
                 if bf16:

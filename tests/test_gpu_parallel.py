@@ -245,3 +245,61 @@ def test_bench_allreduce_microbenchmark_runs_through_rccl(hip_lib):
     assert out["value"] > 0 and out["unit"] == "GB/s"
     out = _bench(["--workload", "allreduce", "--bytes", "33554432"], {})
     assert out["config"]["rccl_ranks"] == 0 and "nothing was exchanged" in out["config"]["workload"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# replicas agree on rank 0's tuned plan (engine._autotune, MILLIEYE_TUNE_SYNC=1 - what bench.py sets for N > 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def _tune_sync_worker(rank, world, port, q, cache_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MILLIEYE_TUNE_SYNC="1",
+                      MILLIEYE_TUNE_CACHE=os.path.join(cache_dir, f"tune_rank{rank}.json"))
+    import torch
+    import torch.distributed as dist
+    from millieye_amd import engine
+    from tests import parity_helpers as ph
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = ph.make_darknet("yolov3-tiny-12", tag="tunesync").cuda().eval()
+    model.compute_dtype = "bf16"
+    x = ph.frames("tunesync/x", 2, 96).cuda()
+    if rank == 1:  # a stale private table: every layer on the smallest tile - rank 0's measurement must win
+        os.environ["MILLIEYE_TUNE_SYNC"] = "0"   # (this rank plans alone here)
+        eng = model.engine_for("bf16")
+        with torch.no_grad():
+            model(x)
+        for k in list(engine._TUNE_CACHE):
+            engine._TUNE_CACHE[k] = (3, 1)
+        eng._plans.clear()
+        os.environ["MILLIEYE_TUNE_SYNC"] = "1"
+        dist.barrier()
+    else:
+        dist.barrier()
+    with torch.no_grad():
+        model(x)
+    plan = model.engine_for("bf16").plan_for(x)
+    q.put((rank, [(int(d.tile), int(d.split_k)) for _m, d in plan.conv_descs if d.cin > 4], engine._TUNE_STATS["synced"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_run_rank0s_tuned_plan(hip_lib, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tune_sync_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, tiles, synced = q.get(timeout=600)
+        got[rank] = (tiles, synced)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] and len(got[0][0]) >= 8, got
+    assert got[0][1] >= 1 and got[1][1] >= 1

@@ -97,7 +97,12 @@ def test_conv_wgrad_and_dgrad(hip_lib, cin, cout, k):
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s", [(2, 10, 12, 32, 64, 3, 1), (3, 13, 13, 64, 255, 1, 1), (2, 16, 16, 3, 32, 3, 1),
                                                 (2, 20, 20, 32, 64, 3, 2), (1, 7, 7, 10, 10, 7, 1), (4, 26, 26, 128, 256, 3, 1),
                                                 (1, 5, 9, 48, 20, 3, 1), (3, 33, 41, 3, 32, 3, 2), (2, 24, 24, 3, 72, 3, 1),
-                                                (1, 9, 9, 3, 30, 3, 1), (6, 53, 53, 128, 160, 3, 1), (8, 48, 48, 132, 128, 3, 1)])
+                                                (1, 9, 9, 3, 30, 3, 1), (6, 53, 53, 128, 160, 3, 1), (8, 48, 48, 132, 128, 3, 1),
+                                                # nine-tap kernel (csrc/wgrad9.hip: 3x3 / stride 1, cin and cout multiples of 64):
+                                                # 13 x 13 (two images per slice), one tiny image (a slice shorter than its
+                                                # halo), a wide map (ring of 16 slots), rectangular, several slices
+                                                (5, 13, 13, 64, 64, 3, 1), (1, 4, 5, 64, 128, 3, 1), (2, 104, 104, 64, 64, 3, 1),
+                                                (3, 20, 37, 128, 64, 3, 1), (8, 52, 52, 64, 192, 3, 1)])
 def test_conv_wgrad_mfma(hip_lib, n, h, w, cin, cout, k, s):
     """me_conv_wgrad_mfma_f32 (matrix-pipe weight gradient, sliced pixel reduction + ordered slab sum) against torch
     CPU autograd: stride 2, ragged / unaligned channel counts (cin 3, cout 255), 1x1 and 7x7 (pad 0), many slices; the last
