@@ -65,7 +65,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not os.environ.get("BENCH_TEST_BACKEND"):
         raise SystemExit(f"[bench] --gpus {args.gpus} but only {have} GPU(s) are visible")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -84,7 +84,19 @@ def init_dist(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"[bench] launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree")
-    if "WORLD_SIZE" in os.environ:  # under a launcher (the driver's, or spawn_ranks above): RCCL even at world size 1
+    test_backend = os.environ.get("BENCH_TEST_BACKEND")  # tests only ("gloo"): N ranks share GPU 0 - RCCL refuses two ranks on
+    # one device, and the suite's lease has one GPU; every other line of the N-rank flow is the production one
+    if "WORLD_SIZE" in os.environ and test_backend:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        local = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group(test_backend, rank=rank, world_size=world)
+        probe = torch.ones(1, device=torch.device("cuda", 0))
+        dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            raise SystemExit(f"[bench] all-reduce over {world} ranks returned {probe.item()}")
+    elif "WORLD_SIZE" in os.environ:  # under a launcher (the driver's, or spawn_ranks above): RCCL even at world size 1
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -635,9 +647,22 @@ def main():
                              "of the stage-3 training step (workload train)")
         model.compute_dtype = args.dtype
     t_pre = time.perf_counter() + args.prewarm_seconds
-    while time.perf_counter() < t_pre:
-        step()
-        torch.cuda.synchronize()
+    def lockstep_until(deadline):
+        """Untimed steps until ``deadline`` - the SAME number on every rank (the training steps hold collectives, plan builds
+        broadcast rank 0's tuned table: a rank that ran one step more than its peers would wait for a partner that never
+        comes).  Every rank votes after each step; all stop as soon as one has reached its deadline."""
+        while True:
+            step()
+            torch.cuda.synchronize()
+            go = time.perf_counter() < deadline
+            if world > 1:
+                vote = torch.tensor([1.0 if go else 0.0], device=dev)
+                dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+                go = bool(vote.item() > 0)
+            if not go:
+                break
+
+    lockstep_until(t_pre)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -663,9 +688,7 @@ def main():
         try:
             model.compute_dtype = "bf16"
             t_alt = time.perf_counter() + 0.5
-            while time.perf_counter() < t_alt:
-                step()  # plans + autotunes the bf16 engine, untimed
-                torch.cuda.synchronize()
+            lockstep_until(t_alt)  # plans + autotunes the bf16 engine, untimed
             for _ in range(args.warmup):
                 step()
             torch.cuda.synchronize()

@@ -303,3 +303,31 @@ def test_replicas_run_rank0s_tuned_plan(hip_lib, tmp_path):
         assert p.exitcode == 0
     assert got[0][0] == got[1][0] and len(got[0][0]) >= 8, got
     assert got[0][1] >= 1 and got[1][1] >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole N = 2 flow of bench.py on the one leased GPU (BENCH_TEST_BACKEND=gloo: both ranks on GPU 0): self-launch, lock-step
+# pre-warm (the same number of untimed steps on every rank), rank 0's tuned plan on both replicas, barrier + max-over-ranks
+# timing, and - for the detector training step - the gradients leaving in chunks through GradChunkReducer every step
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench2(extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_TEST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-seconds", "0.3",
+           "--no-cpu-baseline", "--no-bf16-line", "--no-accuracy", "--no-batch-sweep"] + extra
+    res = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_inference_and_detector_training(hip_lib):
+    out = _bench2(["--workload", "full", "--cfg", "yolov3-tiny-12", "--size", "160", "--batch", "4"])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["global_batch"] == 8
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    out = _bench2(["--workload", "detector_train", "--cfg", "yolov3-tiny-12", "--size", "96", "--batch", "2", "--chunk-mb", "1"])
+    assert out["n_gpus"] == 2 and out["config"]["grad_chunks"] >= 4
+    assert out["config"]["grad_bucket_bytes"] > 30e6 and "reverse-layer chunks" in out["config"]["workload"]
+    assert out["config"]["loss_last_step"] == out["config"]["loss_last_step"] and out["roofline"]["by_pass"]["wgrad"]["ms"] > 0
