@@ -347,7 +347,19 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
     float acc[RPB];
 #pragma unroll
     for (int r = 0; r < RPB; ++r) acc[r] = 0.f;
-    for (int k = 0; k < FEAT; ++k) {
+    // four features per trip: one 16-byte broadcast read per RoI instead of four 4-byte ones (round 4: the loop issued eight
+    // ds_read_b32 per FMA group and was bound by LDS instruction issue); the FMA chain of every (RoI, unit) keeps its k order
+    int k = 0;
+    for (; k + 4 <= FEAT; k += 4) {
+      const float w0 = d.wts.w0t[(k + 0) * HID + t], w1 = d.wts.w0t[(k + 1) * HID + t];
+      const float w2 = d.wts.w0t[(k + 2) * HID + t], w3 = d.wts.w0t[(k + 3) * HID + t];
+#pragma unroll
+      for (int r = 0; r < RPB; ++r) {
+        const float4 f = *reinterpret_cast<const float4*>(&s_feat[r][k]);
+        acc[r] = fmaf(w3, f.w, fmaf(w2, f.z, fmaf(w1, f.y, fmaf(w0, f.x, acc[r]))));
+      }
+    }
+    for (; k < FEAT; ++k) {
       const float w = d.wts.w0t[k * HID + t];
 #pragma unroll
       for (int r = 0; r < RPB; ++r) acc[r] = fmaf(w, s_feat[r][k], acc[r]);
