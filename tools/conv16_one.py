@@ -15,6 +15,8 @@ if len(sys.argv) > 5:
     h, cin, cout = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 dev = torch.device("cuda")
 x = torch.randn((n, h, h, cin), device=dev).to(torch.bfloat16)
+if os.environ.get("P8_ZERO_X"):  # DVFS probe: same instructions and traffic, zero products
+    x.zero_()
 w = (torch.randn((cout, k, k, cin), device=dev) / (k * k * cin) ** 0.5).to(torch.bfloat16)
 sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
 r = torch.randn((n, h, h, cout), device=dev).to(torch.bfloat16)
