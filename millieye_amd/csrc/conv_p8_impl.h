@@ -83,12 +83,11 @@ constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 wave
 // (tools/p8_wgmap.py); the per-stage overhead is now paid once per three taps.  Group g of the next chunk is fetched into slot
 // g right behind the barrier that ends the current chunk's group g.
 // DS = 1 (round 4): DMA duty split.  A wave's loads return IN ORDER (vmcnt retires oldest first), so when every wave issues
-// both streams, a weight slab requested behind the next chunk's patch (an HBM / MALL miss, >= 2 us under load) cannot land
-// before that patch does: with the per-tap ring the patch has to be complete within three stages of its issue, and the
-// stamps show the waits exactly there.  With DS the lower half of the waves issues ONLY weight slabs (L2 hits, needed soon),
-// the upper half ONLY the patch (needed at the next chunk): the weight queue never waits behind a miss, and the patch has
-// the whole chunk to arrive.
-// RB (PIPE = 2 only): slots of the weight ring; a slab is requested RB - 1 stages before its stage.
+// both streams, a weight slab requested behind the next chunk's patch (an HBM / MALL miss) cannot land before that patch
+// does.  With DS the lower half of the waves issues ONLY weight slabs (L2 hits, needed soon), the upper half ONLY the patch
+// (needed at the next chunk).  Measured: neutral to +2 % (profiles/r04_kernel_evolution.md section 1 - the waits it removes
+// were not what bounds the kernel); kept as autotuner candidates (tile ids 621 / 721 / 731).
+// RB (PIPE = 2 only): slots of the weight ring; a slab is requested RB - 1 stages before its stage (deeper rings: slower).
 template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false, int TG = 1, int DS = 0, int RB = 3>
 __global__ __launch_bounds__(64 * WR * WC)
     __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
