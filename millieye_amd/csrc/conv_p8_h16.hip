@@ -124,8 +124,12 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   a.Mp = (long long)p.n * a.Ip;
   a.rows = BM + 2 * a.halo;
   constexpr int NWAVES = WR * WC;
-  constexpr int NWA = DS ? NWAVES / 2 : NWAVES;   // waves that fetch the patch (DS: the upper half, see conv_p8_impl.h)
+  constexpr int NWA = DS ? NWAVES / 2 : NWAVES;   // waves that fetch the patch (DS: the upper half, see conv_p8_impl.h; DS = 4: the four loader waves)
   a.lpa = ((a.rows + 15) / 16 + NWA - 1) / NWA;
+  if (DS == 4) {
+    ME_REQUIRE(a.lpa <= kLpaMax, ME_E_TOOBIG, "me_conv2d_h16: patch of %d rows does not fit (map too wide for this tile)", a.rows);
+    a.lpa = kLpaMax;   // static DMA bookkeeping: every loader issues seven pieces per chunk (the surplus ones out of range)
+  }
   ME_REQUIRE(a.lpa <= kLpaMax, ME_E_TOOBIG, "me_conv2d_h16: patch of %d rows does not fit (map too wide for this tile)", a.rows);
   ME_REQUIRE(a.Mp < (1ll << 31), ME_E_TOOBIG, "me_conv2d_h16: too many padded positions");
   magic_u32((unsigned)a.Ip, &a.ip_m, &a.ip_s);
@@ -170,13 +174,13 @@ int launch_p8(const Conv16P& p, hipStream_t stream) {
   }();
   a.c.nmap = (nmap_env && a.c.splitk == 1 && a.c.tiles_n <= 8 && 8 % a.c.tiles_n == 0) ? 1 : 0;
   if (a.c.splitk > 1)
-    hipLaunchKernelGGL(kern_sk, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
+    hipLaunchKernelGGL(kern_sk, dim3((unsigned)blocks), dim3(64 * (NWAVES + (DS == 4 ? 4 : 0))), lds, stream, a);
   else if (a.c.nmap) {
     const int G = 8 / a.c.tiles_n;
     const unsigned per_xcd = (unsigned)((a.c.tiles_m + G - 1) / G);
-    hipLaunchKernelGGL(kern, dim3(8u * per_xcd), dim3(64 * NWAVES), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(8u * per_xcd), dim3(64 * (NWAVES + (DS == 4 ? 4 : 0))), lds, stream, a);
   } else
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (NWAVES + (DS == 4 ? 4 : 0))), lds, stream, a);
   int rc = me::check_launch("conv3x3_p8_h16");
   if (rc || a.c.splitk == 1) return rc;
   long long rb = (tiles * BM * (BN / 8) + 255) / 256;
@@ -211,7 +215,7 @@ void p8_tile_shape(int tile, int* bm, int* bn) {
                                {621, 256, 128},
                                {721, 256, 128}, {731, 384, 128},
                                {810, 192, 256}, {820, 256, 256}, {821, 256, 128}, {831, 384, 128},
-                               {841, 512, 128}};
+                               {841, 512, 128}, {1210, 192, 256}, {1221, 256, 128}, {1231, 384, 128}};
   *bm = *bn = 0;
   for (const auto& t : ids)
     if (t[0] == tile) {
@@ -274,6 +278,13 @@ int launch_p8_tile(const Conv16P& p, int tile, hipStream_t stream) {
     case 821: return ME_P8R(4, 2, 2, 2, 3);   // 256 x 128
     case 831: return ME_P8R(4, 2, 3, 2, 3);   // 384 x 128
     case 841: return ME_P8R(4, 2, 4, 2, 3);   // 512 x 128
+    // ... + four loader waves (DS = 4): the consumers' load segment is fragment reads only
+#define ME_P8L(WR, WC, MT, NT) \
+  (p.f16 ? launch_p8<WR, WC, MT, NT, 2, 1, 1, 0, 1, 4, 3>(p, stream) : launch_p8<WR, WC, MT, NT, 2, 1, 0, 0, 1, 4, 3>(p, stream))
+    case 1210: return ME_P8L(2, 4, 3, 2);   // 192 x 256
+    case 1221: return ME_P8L(4, 2, 2, 2);   // 256 x 128
+    case 1231: return ME_P8L(4, 2, 3, 2);   // 384 x 128
+#undef ME_P8L
 #undef ME_P8R
     default: break;
   }

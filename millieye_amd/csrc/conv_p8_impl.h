@@ -87,10 +87,15 @@ constexpr int kLpaMax = 7;  // patch DMA instructions per wave and chunk (8 wave
 // does.  With DS the lower half of the waves issues ONLY weight slabs (L2 hits, needed soon), the upper half ONLY the patch
 // (needed at the next chunk).  Measured: neutral to +2 % (profiles/r04_kernel_evolution.md section 1 - the waits it removes
 // were not what bounds the kernel); kept as autotuner candidates (tile ids 621 / 721 / 731).
+// DS = 4 (PIPE = 2): four LOADER waves beside the eight consumers (12 waves, <= 168 VGPRs): waves 8-11 issue every LDS-DMA
+// of the workgroup (weights: BN / 64 pieces per stage each; patch: seven pieces per chunk each, spread over taps 0-5,
+// pieces behind the patch's end are out-of-range no-ops so that the vmcnt bookkeeping is static) and the consumers' load
+// segment is fragment reads only - the ablation without DMA instructions ran the ping-pong loop at 84 % of the matrix pipe.
 // RB (PIPE = 2 only): slots of the weight ring; a slab is requested RB - 1 stages before its stage (deeper rings: slower).
 template <int WR, int WC, int MT, int NT, int PIPE, int MINB, class DT, int ABL = 0, bool SK = false, int TG = 1, int DS = 0, int RB = 3>
-__global__ __launch_bounds__(64 * WR * WC)
-    __attribute__((amdgpu_waves_per_eu(WR * WC * MINB / 4, WR * WC * MINB / 4))) void conv3x3_p8_kernel(P8Args a) {
+__global__ __launch_bounds__(64 * (WR * WC + (DS == 4 ? 4 : 0)))
+    __attribute__((amdgpu_waves_per_eu((WR * WC * MINB + (DS == 4 ? 4 : 0)) / 4, (WR * WC * MINB + (DS == 4 ? 4 : 0)) / 4))) void
+    conv3x3_p8_kernel(P8Args a) {
   using frag = typename DT::frag;
   const P8Conv& p = a.c;
   constexpr int NW = WR * WC;
@@ -101,8 +106,8 @@ __global__ __launch_bounds__(64 * WR * WC)
   constexpr int LPB = BN / 16 / NWB;
   static_assert(LPB >= 1 && BN % 128 == 0, "BN must be a multiple of 128");
   static_assert(TG == 1 || (TG == 3 && PIPE == 1), "tap groups need the register-pipelined variant");
-  static_assert(PIPE != 2 || (NW == 8 && MINB == 1 && TG == 1 && (DS == 0 || DS == 2)), "ping-pong: one 8-wave workgroup per CU");
-  static_assert(DS != 2 || PIPE == 2, "the spread duty split belongs to the ping-pong variant");
+  static_assert(PIPE != 2 || (NW == 8 && MINB == 1 && TG == 1 && (DS == 0 || DS == 2 || DS == 4)), "ping-pong: one 8-wave workgroup per CU");
+  static_assert((DS != 2 && DS != 4) || PIPE == 2, "the spread duty splits belong to the ping-pong variant");
   constexpr unsigned B_TAP = BN * 64u;            // one tap's weight slab of a chunk
   constexpr unsigned B_SLOT = TG * B_TAP;         // a ring slot: one tap, or a group of three
   static_assert(RB == 3 || (PIPE == 2 && RB >= 3 && RB <= 9), "deeper rings: ping-pong variant only");
@@ -142,10 +147,11 @@ __global__ __launch_bounds__(64 * WR * WC)
   const unsigned A_SLOT = (unsigned)lpa * (NWA * 1024u);
   // wave-uniform roles.  DS = 1: waves 0-3 weights, 4-7 patch.  DS = 2 (ping-pong): waves 0, 1 of each half fetch weights,
   // waves 2, 3 of each half the patch - and they spread it over the taps (below)
-  const bool is_b = DS == 2 ? ((wave >> 1) & 1) == 0 : (!DS || wave < NWB);
-  const bool is_a = DS == 2 ? ((wave >> 1) & 1) == 1 : (!DS || wave >= NW - NWA);
-  const int wa = DS == 2 ? (wave & 1) + 2 * (wave >> 2) : wave - (NW - NWA);   // patch-wave index (meaningful when is_a)
-  const int wbi = DS == 2 ? (wave & 1) + 2 * (wave >> 2) : wave;               // weight-wave index (meaningful when is_b)
+  const bool is_loader = DS == 4 && wave >= NW;   // DS = 4: waves 8-11 only load, waves 0-7 only multiply
+  const bool is_b = DS == 4 ? is_loader : DS == 2 ? ((wave >> 1) & 1) == 0 : (!DS || wave < NWB);
+  const bool is_a = DS == 4 ? is_loader : DS == 2 ? ((wave >> 1) & 1) == 1 : (!DS || wave >= NW - NWA);
+  const int wa = DS == 4 ? wave - NW : DS == 2 ? (wave & 1) + 2 * (wave >> 2) : wave - (NW - NWA);   // patch-wave index (meaningful when is_a)
+  const int wbi = DS == 4 ? wave - NW : DS == 2 ? (wave & 1) + 2 * (wave >> 2) : wave;               // weight-wave index (meaningful when is_b)
 
   // first image the patch can touch: descriptor base, so that per-lane offsets stay small and non-negative
   const long long pq0 = q0 - a.halo;
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(64 * WR * WC)
   //   WAR: slab s + 2 goes to the ring slot of slab s - 1, last read by G1 in slot 2s - 1; G0 issues it in slot 2s.
   if constexpr (PIPE == 2) {
     constexpr int D = RB - 1;   // prefetch distance in stages
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int grp = is_loader ? 0 : __builtin_amdgcn_readfirstlane(wave >> 2);   // (loaders keep the first half's barrier count)
     auto wait_vm = [&](auto nc, bool plus_patch) {   // vmcnt(N [+ lpa]); s_waitcnt takes an immediate
       constexpr int N = decltype(nc)::value;
       if (!plus_patch) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); return; }
@@ -559,12 +565,58 @@ __global__ __launch_bounds__(64 * WR * WC)
     };
     if (NODMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else if (DS == 2 && is_a) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (DS == 4 && !is_loader) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * LPB) : "memory");   // patch 0 and slab 0 have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (grp == 1) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+    }
+    if constexpr (DS == 4) {
+      if (is_loader) {
+        // The loader waves' own loop (kept apart from the consumers' unrolled stages: sharing the stage body made the register
+        // allocator spill the accumulators).  Slot 2s: this stage's requests (slab s + 2, the next chunk's patch in pieces);
+        // end of slot 2s + 1: my pieces of slab s + 1 have landed.  Younger than that slab: the patch pieces of stage s - 1
+        // (issued behind it), slab s + 2, the patch pieces of this stage - static counts (a.lpa == 7: pieces past the
+        // patch's end are no-ops that still count).
+        int lrs = 0;
+        auto loader_stage = [&](auto tc, int chunk) {
+          constexpr int T = decltype(tc)::value;
+          const bool more_chunks = chunk + 1 < cs;
+          constexpr int T2 = (T + 2) % 9;
+          const int c2 = chunk + (T + 2 >= 9 ? 1 : 0);
+          if (c2 < cs) issue_b(c2, T2, (unsigned)(lrs == 0 ? RB - 1 : lrs - 1));
+          if (more_chunks) {
+            const unsigned sl = (unsigned)((chunk + 1) & 1);
+            if constexpr (T == 0) {
+              issue_a_piece(chunk + 1, sl, std::integral_constant<int, 0>{});
+              issue_a_piece(chunk + 1, sl, std::integral_constant<int, 1>{});
+            } else if constexpr (T <= 5) {
+              issue_a_piece(chunk + 1, sl, std::integral_constant<int, T + 1>{});
+            }
+          }
+          if (ABL != 5) __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          constexpr int NPP_PREV = T == 0 ? 0 : T == 1 ? 2 : T <= 6 ? 1 : 0;   // patch pieces issued at stage T - 1 / T
+          constexpr int NPP_THIS = T == 0 ? 2 : T <= 5 ? 1 : 0;
+          if (!NODMA) {
+            if (more_chunks) {
+              asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPP_PREV + LPB + NPP_THIS) : "memory");
+            } else if constexpr (T < 8) {
+              asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T <= 6 ? LPB : 0) : "memory");
+            }
+          }
+          if (ABL != 5) __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          lrs = lrs + 1 == RB ? 0 : lrs + 1;
+        };
+        for (int chunk = 0; chunk < cs; ++chunk)
+          static_for([&](auto tc) { loader_stage(tc, chunk); }, std::make_integer_sequence<int, 9>{});
+        if (ABL != 5) __builtin_amdgcn_s_barrier();          // the first half's closing barrier
+        if (DT::kBytes == 2 && !SK && ABL != 6) __syncthreads();   // the barrier the epilogue opens with, then out
+        return;
+      }
     }
     int rs = 0;   // ring slot of the current stage; the slab D stages ahead goes to the slot of the stage before this one
     auto stage_pp = [&](auto tc, int chunk) {
@@ -574,7 +626,7 @@ __global__ __launch_bounds__(64 * WR * WC)
       // slabs behind it (fewer at the very end) and - when it was requested before this chunk's tap-0 patch burst, i.e. for
       // T < D - the next chunk's patch.  Entering a chunk (T = 8) its patch is older than the slab, so it has landed too.
       auto wait_next = [&]() {
-        if (NODMA) return;
+        if (NODMA || DS == 4) return;   // (DS = 4: the consumers have nothing in flight; the loaders wait in their own branch)
         if constexpr (DS == 2) {
           // weight waves never queue behind a patch piece; patch waves: everything of the next chunk by the end of tap 8
           if (is_a) {
@@ -595,12 +647,16 @@ __global__ __launch_bounds__(64 * WR * WC)
         }
       };
       stamp();
+      if constexpr (DS == 4) {
+        // (the loaders run their own loop in front of this one; the consumers request nothing)
+      } else
       {
         constexpr int T2 = (T + D) % 9;
         const int c2 = chunk + (T + D >= 9 ? 1 : 0);
         if (c2 < cs) issue_b(c2, T2, (unsigned)(rs == 0 ? RB - 1 : rs - 1));
       }
-      if constexpr (DS == 2) {
+      if constexpr (DS == 4) {
+      } else if constexpr (DS == 2) {
         // the next chunk's patch leaves in small steps (two pieces at tap 0, one per tap after): a burst of up to 28 KB of
         // misses in front of the weight slabs was what made the two streams cost more together than the sum of each alone
         if (more_chunks) {

@@ -879,6 +879,7 @@ _TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      # 8xx = ping-pong halves (one workgroup per CU, its halves half a stage apart)
                      621: (256, 128), 721: (256, 128), 731: (384, 128),
                      810: (192, 256), 820: (256, 256), 821: (256, 128), 831: (384, 128), 841: (512, 128),
+                     1210: (192, 256), 1221: (256, 128), 1231: (384, 128),  # ping-pong + four loader waves
                      # weight-stationary streaming 1x1 (csrc/conv1x1_ws_h16.hip): persistent grid, 32-row tiles, no split-K
                      50: (32, 256),
                      # weight-stationary 3x3 for cin 32 / 64 (csrc/conv3x3_ws_h16.hip): 2-D tiles, persistent grid, no split-K
@@ -887,7 +888,7 @@ _TUNE_TILES_TAIL = (41, 42, 43, 44, 45)  # fp32: tiles 1-5 with the last partial
 _TUNE_TILES_P8_F32 = (201, 221)  # fp32 is matrix-pipe bound: the big tiles' pad positions / quantisation cost more than
 # their traffic saves (tools/p8_bench_f32.py: only the 2-workgroup tiles come close to the 64x64 per-tap tile)
 _TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321, 421, 431, 441,   # 4xx: a barrier per three taps
-                  621, 721, 731, 810, 831)  # round 4: duty split, ping-pong
+                  621, 721, 731, 810, 831, 1210, 1231)  # round 4: duty split, ping-pong, ping-pong + loader waves
 
 
 def _autotune_enabled():
@@ -901,7 +902,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v13.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v14.json")  # bump with every kernel generation
 
 
 def _tune_load():

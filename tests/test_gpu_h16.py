@@ -359,9 +359,9 @@ def test_detector_16bit_608_batch16(hip_lib, dtype):
     assert e_batch <= bound, f"{dtype}: mean relative error vs fp32 {e_batch:.2e}"
 
 
-P8_TILES_256 = (100, 110, 120, 200, 810, 820)
+P8_TILES_256 = (100, 110, 120, 200, 810, 820, 1210)
 P8_TILES_128 = (101, 121, 131, 141, 201, 221, 301, 311, 321, 331, 421, 431, 441,
-                621, 721, 731, 821, 831, 841)   # 6xx / 7xx: DMA duty split, 8xx: ping-pong halves (round 4)
+                621, 721, 731, 821, 831, 841, 1221, 1231)   # 6xx / 7xx: DMA duty split, 8xx: ping-pong halves (round 4)
 P8_CASES = [
     # name, n, h, w, cin, cout, act, res
     ("13x13 two images per tile", 5, 13, 13, 64, 256, 1, True),

@@ -13,7 +13,7 @@ LAYERS = [(208, 32, 64), (104, 64, 128), (52, 128, 256), (26, 256, 512), (13, 51
 if os.environ.get("P8_KSCAN"):   # fixed output shape, K swept: fixed cost (prologue + epilogue) vs per-stage cost
     LAYERS = [(26, 32, 512), (26, 64, 512), (26, 128, 512), (26, 256, 512), (26, 512, 512)]
 OLD = (1, 2, 3, 4, 11, 12, 13, 14)
-NEW = (110, 121, 131, 200, 201, 221, 301, 311, 321, 331, 421, 431, 441, 621, 721, 731, 810, 820, 821, 831, 841)
+NEW = (110, 121, 131, 200, 201, 221, 301, 311, 321, 331, 421, 431, 441, 621, 721, 731, 810, 820, 821, 831, 841, 1210, 1221, 1231)
 
 
 def time_tile(x, w, sc, sh, r, out, tile, reps=20, split=1):
