@@ -183,14 +183,25 @@ def stage_roofline(model, net, x, step, rois, reps=5):
         for k, v in work.items():
             e[k] += v
 
-    engine.run(x)
+    _plan, _rows_alive = engine.run(x)  # (the decode descriptors point into this tensor)
     torch.cuda.synchronize()
+    # Network.forward's detector run decodes all [yolo] scales in one launch that also fills the NMS candidate lists
+    cand = None
+    if net is not None and getattr(plan, "yolo_tail", None) is not None:
+        cand = (float(net.conf_thresh), hip.nms_workspace(plan.n, plan.rows, x.device)[0])
     for _ in range(reps):
         evs = []
+        decoded = False
         for fn, args, _k, name in plan.launches:
+            if cand is not None and name.startswith("yolo") and decoded:
+                continue
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            fn(*args, stream)
+            if cand is not None and name.startswith("yolo"):
+                lib.me_yolo_decode_cand_multi_f32(plan.yolo_tail, len(plan.yolo_tail), cand[0], cand[1], 1, stream)
+                decoded = True
+            else:
+                fn(*args, stream)
             b.record()
             evs.append((name, fn, a, b))
         torch.cuda.synchronize()
@@ -206,11 +217,13 @@ def stage_roofline(model, net, x, step, rois, reps=5):
                         flops=float(_conv_flops(d)))
             elif fn is lib.me_yolo_decode_f32:
                 rows_c = plan.rows * (5 + (plan.num_classes or 0))
-                add("YOLO decode", ms, bytes=0.0)  # bytes added once below (three launches share the output tensor)
+                add("YOLO decode", ms, bytes=0.0)  # bytes added once below (the scales share the output tensor)
             else:
                 add("pool / copy", ms)
     if "YOLO decode" in acc:
         acc["YOLO decode"]["bytes"] = reps * 2.0 * 4.0 * n * plan.rows * (5 + (plan.num_classes or 0))
+        if cand is not None:  # the launch the full pipeline really issues
+            acc["YOLO decode + NMS candidate lists (one launch for the three scales)"] = acc.pop("YOLO decode")
     if net is not None:
         marks = []
         net._stage_cb = lambda name: marks.append((name, _ev()))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 8
+#define ME_ABI_VERSION 9
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -185,6 +185,10 @@ int me_nms_batched_f32(const me_nms_desc* d, void* stream);
  * me_nms_batched_prepped_f32 then runs selection + emit on those lists (same desc as me_nms_batched_f32, same workspace,
  * writeback_xyxy must be 0).  Results are identical to me_yolo_decode_f32 + me_nms_batched_f32. */
 int me_yolo_decode_cand_f32(const me_yolo_desc* y, float conf_thresh, void* nms_workspace, int32_t first, void* stream);
+/* the same for 1 - 3 [yolo] scales of one forward in ONE launch (Darknet.forward's three decodes, yolov3/models.py:259-262, once
+ * the last head convolution has run); the scales share n, rows_total and out. */
+int me_yolo_decode_cand_multi_f32(const me_yolo_desc* const* ys, int32_t count, float conf_thresh, void* nms_workspace,
+                                  int32_t first, void* stream);
 int me_nms_batched_prepped_f32(const me_nms_desc* d, void* stream);
 
 /* plain torchvision-style nms / batched_nms on explicit boxes (box_ops.* re-export used by
@@ -259,7 +263,7 @@ typedef struct me_heads_desc {
   float* refine_out;
   float* mask1_out;
   float* out_rows;
-  uint8_t* keep;
+  uint8_t* keep;               /* [cap]: 1 = row kept; the launch also writes 0 into the slots behind the last RoI */
   float* sort_key;
   /* training mode (all four non-NULL): the launch stops after the pooled features / hidden layer /
    * small dot products and stores them for the backward pass instead of running the scalar tail:
@@ -275,6 +279,11 @@ typedef struct me_heads_desc {
    * per CU to hide them behind) and the heads kernel reads the pooled features back; same samples, same arithmetic.  NULL =
    * the single fused launch. */
   float* pool_scratch;
+  /* 1: img_map holds the 490 score-map channels bin-major - channel (ph * 7 + pw) * 10 + c_out instead of the reference's
+   * (c_out * 7 + ph) * 7 + pw (my_models.py:47-52 feeds ps_roi_align) - so that the ten values a PS-RoIAlign sample point needs
+   * are 40 contiguous bytes; the caller permutes the output channels of the 1x1 convolution that writes the map (its weight
+   * rows), nothing else changes.  0: reference order. */
+  int32_t img_bin_major;
 } me_heads_desc;
 int me_roi_heads_f32(const me_heads_desc* d, void* stream);
 /* me_compact_sort_rows_f32 - the tail of Network.forward (my_models.py:517-539): keep the rows whose `keep` byte is set

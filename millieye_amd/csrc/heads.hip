@@ -15,6 +15,8 @@
 
 namespace {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 constexpr int P = 7;            // pooled size (my_models.py:495-496)
 constexpr int PP = P * P;       // 49
 constexpr int C_OUT = 10;       // score-map groups
@@ -205,11 +207,20 @@ __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.1f * v;
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
 // scalar tail of one RoI (shared by the fused inference kernel and me_heads_tail_f32)
-__device__ void tail_one(const me_heads_desc& d, const float* sm, const float* roi, int k, int n_img) {
+struct TailW {  // the tail's small weights: ensemble head fc1 [32][2] / bias [32] / fc2 [2][64], radar_net BN + 1x1
+  const float *e1w, *e1b, *e2w, *rw2, *rscale, *rshift, *rb2;
+};
+__device__ __forceinline__ TailW tail_weights(const me_heads_desc& d) {
+  return TailW{d.wts.e1w, d.wts.e1b, d.wts.e2w, d.wts.rw2, d.wts.rscale, d.wts.rshift, d.wts.rb2};
+}
+
+__device__ __forceinline__ void tail_one(const me_heads_desc& d, const float* sm, const float* roi, int k, int n_img,
+                                         const TailW& tw) {
+  const float *e1w = tw.e1w, *e1b = tw.e1b, *e2w = tw.e2w;
   const float cls0 = sigmoidf(sm[4]), cls1 = sigmoidf(sm[5]);
-  float rad = d.wts.rb2[0];
+  float rad = tw.rb2[0];
 #pragma unroll
-  for (int o = 0; o < C_OUT; ++o) rad = fmaf(d.wts.rw2[o], leaky(sm[6 + o] * d.wts.rscale[o] + d.wts.rshift[o]), rad);
+  for (int o = 0; o < C_OUT; ++o) rad = fmaf(tw.rw2[o], leaky(sm[6 + o] * tw.rscale[o] + tw.rshift[o]), rad);
   const float radar_conf = sigmoidf(rad);
   const float conf = sigmoidf(radar_conf + cls0);  // sigmoid applied twice on purpose (quirk q2)
   const bool is_img = k < n_img;
@@ -222,11 +233,11 @@ __device__ void tail_one(const me_heads_desc& d, const float* sm, const float* r
     float o0 = d.wts.e2b[0], o1 = d.wts.e2b[1];
 #pragma unroll 4
     for (int u = 0; u < 32; ++u) {
-      const float wa = d.wts.e1w[2 * u], wb = d.wts.e1w[2 * u + 1], bb = d.wts.e1b[u];
+      const float wa = e1w[2 * u], wb = e1w[2 * u + 1], bb = e1b[u];
       const float h0 = leaky(wa * conf + wb * yolo0 + bb);
       const float h1 = leaky(wa * cls1 + wb * yolo1 + bb);
-      o0 += d.wts.e2w[u] * h0 + d.wts.e2w[32 + u] * h1;
-      o1 += d.wts.e2w[64 + u] * h0 + d.wts.e2w[96 + u] * h1;
+      o0 += e2w[u] * h0 + e2w[32 + u] * h1;
+      o1 += e2w[64 + u] * h0 + e2w[96 + u] * h1;
     }
     const float m = fmaxf(o0, o1);
     const float e0 = expf(o0 - m), e1 = expf(o1 - m);
@@ -259,31 +270,161 @@ __device__ void tail_one(const me_heads_desc& d, const float* sm, const float* r
   o[0] = roi[0]; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = p; o[6] = c6; o[7] = c7;
 }
 
-// RoI pooling of one RoI per workgroup into d.pool_scratch [cap][2 * FEAT] (see me_heads_desc.pool_scratch)
+// RoI pooling of one RoI per workgroup into d.pool_scratch [cap][2 * FEAT] (see me_heads_desc.pool_scratch).  Thread order:
+// (bin, channel) with the channel fastest - the ten lanes of a bin share their sample points, so on the radar map (NHWC, 10
+// channels) and on a bin-major image map (me_heads_desc.img_bin_major) a sample corner is ONE 40-byte read per ten lanes instead
+// of ten cache lines; the values go through LDS to their slots f = c * 49 + bin and leave as contiguous rows.
 __global__ __launch_bounds__(256) void roi_pool_kernel(me_heads_desc d) {
   __shared__ float s_box[5];
+  __shared__ float s_out[2 * FEAT];
   const int t = threadIdx.x;
   const int n_img = *d.n_img;
   const int k = blockIdx.x;
   if (k >= n_img + d.n_radar) return;
   if (t < 5) s_box[t] = (k < n_img) ? d.img_boxes[(long long)k * d.box_cols + t] : d.radar_boxes[(long long)(k - n_img) * 5 + t];
   __syncthreads();
-  float* out = d.pool_scratch + (long long)k * 2 * FEAT;
-  for (int f = t; f < 2 * FEAT; f += 256) {
+  for (int i = t; i < 2 * FEAT; i += 256) {
+    const int part = i >= FEAT ? 1 : 0, q = i - part * FEAT;
+    const int bin = q / C_OUT, c = q - bin * C_OUT;
+    const int ph = bin / P, pw = bin - ph * P;
+    const int f = c * PP + bin;  // = (c * 7 + ph) * 7 + pw
     float v;
-    if (f < FEAT) {
-      const int pw = f % P, ph = (f / P) % P;
-      v = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_box, d.spatial_scale, f, ph, pw);
-    } else {
-      const int g = f - FEAT;
-      const int pw = g % P, ph = (g / P) % P, c = g / PP;
-      v = roi_sample(d.radar_map, d.radar_pitch, d.rh, d.rw, s_box, d.spatial_scale, c, ph, pw);
-    }
-    out[f] = v;
+    if (!part) v = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_box, d.spatial_scale, d.img_bin_major ? q : f, ph, pw);
+    else v = roi_sample(d.radar_map, d.radar_pitch, d.rh, d.rw, s_box, d.spatial_scale, c, ph, pw);
+    s_out[part * FEAT + f] = v;
   }
+  __syncthreads();
+  float* out = d.pool_scratch + (long long)k * 2 * FEAT;
+  for (int f = t; f < 2 * FEAT; f += 256) out[f] = s_out[f];
 }
 
-__global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
+// ---- the same pooling, one thread per BIN and all ten channels --------------------------------------------------------------------
+// roi_pool_kernel is VALU-bound: every (bin, channel) thread redoes the bin's sample geometry (two divisions per sample point,
+// the range tests, the bilinear weights) - ten times per bin.  Here a thread owns a bin: geometry and weights once per sample
+// point, then ten (value * weight) sums whose corner values are contiguous floats.  Per channel the operations and their
+// order are those of ps_sample / roi_sample + bilinear_nhwc above (FP contraction off), so the pooled values are the same bits.
+__device__ __forceinline__ void bilinear10(const float* img, long long pitch, int height, int width, int cbase, int cstride,
+                                           float y, float x, float* acc) {
+#pragma clang fp contract(off)
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return;  // (the sample is +0: acc + 0 = acc)
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - y_low, lx = x - x_low;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  const float* p1 = img + ((long long)y_low * width + x_low) * pitch + cbase;
+  const float* p2 = img + ((long long)y_low * width + x_high) * pitch + cbase;
+  const float* p3 = img + ((long long)y_high * width + x_low) * pitch + cbase;
+  const float* p4 = img + ((long long)y_high * width + x_high) * pitch + cbase;
+  float v1[C_OUT], v2[C_OUT], v3[C_OUT], v4[C_OUT];
+#pragma unroll
+  for (int c = 0; c < C_OUT; ++c) {
+    v1[c] = p1[c * cstride];
+    v2[c] = p2[c * cstride];
+    v3[c] = p3[c * cstride];
+    v4[c] = p4[c * cstride];
+  }
+#pragma unroll
+  for (int c = 0; c < C_OUT; ++c) acc[c] += (w1 * v1[c] + w2 * v2[c] + w3 * v3[c] + w4 * v4[c]);
+}
+
+// bin (ph, pw) of torchvision.ops.ps_roi_align: channels cbase + c * cstride, c < 10
+__device__ void ps_sample10(const float* map, long long pitch, int height, int width, const float* roi, float scale,
+                            int cbase, int cstride, int ph, int pw, float* out) {
+#pragma clang fp contract(off)
+  const int b = (int)roi[0];
+  const float sw = roi[1] * scale - 0.5f, sh = roi[2] * scale - 0.5f;
+  const float ew = roi[3] * scale - 0.5f, eh = roi[4] * scale - 0.5f;
+  const float roi_w = ew - sw, roi_h = eh - sh;
+  const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
+  const float hstart = (float)ph * bin_h + sh;
+  const float wstart = (float)pw * bin_w + sw;
+  const int gh = grid_of(roi_h), gw = grid_of(roi_w);
+  const float count = (float)(gh * gw);
+  const float* img = map + (long long)b * height * width * pitch;
+  int ylo, yhi, xlo, xhi;
+  sample_range(hstart, bin_h, gh, (float)height, &ylo, &yhi);
+  sample_range(wstart, bin_w, gw, (float)width, &xlo, &xhi);
+  float acc[C_OUT];
+#pragma unroll
+  for (int c = 0; c < C_OUT; ++c) acc[c] = 0.f;
+  for (int iy = ylo; iy <= yhi; ++iy) {
+    const float y = hstart + ((float)(iy + .5f)) * bin_h / (float)gh;
+    for (int ix = xlo; ix <= xhi; ++ix) {
+      const float x = wstart + ((float)(ix + .5f)) * bin_w / (float)gw;
+      bilinear10(img, pitch, height, width, cbase, cstride, y, x, acc);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C_OUT; ++c) out[c] = acc[c] / count;
+}
+
+// bin (ph, pw) of torchvision.ops.roi_align(aligned=False, sampling_ratio=-1): channels 0 .. 9
+__device__ void roi_sample10(const float* map, long long pitch, int height, int width, const float* roi, float scale,
+                             int ph, int pw, float* out) {
+#pragma clang fp contract(off)
+  const int b = (int)roi[0];
+  const float sw = roi[1] * scale - 0.0f, sh = roi[2] * scale - 0.0f;
+  const float ew = roi[3] * scale - 0.0f, eh = roi[4] * scale - 0.0f;
+  float roi_w = ew - sw, roi_h = eh - sh;
+  roi_w = roi_w > 1.f ? roi_w : 1.f;
+  roi_h = roi_h > 1.f ? roi_h : 1.f;
+  const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
+  const int gh = grid_of(roi_h), gw = grid_of(roi_w);
+  const int cnt = gh * gw;
+  const float count = (float)(cnt > 1 ? cnt : 1);
+  const float* img = map + (long long)b * height * width * pitch;
+  const float ybase = sh + ph * bin_h, xbase = sw + pw * bin_w;
+  int ylo, yhi, xlo, xhi;
+  sample_range(ybase, bin_h, gh, (float)height, &ylo, &yhi);
+  sample_range(xbase, bin_w, gw, (float)width, &xlo, &xhi);
+  float acc[C_OUT];
+#pragma unroll
+  for (int c = 0; c < C_OUT; ++c) acc[c] = 0.f;
+  for (int iy = ylo; iy <= yhi; ++iy) {
+    const float yy = ybase + ((float)(iy + .5f)) * bin_h / (float)gh;
+    for (int ix = xlo; ix <= xhi; ++ix) {
+      const float xx = xbase + ((float)(ix + .5f)) * bin_w / (float)gw;
+      bilinear10(img, pitch, height, width, 0, 1, yy, xx, acc);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C_OUT; ++c) out[c] = acc[c] / count;
+}
+
+// one RoI per workgroup of 128 threads: thread t < 49 = image bin t, 49 <= t < 98 = radar bin t - 49
+__global__ __launch_bounds__(128) void roi_pool10_kernel(me_heads_desc d) {
+  __shared__ float s_box[5];
+  __shared__ float s_out[2 * FEAT];
+  const int t = threadIdx.x;
+  const int n_img = *d.n_img;
+  const int k = blockIdx.x;
+  if (k >= n_img + d.n_radar) return;
+  if (t < 5) s_box[t] = (k < n_img) ? d.img_boxes[(long long)k * d.box_cols + t] : d.radar_boxes[(long long)(k - n_img) * 5 + t];
+  __syncthreads();
+  if (t < 2 * PP) {
+    const int part = t >= PP ? 1 : 0, bin = t - part * PP;
+    const int ph = bin / P, pw = bin - ph * P;
+    float o[C_OUT];
+    if (!part) {
+      if (d.img_bin_major) ps_sample10(d.img_map, d.img_pitch, d.fh, d.fw, s_box, d.spatial_scale, bin * C_OUT, 1, ph, pw, o);
+      else ps_sample10(d.img_map, d.img_pitch, d.fh, d.fw, s_box, d.spatial_scale, bin, PP, ph, pw, o);
+    } else {
+      roi_sample10(d.radar_map, d.radar_pitch, d.rh, d.rw, s_box, d.spatial_scale, ph, pw, o);
+    }
+#pragma unroll
+    for (int c = 0; c < C_OUT; ++c) s_out[part * FEAT + c * PP + bin] = o[c];
+  }
+  __syncthreads();
+  float* out = d.pool_scratch + (long long)k * 2 * FEAT;
+  for (int f = t; f < 2 * FEAT; f += 128) out[f] = s_out[f];
+}
+
+template <int KC>  // rows of W0 per prefetched chunk (phase B)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KC == 4 ? 4 : 2))) void roi_heads_kernel(me_heads_desc d) {
   __shared__ __attribute__((aligned(16))) float s_feat[RPB][2 * FEAT];  // [r][0:490] image (PS-RoIAlign), [490:980] radar (RoIAlign)
   __shared__ float s_hid[RPB][HID];
   __shared__ float s_small[RPB][16];       // 0-3 reg, 4-5 cls logits(0,1), 6-15 radar conv
@@ -293,6 +434,8 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
   const int n_img = *d.n_img;
   const int total = n_img + d.n_radar;
   const int k0 = blockIdx.x * RPB;
+  // slots behind the last RoI keep nothing (me_compact_sort_rows_f32 reads keep[0 : cap]; the caller need not clear it)
+  if (t < RPB && k0 + t >= total && k0 + t < d.n_img_cap + d.n_radar) d.keep[k0 + t] = 0;
   if (k0 >= total) return;
   const int nr = (total - k0 < RPB) ? total - k0 : RPB;
 
@@ -332,7 +475,8 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
     float v;
     if (f < FEAT) {
       const int pw = f % P, ph = (f / P) % P;
-      v = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_roi[r], d.spatial_scale, f, ph, pw);
+      v = ps_sample(d.img_map, d.img_pitch, d.fh, d.fw, s_roi[r], d.spatial_scale,
+                    d.img_bin_major ? (ph * P + pw) * C_OUT + f / PP : f, ph, pw);
     } else {
       const int g = f - FEAT;
       const int pw = g % P, ph = (g / P) % P, c = g / PP;
@@ -348,8 +492,40 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
 #pragma unroll
     for (int r = 0; r < RPB; ++r) acc[r] = 0.f;
     // four features per trip: one 16-byte broadcast read per RoI instead of four 4-byte ones (round 4: the loop issued eight
-    // ds_read_b32 per FMA group and was bound by LDS instruction issue); the FMA chain of every (RoI, unit) keeps its k order
-    int k = 0;
+    // ds_read_b32 per FMA group and was bound by LDS instruction issue); the FMA chain of every (RoI, unit) keeps its k order.
+    // The weights come in chunks of KC rows, the next chunk's loads in flight while this one is used: with four loads per trip
+    // the lone workgroup of a CU (batch <= 8: fewer workgroups than CUs) waited one L2 latency per trip - ~50 us per launch
+    // whatever the batch.
+    // whatever the batch.  KC = 4 (many workgroups per CU: the other waves cover the latency, 97 VGPRs) skips the chunks.
+    constexpr int NCH = KC >= 16 ? FEAT / KC : 0;  // 15 chunks of 32 = 480 rows, the last 10 rows below
+    const float* wcol = d.wts.w0t + t;
+    float wa[KC], wb[KC];
+    auto fetch = [&](float* wreg, int c) {
+#pragma unroll
+      for (int u = 0; u < KC; ++u) wreg[u] = wcol[(c * KC + u) * HID];
+    };
+    auto use = [&](const float* wreg, int c) {
+#pragma unroll
+      for (int u = 0; u < KC; u += 4) {
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) {
+          const float4 f = *reinterpret_cast<const float4*>(&s_feat[r][c * KC + u]);
+          acc[r] = fmaf(wreg[u + 3], f.w, fmaf(wreg[u + 2], f.z, fmaf(wreg[u + 1], f.y, fmaf(wreg[u], f.x, acc[r]))));
+        }
+      }
+    };
+    if constexpr (NCH > 0) {
+      fetch(wa, 0);
+      int c = 0;
+      for (; c + 1 < NCH; c += 2) {
+        fetch(wb, c + 1);
+        use(wa, c);
+        if (c + 2 < NCH) fetch(wa, c + 2);
+        use(wb, c + 1);
+      }
+      if (c < NCH) use(wa, c);
+    }
+    int k = NCH * KC;
     for (; k + 4 <= FEAT; k += 4) {
       const float w0 = d.wts.w0t[(k + 0) * HID + t], w1 = d.wts.w0t[(k + 1) * HID + t];
       const float w2 = d.wts.w0t[(k + 2) * HID + t], w3 = d.wts.w0t[(k + 3) * HID + t];
@@ -378,10 +554,12 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
       float acc = 0.f;
       if (j < 6) {
         const float* wrow = (j < 4) ? d.wts.w1 + j * HID : d.wts.w2 + (j - 4) * HID;
-        for (int k = 0; k < HID; ++k) acc = fmaf(wrow[k], s_hid[r][k], acc);
+#pragma unroll 32
+        for (int k = 0; k < HID; ++k) acc = fmaf(wrow[k], s_hid[r][k], acc);  // (32 weight loads in flight per trip)
         acc += (j < 4) ? d.wts.b1[j] : d.wts.b2[j - 4];
       } else {
         const float* wrow = d.wts.rw + (j - 6) * FEAT;
+#pragma unroll 35
         for (int k = 0; k < FEAT; ++k) acc = fmaf(wrow[k], s_feat[r][FEAT + k], acc);
       }
       s_small[r][j] = acc;
@@ -404,7 +582,210 @@ __global__ __launch_bounds__(256) void roi_heads_kernel(me_heads_desc d) {
   }
 
   // phase D: one thread per RoI - scalar tail
-  if (t < nr) tail_one(d, s_small[t], s_roi[t], k0 + t, n_img);
+  if (t < nr) tail_one(d, s_small[t], s_roi[t], k0 + t, n_img, tail_weights(d));
+}
+
+
+// ---- the same heads on the matrix pipe (inference, pooled features in d.pool_scratch) ----------------------------------------
+// roi_heads_kernel keeps a hidden unit per thread and reads every RoI's features by LDS broadcast (4 MB of LDS reads per
+// workgroup of 8 RoIs), W0 (500 KB) streams from the L2 once per 8 RoIs, and the small dot products of phase C walk their
+// weight rows with dependent-latency global loads: ~50 us per workgroup whatever the batch.  Here a workgroup owns RM = 32 RoIs:
+// * net0 is the GEMM [32 x 490] x [490 x 256] on v_mfma_f32_32x32x2_f32 (wave v: units 64 v .. 64 v + 63 = two 32 x 32 tiles;
+//   A = the features from LDS, one ds_read_b32 per step shared by both tiles; B = W0 rows straight from the L2, 128-byte rows,
+//   three chunks of seven steps in rotation).  The MFMA accumulates k in order with fp32 FMAs, like the VALU chain, and W0 is
+//   read once per 32 RoIs;
+// * the weights of phase C (net1 / net2: 6 x 256, radar_net conv: 10 x 490) and of the ensemble head sit in LDS, fetched with
+//   the first features; the chains read weights and features four k at a time (same k order);
+// * the image features and - after net0 - the radar features share one LDS buffer.
+constexpr int RM = 32;
+constexpr int FPI = FEAT + 2;  // 492: rows 16-byte aligned
+constexpr int HP = HID + 4;    // 260
+constexpr int kHeadsMfmaFloats = RM * FPI + RM * HP + RM * 16 + RM * 5 + 256 + 6 * HID + C_OUT * FPI;
+constexpr size_t kHeadsMfmaLds = (size_t)kHeadsMfmaFloats * sizeof(float);
+
+__global__ __launch_bounds__(256) void roi_heads_mfma_kernel(me_heads_desc d, int stop) {
+  extern __shared__ __attribute__((aligned(16))) float heads_lds[];
+  float* s_f = heads_lds;            // [RM][FPI] image features, then radar features
+  float* s_hid = s_f + RM * FPI;     // [RM][HP]
+  float* s_small = s_hid + RM * HP;  // [RM][16]: 0-3 reg, 4-5 cls logits, 6-15 radar conv
+  float* s_roi = s_small + RM * 16;  // [RM][5]
+  float* s_ens = s_roi + RM * 5;     // [256] e1w [32][2], e1b [32], e2w [2][64], rw2 [10], rscale [10], rshift [10], rb2
+  float* s_w12 = s_ens + 256;        // [6][HID] net1 rows 0-3, net2 rows 0-1
+  float* s_rw = s_w12 + 6 * HID;     // [C_OUT][FPI] radar_net 7x7 conv
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int n_img = *d.n_img;
+  const int total = n_img + d.n_radar;
+  const int k0 = blockIdx.x * RM;
+  if (t < RM && k0 + t >= total && k0 + t < d.n_img_cap + d.n_radar) d.keep[k0 + t] = 0;  // (see roi_heads_kernel)
+  if (k0 >= total) return;
+  const int nr = (total - k0 < RM) ? total - k0 : RM;
+  if (t < RM * 5) {
+    const int r = t / 5, c = t % 5;
+    float v = 0.f;
+    if (r < nr) {
+      const int k = k0 + r;
+      v = (k < n_img) ? d.img_boxes[(long long)k * d.box_cols + c] : d.radar_boxes[(long long)(k - n_img) * 5 + c];
+    }
+    s_roi[r * 5 + c] = v;
+  }
+  // pooled rows -> registers -> LDS (rows behind nr: zeros); part = 0 image half, 1 radar half of a pool_scratch row.  All 32 rows
+  // = 64 loads per thread in flight at once (one wave per SIMD: registers are free)
+  auto feats_issue = [&](float (*st)[2], int part) {
+    const float* src = d.pool_scratch + (long long)k0 * 2 * FEAT + part * FEAT;
+#pragma unroll
+    for (int u = 0; u < RM; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int f = t + 256 * h;
+        st[u][h] = (u < nr && f < FEAT) ? src[(long long)u * 2 * FEAT + f] : 0.f;
+      }
+  };
+  auto feats_commit = [&](float (*st)[2]) {
+#pragma unroll
+    for (int u = 0; u < RM; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int f = t + 256 * h;
+        if (f < FEAT) s_f[u * FPI + f] = st[u][h];
+      }
+  };
+  float radar[RM][2];  // the radar rows wait in registers until net0 is done with the image rows
+  {
+    float img[RM][2];
+    feats_issue(img, 0);
+    // the small weights, in flight with the features
+    float wst[26];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = t + 256 * u;  // < 1536
+      wst[u] = i < 4 * HID ? d.wts.w1[i] : d.wts.w2[i - 4 * HID];
+    }
+#pragma unroll
+    for (int u = 0; u < 20; ++u) {
+      const int i = t + 256 * u;
+      wst[6 + u] = i < C_OUT * FEAT ? d.wts.rw[i] : 0.f;
+    }
+    float ens = 0.f;
+    if (t < 64) ens = d.wts.e1w[t];
+    else if (t < 96) ens = d.wts.e1b[t - 64];
+    else if (t < 224) ens = d.wts.e2w[t - 96];
+    else if (t < 234) ens = d.wts.rw2[t - 224];
+    else if (t < 244) ens = d.wts.rscale[t - 234];
+    else if (t < 254) ens = d.wts.rshift[t - 244];
+    else if (t == 254) ens = d.wts.rb2[0];
+    feats_issue(radar, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) s_w12[t + 256 * u] = wst[u];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) {
+      const int i = t + 256 * u;
+      if (i < C_OUT * FEAT) s_rw[(i / FEAT) * FPI + i % FEAT] = wst[6 + u];
+    }
+    s_ens[t] = ens;
+    feats_commit(img);
+  }
+  __syncthreads();
+  if (stop == 1) return;  // (tools/heads_phases.py: time of the launch up to here)
+
+  // phase B: net0 on the matrix pipe
+  {
+    const int m = lane & 31, hh = lane >> 5;
+    const float* arow = s_f + m * FPI + hh;                             // A[m][2 s + hh]
+    const float* brow = d.wts.w0t + (long long)hh * HID + 64 * wv + m;  // B[2 s + hh][64 wv + m] (+ 32: second tile)
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+    constexpr int KS = 7, NCH = (FEAT / 2) / KS;  // 245 steps = 35 chunks of 7
+    float b0[KS][2], b1[KS][2], b2[KS][2], a0[KS], a1[KS], a2[KS];
+    auto fetch = [&](float (*b)[2], float* a, int c) {  // both operands of chunk c: W0 rows from the L2, features from LDS
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        const float* p = brow + (long long)(c * KS + u) * 2 * HID;
+        b[u][0] = p[0];
+        b[u][1] = p[32];
+      }
+#pragma unroll
+      for (int u = 0; u < KS; ++u) a[u] = arow[(c * KS + u) * 2];
+      __builtin_amdgcn_sched_barrier(0);  // (keep the loads two chunks ahead of their MFMAs)
+    };
+    auto use = [&](float (*b)[2], const float* a) {
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][1], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(b0, a0, 0);
+    fetch(b1, a1, 1);
+    int c = 0;
+    for (; c + 2 < NCH; c += 3) {  // two chunks of loads in flight behind the one in use
+      fetch(b2, a2, c + 2);
+      use(b0, a0);
+      if (c + 3 < NCH) fetch(b0, a0, c + 3);
+      use(b1, a1);
+      if (c + 4 < NCH) fetch(b1, a1, c + 4);
+      use(b2, a2);
+    }
+    if (c < NCH) use(b0, a0);
+    if (c + 1 < NCH) use(b1, a1);
+    // register e of lane (m, hh) = RoI (e & 3) + 8 (e >> 2) + 4 hh, unit 64 wv + m (+ 32)
+    const float bias0 = d.wts.b0[64 * wv + m], bias1 = d.wts.b0[64 * wv + 32 + m];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      s_hid[r * HP + 64 * wv + m] = leaky(acc0[e] + bias0);
+      s_hid[r * HP + 64 * wv + 32 + m] = leaky(acc1[e] + bias1);
+    }
+  }
+  __syncthreads();  // every wave is done with the image features; the hidden vectors are complete
+  if (stop == 2) return;
+  feats_commit(radar);
+
+  // phase C: (RoI r = t >> 3, j): j < 6 -> net1 rows 0-3 / net2 rows 0-1 over the hidden vector; 6 <= j < 16 -> radar_net 7x7 conv
+  // output j - 6 over the pooled radar feature: lane (t & 7) takes the hidden-vector row (t & 7) < 6, then radar outputs (t & 7)
+  // and, for (t & 7) < 2, 8 + (t & 7).
+  {
+    const int r = t >> 3, jj = t & 7;
+    if (r < nr && jj < 6) {
+      const float4* wrow = reinterpret_cast<const float4*>(s_w12 + jj * HID);
+      const float4* hrow = reinterpret_cast<const float4*>(s_hid + r * HP);
+      float acc = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < HID / 4; ++k) {
+        const float4 w = wrow[k], h = hrow[k];
+        acc = fmaf(w.w, h.w, fmaf(w.z, h.z, fmaf(w.y, h.y, fmaf(w.x, h.x, acc))));
+      }
+      s_small[r * 16 + jj] = acc + ((jj < 4) ? d.wts.b1[jj] : d.wts.b2[jj - 4]);
+    }
+    __syncthreads();  // the radar rows are in LDS
+    if (stop == 3) return;
+    if (r < nr) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int o = jj + 8 * half;  // radar conv output
+        if (o < C_OUT) {
+          const float4* wrow = reinterpret_cast<const float4*>(s_rw + o * FPI);
+          const float4* frow = reinterpret_cast<const float4*>(s_f + r * FPI);
+          float acc = 0.f;
+#pragma unroll 8
+          for (int k = 0; k < FEAT / 4; ++k) {  // 122 x 4 = 488
+            const float4 w = wrow[k], f = frow[k];
+            acc = fmaf(w.w, f.w, fmaf(w.z, f.z, fmaf(w.y, f.y, fmaf(w.x, f.x, acc))));
+          }
+          for (int k = FEAT / 4 * 4; k < FEAT; ++k) acc = fmaf(s_rw[o * FPI + k], s_f[r * FPI + k], acc);
+          s_small[r * 16 + 6 + o] = acc;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (stop == 4) return;
+  // phase D: one thread per RoI - scalar tail (its weights from LDS)
+  if (t < nr)
+    tail_one(d, s_small + t * 16, s_roi + t * 5, k0 + t, n_img,
+             TailW{s_ens, s_ens + 64, s_ens + 96, s_ens + 224, s_ens + 234, s_ens + 244, s_ens + 254});
 }
 
 
@@ -543,7 +924,7 @@ __global__ __launch_bounds__(256) void heads_tail_kernel(me_heads_desc d, const 
   float roi[5];
   for (int c = 0; c < 5; ++c)
     roi[c] = (i < n_img) ? d.img_boxes[(long long)i * d.box_cols + c] : d.radar_boxes[(long long)(i - n_img) * 5 + c];
-  tail_one(d, small + 16ll * i, roi, i, n_img);
+  tail_one(d, small + 16ll * i, roi, i, n_img, tail_weights(d));
 }
 
 __global__ __launch_bounds__(256) void heads_loss_kernel(const float* mask1, const float* refine,
@@ -748,11 +1129,26 @@ int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
   const int cap = d->n_img_cap + d->n_radar;
   if (cap == 0) return 0;
   if (d->pool_scratch) {
-    hipLaunchKernelGGL(roi_pool_kernel, dim3(cap), dim3(256), 0, stream, *d);
+    static const int pool10 = getenv("MILLIEYE_POOL10") ? atoi(getenv("MILLIEYE_POOL10")) : 1;
+    if (pool10) hipLaunchKernelGGL(roi_pool10_kernel, dim3(cap), dim3(128), 0, stream, *d);
+    else hipLaunchKernelGGL(roi_pool_kernel, dim3(cap), dim3(256), 0, stream, *d);
     const int rc = me::check_launch("roi_pool_kernel");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(roi_heads_kernel, dim3((cap + RPB - 1) / RPB), dim3(256), 0, stream, *d);
+  static const int mfma_env = getenv("MILLIEYE_HEADS_MFMA") ? atoi(getenv("MILLIEYE_HEADS_MFMA")) : 1;
+  if (mfma_env && d->pool_scratch && !d->save_small) {  // inference on pooled rows: net0 on the matrix pipe, 32 RoIs per workgroup
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_heads_mfma_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHeadsMfmaLds);
+    ME_HIP(attr);
+    static const int stop = getenv("MILLIEYE_HEADS_STOP") ? atoi(getenv("MILLIEYE_HEADS_STOP")) : 0;  // profiling only
+    hipLaunchKernelGGL(roi_heads_mfma_kernel, dim3((cap + RM - 1) / RM), dim3(256), kHeadsMfmaLds, stream, *d, stop);
+    return me::check_launch("roi_heads_mfma_kernel");
+  }
+  // few workgroups (batch <= 16: at most two per CU): deep weight prefetch, 189 VGPRs; more: the four-row loop keeps four waves per SIMD
+  const int wgs = (cap + RPB - 1) / RPB;
+  static const int kc_env = getenv("MILLIEYE_HEADS_KC") ? atoi(getenv("MILLIEYE_HEADS_KC")) : 0;
+  if (kc_env ? kc_env == 32 : wgs <= 512) hipLaunchKernelGGL(roi_heads_kernel<32>, dim3(wgs), dim3(256), 0, stream, *d);
+  else hipLaunchKernelGGL(roi_heads_kernel<4>, dim3(wgs), dim3(256), 0, stream, *d);
   return me::check_launch("roi_heads_kernel");
 }
 

@@ -232,10 +232,19 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(float* pred, int rows, in
 // decode that wrote it (78 - 100 us at batch 32, the largest part of the NMS stage after round 3's select rewrite).
 // One wave per row (5 + C <= 128 elements: lane k and k + 64), 64 rows per workgroup, one global atomic per workgroup.
 struct YoloCand {
-  me_yolo_desc y;
+  me_yolo_desc y[3];  // the [yolo] scales of one launch (count of them used)
+  int wg_end[3];      // exclusive prefix sums of the workgroups per scale
+  int count;
   float conf_thresh;
 };
 
+// RPW rows per wave (4 * RPW per workgroup).  Every row's raw values are fetched before the first one is decoded: with the loads
+// inside the row loop a wave paid one load latency plus the previous row's store acknowledgement per row (stores count in vmcnt
+// on gfx9) - 1.3 - 2.7 us per row, 21 - 43 us per scale at ANY batch size.  Small batches take RPW = 1 / 4 so that the rows
+// spread over the whole chip.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v);  // (DPP network, defined with the select kernel)
+
+template <int RPW>
 __global__ __launch_bounds__(256) void yolo_decode_cand_kernel(YoloCand d, NmsWs w) {
 #pragma clang fp contract(off)
   __shared__ float4 s_box[64];
@@ -243,7 +252,10 @@ __global__ __launch_bounds__(256) void yolo_decode_cand_kernel(YoloCand d, NmsWs
   __shared__ float s_lab[64], s_cls[64];
   __shared__ int s_n, s_base, s_nan;
   __shared__ unsigned s_max;
-  const me_yolo_desc& y = d.y;
+  int sc = 0, bx = blockIdx.x;
+  if (d.count > 1 && bx >= d.wg_end[0]) sc = (d.count > 2 && bx >= d.wg_end[1]) ? 2 : 1;
+  if (sc) bx -= d.wg_end[sc - 1];
+  const me_yolo_desc& y = d.y[sc];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int img = blockIdx.y;
   const int per = y.num_classes + 5;
@@ -255,29 +267,41 @@ __global__ __launch_bounds__(256) void yolo_decode_cand_kernel(YoloCand d, NmsWs
     s_max = 0u;
   }
   __syncthreads();
-  for (int i = 0; i < 16; ++i) {
-    const int rr = blockIdx.x * 64 + wv * 16 + i;  // row of this scale
-    if (rr >= rows_scale) break;                   // (uniform per wave)
+  const int rr0 = __builtin_amdgcn_readfirstlane(bx * (4 * RPW) + wv * RPW);  // (row arithmetic on the scalar unit)
+  float t[RPW][2];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int rr = rr0 + i;
     const int a = rr / gg, pix = rr - a * gg;
     const float* xin = y.x + ((long long)img * gg + pix) * y.x_pitch + a * per;
-    const int row = y.row_offset + rr;             // row of the prediction tensor
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) t[i][hlf] = (rr < rows_scale && lane + 64 * hlf < per) ? xin[lane + 64 * hlf] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int rr = rr0 + i;  // row of this scale
+    if (rr >= rows_scale) break;  // (uniform per wave)
+    const int a = rr / gg, pix = rr - a * gg;
+    const int row = y.row_offset + rr;  // row of the prediction tensor
     float* out = y.out + ((long long)img * y.rows_total + row) * per;
     const float aw = y.anchors[2 * a], ah = y.anchors[2 * a + 1];
+    const float gx = (float)(pix % y.g), gy = (float)(pix / y.g);
     float v[2] = {0.f, 0.f};
+    // the kernel is VALU-bound (one wave per row of 85 values): ONE expf per element - of t for the w / h lanes, of -t for the
+    // sigmoid lanes - instead of the three divergent paths; every element still sees the reference's operations in their order
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
       const int k = lane + 64 * hlf;
       if (k < per) {
-        const float t = xin[k];
+        const float tt = t[i][hlf];
+        const bool wh = hlf == 0 && (k == 2 || k == 3);
+        const float e = expf(wh ? tt : -tt);
         float o;
-        if (k < 2) {
-          const float sg = 1.f / (1.f + expf(-t));
-          const float gxy = (k == 0) ? (float)(pix % y.g) : (float)(pix / y.g);
-          o = (sg + gxy) * y.stride;
-        } else if (k < 4) {
-          o = (expf(t) * (k == 2 ? aw : ah)) * y.stride;
+        if (wh) {
+          o = (e * (k == 2 ? aw : ah)) * y.stride;  // exp(t) * (anchor / stride), then * stride (yolov3/models.py:126,162-163,168)
         } else {
-          o = 1.f / (1.f + expf(-t));
+          const float sg = 1.f / (1.f + e);
+          o = (hlf == 0 && k < 2) ? (sg + (k == 0 ? gx : gy)) * y.stride : sg;
         }
         out[k] = o;
         v[hlf] = o;
@@ -285,29 +309,28 @@ __global__ __launch_bounds__(256) void yolo_decode_cand_kernel(YoloCand d, NmsWs
     }
     const float conf = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 4));
     if (!(conf >= d.conf_thresh)) continue;  // uniform
-    // class max / argmax (torch.max(1) semantics, see cls_beats)
+    // class max / argmax with torch.max(1) semantics (see cls_beats: any NaN beats every number, first NaN wins; else the larger
+    // value, ties to the lower index) as ONE 64-bit wave maximum over the DPP network: high word = order-preserving bits of the
+    // score (every NaN -> 0xFFFFFFFF; -0 -> +0, which compare equal), low word = ~index; lanes without a class hold 0
+    auto class_key = [](float sc, int idx) {
+      const unsigned hi = (sc != sc) ? 0xFFFFFFFFu : sortable(sc + 0.f);
+      return ((unsigned long long)hi << 32) | (0xFFFFFFFFu - (unsigned)idx);
+    };
+    unsigned long long ck = 0ull;
+    if (lane >= 5 && lane < per) ck = class_key(v[0], lane - 5);
+    if (lane + 64 < per) {
+      const unsigned long long c1 = class_key(v[1], lane + 59);
+      ck = c1 > ck ? c1 : ck;
+    }
+    ck = wave_max_u64(ck);
     float best = -INFINITY;
-    int arg = 0x7fffffff;
-    if (lane >= 5 && lane < per) {
-      best = v[0];
-      arg = lane - 5;
-    }
-    if (lane + 64 < per && (arg == 0x7fffffff || cls_beats(v[1], lane + 59, best, arg))) {
-      best = v[1];
-      arg = lane + 59;
-    }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-      const float ov = __shfl_xor(best, sft, 64);
-      const int oi = __shfl_xor(arg, sft, 64);
-      if (oi != 0x7fffffff && (arg == 0x7fffffff || cls_beats(ov, oi, best, arg))) {
-        best = ov;
-        arg = oi;
-      }
-    }
-    if (y.num_classes <= 0) {
-      best = -INFINITY;
-      arg = 0;
+    int arg = 0;
+    if (y.num_classes > 0) {
+      arg = (int)(0xFFFFFFFFu - (unsigned)(ck & 0xFFFFFFFFull));
+      const int src = arg + 5;  // element index of the winner: lane src & 63 of half src >> 6
+      const float b0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), src & 63));
+      const float b1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[1]), src & 63));
+      best = src < 64 ? b0 : b1;
     }
     const float cx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 0));
     const float cy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[0]), 1));
@@ -752,7 +775,9 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs w, int use_offsets)
 
 // matrix: item = (image, block row bi, block column bj >= bi) of 64 x 64 candidates; persistent grid, one wave per item.
 // Lane i owns sorted candidate bi * 64 + i and tests it against the 64 column candidates (broadcast by readlane).
-__global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float iou_thresh) {
+// parts = 4 (small batches: fewer items than SIMDs): an item is split into four waves of 16 columns, each storing its quarter of
+// the 64-bit word.
+__global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float iou_thresh, int parts) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -765,7 +790,9 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
     return w.legacy ? 0 : (c + 63) >> 6;
   };
   W = blocks_of(0);
-  for (int q = wave_global;; q += nwaves) {
+  const int cols = 64 / parts;
+  for (int qp = wave_global;; qp += nwaves) {
+    const int q = qp / parts, part = qp - q * parts;
     while (img < n && q >= first + W * W) {
       first += W * W;
       ++img;
@@ -784,7 +811,7 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
     const float ra = box_area(rb), ca = box_area(cb);
     unsigned long long bits = 0ull;
 #pragma unroll 8
-    for (int b = 0; b < 64; ++b) {
+    for (int b = part * cols; b < (part + 1) * cols; ++b) {
       float4 bjx;
       bjx.x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.x), b));
       bjx.y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cb.y), b));
@@ -805,7 +832,11 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
         bits |= 1ull << b;
       }
     }
-    if (row < cnt) w.mat[((long long)img * w.matn + row) * w.wc + bj] = bits;
+    if (row < cnt) {
+      unsigned long long* word = &w.mat[((long long)img * w.matn + row) * w.wc + bj];
+      if (parts == 1) *word = bits;
+      else reinterpret_cast<unsigned short*>(word)[part] = (unsigned short)(bits >> (16 * part));
+    }
   }
 }
 
@@ -814,7 +845,11 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(NmsWs w, int n, float i
 constexpr int SCAN_THREADS = 1024;
 constexpr int CONT_KEEP = 1024;  // the continuation keeps the winners' boxes in LDS: max_det up to this (batched NMS: 200)
 
-__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(NmsWs w, int max_det, float iou_thresh, int* out_count) {
+// bulk != 0: the whole bit matrix of the image (matn x wc words, <= 128 KB) is read into LDS up front - eight 16-byte loads in
+// flight per thread, one memory latency - and wave 0 walks the blocks without a barrier in between; the two-buffer pipeline
+// below paid a fetch latency and two 16-wave barriers per block of 64 candidates (2.5 us x 16 blocks at any batch size).
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(NmsWs w, int max_det, float iou_thresh, int* out_count,
+                                                                int bulk) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
   const int img = blockIdx.x;
@@ -827,7 +862,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(NmsWs w, int max
   const int nblk = (cnt + 63) >> 6;
   unsigned long long* buf[2] = {reinterpret_cast<unsigned long long*>(scan_lds),
                                 reinterpret_cast<unsigned long long*>(scan_lds) + 64 * wc};
-  int* s_keep = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(scan_lds) + 128 * wc);  // [keep_cap] sorted positions
+  int* s_keep = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(scan_lds) +
+                                       (bulk ? w.matn : 128) * wc);  // [keep_cap] sorted positions
   __shared__ int s_stop, s_kept;
   __shared__ unsigned long long s_mask[NWV], s_diag[64];
   const unsigned long long* mat = w.mat + (long long)img * w.matn * wc;
@@ -849,8 +885,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(NmsWs w, int max
     s_stop = 0;
     s_kept = 0;
   }
-  fetch(0);
-  put(0);
+  if (!bulk) {
+    fetch(0);
+    put(0);
+  }
   __syncthreads();
   unsigned long long rem = 0ull;  // wave 0: lane l = removed bits of candidates 64 l .. 64 l + 63
   int kept = 0;
@@ -859,41 +897,77 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(NmsWs w, int max
   auto resolve = [&](unsigned long long curbits, unsigned long long valid, unsigned dlo, unsigned dhi, int blk) {
     unsigned long long avail = ~curbits & valid;
     unsigned long long keptmask = 0ull;
-    while (avail != 0ull && kept < max_det) {
+    const int before = kept;
+    while (avail != 0ull && kept < max_det) {  // (scalar unit only: ctz, two readlanes, a few 64-bit bit operations per winner)
       const int i = __builtin_ctzll(avail);
       keptmask |= 1ull << i;
-      if (lane == 0) s_keep[kept] = (blk << 6) + i;
       ++kept;
       const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
       const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
       curbits |= ((unsigned long long)hi << 32) | lo;
       avail = ~curbits & valid & (i == 63 ? 0ull : (~0ull << (i + 1)));
     }
+    if ((keptmask >> lane) & 1ull)  // the winners' sorted positions, in order, by all lanes at once
+      s_keep[before + __builtin_popcountll(keptmask & ((1ull << lane) - 1ull))] = (blk << 6) + lane;
     return keptmask;
   };
+  // wave 0, block blk with its 64 matrix rows at B
+  auto wave0_block = [&](const unsigned long long* B, int blk) {
+    // diagonal word of this lane's row (lower-triangular / stale words are never read: word index >= block index)
+    const unsigned long long diag = B[lane * wc + blk];
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rem, blk);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), blk);
+    const int last = cnt - (blk << 6);
+    const unsigned long long valid = last >= 64 ? ~0ull : ((1ull << last) - 1ull);
+    const unsigned long long keptmask =
+        resolve(((unsigned long long)rhi << 32) | rlo, valid, (unsigned)diag, (unsigned)(diag >> 32), blk);
+    // the winners' rows into the removed mask: lane = (group g of four, word); four winners per LDS read, the groups merged by
+    // two butterfly steps; lane l < wc ends up with word l like before
+    const int word = lane & 15, g = lane >> 4;
+    unsigned long long km = keptmask, acc = 0ull;
+    while (km != 0ull) {
+      int pick[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pick[u] = km != 0ull ? __builtin_ctzll(km) : -1;
+        km &= km - 1ull;  // (0 stays 0)
+      }
+      const int mine = g == 0 ? pick[0] : (g == 1 ? pick[1] : (g == 2 ? pick[2] : pick[3]));
+      if (mine >= 0 && word < wc) acc |= B[mine * wc + word];
+    }
+    acc |= __shfl_xor(acc, 16, 64);
+    acc |= __shfl_xor(acc, 32, 64);
+    rem |= acc;
+  };
+  if (bulk) {
+    unsigned long long* all = reinterpret_cast<unsigned long long*>(scan_lds);
+    const int pieces_all = nblk * 64 * wc / 2;  // rows >= cnt of the last block were never written: zeros
+    for (int p0 = 0; p0 < pieces_all; p0 += 8 * SCAN_THREADS) {
+      ulonglong2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pc = p0 + u * SCAN_THREADS + t;
+        v[u] = make_ulonglong2(0ull, 0ull);
+        if (pc < pieces_all && (pc * 2) / wc < cnt) v[u] = *reinterpret_cast<const ulonglong2*>(mat + (long long)pc * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pc = p0 + u * SCAN_THREADS + t;
+        if (pc < pieces_all) *reinterpret_cast<ulonglong2*>(all + (long long)pc * 2) = v[u];
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
+      for (int blk = 0; blk < nblk && kept < max_det; ++blk) wave0_block(all + (long long)blk * 64 * wc, blk);
+      if (lane == 0) s_kept = kept;
+    }
+  } else
   for (int blk = 0; blk < nblk; ++blk) {
     const int cur = blk & 1;
     const bool more = blk + 1 < nblk;
     if (more) fetch(blk + 1);  // in flight while wave 0 works
     if (wv == 0) {
-      const unsigned long long* B = buf[cur];
-      // diagonal word of this lane's row (lower-triangular / stale words are never read: word index >= block index)
-      const unsigned long long diag = B[lane * wc + blk];
-      const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rem, blk);
-      const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), blk);
-      const int last = cnt - (blk << 6);
-      const unsigned long long valid = last >= 64 ? ~0ull : ((1ull << last) - 1ull);
-      const unsigned long long keptmask =
-          resolve(((unsigned long long)rhi << 32) | rlo, valid, (unsigned)diag, (unsigned)(diag >> 32), blk);
-      // the winners' rows into the removed mask: lane = word
-      if (lane < wc) {
-        unsigned long long km = keptmask;
-        while (km != 0ull) {
-          const int i = __builtin_ctzll(km);
-          km &= km - 1ull;
-          rem |= B[i * wc + lane];
-        }
-      }
+      wave0_block(buf[cur], blk);
       if (lane == 0) {
         s_kept = kept;
         if (kept >= max_det) s_stop = 1;
@@ -1017,11 +1091,13 @@ inline int launch_matrix_path(const NmsWs& w, int n, int use_offsets, float iou_
   hipLaunchKernelGGL(nms_rank_kernel, dim3((w.cap + 255) / 256, n), dim3(256), 0, stream, w, use_offsets);
   int rc = me::check_launch("nms_rank_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_matrix_kernel, dim3(1024), dim3(256), 0, stream, w, n, iou_thresh);
+  hipLaunchKernelGGL(nms_matrix_kernel, dim3(1024), dim3(256), 0, stream, w, n, iou_thresh, n * 136 < 2048 ? 4 : 1);
   rc = me::check_launch("nms_matrix_kernel");
   if (rc) return rc;
   const int keep_cap = max_det < w.cap ? max_det : w.cap;
-  size_t lds = (size_t)128 * w.wc * 8;                                       // two blocks of matrix rows ...
+  static const int bulk_env = getenv("MILLIEYE_NMS_BULK") ? atoi(getenv("MILLIEYE_NMS_BULK")) : 1;
+  const int bulk = bulk_env && (size_t)w.matn * w.wc * 8 + (size_t)keep_cap * 4 <= 150 * 1024;  // the whole matrix in LDS
+  size_t lds = (size_t)(bulk ? w.matn : 128) * w.wc * 8;                     // all / two blocks of matrix rows ...
   if (max_det <= CONT_KEEP && lds < (size_t)CONT_KEEP * 16) lds = (size_t)CONT_KEEP * 16;  // ... or the continuation's winner boxes
   lds += (size_t)keep_cap * 4;
   static bool attr = false;
@@ -1031,7 +1107,7 @@ inline int launch_matrix_path(const NmsWs& w, int n, int use_offsets, float iou_
     attr = true;
   }
   ME_REQUIRE(lds <= 150 * 1024, ME_E_TOOBIG, "me_nms: max_det %d too large for the scan kernel's LDS", max_det);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(SCAN_THREADS), lds, stream, w, max_det, iou_thresh, out_count);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(SCAN_THREADS), lds, stream, w, max_det, iou_thresh, out_count, bulk);
   return me::check_launch("nms_scan_kernel");
 }
 
@@ -1051,24 +1127,50 @@ int me_nms_batched_f32(const me_nms_desc* d, void* stream) { return nms_batched(
 /* the candidate lists are already in the workspace (me_yolo_decode_cand_f32 of every scale): select + emit only */
 int me_nms_batched_prepped_f32(const me_nms_desc* d, void* stream) { return nms_batched(d, stream, 1); }
 
-int me_yolo_decode_cand_f32(const me_yolo_desc* y, float conf_thresh, void* nms_workspace, int32_t first, void* stream_) {
+int me_yolo_decode_cand_multi_f32(const me_yolo_desc* const* ys, int32_t count, float conf_thresh, void* nms_workspace,
+                                  int32_t first, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  ME_REQUIRE(y && y->x && y->out && nms_workspace, ME_E_NULLPTR, "me_yolo_decode_cand_f32: null pointer");
-  ME_REQUIRE(y->n > 0 && y->g > 0 && y->num_anchors > 0 && y->num_anchors <= 8 && y->num_classes >= 0 &&
-                 y->num_classes + 5 <= 128, ME_E_BADARG, "me_yolo_decode_cand_f32: bad dimensions (5 + classes <= 128)");
-  ME_REQUIRE(y->x_pitch >= y->num_anchors * (y->num_classes + 5), ME_E_BADARG, "me_yolo_decode_cand_f32: x_pitch too small");
-  ME_REQUIRE(y->row_offset >= 0 && y->row_offset + y->num_anchors * y->g * y->g <= y->rows_total && y->rows_total <= MAX_ROWS,
-             ME_E_BADARG, "me_yolo_decode_cand_f32: rows out of range");
-  ME_REQUIRE(y->n <= 65535 && y->stride > 0.f, ME_E_BADARG, "me_yolo_decode_cand_f32: bad batch / stride");
+  ME_REQUIRE(ys && nms_workspace, ME_E_NULLPTR, "me_yolo_decode_cand_f32: null pointer");
+  ME_REQUIRE(count >= 1 && count <= 3, ME_E_BADARG, "me_yolo_decode_cand_f32: 1 - 3 scales per launch (got %d)", count);
   ME_REQUIRE((reinterpret_cast<uintptr_t>(nms_workspace) & 255u) == 0, ME_E_ALIGN, "me_yolo_decode_cand_f32: workspace alignment");
-  NmsWs w = carve(nms_workspace, y->n, y->rows_total);
-  if (first) ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * y->n, stream));
+  long long rows_all = 0;
+  for (int i = 0; i < count; ++i) {
+    const me_yolo_desc* y = ys[i];
+    ME_REQUIRE(y && y->x && y->out, ME_E_NULLPTR, "me_yolo_decode_cand_f32: null pointer");
+    ME_REQUIRE(y->n > 0 && y->g > 0 && y->num_anchors > 0 && y->num_anchors <= 8 && y->num_classes >= 0 &&
+                   y->num_classes + 5 <= 128, ME_E_BADARG, "me_yolo_decode_cand_f32: bad dimensions (5 + classes <= 128)");
+    ME_REQUIRE(y->x_pitch >= y->num_anchors * (y->num_classes + 5), ME_E_BADARG, "me_yolo_decode_cand_f32: x_pitch too small");
+    ME_REQUIRE(y->row_offset >= 0 && y->row_offset + y->num_anchors * y->g * y->g <= y->rows_total && y->rows_total <= MAX_ROWS,
+               ME_E_BADARG, "me_yolo_decode_cand_f32: rows out of range");
+    ME_REQUIRE(y->n <= 65535 && y->stride > 0.f, ME_E_BADARG, "me_yolo_decode_cand_f32: bad batch / stride");
+    ME_REQUIRE(y->n == ys[0]->n && y->rows_total == ys[0]->rows_total && y->out == ys[0]->out, ME_E_BADARG,
+               "me_yolo_decode_cand_f32: the scales of one launch share the batch and the prediction tensor");
+    rows_all += (long long)y->num_anchors * y->g * y->g;
+  }
+  const int n = ys[0]->n;
+  NmsWs w = carve(nms_workspace, n, ys[0]->rows_total);
+  if (first) ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * n, stream));
+  // rows per wave: 16 when that still leaves >= 2048 workgroups, else 4, else 1 (batch 1: 10 647 rows over 2 662 workgroups)
+  const long long wg16 = rows_all * n / 64;
+  const int rpw = wg16 >= 2048 ? 16 : (wg16 >= 512 ? 4 : 1);
   YoloCand d;
-  d.y = *y;
+  d.count = count;
   d.conf_thresh = conf_thresh;
-  const int rows_scale = y->num_anchors * y->g * y->g;
-  hipLaunchKernelGGL(yolo_decode_cand_kernel, dim3((rows_scale + 63) / 64, y->n), dim3(256), 0, stream, d, w);
+  int wgs = 0;
+  for (int i = 0; i < 3; ++i) {
+    d.y[i] = *ys[i < count ? i : 0];
+    if (i < count) wgs += (ys[i]->num_anchors * ys[i]->g * ys[i]->g + 4 * rpw - 1) / (4 * rpw);
+    d.wg_end[i] = wgs;
+  }
+  const dim3 grid(wgs, n), block(256);
+  if (rpw == 16) hipLaunchKernelGGL(yolo_decode_cand_kernel<16>, grid, block, 0, stream, d, w);
+  else if (rpw == 4) hipLaunchKernelGGL(yolo_decode_cand_kernel<4>, grid, block, 0, stream, d, w);
+  else hipLaunchKernelGGL(yolo_decode_cand_kernel<1>, grid, block, 0, stream, d, w);
   return me::check_launch("yolo_decode_cand_kernel");
+}
+
+int me_yolo_decode_cand_f32(const me_yolo_desc* y, float conf_thresh, void* nms_workspace, int32_t first, void* stream) {
+  return me_yolo_decode_cand_multi_f32(&y, 1, conf_thresh, nms_workspace, first, stream);
 }
 
 static int nms_batched(const me_nms_desc* d, void* stream_, int prepped) {

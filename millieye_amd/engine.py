@@ -556,6 +556,11 @@ class DarknetEngine:
                 out[i] = None  # decoded rows are never routed
             i += 1
 
+        # the [yolo] decodes go behind the last convolution: one launch for all scales (me_yolo_decode_cand_multi_f32) instead of
+        # three small ones in the middle of the dependent chain; the detection maps stay live until then (liveness below)
+        if os.environ.get("MILLIEYE_DECODE_LAST", "1") != "0":
+            ops = [op for op in ops if op["kind"] != "yolo"] + [op for op in ops if op["kind"] == "yolo"]
+
         # liveness (op index granularity)
         for oi, op in enumerate(ops):
             for key in ("x", "res", "a", "b"):
@@ -729,6 +734,10 @@ class DarknetEngine:
                 yl.img_dim = h
                 yl.grid_size = op["g"]
                 yl.stride = stride
+        k = len(plan.yolo_descs)
+        plan.yolo_tail = None  # the decodes are the last launches: Network.forward's candidate-list decode takes them in one launch
+        if 1 <= k <= 3 and all(name.startswith("yolo") for _f, _a, _k, name in launches[-k:]):
+            plan.yolo_tail = (C.c_void_p * k)(*[C.addressof(dsc) for dsc in plan.yolo_descs])
         # shared scratch for the deterministic split-K slabs (launches are serial on one stream)
         ws_fn = lib.me_conv2d_h16_workspace_bytes if bf16 else lib.me_conv2d_workspace_bytes
         need = max([ws_fn(C.byref(d)) for _m, d in plan.conv_descs] + [0])
@@ -817,7 +826,14 @@ class DarknetEngine:
         decode_cand = hip.lib().me_yolo_decode_cand_f32 if cand is not None else None
         for fn, args, _keep, name in plan.launches:
             if decode_cand is not None and name.startswith("yolo"):
-                rc = decode_cand(args[0], cand[0], cand[1], first, stream)
+                if plan.yolo_tail is not None:
+                    if first:
+                        rc = hip.lib().me_yolo_decode_cand_multi_f32(plan.yolo_tail, len(plan.yolo_tail), cand[0], cand[1], 1,
+                                                                     stream)
+                    else:
+                        continue
+                else:
+                    rc = decode_cand(args[0], cand[0], cand[1], first, stream)
                 first = 0
             else:
                 rc = fn(*args, stream)

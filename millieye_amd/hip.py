@@ -112,6 +112,7 @@ class HeadsDesc(C.Structure):
         ("save_feat_img", C.c_void_p), ("save_feat_rad", C.c_void_p), ("save_hidden", C.c_void_p),
         ("save_small", C.c_void_p),
         ("pool_scratch", C.c_void_p),
+        ("img_bin_major", C.c_int32),
     ]
 
 
@@ -215,6 +216,7 @@ SIGNATURES = {
     "me_conv_wgrad_mfma_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
                                + [C.c_void_p, C.c_int64, C.c_void_p]),
     "me_yolo_decode_cand_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
+    "me_yolo_decode_cand_multi_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "me_nms_batched_prepped_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "me_conv_wgrad_mfma_oihw_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
                                     + [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -260,8 +262,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 8:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 8")
+    if lib_.me_abi_version() != 9:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 9")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "

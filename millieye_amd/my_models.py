@@ -240,6 +240,34 @@ class _HeadPack:
         return self.t
 
 
+class _BinMajorRows:
+    """``cnn_layers_1``'s packed 1x1 weights with the 490 output channels reordered bin-major: channel ``(ph*7+pw)*10 + c_out``
+    holds the reference's channel ``(c_out*7+ph)*7+pw`` (my_models.py:47-52 -> ps_roi_align, :495).  The score map is only read
+    by the RoI pooling launch, which then finds the ten values of a sample point in 40 contiguous bytes
+    (``me_heads_desc.img_bin_major``).  A row permutation of weight / scale / shift: every output value is computed exactly as
+    before, it only lands in another channel slot.  Re-derived when the underlying pack changes."""
+
+    def __init__(self, cw):
+        self.cw = cw
+        self.wgt = self.scale = self.shift = None
+        self._key = None
+        self._perm = None
+
+    def refresh(self, device):
+        self.cw.refresh(device)
+        key = (self.cw._stamp, self.cw.wgt.data_ptr())
+        if key != self._key:
+            if self._perm is None or self._perm.device != self.cw.wgt.device:
+                q = torch.arange(490, device=self.cw.wgt.device)
+                self._perm = (q % 10) * 49 + q // 10
+            with torch.no_grad():
+                self.wgt = self.cw.wgt.index_select(0, self._perm).contiguous()
+                self.scale = self.cw.scale.index_select(0, self._perm).contiguous()
+                self.shift = self.cw.shift.index_select(0, self._perm).contiguous()
+            self._key = key
+        return self
+
+
 class Network(nn.Module):
     """milliEye stage-3 network (reference my_models.py:411-641)."""
 
@@ -269,9 +297,9 @@ class Network(nn.Module):
         if self._packs is None:
             rc = self.radar_cnn_layers
             packs = dict(
-                img=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1]),
-                bf16=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1], "bf16"),
-                f16=ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1], "f16"),
+                img=_BinMajorRows(ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1])),
+                bf16=_BinMajorRows(ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1], "bf16")),
+                f16=_BinMajorRows(ConvWeights(self.img_cnn_layers.net[0], self.img_cnn_layers.net[1], "f16")),
                 r1=ConvWeights(rc.conv1[0], rc.conv1[1]),
                 r2=ConvWeights(rc.conv2[0], rc.conv2[1]),
                 r3=ConvWeights(rc.conv3[0], rc.conv3[1]),
@@ -353,7 +381,8 @@ class Network(nn.Module):
         return radar_score_map, mh, mw
 
     def _roi_score_map(self, plan, n, dev):
-        """roi_score_map [n,fh,fw,490] = cnn_layers_1 on the detector's feature tap, on the current stream."""
+        """roi_score_map [n,fh,fw,490] = cnn_layers_1 on the detector's feature tap, on the current stream; channels bin-major
+        (:class:`_BinMajorRows`)."""
         packs = self._get_packs()
         tap16 = getattr(plan, "dtype", "f32") != "f32"
         packs[plan.dtype if tap16 else "img"].refresh(dev)
@@ -459,13 +488,13 @@ class Network(nn.Module):
         refine = torch.empty((cap, 2), **f32)
         mask1 = torch.empty((cap,), **f32)
         rows = torch.empty((cap, 8), **f32)
-        keep = torch.zeros((cap,), device=dev, dtype=torch.uint8)
+        keep = torch.empty((cap,), device=dev, dtype=torch.uint8)  # (the heads launch clears the slots behind the last RoI)
         key = torch.empty((cap,), **f32)
 
         hw = packs["heads"].refresh(dev)
         d = hip.HeadsDesc()
         d.img_map, d.radar_map = roi_score_map.data_ptr(), radar_score_map.data_ptr()
-        d.img_pitch, d.radar_pitch = 490, 12
+        d.img_pitch, d.radar_pitch, d.img_bin_major = 490, 12, 1
         d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16
         d.rh, d.rw = rh_, rw_
         d.img_boxes, d.n_img, d.n_img_cap, d.box_cols = img_boxes.data_ptr(), n_img_dev.data_ptr(), cap_img, cols

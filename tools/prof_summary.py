@@ -36,6 +36,21 @@ def main():
         for k, gx, gy, gz, n, avg, tot in cur.execute(q):
             print(f"{short(k)[:70]:70s} grid {gx:8d} {gy:5d} {gz:4d} calls {n:5d} avg {avg / 1e3:8.1f} us total {tot / 1e3:10.1f} us")
         return
+    if "--timeline" in sys.argv:  # the last K dispatches in start order: duration and the idle gap before each
+        k = int(sys.argv[sys.argv.index("--timeline") + 1])
+        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        disp = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch"))
+        sym = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
+        q = (f"select s.kernel_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x, d.start, d.end "
+             f"from {disp} d join {sym} s on d.kernel_id = s.id order by d.start desc limit {k + 1}")
+        rows = list(cur.execute(q))[::-1]
+        print(f"# last {k} dispatches - {db}")
+        busy = 0
+        for prev, r in zip(rows, rows[1:]):
+            busy += r[6] - r[5]
+            print(f"{short(r[0])[:64]:64s} wgs {r[1] * r[2] * r[3] // max(r[4], 1):6d} x {r[4]:4d}  {(r[6] - r[5]) / 1e3:8.2f} us  gap {(r[5] - prev[6]) / 1e3:7.2f} us")
+        print(f"# span {(rows[-1][6] - rows[1][5]) / 1e3:.1f} us, busy {busy / 1e3:.1f} us")
+        return
     print(f"# kernel-trace --stats summary - {db}")
     print(f"{'kernel':90s} {'calls':>7s} {'total us':>12s} {'avg us':>10s} {'%':>7s}")
     for name, calls, total, avg, pct in cur.execute("select * from top_kernels"):
