@@ -506,8 +506,11 @@ class Network(nn.Module):
             setattr(d.wts, name, hw[name].data_ptr())
         d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
         d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
-        pooled = torch.empty((cap, 980), **f32)  # the RoI pooling as its own launch (me_heads_desc.pool_scratch)
-        d.pool_scratch = pooled.data_ptr()
+        if not getattr(self, "_fused_heads", False):
+            pooled = torch.empty((cap, 980), **f32)  # the RoI pooling as its own launch (me_heads_desc.pool_scratch)
+            d.pool_scratch = pooled.data_ptr()
+        # (``_fused_heads``: the single-launch VALU kernel with the pooling inside - kept as the cross-check of the two-launch
+        # path, tests/test_gpu_network.py)
         hip.check(lib.me_roi_heads_f32(C.byref(d), hip.stream_ptr()), "me_roi_heads_f32")
         mark("roi_heads")
         self.refinement_head.count += 1

@@ -191,6 +191,25 @@ def test_network_forward_is_repeatable(hip_lib):
         assert torch.equal(first, again)
 
 
+@pytest.mark.parametrize("case", [0, 1])
+def test_two_launch_heads_equal_the_fused_launch(hip_lib, case):
+    """Per-bin RoI pooling + the heads on the fp32 matrix pipe (32 RoIs per workgroup, v_mfma_f32_32x32x2_f32 for net0) against
+    the single fused VALU launch (a thread per pooled value, a hidden unit per thread): the same rows.  The pooled values are
+    the same operations in the same order, the MFMA accumulates k in order with fp32 FMAs like the VALU chain - measured
+    bit-identical; the bar is 2e-6 relative so that a different FMA grouping inside the matrix pipe would not be a failure."""
+    name, cfg, n, s, conf = NETWORK_CASES[case]
+    net = _build(name, cfg, conf).eval()
+    net = net.to(net.device)
+    x, maps, rboxes = _inputs(name, n, s)
+    split = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).clone()
+    net._fused_heads = True
+    fused = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).clone()
+    net._fused_heads = False
+    assert split.shape == fused.shape and split.shape[0] > 0
+    torch.testing.assert_close(split, fused, rtol=2e-6, atol=2e-6)
+    print(f"two-launch heads vs fused launch ({name}): bit-identical = {bool(torch.equal(split, fused))}")
+
+
 def test_no_rois_at_all(hip_lib):
     """Nothing passes the confidence threshold and there is no radar proposal: the reference's empty [0,8] result (its
     torch ops run on empty tensors), for modes 0 and 1, and with radar proposals only."""

@@ -118,3 +118,68 @@ def test_nms_properties_and_edges(hip_lib):
     keep = box_ops.batched_nms(b.cuda(), pred[0, :, 4].cuda(), lab.cuda(), 0.3).cpu()
     assert torch.equal(keep, tv_ops.batched_nms(b, pred[0, :, 4], lab, 0.3))
     assert box_ops.batched_nms(torch.zeros((0, 4)).cuda(), torch.zeros(0).cuda(), torch.zeros(0).cuda(), .5).numel() == 0
+
+
+@pytest.mark.parametrize("n", [1, 6, 24])  # 1 / 4 / 16 rows per wave
+def test_decode_with_candidate_lists_one_launch_for_three_scales(hip_lib, n):
+    """me_yolo_decode_cand_multi_f32 (Network.forward's detector run: the three [yolo] scales in one launch that also fills the
+    NMS candidate lists) against the plain decode (me_yolo_decode_f32 per scale) + me_nms_batched_f32, and against
+    me_yolo_decode_cand_f32 per scale: the same prediction rows and the same kept detections, bit for bit."""
+    import ctypes as C
+    from millieye_amd import hip
+    nc, na, img = 12, 3, 416
+    anchors = [[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]]
+    grids = (13, 26, 52)
+    rows = sum(na * g * g for g in grids)
+    pitch = 64  # >= 3 * 17 channels
+    raws = [torch.from_numpy(synth.normal(f"decode3/{n}/{g}", (n, g, g, pitch)) * 2.0 - 1.5).cuda().contiguous() for g in grids]
+    raws[0][0, 0, 0, 4] = float("nan")  # a NaN objectness (never a candidate) and a NaN class score (wins the class max)
+    raws[1][0, 1, 1, 5 + 3] = float("nan")
+    raws[1][0, 1, 1, 4] = 5.0
+    plain = torch.empty((n, rows, 5 + nc), device="cuda")
+    off = 0
+    descs = []
+    for g, raw, an in zip(grids, raws, anchors):
+        d = hip.YoloDesc()
+        d.x, d.x_pitch = raw.data_ptr(), pitch
+        d.n, d.g, d.num_anchors, d.num_classes = n, g, na, nc
+        d.rows_total, d.row_offset, d.stride = rows, off, img / g
+        for k, (aw, ah) in enumerate(an):
+            d.anchors[2 * k], d.anchors[2 * k + 1] = aw / (img / g), ah / (img / g)
+        d.out = plain.data_ptr()
+        hip.check(hip.lib().me_yolo_decode_f32(C.byref(d), hip.stream_ptr()), "me_yolo_decode_f32")
+        descs.append(d)
+        off += na * g * g
+    det0, cnt0 = hip.nms_batched(plain.clone(), 0.3, 0.4, 200, writeback_xyxy=False)
+    ws, _keep = hip.nms_workspace(n, rows, torch.device("cuda"))
+    results = []
+
+    def same_bits(a, b):  # NaNs in the same places (any payload), everything else bit for bit
+        an, bn = torch.isnan(a), torch.isnan(b)
+        return bool(torch.equal(an, bn)) and bool(torch.equal(a[~an].view(torch.int32), b[~bn].view(torch.int32)))
+
+    for multi in (True, False):
+        out = torch.zeros_like(plain)
+        for d in descs:
+            d.out = out.data_ptr()
+        if multi:
+            ptrs = (C.c_void_p * 3)(*[C.addressof(d) for d in descs])
+            hip.check(hip.lib().me_yolo_decode_cand_multi_f32(ptrs, 3, 0.3, ws, 1, hip.stream_ptr()), "multi")
+        else:
+            for i, d in enumerate(descs):
+                hip.check(hip.lib().me_yolo_decode_cand_f32(C.byref(d), 0.3, ws, int(i == 0), hip.stream_ptr()), "single")
+        det, cnt = hip.nms_batched(out, 0.3, 0.4, 200, writeback_xyxy=False, prepped=True)
+        torch.cuda.synchronize()
+        results.append((out, det, cnt))
+    for out, det, cnt in results:
+        assert same_bits(out, plain), "decoded rows differ from me_yolo_decode_f32"
+        assert torch.equal(cnt, cnt0)
+        for i in range(n):
+            k = int(cnt0[i])
+            assert k > 0
+            assert same_bits(det[i, :k], det0[i, :k]), f"image {i}: kept rows differ"
+    # refusals
+    ptrs = (C.c_void_p * 3)(*[C.addressof(d) for d in descs])
+    assert hip.lib().me_yolo_decode_cand_multi_f32(ptrs, 4, 0.3, ws, 1, hip.stream_ptr()) != 0
+    descs[1].n = n + 1
+    assert hip.lib().me_yolo_decode_cand_multi_f32(ptrs, 3, 0.3, ws, 1, hip.stream_ptr()) != 0
