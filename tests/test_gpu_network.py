@@ -210,6 +210,29 @@ def test_two_launch_heads_equal_the_fused_launch(hip_lib, case):
     print(f"two-launch heads vs fused launch ({name}): bit-identical = {bool(torch.equal(split, fused))}")
 
 
+def test_bin_major_score_map_follows_weight_updates(hip_lib):
+    """The 1x1 score-map convolution runs on row-permuted copies of its packed weights (bin-major channels for the pooling
+    launch): an in-place update of the module's parameters must reach them - the rows after the update equal the oracle's on the
+    updated state and differ from the rows before."""
+    from oracle import network_ref
+    name, cfg, n, s, conf = NETWORK_CASES[0]
+    net = _build(name, cfg, conf).eval()
+    net = net.to(net.device)
+    x, maps, rboxes = _inputs(name, n, s)
+    before = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).clone()
+    with torch.no_grad():
+        net.img_cnn_layers.net[0].weight.mul_(1.25)
+        net.img_cnn_layers.net[1].bias.add_(0.05)
+    after = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).clone()
+    net._fused_heads = True
+    fused = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).clone()
+    assert torch.equal(after, fused)
+    assert after.shape != before.shape or not torch.equal(after, before)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    ref = network_ref.network_forward(cfgs.KNOWN[cfg](), sd, x, maps, rboxes, 0, conf_thresh=conf)
+    _cmp_rows(after, ref, "after an in-place weight update")
+
+
 def test_no_rois_at_all(hip_lib):
     """Nothing passes the confidence threshold and there is no radar proposal: the reference's empty [0,8] result (its
     torch ops run on empty tensors), for modes 0 and 1, and with radar proposals only."""
