@@ -101,11 +101,14 @@ class ConvWeights:
         self._stamp = None
 
     def _sources(self):
-        ts = [self.conv.weight]
-        if self.conv.bias is not None:
-            ts.append(self.conv.bias)
+        # (straight from the modules' dicts: nn.Module.__getattr__ is ~5x slower and this runs in every forward)
+        cp = self.conv._parameters
+        ts = [cp["weight"]]
+        if cp.get("bias") is not None:
+            ts.append(cp["bias"])
         if self.bn is not None:
-            ts += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+            bp, bb = self.bn._parameters, self.bn._buffers
+            ts += [bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"]]
         return ts
 
     def stamp(self):
@@ -384,12 +387,13 @@ class DarknetEngine:
                     "module3_our_dataset/train.py:170)")
         stamp = tuple([(t.data_ptr(), t._version) for t in [dct[key] for dct, key in slots]]) + (str(device), _EPOCH[0])
         if stamp == self._fast_stamp:
-            return
+            return False
         for i, d in enumerate(self.model.module_defs):
             if d["type"] == "convolutional":
                 if self._conv_weights(i).refresh(device) == "realloc" and self._plans:
                     self._plans.clear()  # descriptors hold the old pointers
         self._fast_stamp = stamp
+        return True
 
     # ---------------------------------------------------------------------------------- planning
     def _build(self, n, h, w, device, keep_raw=False):
@@ -795,23 +799,36 @@ class DarknetEngine:
             raise hip.MeError("Darknet input must be a 4-D CUDA float32 tensor [N,C,H,W]; this path has no CPU "
                               "fallback (the CPU restatement is oracle/, test infrastructure only)")
         x = x.contiguous()
-        self.refresh_weights(x.device)
-        plan = self.plan_for(x, keep_raw)
-        if _graphs_enabled() and not torch.cuda.is_current_stream_capturing():
+        # The parameter check (one pass over ~370 tensors, ~50 us) normally finds nothing, and whatever the host does in front of
+        # the first launch is idle time of the GPU: with a plan in hand the launches go out FIRST on the packed weights of the
+        # last run, then the check runs behind them; if a parameter did change, the weights are re-packed and the forward is
+        # issued again on the same stream (same buffers: the stale results are overwritten before anyone can read them).
+        n_, _, h_, w_ = x.shape
+        plan = self._plans.get((n_, h_, w_, x.device.index, bool(keep_raw))) \
+            if self.__dict__.get("_fast_stamp") is not None else None
+        early = plan is not None and _SPECULATIVE and not _graphs_enabled()
+        if not early:
+            self.refresh_weights(x.device)
+            plan = self.plan_for(x, keep_raw)
+            if _graphs_enabled() and not torch.cuda.is_current_stream_capturing():
+                plan.nms_prepped = None
+                return self._run_graph(plan, x)
+        while True:
+            yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
+                                   device=x.device)
+            cand = None
             plan.nms_prepped = None
-            return self._run_graph(plan, x)
-        yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
-                               device=x.device)
-        cand = None
-        plan.nms_prepped = None
-        if nms_conf is not None and plan.yolo_descs and 5 + (plan.num_classes or 0) <= 128 and plan.rows <= 32768 \
-                and plan.n <= 65535:
-            ws_ptr, _keep = hip.nms_workspace(plan.n, plan.rows, x.device)
-            cand = (float(nms_conf), ws_ptr)
-            plan.nms_prepped = float(nms_conf)
-        self._launch_all(plan, x, yolo_out, cand)
-        plan.last_input = x  # keep the caller's tensor alive until the stream has consumed it
-        return plan, yolo_out
+            if nms_conf is not None and plan.yolo_descs and 5 + (plan.num_classes or 0) <= 128 and plan.rows <= 32768 \
+                    and plan.n <= 65535:
+                ws_ptr, _keep = hip.nms_workspace(plan.n, plan.rows, x.device)
+                cand = (float(nms_conf), ws_ptr)
+                plan.nms_prepped = float(nms_conf)
+            self._launch_all(plan, x, yolo_out, cand)
+            plan.last_input = x  # keep the caller's tensor alive until the stream has consumed it
+            if not early or not self.refresh_weights(x.device):
+                return plan, yolo_out
+            early = False  # a parameter changed since the last run: again, on the fresh weights (and a fresh plan if they moved)
+            plan = self.plan_for(x, keep_raw)
 
     @staticmethod
     def _launch_all(plan, x, yolo_out, cand=None):
@@ -905,6 +922,9 @@ _TUNE_TILES_P8_F32 = (201, 221)  # fp32 is matrix-pipe bound: the big tiles' pad
 # their traffic saves (tools/p8_bench_f32.py: only the 2-workgroup tiles come close to the 64x64 per-tap tile)
 _TUNE_TILES_P8 = (100, 110, 120, 101, 121, 131, 141, 200, 201, 221, 311, 321, 421, 431, 441,   # 4xx: a barrier per three taps
                   621, 721, 731, 810, 831, 1210, 1231)  # round 4: duty split, ping-pong, ping-pong + loader waves
+
+
+_SPECULATIVE = os.environ.get("MILLIEYE_CHECK_FIRST", "0") != "1"  # (=1: parameter check in front of the launches, as before)
 
 
 def _autotune_enabled():

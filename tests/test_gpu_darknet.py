@@ -56,6 +56,18 @@ def test_shapes_config0_and_repeatability(hip_lib):
         model.module_list[0][0].weight.mul_(0.5)
         _, yolo3 = model(x.cuda())
     assert not torch.equal(yolo, yolo3)
+    # the engine issues the launches before it checks the parameters (and issues them again when one changed): the result of
+    # the call right after an update equals the result once every pack has been rebuilt from scratch
+    from millieye_amd import engine as _engine
+    with torch.no_grad():
+        model.module_list[2][0].weight.add_(0.01)          # a later layer this time; BatchNorm statistics too
+        model.module_list[2][1].running_mean.add_(0.02)
+        fm4, yolo4 = model(x.cuda())
+        _engine._EPOCH[0] += 1                               # every packed copy is stale now
+        fm5, yolo5 = model(x.cuda())
+        fm6, yolo6 = model(x.cuda())
+    assert not torch.equal(yolo3, yolo4)
+    assert torch.equal(yolo4, yolo5) and torch.equal(fm4, fm5) and torch.equal(yolo5, yolo6)
 
 
 def test_cpu_input_is_rejected_loudly(hip_lib):
