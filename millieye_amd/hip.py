@@ -294,7 +294,14 @@ def check(rc, what):
         raise MeError(f"{what} failed (rc={rc}): {msg}")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current torch stream of the current device as a ``hipStream_t`` for the C ABI.  ``torch.cuda.current_stream()`` builds
+    a Stream object (~6 us; a forward asks ~20 times), the raw query is a C call."""
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -466,7 +466,7 @@ class Network(nn.Module):
         if cb is None and model_mode != 1:
             self._check_eval()
             entered = torch.cuda.Event()
-            entered.record(torch.cuda.current_stream(dev))
+            entered.record()  # (on the current stream)
         if entered is not None and os.environ.get("MILLIEYE_RADAR_FIRST") == "1":  # (A/B: the previous order)
             side = self._side_stream(dev)
             side.wait_event(entered)
