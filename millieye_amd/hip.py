@@ -305,11 +305,6 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def stream_synchronize():
-    """Block until the current torch stream of the current device has drained."""
-    torch.cuda.current_stream().synchronize()
-
-
 def _require_cuda_f32(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
         raise MeError(f"{name} must be a CUDA float32 tensor (got {type(t).__name__}"

@@ -559,21 +559,10 @@ class Network(nn.Module):
 
         # ---- keep positives, order by confidence (reference :517-539): one launch, then the one host sync (the row count)
         ordered = torch.empty((cap, 8), **f32)
-        if os.environ.get("MILLIEYE_COUNT_MEMCPY") == "1":  # (A/B: the row count through a device word + a blocking copy)
-            n_out = torch.empty((1,), device=dev, dtype=torch.int32)
-            hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
-                                                   n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
-            n_rows = int(n_out.item())
-        else:
-            # the kernel stores the row count straight into pinned host memory (one address space on this platform): the host
-            # waits for the stream and reads it - no copy launch between the last kernel and the caller
-            n_host = self.__dict__.get("_count_host")
-            if n_host is None:
-                n_host = self.__dict__["_count_host"] = torch.zeros((1,), dtype=torch.int32).pin_memory()
-            hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
-                                                   n_host.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
-            hip.stream_synchronize()
-            n_rows = int(n_host[0])
+        n_out = torch.empty((1,), device=dev, dtype=torch.int32)
+        hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
+                                               n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+        n_rows = int(n_out.item())
         output = ordered[:n_rows]
         mark("output")
         self._last = dict(regress=regress, refine=refine, mask1=mask1, n_img=n_img_dev, img_boxes=img_boxes)
