@@ -265,7 +265,9 @@ def _chunk_worker(rank, world, port, q):
     for i, t in enumerate(grads):
         red.push(f"p{i}", t)
     done = red.finish()
-    q.put((rank, red.chunks_last, red.bytes_last, {k: v.clone() for k, v in done.items()}, [t.clone() for t in grads]))
+    # by value (numpy): a tensor would travel as a shared-memory handle that dies with this process
+    q.put((rank, red.chunks_last, red.bytes_last, {k: v.numpy().copy() for k, v in done.items()},
+           [t.numpy().copy() for t in grads]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -287,7 +289,7 @@ def test_grad_chunk_reducer_two_ranks_gloo():
     got = {}
     for _ in range(2):
         rank, chunks, nbytes, done, mine = q.get(timeout=300)
-        got[rank] = (chunks, nbytes, done, mine)
+        got[rank] = (chunks, nbytes, {k: torch.from_numpy(v) for k, v in done.items()}, [torch.from_numpy(t) for t in mine])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
