@@ -20,6 +20,8 @@ import ctypes as C
 import random
 
 import numpy as np
+import os
+
 import torch
 
 from . import hip
@@ -260,7 +262,6 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
                                                 int(net.class_idx), int(net.class_num), img_boxes.data_ptr(),
                                                 n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
-        n_img = int(n_img_dev.item())  # the labelling below is host work anyway (reference :556)
         if plan.tap is None:
             raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         fh, fw, fc = plan.tap_shape
@@ -269,7 +270,6 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
             radar_boxes_location[:, 1:] *= size
         n_radar = int(radar_boxes_location.shape[0])
         rb = radar_boxes_location.to(**f32).contiguous() if n_radar else torch.zeros((0, 5), **f32)
-        k = n_img + n_radar
         pix = n * fh * fw
         ws_t = torch.empty(int(lib.me_bn_workspace_bytes(512)) + 256, dtype=torch.uint8, device=dev)
         ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256
@@ -320,12 +320,6 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         radar["r4"] = r4
 
         # ---- heads, part A: pooling + net0 + small dot products (saved for backward) -----------------
-        cap = max(k, 1)
-        feat_img, feat_rad = _f32(dev, cap, 490), _f32(dev, cap, 490)
-        hidden, small = _f32(dev, cap, 256), _f32(dev, cap, 16)
-        regress, refine, mask1 = _f32(dev, cap, 4), _f32(dev, cap, 2), _f32(dev, cap)
-        rows, key = _f32(dev, cap, 8), _f32(dev, cap)
-        keep = torch.zeros((cap,), device=dev, dtype=torch.uint8)
         wts = dict(
             w0t=rh.net0[0].weight.detach().t().contiguous(), b0=rh.net0[0].bias.detach().contiguous(),
             w1=rh.net1[0].weight.detach().contiguous(), b1=rh.net1[0].bias.detach().contiguous(),
@@ -337,6 +331,18 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
             rb2=rh.radar_net[3].bias.detach().reshape(1).contiguous(),
             e1w=eh.fc1[0].weight.detach().contiguous(), e1b=eh.fc1[0].bias.detach().contiguous(),
             e2w=eh.fc2[0].weight.detach().contiguous(), e2b=eh.fc2[0].bias.detach().contiguous())
+        # The one host sync of the forward: the number of image proposals (the labelling below is host work anyway, reference
+        # :556).  Everything above it - both score maps with their BatchNorms, the weight layouts - needs nothing from the
+        # detector's boxes and is ISSUED before the host waits, so it queues up behind the detector instead of starting when the
+        # GPU has already gone idle (the step's second half is bound by the host).
+        n_img = int(n_img_dev.item())
+        k = n_img + n_radar
+        cap = max(k, 1)
+        feat_img, feat_rad = _f32(dev, cap, 490), _f32(dev, cap, 490)
+        hidden, small = _f32(dev, cap, 256), _f32(dev, cap, 16)
+        regress, refine, mask1 = _f32(dev, cap, 4), _f32(dev, cap, 2), _f32(dev, cap)
+        rows, key = _f32(dev, cap, 8), _f32(dev, cap)
+        keep = torch.zeros((cap,), device=dev, dtype=torch.uint8)
         d = hip.HeadsDesc()
         d.img_map, d.radar_map, d.img_pitch, d.radar_pitch = a1.data_ptr(), r4.data_ptr(), 490, 10
         d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16

@@ -41,4 +41,4 @@ print("ms/step", (time.perf_counter() - t0) / 20 * 1e3)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("ROWS", "28")))
