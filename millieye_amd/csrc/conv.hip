@@ -25,6 +25,10 @@
 
 namespace me32 {  // conv_p8_f32.hip: patch-resident big tiles (tile ids >= 100)
 int launch_p8_tile(const ConvP& p, int tile, hipStream_t stream);
+bool ws1x1_f32_eligible(const ConvP& p);  // conv_ws_f32.hip: weight-stationary short-K layers (tile ids 50 / 60)
+int launch_ws1x1_f32(const ConvP& p, hipStream_t stream);
+bool ws3x3_f32_eligible(const ConvP& p);
+int launch_ws3x3_f32(const ConvP& p, hipStream_t stream);
 bool stem_mfma_eligible(const ConvP& p);  // stem_mfma_f32.hip
 int launch_stem_mfma(const ConvP& p, hipStream_t stream);
 }  // namespace me32
@@ -1587,6 +1591,10 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   p.splitk = plan.splitk;
   p.partial = reinterpret_cast<float*>(d->workspace);
   if (plan.tile >= 100) return me32::launch_p8_tile(p, plan.tile, stream);
+  if (plan.tile == 50 || plan.tile == 60) {  // weight-stationary streaming kernels (conv_ws_f32.hip): whole K per wave, no split
+    ME_REQUIRE(d->split_k <= 1, ME_E_BADARG, "me_conv2d_f32: tile %d has no split-K form", plan.tile);
+    return plan.tile == 50 ? me32::launch_ws1x1_f32(p, stream) : me32::launch_ws3x3_f32(p, stream);
+  }
   switch (plan.tile) {
     // production tiles: buffer-addressed LDS-DMA pipeline (falls back to conv_igemm_dma_f32 when cin % 16 != 0
     // or the offsets do not fit the descriptor window)

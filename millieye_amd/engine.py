@@ -938,7 +938,7 @@ def _tune_file():
     if path:
         return path
     base = os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    return os.path.join(base, "millieye_amd", "conv_tune_v14.json")  # bump with every kernel generation
+    return os.path.join(base, "millieye_amd", "conv_tune_v15.json")  # bump with every kernel generation
 
 
 def _tune_load():
@@ -1100,8 +1100,17 @@ def _autotune(plan, lib):
                 tiles = tiles + _TUNE_TILES_TAIL
             if d.ksize == 3 and d.stride == 1 and d.upsample == 1 and d.wgt_tiled:
                 tiles = tiles + _TUNE_TILES_P8_F32
+            # round 5: weight-stationary streaming kernels for the short-K layers (csrc/conv_ws_f32.hip; the library refuses
+            # shapes without an instance).  MILLIEYE_NO_WS32 = "50", "60" or "50,60" keeps them out (A/B)
+            no_ws32 = os.environ.get("MILLIEYE_NO_WS32", "")
+            if d.ksize == 1 and d.stride == 1 and d.upsample == 1 and not d.res and d.act != hip.ACT_SIGMOID \
+                    and d.cin in (64, 128, 256, 384, 512) and "50" not in no_ws32:
+                tiles = tiles + (50,)
+            if d.ksize == 3 and d.pad == 1 and d.cin in (32, 64) and d.upsample == 1 and d.act != hip.ACT_SIGMOID \
+                    and "60" not in no_ws32:
+                tiles = tiles + (60,)
         for tile in tiles:
-            bm, bn = _TILE_SHAPES_BF16[tile] if (bf16 or tile >= 100) else \
+            bm, bn = _TILE_SHAPES_BF16[tile] if (bf16 or tile >= 100 or tile in (50, 60)) else \
                 {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (256, 128), 7: (64, 64)}[tile % 40]
             ntiles = -(-d.n * d.ho * d.wo // bm) * -(-d.cout // bn)
             tail = not bf16 and tile in _TUNE_TILES_TAIL

@@ -335,6 +335,77 @@ def test_conv_p8_patch_resident_f32(hip_lib, tile):
     assert torch.equal(wide[..., 16:16 + cout], a1) and float(wide[..., :16].abs().max()) == 0
 
 
+WS1_PAIRS = ((64, 32), (64, 64), (64, 128), (128, 64), (128, 128), (256, 128), (256, 255), (384, 128), (512, 256), (512, 255))
+
+
+@pytest.mark.parametrize("cin,cout", WS1_PAIRS)
+def test_conv_ws1x1_f32(hip_lib, cin, cout):
+    """Tile 50 of me_conv2d_f32 (csrc/conv_ws_f32.hip: weights in registers, activations streamed through an LDS ring,
+    persistent grid): every built cin against the CPU convolution at the fp32 bar (1e-3) - ragged M (rows behind the last
+    pixel are zero-filled by the DMA range check), more tiles than ring slots and more tiles than workgroups' first round,
+    ragged cout (255: the detection convolutions), linear / leaky, a channel slice as input, a pitched output - and BIT-identical
+    to the per-tap 64x64 tile without split-K (same accumulation order, same epilogue expression)."""
+    from millieye_amd import hip
+    _conv_case(hip, f"w1a{cin}_{cout}", 3, 13, 11, cin, cout, 1, 1, 1, tile=50)                 # 429 rows: ragged last tile
+    _conv_case(hip, f"w1b{cin}_{cout}", 1, 5, 5, cin, cout, 1, 1, 0, tile=50, x_slice=32)      # fewer rows than a tile, linear, slice
+    n, h, w = (6, 52, 52) if cin <= 256 else (4, 26, 26)
+    x = _t(f"w1x{cin}", (n, h, w, cin)).cuda()
+    wg = torch.from_numpy(synth.normal(f"w1w{cin}_{cout}", (cout, 1, 1, cin), 0, (2.0 / cin) ** 0.5)).cuda()
+    sc, sh = _t("w1s", (cout,), 0.5, 1.5).cuda(), _t("w1b", (cout,), -0.5, 0.5).cuda()
+    a0 = hip.conv2d(x, wg, sc, sh, 1, 1, 0, 1, tile=3, split_k=1)
+    a1 = hip.conv2d(x, wg, sc, sh, 1, 1, 0, 1, tile=50)
+    a2 = hip.conv2d(x, wg, sc, sh, 1, 1, 0, 1, tile=50)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2)
+    assert torch.equal(a1, a0), f"max diff {float((a1 - a0).abs().max())}"
+    wide = torch.zeros((n, h, w, cout + 9), device="cuda")
+    hip.conv2d(x, wg, sc, sh, 1, 1, 0, 1, tile=50, out=wide[..., 4:4 + cout])
+    assert torch.equal(wide[..., 4:4 + cout], a1) and float(wide[..., :4].abs().max()) == 0 and \
+        float(wide[..., 4 + cout:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(32, 64, 1), (32, 64, 2), (64, 128, 1), (64, 128, 2), (32, 48, 1), (64, 255, 2)])
+def test_conv_ws3x3_f32(hip_lib, cin, cout, stride):
+    """Tile 60 of me_conv2d_f32 (weight-stationary 3x3 for 32 / 64 input channels; 2-D output tiles whose input patch sits in
+    one LDS ring slot, the nine taps as pixel shifts): odd map sizes (ragged tiles on both axes, borders everywhere), both
+    strides, fused shortcut, ragged cout, channel slices - against the CPU convolution (1e-3) and bit-identical to the per-tap
+    64x64 tile without split-K."""
+    from millieye_amd import hip
+    tag = f"w3{cin}_{cout}_{stride}"
+    _conv_case(hip, tag + "a", 2, 13, 11, cin, cout, 3, stride, 1, tile=60, residual=(stride == 1))
+    _conv_case(hip, tag + "b", 1, 37, 50, cin, cout, 3, stride, 0, tile=60, x_slice=32)
+    _conv_case(hip, tag + "c", 3, 5, 3, cin, cout, 3, stride, 1, tile=60)
+    n, h, w = 3, 52, 44
+    x = _t(tag + "x", (n, h, w, cin)).cuda()
+    wg = torch.from_numpy(synth.normal(tag + "w", (cout, 3, 3, cin), 0, (2.0 / (9 * cin)) ** 0.5)).cuda()
+    sc, sh = _t("w3s", (cout,), 0.5, 1.5).cuda(), _t("w3b", (cout,), -0.5, 0.5).cuda()
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = _t(tag + "r", (n, ho, wo, cout)).cuda() if stride == 1 else None
+    a0 = hip.conv2d(x, wg, sc, sh, 3, stride, 1, 1, residual=res, tile=3, split_k=1)
+    a1 = hip.conv2d(x, wg, sc, sh, 3, stride, 1, 1, residual=res, tile=60)
+    a2 = hip.conv2d(x, wg, sc, sh, 3, stride, 1, 1, residual=res, tile=60)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2)
+    assert torch.equal(a1, a0), f"max diff {float((a1 - a0).abs().max())}"
+
+
+def test_conv_ws_f32_refuses_what_it_cannot_do(hip_lib):
+    from millieye_amd import hip
+    one, zero = torch.ones(64).cuda(), torch.zeros(64).cuda()
+    x = torch.zeros((1, 8, 8, 48)).cuda()
+    with pytest.raises(hip.MeError):   # cin without an instance
+        hip.conv2d(x, torch.zeros((64, 1, 1, 48)).cuda(), one, zero, 1, 1, 0, 1, tile=50)
+    x = torch.zeros((1, 8, 8, 64)).cuda()
+    with pytest.raises(hip.MeError):   # sigmoid epilogue
+        hip.conv2d(x, torch.zeros((64, 1, 1, 64)).cuda(), one, zero, 1, 1, 0, 2, tile=50)
+    with pytest.raises(hip.MeError):   # upsampling epilogue
+        hip.conv2d(x, torch.zeros((64, 1, 1, 64)).cuda(), one, zero, 1, 1, 0, 1, tile=50, upsample=2)
+    with pytest.raises(hip.MeError):   # 3x3 with 128 input channels
+        hip.conv2d(torch.zeros((1, 8, 8, 128)).cuda(), torch.zeros((64, 3, 3, 128)).cuda(), one, zero, 3, 1, 1, 1, tile=60)
+    with pytest.raises(hip.MeError):   # no split-K form
+        hip.conv2d(x, torch.zeros((64, 1, 1, 64)).cuda(), one, zero, 1, 1, 0, 1, tile=50, split_k=2)
+
+
 def test_conv_p8_f32_refuses_what_it_cannot_do(hip_lib):
     from millieye_amd import hip
     x = torch.zeros((1, 8, 8, 32)).cuda()

@@ -30,6 +30,10 @@ SHAPES = [
     ("3x3 512->1024 @13", 13, 512, 1024, 3, 1),
     ("1x1 1024->255 @13", 13, 1024, 255, 1, 1),
     ("1x1 768->256 @26", 26, 768, 256, 1, 1),
+    ("s2 64->128 @208", 208, 64, 128, 3, 2),
+    ("1x1 384->128 @52", 52, 384, 128, 1, 1),
+    ("1x1 256->255 @52", 52, 256, 255, 1, 1),
+    ("1x1 512->255 @26", 26, 512, 255, 1, 1),
 ]
 
 
@@ -42,6 +46,7 @@ def main():
     ap.add_argument("--splits", default="0", help="comma list of split_k values (0 = auto)")
     ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed load before each measurement")
     ap.add_argument("--res", action="store_true", help="fused residual add (the [shortcut] epilogue)")
+    ap.add_argument("--zero", action="store_true", help="zero activations: same instructions and traffic, zero products (DVFS check)")
     ap.add_argument("--custom", default="", help="extra shape 'hw,cin,cout,k,stride' (square input)")
     args = ap.parse_args()
     if args.custom:
@@ -62,6 +67,8 @@ def main():
         pad = (k - 1) // 2
         ho = (hw + 2 * pad - k) // s + 1
         x = torch.randn((n, hw, hw, cin), device=dev)
+        if args.zero:
+            x.zero_()
         w = torch.randn((cout, k, k, cin), device=dev) * 0.05
         sc = torch.ones(cout, device=dev)
         sh = torch.zeros(cout, device=dev)
@@ -81,7 +88,9 @@ def main():
             if sk > 1 and not 41 <= t <= 45 and sk * n * ho * ho * cout * 4 > ws.numel() - 256:
                 continue
             stream = hip.stream_ptr()
-            hip.check(lib.me_conv2d_f32(C.byref(d), stream), "conv")
+            if lib.me_conv2d_f32(C.byref(d), stream) != 0:   # a tile that refuses the shape (weight-stationary ids 50 / 60, patch tiles)
+                row.append(f"t{t}/k{sk}: refused")
+                continue
             torch.cuda.synchronize()
             # the GPU needs ~100 ms of sustained load to reach its steady clocks: pre-warm every variant for
             # the same wall time, otherwise the first one measured looks 15 % slower than it is
