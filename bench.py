@@ -50,6 +50,11 @@ def parse():
                     help="storage of the detector activations / weights: f32 (default, the parity mode), bf16 or f16 "
                          "(BASELINE configs[2]/[4]: 16-bit operands, fp32 accumulate; inference workloads only)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed clock ramp-up before the warmup")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak (default): --batch frames PER GPU; strong: --batch frames in total, sharded over the ranks "
+                         "(parallel.shard_range).  An N > 1 weak run of an inference workload also times the strong reading "
+                         "and reports it as `strong_scaling` in the same line")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1 weak runs: skip the extra strong-scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the extra bf16-storage-mode measurement")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra batch 1 / 8 measurements")
@@ -161,6 +166,18 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TF = 157.3
 
 
+def roi_stage_bytes(rois, n, fh, fw, rh, rw, weight_bytes, box_cols):
+    """SURVEY 8(d) algorithmic bytes of the "RoI pooling + heads" stage (two launches: roi_pool10_kernel, roi_heads_mfma_kernel):
+    every operand ONCE - both score maps in (image [n,fh,fw,490], radar [n,rh,rw,12] fp32), the pooled features
+    (980 floats per RoI) out of the pooling launch and back into the heads launch, the head weights once, the RoI rows in
+    and the per-RoI results out (regress 4 + refine 2 + mask 1 + row 8 + key 1 floats + 1 keep byte).  No re-read term:
+    what a kernel re-fetches through L2 (e.g. W0 per workgroup) is traffic, not algorithmic bytes."""
+    maps = 4.0 * n * (fh * fw * 490 + rh * rw * 12)
+    pooled = 2.0 * 4.0 * 980 * rois
+    rows = 4.0 * box_cols * rois + (4.0 * (4 + 2 + 1 + 8 + 1) + 1.0) * rois
+    return maps + pooled + float(weight_bytes) + rows
+
+
 def stage_roofline(model, net, x, step, rois, reps=5):
     """Achieved fraction of the bounding roofline per stage of one step (north_star: "achieved-fraction-of-roofline
     per stage"), from HIP events recorded in sequence inside real steps.  Detector stages come from per-launch
@@ -240,8 +257,11 @@ def stage_roofline(model, net, x, step, rois, reps=5):
                 elif n1 == "score_maps":
                     add("score maps (1x1 256->490 + radar CNN)", ms, flops=n * (0.170e9 + 0.128e9) * (size / 416.0) ** 2)
                 elif n1 == "roi_heads":
+                    fh, fw, _fc = plan.tap_shape
+                    hw = net._get_packs()["heads"].refresh(x.device)
                     add("RoI pooling + refinement / ensemble heads", ms, flops=rois * 0.27e6,
-                        bytes=rois * (2 * 490 * 4 * 4.0) + (rois / 8.0) * 490 * 256 * 4.0)
+                        bytes=roi_stage_bytes(rois, n, fh, fw, fh, fw, sum(t.numel() * t.element_size() for t in hw.values()),
+                                              8 + int(net.class_num)))
                 elif n1 == "output":
                     add("compaction + sort of output rows", ms)
         net._stage_cb = None
@@ -254,7 +274,8 @@ def stage_roofline(model, net, x, step, rois, reps=5):
             row.update(bound="mfma", achieved=round(tf, 2), peak=mfma_peak, unit="TFLOP/s", frac=round(tf / mfma_peak, 4))
         elif e["bytes"]:
             gbs = e["bytes"] / reps / (ms * 1e-3) / 1e9
-            row.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4))
+            row.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                       algorithmic_bytes=int(e["bytes"] / reps))
             if e["flops"]:
                 row["gflops"] = round(e["flops"] / reps / (ms * 1e-3) / 1e9, 1)
         elif e["flops"]:
@@ -541,9 +562,22 @@ def main():
     from millieye_amd.yolov3.models import Darknet
 
     batch = args.batch or (32 if args.workload in ("full", "module2") else 8)
+    gbatch = batch  # frames per step over all ranks (strong) / per GPU (weak)
+    strong = args.scaling == "strong"
+    if strong and args.workload not in ("full", "detector", "module2"):
+        raise SystemExit("--scaling strong: inference workloads (full, detector, module2) - the training steps keep a fixed "
+                         "per-GPU batch")
+    if strong and batch < world:
+        raise SystemExit(f"--scaling strong: {batch} frames cannot be sharded over {world} ranks")
     conf_thresh = 0.2
     cfg_path = cfgs.write_cfg(args.cfg, os.path.join("/tmp", f"millieye_bench_cfg_{os.getuid()}_{rank}"))
-    frames_cpu = torch.from_numpy(synth.uniform(f"bench/frames/{rank}", (batch, 3, args.size, args.size)))
+    from millieye_amd import parallel as par
+    if strong:  # ONE global batch (rank 0's frames), every rank takes its contiguous share
+        lo, hi = par.shard_range(gbatch, rank, world)
+        frames_cpu = torch.from_numpy(synth.uniform("bench/frames/0", (gbatch, 3, args.size, args.size)))[lo:hi].contiguous()
+        batch = hi - lo
+    else:
+        frames_cpu = torch.from_numpy(synth.uniform(f"bench/frames/{rank}", (batch, 3, args.size, args.size)))
     x = frames_cpu.to(dev)
     radar = None
     if args.workload == "detector_train":
@@ -611,8 +645,14 @@ def main():
         state_cpu = {k: v.clone() for k, v in net.state_dict().items()}
         net = net.to(dev)
         model = net.base_detector
-        maps_np, boxes_np = synth.radar_inputs(f"bench/radar/{rank}", batch, args.size // 16, boxes_per_image=2)
-        maps_cpu, boxes_cpu = torch.from_numpy(maps_np), torch.from_numpy(boxes_np)
+        if strong:
+            maps_np, boxes_np = synth.radar_inputs("bench/radar/0", gbatch, args.size // 16, boxes_per_image=2)
+            _x, maps_cpu, boxes_cpu, _t = par.shard_batch(torch.empty((gbatch, 0)), torch.from_numpy(maps_np),
+                                                          torch.from_numpy(boxes_np), None, rank, world)
+            maps_cpu = maps_cpu.contiguous()
+        else:
+            maps_np, boxes_np = synth.radar_inputs(f"bench/radar/{rank}", batch, args.size // 16, boxes_per_image=2)
+            maps_cpu, boxes_cpu = torch.from_numpy(maps_np), torch.from_numpy(boxes_np)
         maps_d, boxes_d = maps_cpu.to(dev), boxes_cpu.to(dev)
         radar = (maps_cpu, boxes_cpu, conf_thresh)
         last = {}
@@ -660,10 +700,11 @@ def main():
                              "of the stage-3 training step (workload train)")
         model.compute_dtype = args.dtype
     t_pre = time.perf_counter() + args.prewarm_seconds
-    def lockstep_until(deadline):
+    def lockstep_until(deadline, step=None):
         """Untimed steps until ``deadline`` - the SAME number on every rank (the training steps hold collectives, plan builds
         broadcast rank 0's tuned table: a rank that ran one step more than its peers would wait for a partner that never
         comes).  Every rank votes after each step; all stop as soon as one has reached its deadline."""
+        step = step or main_step
         while True:
             step()
             torch.cuda.synchronize()
@@ -674,6 +715,27 @@ def main():
                 go = bool(vote.item() > 0)
             if not go:
                 break
+
+    main_step = step
+
+    def timed(fn, k):
+        """K steps bracketed by a barrier + synchronize on both sides, max over the ranks (the contract's protocol)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([e], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
 
     lockstep_until(t_pre)
     for _ in range(args.warmup):
@@ -728,6 +790,44 @@ def main():
             alt = {"error": f"{type(exc).__name__}: {exc}"}
             model.compute_dtype = "f32"
 
+    # The other reading of "@batch32" on N GPUs: the metric's 32 frames in TOTAL, sharded over the ranks
+    # (parallel.shard_range) - strong scaling - next to the weak line above (32 per GPU).  Same protocol, same K.
+    strong_leg = None
+    if world > 1 and not strong and not args.no_strong_leg and args.dtype == "f32" \
+            and args.workload in ("full", "detector", "module2") and batch >= world:
+        try:
+            lo, hi = par.shard_range(batch, rank, world)
+            xs = torch.from_numpy(synth.uniform("bench/frames/0", (batch, 3, args.size, args.size)))[lo:hi].contiguous().to(dev)
+            if args.workload == "full":
+                m_np, b_np = synth.radar_inputs("bench/radar/0", batch, args.size // 16, boxes_per_image=2)
+                _x, ms_, bs_, _t = par.shard_batch(torch.empty((batch, 0)), torch.from_numpy(m_np), torch.from_numpy(b_np),
+                                                   None, rank, world)
+                ms_, bs_ = ms_.contiguous().to(dev), bs_.to(dev)
+
+                def step_s():
+                    with torch.no_grad():
+                        return net(xs, ms_, bs_.clone(), 0)
+            elif args.workload == "module2":
+                def step_s():
+                    with torch.no_grad():
+                        return net2(xs)
+            else:
+                def step_s():
+                    with torch.no_grad():
+                        return model(xs)
+            lockstep_until(time.perf_counter() + 0.5, step_s)  # plans (+ rank 0's tuned table) for the shard shape, untimed
+            for _ in range(args.warmup):
+                step_s()
+            e_s = timed(step_s, args.steps)
+            strong_leg = {"scaling": "strong", "global_batch": batch, "frames_per_gpu": hi - lo if rank else
+                          [par.shard_range(batch, r, world)[1] - par.shard_range(batch, r, world)[0] for r in range(world)],
+                          "value": round(batch * args.steps / e_s, 2), "unit": "frames/s",
+                          "ms_per_step": round(e_s / args.steps * 1e3, 4),
+                          "note": "the same metric read as 32 frames in total: one global batch sharded over the ranks, no "
+                                  "data-path collective; barrier + max-over-ranks timing like `value`"}
+        except Exception as exc:  # the extra leg must never take the measurement down with it (same exception on every rank)
+            strong_leg = {"error": f"{type(exc).__name__}: {exc}"}
+
     # north_star: "frames/sec ... at batch 1/8/32": the same step at batch 1 and 8 (rank 0's frames; untimed plan building
     # and autotuning first), fp32 and bf16 storage, reported beside - never instead of - `value`
     os.environ["MILLIEYE_TUNE_SYNC"] = "0"  # from here on rank 0 plans alone (batch sweep, stage table, accuracy leg)
@@ -776,7 +876,7 @@ def main():
         from millieye_amd import detector_train as dtr
         det_passes = dtr.profile_step_passes(step)
     if rank == 0:
-        frames = batch * world * args.steps
+        frames = (gbatch if strong else batch * world) * args.steps
         plan = model.engine_for(model.compute_dtype).plan_for(x)
         bf16 = args.dtype != "f32"
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
@@ -790,14 +890,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"{args.cfg}.cfg {args.size}x{args.size} "
                             + (f"{args.dtype}-storage ({args.dtype} operands, fp32 accumulate)" if bf16 else "fp32")
-                            + f" inference, batch={batch} per GPU, "
+                            + (f" inference, batch={gbatch} in total sharded over the ranks, " if strong else
+                               f" inference, batch={batch} per GPU, ")
                             + ("Darknet.forward -> featuremap + yolo_outputs" if args.workload == "detector" else
                                "full milliEye: Darknet.forward -> NMS -> Network.forward mode 0 (R-CNN head + radar "
                                "fusion, 2 radar boxes/frame) -> output rows" if args.workload == "full" else
@@ -811,7 +912,7 @@ def main():
                             + ", synthetic frames U[0,1), deterministic trained-like weights",
                 "stage": args.workload,
                 "batch_per_gpu": batch,
-                "global_batch": batch * world,
+                "global_batch": gbatch if strong else batch * world,
                 "img_size": args.size,
                 "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, "
                                + ("one SUM all-reduce of the gradient bucket per step (RCCL)" if args.workload == "train" else
@@ -838,6 +939,8 @@ def main():
         }
         if sweep:
             out["batch_sweep"] = sweep
+        if strong_leg is not None:
+            out["strong_scaling"] = strong_leg
         if alt is not None and "error" in alt:
             out["bf16_storage_mode"] = alt
         elif alt is not None:

@@ -244,7 +244,7 @@ int launch_w1(const ConvP& p, hipStream_t stream) {
   }
   if (getenv("MILLIEYE_WS32_DEBUG")) {
     int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64 * NW, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64 * NW, lds);
     fprintf(stderr, "[ws32] 1x1 cin %d: grid %u x %d threads, lds %zu, tiles_m %d grid_m %d tiles_n %d, occupancy API %d blocks/CU\n", CIN,
             grid.x, 64 * NW, lds, a.tiles_m, a.grid_m, tiles_n, nb);
   }

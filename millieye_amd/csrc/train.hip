@@ -672,12 +672,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_v4_kernel(const float* 
 // (2) OHWI slabs -> OIHW parameter layout: a block owns one output channel x 64 input channels x all taps; the slab reads
 // are runs of 64 floats per tap, the sums turn through LDS ([ci][tap], odd pitch) and leave as one contiguous run.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_oihw_kernel(const float* __restrict__ slabs, float* DW, long long count,
-                                                                     int splits, int kk, int cin) {
+                                                                     int splits, int kk, int cin, int vec16) {
   extern __shared__ float s_t[];  // [64][kk | 1]
   const int pitch = kk | 1;
   const int co = blockIdx.y, c0 = blockIdx.x * 64;
   const int nc = cin - c0 < 64 ? cin - c0 : 64;
-  if ((cin & 3) == 0 && nc == 64) {
+  if (vec16 && nc == 64) {  // (vec16: cin % 4 == 0 and a 16-byte aligned workspace, checked by the host side)
     // 16-byte loads, eight slabs in flight per lane (round 4: the scalar loop below kept 4 KB per workgroup in flight and
     // summed 38 MB of nine-tap slabs at 1.5 - 2.5 TB/s)
     for (int i = threadIdx.x; i < kk * 16; i += 256) {
@@ -1466,7 +1466,7 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
   if (oihw && ksize > 1 && cout < 65536) {
     const int kk = ksize * ksize;
     hipLaunchKernelGGL(conv_wgrad_reduce_oihw_kernel, dim3((cin + 63) / 64, cout), dim3(256), 64 * (kk | 1) * sizeof(float),
-                       stream, slabs, dw, count, splits, kk, cin);
+                       stream, slabs, dw, count, splits, kk, cin, ((cin & 3) == 0 && me::aligned16(workspace)) ? 1 : 0);
   } else if (!(oihw && ksize > 1) && count % 4 == 0 && me::aligned16(dw) && me::aligned16(workspace)) {
     hipLaunchKernelGGL(conv_wgrad_reduce_v4_kernel, dim3(grid1d(count / 4)), dim3(256), 0, stream, slabs, dw, count / 4, splits);
   } else {

@@ -806,7 +806,11 @@ class DarknetEngine:
         n_, _, h_, w_ = x.shape
         plan = self._plans.get((n_, h_, w_, x.device.index, bool(keep_raw))) \
             if self.__dict__.get("_fast_stamp") is not None else None
-        early = plan is not None and _SPECULATIVE and not _graphs_enabled()
+        # ... except where a second issue would be wrong or wasteful: under a caller's stream capture (the stale
+        # pass and the re-pack would both be captured) and with autograd recording (a forward that follows an optimizer step -
+        # the evaluation inside a training loop - would pay the launches twice); MILLIEYE_CHECK_FIRST=1 turns it off for good.
+        early = plan is not None and _SPECULATIVE and not _graphs_enabled() and not torch.is_grad_enabled() \
+            and not torch.cuda.is_current_stream_capturing()
         if not early:
             self.refresh_weights(x.device)
             plan = self.plan_for(x, keep_raw)

@@ -54,6 +54,7 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
         model.train()
         model.base_detector.eval()
         start_time = time.time()
+        parallel.begin_epoch(dataloader, epoch, device)  # equal batch counts on every rank + the sampler's epoch
         for batch_i, (_, imgs, targets) in enumerate(dataloader):
             batches_done = len(dataloader) * epoch + batch_i
             epoch_batches_left = len(dataloader) - (batch_i + 1)

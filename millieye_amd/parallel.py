@@ -11,7 +11,8 @@ in this build and deliberately minimal, shaped for xGMI:
   (pure latency on xGMI; bucketing / overlap machinery would only add launches).  Negative sampling uses
   each rank's own ``random`` stream, BatchNorm statistics are per shard (like per-GPU BN in any DDP run);
   with eval-mode BatchNorm and no sub-sampling the summed shard gradients equal the 1-way step exactly
-  (tests/test_parallel_cpu.py::test_dp_stage3_step_equals_one_way).
+  (tests/test_parallel_cpu.py::test_dp_stage3_step_equals_one_way).  This holds for STAGE 3 ONLY: the detector's YOLO
+  loss is a per-batch mean, see :class:`GradChunkReducer` (``average=True``).
 
 * **Detector training** (row a6; the reference never trains the detector, ``train.py:98`` freezes it): 61.9 M parameters =
   247.8 MB of fp32 gradients next to a ~20 ms step.  One flat bucket behind the whole backward would put the entire
@@ -29,7 +30,30 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["shard_range", "shard_batch", "merge_outputs", "flatten_grads", "allreduce_gradients", "GradChunkReducer",
-           "overlap_detector_allreduce"]
+           "overlap_detector_allreduce", "begin_epoch"]
+
+
+def begin_epoch(dataloader, epoch, device=None):
+    """Top of every epoch of a data-parallel training loop (train.py, module2/train.py):
+
+    * every rank must issue the same number of collectives - the optimizer step (and its all-reduce) is keyed on the local
+      batch counter, so an uneven shard would hang the job: fail loudly instead;
+    * ``DistributedSampler(shuffle=True)`` derives its permutation from ``seed + epoch``: without ``set_epoch`` every epoch
+      replays epoch 0's order and every rank keeps the same fixed 1/N shard for the whole run (the single-process loop
+      reshuffles through ``DataLoader(shuffle=True)``).
+
+    No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    on_gpu = dist.get_backend() == "nccl"
+    lens = torch.tensor([len(dataloader), -len(dataloader)], dtype=torch.int64, device=device if on_gpu else "cpu")
+    dist.all_reduce(lens, op=dist.ReduceOp.MAX)
+    if int(lens[0]) != -int(lens[1]):
+        raise RuntimeError(f"ranks see different batch counts per epoch (min {-int(lens[1])}, max {int(lens[0])}): "
+                           "shard the dataset evenly (DistributedSampler pads to equal counts; main() does)")
+    sampler = getattr(dataloader, "sampler", None)
+    if hasattr(sampler, "set_epoch"):
+        sampler.set_epoch(epoch)
 
 
 def shard_range(n_frames, rank, world):
@@ -165,13 +189,19 @@ class GradChunkReducer:
     """SUM all-reduce of a gradient stream in production order, one collective per ``chunk_bytes``, each on a dedicated
     communication stream that only waits for the streams its members were produced on.
 
+    Scaling: the exchange SUMS the ranks' gradients.  Stage 3's loss terms are sums over proposals, so the summed shard
+    gradients ARE the 1-way step.  The YOLO loss of the detector is a per-batch MEAN (yolov3/models.py:163-168 of the
+    reference): summing N shard-mean gradients gives ~N times the gradient of the same global batch on one GPU.
+    ``average=True`` divides every reduced chunk by the world size (the gradient of the mean over the global batch, up to
+    the per-shard object counts in the means) - use it, or scale the learning rate, when a single-GPU schedule is kept.
+
     ``begin(dev)`` -> ``push(name, grad, stream)`` for every gradient as soon as its kernels are enqueued -> ``finish()``
     returns ``{name: reduced gradient}`` (views of the reduced flat chunks: no copy back) and makes the caller's stream
     wait for the exchanges.  The members of a chunk are concatenated on the communication stream (one batched copy), so
     the producers never wait for the pack.  ``chunks_last`` / ``bytes_last`` describe the last backward."""
 
-    def __init__(self, chunk_bytes=32 << 20, group=None):
-        self.chunk_bytes, self.group = int(chunk_bytes), group
+    def __init__(self, chunk_bytes=32 << 20, group=None, average=False):
+        self.chunk_bytes, self.group, self.average = int(chunk_bytes), group, bool(average)
         self._comm = {}
         self.chunks_last = self.bytes_last = 0
         self._cur, self._cur_bytes, self._streams, self._done, self._flats = [], 0, [], {}, []
@@ -211,6 +241,8 @@ class GradChunkReducer:
             flat = torch.cat([g.reshape(-1) for _n, g in members]) if len(members) > 1 else members[0][1].reshape(-1).clone()
             if distributed:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                if self.average:
+                    flat.div_(dist.get_world_size(self.group))
             off = 0
             for name, g in members:
                 n = g.numel()
@@ -244,14 +276,16 @@ class GradChunkReducer:
         return done
 
 
-def overlap_detector_allreduce(model, chunk_bytes=32 << 20, group=None):
+def overlap_detector_allreduce(model, chunk_bytes=32 << 20, group=None, average=False):
     """Attach a :class:`GradChunkReducer` to a ``Darknet``: ``loss.backward()`` of ``Darknet.forward(x, targets)`` then
     hands every layer's gradients to it as they are produced and returns already-reduced gradients (do NOT call
     ``allreduce_gradients`` on the detector parameters as well).  Without a process group there is nothing to exchange:
-    nothing is attached and ``None`` is returned."""
+    nothing is attached and ``None`` is returned.  The gradients are SUMMED over the ranks; the detector's loss is a
+    per-batch mean, so that is ~world_size times the 1-way gradient - pass ``average=True`` to divide by the world size
+    (see :class:`GradChunkReducer`)."""
     if not (dist.is_available() and dist.is_initialized()):
         model.__dict__.pop("_grad_reducer", None)
         return None
-    red = GradChunkReducer(chunk_bytes, group)
+    red = GradChunkReducer(chunk_bytes, group, average)
     model.__dict__["_grad_reducer"] = red
     return red

@@ -82,18 +82,7 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
         model.train()
         model.base_detector.eval()
         start_time = time.time()
-        if distributed:
-            # every rank must issue the same number of collectives: the step (and its all-reduce) is keyed on the local
-            # batch counter, so an uneven shard would hang the job - fail loudly instead
-            lens = torch.tensor([len(dataloader), -len(dataloader)], dtype=torch.int64, device=device if
-                                torch.distributed.get_backend() == "nccl" else "cpu")
-            torch.distributed.all_reduce(lens, op=torch.distributed.ReduceOp.MAX)
-            if int(lens[0]) != -int(lens[1]):
-                raise RuntimeError(f"ranks see different batch counts per epoch (min {-int(lens[1])}, max {int(lens[0])}): "
-                                   "shard the dataset evenly (DistributedSampler pads to equal counts; main() does)")
-            sampler = getattr(dataloader, "sampler", None)
-            if hasattr(sampler, "set_epoch"):
-                sampler.set_epoch(epoch)
+        parallel.begin_epoch(dataloader, epoch, device)  # equal batch counts on every rank + the sampler's epoch
         for batch_i, (_, imgs, targets, radar_boxes, radar_maps) in enumerate(dataloader):
             batches_done = len(dataloader) * epoch + batch_i
             epoch_batches_left = len(dataloader) - (batch_i + 1)

@@ -266,7 +266,7 @@ class Darknet(nn.Module):
         detector backward is not built (no reference script trains the detector)."""
         if targets is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(x, targets)
-        if any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
+        if self._any_bn_training():
             # model.train() without autograd (reference :35,247-267: legal, batch statistics, running statistics updated):
             # the inference engine folds BatchNorm into the convolution and cannot do that - the training path's forward can
             return self._forward_batch_stats(x, targets)
@@ -287,6 +287,27 @@ class Darknet(nn.Module):
                 loss = loss + layer.loss_from_raw(raw, targets)
             return loss, self.featuremap, yolo_outputs
         return self.featuremap, yolo_outputs
+
+    def _any_bn_training(self):
+        """True when a BatchNorm of the detector is in train() mode.  The (container, key, BatchNorm) triples are collected once
+        (a walk over ``self.modules()`` - ~250 modules - was 50-100 us of host time in front of the first launch of every
+        inference call) and re-validated per call by one dict lookup each, so a replaced block or BatchNorm
+        triggers a fresh walk."""
+        cached = self.__dict__.get("_bn_triples")
+        blocks = self._modules["module_list"]._modules
+        if cached is not None and cached[0] == len(blocks):
+            ok = True
+            for cont, key, bn in cached[1]:
+                if cont.get(key) is not bn:
+                    ok = False
+                    break
+                if bn.training:
+                    return True
+            if ok and all(blocks.get(k) is b for k, b in cached[2]):
+                return False
+        triples = [(m._modules, k, c) for m in self.modules() for k, c in m._modules.items() if isinstance(c, nn.BatchNorm2d)]
+        self.__dict__["_bn_triples"] = (len(blocks), triples, list(blocks.items()))
+        return any(bn.training for _c, _k, bn in triples)
 
     def _forward_batch_stats(self, x, targets):
         """``Darknet.forward`` under ``model.train()`` outside autograd: BatchNorm layers in train() mode normalise with the

@@ -320,7 +320,7 @@ def test_demo_frame_step(hip_lib):
 def test_headline_workload_batch32_vs_oracle(hip_lib):
     """The configuration the metric is quoted on, end to end: yolov3.cfg (Darknet-53) 416x416, batch 32, full
     ``Network.forward`` mode 0 with two radar boxes per frame.  The CPU oracle needs seconds per frame, so it runs on
-    four frames of the batch one at a time (frames are independent units; row order inside a frame is the batch run's
+    eight frames of the batch one at a time (frames are independent units; row order inside a frame is the batch run's
     order because the descending-confidence sort is stable); all 32 frames are compared with their batch-1 HIP runs."""
     from oracle import network_ref
     name, cfg, n, s, conf = "headline", "yolov3", 32, 416, 0.2
@@ -335,7 +335,7 @@ def test_headline_workload_batch32_vs_oracle(hip_lib):
     with torch.no_grad():
         out = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0).cpu()
         # every one of the 32 frames: the rows of frame f in the batch run are the rows of the batch-1 run of frame f (1e-3;
-        # tile and split-K choices follow the batch, so the accumulation order differs) - the four oracle frames below then
+        # tile and split-K choices follow the batch, so the accumulation order differs) - the eight oracle frames below then
         # pin the batch-1 arithmetic, this loop pins the batching
         for f in range(n):
             rb = rboxes[rboxes[:, 0] == f].clone()
@@ -347,7 +347,7 @@ def test_headline_workload_batch32_vs_oracle(hip_lib):
     assert out.shape[0] > 32 and out.shape[1] == 8
     text = cfgs.KNOWN[cfg]()
     total = 0
-    for f in (0, 13, 22, 31):
+    for f in (0, 4, 9, 13, 18, 22, 27, 31):  # (eight oracle frames, every fourth of the batch)
         rb = rboxes[rboxes[:, 0] == f].clone()
         rb[:, 0] = 0
         ref = network_ref.network_forward(text, sd, x[f:f + 1], maps[f:f + 1], rb, 0, conf_thresh=conf, tap_module=91)
@@ -355,7 +355,7 @@ def test_headline_workload_batch32_vs_oracle(hip_lib):
         got[:, 0] = 0
         _cmp_rows_ties(got, ref, f"headline batch-32 run, frame {f}")
         total += ref.shape[0]
-    assert total >= 8, "the sampled frames must carry detections"
+    assert total >= 16, "the sampled frames must carry detections"
 
 
 def test_two_process_pipeline_equals_the_sequential_fuser(hip_lib):
@@ -380,3 +380,109 @@ def test_two_process_pipeline_equals_the_sequential_fuser(hip_lib):
     for (rows, info), (rows_w, info_w) in zip(got, want):
         assert torch.equal(rows, rows_w) and info["mode"] == info_w["mode"] == 0
     assert len(got[-1][0]) > 0
+
+
+def test_roi_heads_direct_2400_rois_vs_oracle(hip_lib):
+    """``me_roi_heads_f32`` (roi_pool10_kernel + roi_heads_mfma_kernel, the product's two-launch path)
+    called directly through the C ABI on synthetic score maps and 2 400 image proposals + 64 radar boxes over 8 frames
+    (degenerate / out-of-range / inverted boxes included), then ``me_compact_sort_rows_f32`` - against the oracle's
+    tv_ops RoI pooling + refinement / ensemble heads + box_regress + stable sort.  The new heads no longer lean on the four
+    headline frames."""
+    import ctypes as C
+
+    from millieye_amd import hip
+    from oracle import network_ref as nr
+    from oracle import tv_ops
+    name, n, fh, fw, k_img, k_rad = "headsdirect", 8, 26, 26, 2400, 64
+    size = 16.0 * fh
+    net = _build(name, "yolov3-tiny-12", 0.2).eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(net.device)
+    dev = torch.device("cuda")
+    m490 = torch.from_numpy(synth.uniform(name + "/m490", (n, 490, fh, fw), -1, 1))
+    m10 = torch.from_numpy(synth.uniform(name + "/m10", (n, 10, fh, fw), 0, 1))
+    rois = _rois(name + "/img", k_img, n, size)
+    rois = rois[torch.sort(rois[:, 0], stable=True).indices]  # image order, like the proposal assembly
+    cols = 8 + net.class_num
+    img_boxes = torch.zeros((k_img, cols))
+    img_boxes[:, :5] = rois
+    img_boxes[:, 5:] = torch.from_numpy(synth.uniform(name + "/conf", (k_img, cols - 5), 0.05, 0.95))
+    img_boxes[:, 7] = 0.0
+    rad = _rois(name + "/rad", k_rad, n, size)[3:]  # (the degenerate boxes stay among the image proposals)
+    k_rad = rad.shape[0]
+    cap_img = k_img + 100  # slots behind the last proposal, like n * detections_per_img
+    cap = cap_img + k_rad
+
+    # oracle
+    boxes_all = torch.cat((img_boxes[:, :5], rad), 0)
+    crop_img = tv_ops.ps_roi_align(m490, boxes_all, (7, 7), spatial_scale=1. / 16)
+    crop_rad = tv_ops.roi_align(m10, boxes_all, (7, 7), spatial_scale=1. / 16)
+    regress_ref, refine_ref = nr.refinement(sd, crop_rad, crop_img)
+    yolo_vec = torch.cat((img_boxes[:, 5:6], img_boxes[:, 8:]), 1)
+    masks_img = nr.ensemble(sd, refine_ref[:k_img], yolo_vec)
+    mask1_ref = torch.cat((masks_img[:, 0], refine_ref[k_img:, 0]), 0)
+
+    # product: bin-major image map (channel (ph*7+pw)*10 + c holds the reference's channel (c*7+ph)*7+pw), radar map pitch 12
+    q = torch.arange(490)
+    img_map = m490.permute(0, 2, 3, 1)[..., (q % 10) * 49 + q // 10].contiguous().to(dev)
+    rad_map = torch.zeros((n, fh, fw, 12))
+    rad_map[..., :10] = m10.permute(0, 2, 3, 1)
+    rad_map = rad_map.to(dev)
+    boxes_d = torch.zeros((cap_img, cols))
+    boxes_d[:k_img] = img_boxes
+    boxes_d = boxes_d.to(dev)
+    n_img_d = torch.tensor([k_img], dtype=torch.int32, device=dev)
+    rad_d = rad.contiguous().to(dev)
+    f32 = dict(device=dev, dtype=torch.float32)
+    regress, refine, mask1 = torch.empty((cap, 4), **f32), torch.empty((cap, 2), **f32), torch.empty((cap,), **f32)
+    rows, key = torch.empty((cap, 8), **f32), torch.empty((cap,), **f32)
+    keep = torch.full((cap,), 7, device=dev, dtype=torch.uint8)
+    pooled = torch.empty((cap, 980), **f32)
+    hw = net._get_packs()["heads"].refresh(dev)
+    d = hip.HeadsDesc()
+    d.img_map, d.radar_map = img_map.data_ptr(), rad_map.data_ptr()
+    d.img_pitch, d.radar_pitch, d.img_bin_major = 490, 12, 1
+    d.n, d.fh, d.fw, d.spatial_scale, d.rh, d.rw = n, fh, fw, 1.0 / 16, fh, fw
+    d.img_boxes, d.n_img, d.n_img_cap, d.box_cols = boxes_d.data_ptr(), n_img_d.data_ptr(), cap_img, cols
+    d.radar_boxes, d.n_radar = rad_d.data_ptr(), k_rad
+    d.thr_img, d.thr_radar, d.regress = 0.0, 0.0, 1
+    for nm in ("w0t", "b0", "w1", "b1", "w2", "b2", "rw", "rscale", "rshift", "rw2", "rb2", "e1w", "e1b", "e2w", "e2b"):
+        setattr(d.wts, nm, hw[nm].data_ptr())
+    d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
+    d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
+    d.pool_scratch = pooled.data_ptr()
+    lib = hip.lib()
+    hip.check(lib.me_roi_heads_f32(C.byref(d), hip.stream_ptr()), "me_roi_heads_f32")
+    ordered = torch.empty((cap, 8), **f32)
+    n_out = torch.empty((1,), device=dev, dtype=torch.int32)
+    hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
+                                           n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+    torch.cuda.synchronize()
+
+    # RoIs are indexed compactly (image proposals, then radar boxes).  The pooled features are bit-exact (same operations in
+    # the same order); the NaN row of the zero-area PS-RoI included
+    k = k_img + k_rad
+    got_pool = pooled[:k].cpu()
+    want_img, want_rad = crop_img.reshape(k, 490), crop_rad.reshape(k, 490)
+    same = (got_pool[:, :490].view(torch.int32) == want_img.view(torch.int32)) | (got_pool[:, :490].isnan() & want_img.isnan())
+    assert bool(same.all()), "image-branch pooled features differ from tv_ops.ps_roi_align"
+    assert torch.equal(got_pool[:, 490:].view(torch.int32), want_rad.view(torch.int32)), "radar-branch pooled features differ"
+    finite = torch.isfinite(regress_ref).all(1) & torch.isfinite(refine_ref).all(1) & torch.isfinite(mask1_ref)
+    assert int(finite.sum()) >= k - 2  # (only the zero-area PS-RoI is NaN)
+    torch.testing.assert_close(regress[:k].cpu()[finite], regress_ref[finite], rtol=TOL, atol=TOL)
+    torch.testing.assert_close(refine[:k].cpu()[finite], refine_ref[finite], rtol=TOL, atol=TOL)
+    torch.testing.assert_close(mask1[:k].cpu()[finite], mask1_ref[finite], rtol=TOL, atol=TOL)
+    assert bool((keep[k:cap] == 0).all()), "slots behind the last RoI must keep nothing"
+
+    # rows: kept = mask > threshold; the oracle's assembly (network_ref.network_forward) on the same proposals
+    radar_rows = torch.cat((rad, refine_ref[k_img:], torch.zeros((k_rad, 1)), refine_ref[k_img:, 1:]), -1)
+    boxes = torch.cat((img_boxes[:, :8], radar_rows[:, :8]), 0)
+    positive = mask1_ref > 0.0
+    located = nr.box_regress(regress_ref[positive], boxes[positive, 1:5])
+    out_ref = torch.cat((boxes[positive, :1], located, mask1_ref[positive, None], boxes[positive, 6:8]), -1)
+    tmp = mask1_ref.clone()
+    tmp[k_img:] /= 5
+    out_ref = out_ref[torch.sort(tmp[positive], descending=True, stable=True).indices]
+    got = ordered[: int(n_out.item())].cpu()
+    assert got.shape[0] >= 2000
+    _cmp_rows_ties(got, out_ref, "direct heads call, 2400 + 61 RoIs")

@@ -327,6 +327,14 @@ def test_bench_two_ranks_inference_and_detector_training(hip_lib):
     out = _bench2(["--workload", "full", "--cfg", "yolov3-tiny-12", "--size", "160", "--batch", "4"])
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["global_batch"] == 8
     assert out["value"] > 0 and out["scaling"] == "weak"
+    # both readings of "@batch N" in the one line: the weak value above (4 per GPU) and the same 4 frames
+    # in total sharded 2 + 2
+    ss = out["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["global_batch"] == 4 and ss["frames_per_gpu"] == [2, 2] and ss["value"] > 0
+    out = _bench2(["--workload", "full", "--cfg", "yolov3-tiny-12", "--size", "160", "--batch", "5", "--scaling", "strong"])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 5 and out["config"]["batch_per_gpu"] == 3
+    assert out["value"] > 0 and "strong_scaling" not in out and out["config"]["rois_last_step"] >= 6
+    assert abs(out["value"] - 5 * out["steps"] / (out["ms_per_step"] * out["steps"] * 1e-3)) < 0.01 * out["value"]
     out = _bench2(["--workload", "detector_train", "--cfg", "yolov3-tiny-12", "--size", "96", "--batch", "2", "--chunk-mb", "1"])
     assert out["n_gpus"] == 2 and out["config"]["grad_chunks"] >= 4
     assert out["config"]["grad_bucket_bytes"] > 30e6 and "reverse-layer chunks" in out["config"]["workload"]

@@ -178,3 +178,61 @@ def test_dropin_directories_export_the_reference_import_names():
                              text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.strip().splitlines()[-1] == expect[d], out.stdout
+
+
+def test_bench_roi_stage_bytes_are_algorithmic():
+    """the "RoI pooling + heads" row of bench.py's stage table prices SURVEY 8(d) algorithmic bytes (every
+    operand once), not the L2 re-reads of a retired kernel; and any committed stage table is self-consistent
+    (frac == algorithmic_bytes / ms / peak)."""
+    import glob
+    import json
+
+    import bench
+
+    rois, n, fh, fw, wbytes, cols = 6449, 32, 52, 52, 1_300_000, 9
+    got = bench.roi_stage_bytes(rois, n, fh, fw, fh, fw, wbytes, cols)
+    maps = 4 * n * (fh * fw * 490 + fh * fw * 12)
+    per_roi = 2 * 4 * 980 + 4 * cols + 4 * 16 + 1
+    assert got == pytest.approx(maps + per_roi * rois + wbytes)
+    # marginal bytes per RoI: the pooled features out + back and the rows, no weight re-read (490 * 256 * 4 / 8 per RoI in r04)
+    step = bench.roi_stage_bytes(rois + 8, n, fh, fw, fh, fw, wbytes, cols) - got
+    assert step == pytest.approx(8 * per_roi) and step < 8 * 8200
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "profiles", "r05_bench_*.json")):
+        for line in open(path):
+            line = line.strip()
+            if not line.startswith("{"):
+                continue
+            rec = json.loads(line)
+            for row in rec.get("stages", []):
+                if row.get("bound") == "hbm" and "algorithmic_bytes" in row and row["ms"] > 0:
+                    gbs = row["algorithmic_bytes"] / (row["ms"] * 1e-3) / 1e9
+                    assert row["frac"] <= gbs / bench.HBM_PEAK_GBS * 1.02 + 1e-4, (path, row)
+
+
+def test_head_caches_follow_replaced_inner_modules():
+    """the head weight slots / BatchNorm lists are re-read from the leaf modules on every call - replacing an INNER
+    module (``refinement_head.radar_net[1] = BatchNorm2d(..)``, ``net0 = Sequential(..)``) under an unchanged top-level child,
+    or a detector block's BatchNorm, must not leave stale tensors behind."""
+    from millieye_amd.my_models import Network, _HeadPack, define_yolo
+    net = Network(define_yolo(ph.cfg_path("yolov3-tiny-12")), 0.2).eval()
+    pack = _HeadPack(net)
+    first = pack._slots()
+    assert all(dct[key] is t for (dct, key), t in zip(first, pack._sources()))
+    assert net._head_bns()[4] is net.refinement_head.radar_net[1] and net._head_bns()[0] is net.img_cnn_layers.net[1]
+    net.refinement_head.radar_net[1] = torch.nn.BatchNorm2d(net.refinement_head.radar_net[1].num_features)
+    net.refinement_head.net0 = torch.nn.Sequential(torch.nn.Linear(490, 256), torch.nn.LeakyReLU(0.1))
+    second = pack._slots()
+    assert second is not first
+    assert all(dct[key] is t for (dct, key), t in zip(second, pack._sources()))
+    assert net._head_bns()[4] is net.refinement_head.radar_net[1] and net._head_bns()[4].training
+    with pytest.raises(NotImplementedError):
+        net._check_eval()  # the fresh BatchNorm is in train() mode, the others are not
+    det = net.base_detector
+    assert not det._any_bn_training()
+    block = det.module_list[0]
+    bn_name = [k for k, m in block._modules.items() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    setattr(block, bn_name, torch.nn.BatchNorm2d(block._modules[bn_name].num_features))
+    assert det._any_bn_training()
+    det.eval()
+    assert not det._any_bn_training()

@@ -310,3 +310,67 @@ def test_overlap_detector_allreduce_needs_a_process_group():
         pass
     m = M()
     assert par.overlap_detector_allreduce(m) is None and "_grad_reducer" not in m.__dict__
+
+
+def _epoch_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = torch.utils.data.TensorDataset(torch.arange(16))
+    sampler = torch.utils.data.distributed.DistributedSampler(data, shuffle=True)
+    loader = torch.utils.data.DataLoader(data, batch_size=2, sampler=sampler)
+    orders = []
+    for epoch in range(3):
+        par.begin_epoch(loader, epoch)
+        orders.append([int(v) for (b,) in loader for v in b])
+    # the averaging form of the chunk reducer: mean over the ranks instead of the sum
+    red = par.GradChunkReducer(1 << 10, average=True)
+    red.begin("cpu")
+    red.push("g", torch.full((5,), float(rank + 1)))
+    mean = red.finish()["g"].tolist()
+    # uneven batch counts are refused on every rank
+    uneven = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.arange(4 + 2 * rank)), batch_size=2)
+    try:
+        par.begin_epoch(uneven, 0)
+        refused = False
+    except RuntimeError:
+        refused = True
+    q.put((rank, orders, mean, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_begin_epoch_reshuffles_the_distributed_sampler_two_ranks():
+    """both training loops call ``parallel.begin_epoch`` at the top of every epoch - the sampler's
+    permutation changes from epoch to epoch, the two ranks' shards stay disjoint and cover the dataset, an uneven shard is
+    refused; and ``GradChunkReducer(average=True)`` returns the mean over the ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, orders, mean, refused = q.get(timeout=300)
+        got[rank] = (orders, mean, refused)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for epoch in range(3):
+        a, b = got[0][0][epoch], got[1][0][epoch]
+        assert sorted(a + b) == list(range(16)) and not set(a) & set(b)
+    for rank in (0, 1):
+        orders, mean, refused = got[rank]
+        assert orders[0] != orders[1] and orders[1] != orders[2]  # (without set_epoch all three are identical)
+        assert mean == [1.5] * 5 and refused
+    import inspect
+    from millieye_amd import train as t3
+    from millieye_amd.module2 import train as t2
+    for mod in (t3, t2):
+        assert "parallel.begin_epoch(dataloader, epoch" in inspect.getsource(mod.train_loop)
