@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 9
+#define ME_ABI_VERSION 10
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -92,6 +92,15 @@ typedef struct me_conv_desc {
                              order 0..k-1 and applies the epilogue - same bits as the two-pass form, one launch less).  NULL, or
                              fewer counters than tiles: the slabs are reduced by a second launch.  One array per stream. */
   int64_t tile_counters_len;
+  /* ABI 10: per-column-class tap masks.  tap_mask_cols > 0: the output channels form cout / tap_mask_cols (<= 4) classes of
+     tap_mask_cols consecutive channels; bit t of tap_mask[class] clear = tap t (ky * ksize + kx) of that class's filters is all
+     zero and is SKIPPED (its K stages are neither fetched nor multiplied) - the caller guarantees the zeros.  Used by the data
+     gradient of the 3x3 / stride-2 layers (one 2x2 convolution computes the four output-parity classes; 7 of its 16
+     (class, tap) pairs are structurally zero, detector_train.py).  Needs ksize^2 <= 16, cin % 16 == 0, upsample 1, no K split
+     (split_k <= 1), tile 0 - 5 with a tile width that divides tap_mask_cols; 0 = off (every tap of every channel). */
+  uint32_t tap_mask[4];
+  int32_t tap_mask_cols;
+  int32_t reserved0;
 } me_conv_desc;
 int me_conv2d_f32(const me_conv_desc* d, void* stream);
 /* scratch the automatic plan would like for this descriptor (0 = none). Small-M layers (13x13, 26x26

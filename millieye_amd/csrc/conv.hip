@@ -767,7 +767,16 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
     // select) is paid once per tap.  A workgroup sweeps its input rows once per tap, so those rows have to survive in L2
     // from one sweep to the next - they do as long as the weights leave room (choose_order).
     int tap = 0, cc = 0, ky = 0, kx = 0;
-    if (s_begin != 0) {  // K-split pieces only: whole tiles skip the divisions
+    // Column-class tap masks (me_conv_desc.tap_mask): the K walk of this tile visits only the set taps of its class.
+    unsigned tmask = 0xFFFFFFFFu;
+    if (p.mask_cols) {   // (whole tiles only: the host refuses a K split with masks; a class is a multiple of BN columns wide)
+      tmask = p.tapmask[n0 / p.mask_cols] & ((1u << (p.ks * p.ks)) - 1u);
+      tap = __builtin_ctz(tmask);
+      ky = tap / p.ks;
+      kx = tap - ky * p.ks;
+      s_begin = 0;
+      s_end = __builtin_popcount(tmask) * p.cs;
+    } else if (s_begin != 0) {  // K-split pieces only: whole tiles skip the divisions
       tap = s_begin / p.cs;
       cc = s_begin - tap * p.cs;
       ky = tap / p.ks;
@@ -776,7 +785,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
     unsigned a_off = 0, b_off = 0;  // scalar byte offsets of the next stage to issue
     auto enter_tap = [&]() {        // VALU work only here: once per filter tap
 #pragma unroll
-      for (int j = 0; j < LA; ++j) v_cur[j] = (BABL == 1 || ((v_pad[j] >> tap) & 1u)) ? kOobOffset : v_base[j];
+      for (int j = 0; j < LA; ++j) v_cur[j] = (BABL == 1 || ((v_pad[j] >> (tap & 31)) & 1u)) ? kOobOffset : v_base[j];
       a_off = (unsigned)(ky * p.w + kx) * pitch4;
       b_off = (unsigned)tap * (unsigned)p.cs * b_step;
     };
@@ -791,11 +800,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
       b_off += b_step;
       if (++cc == p.cs) {
         cc = 0;
-        ++tap;
-        if (++kx == p.ks) {
-          kx = 0;
-          ++ky;
-        }
+        do {   // (one trip without masks)
+          ++tap;
+          if (++kx == p.ks) {
+            kx = 0;
+            ++ky;
+          }
+        } while (tap < p.ks * p.ks && !((tmask >> tap) & 1u));
         enter_tap();
       }
     };
@@ -1401,6 +1412,9 @@ int launch_buf(ConvP& p, hipStream_t stream) {
     else
       return launch_igemm<128, 128, 16, 2, 2>(p, stream);
   }
+  if (p.mask_cols)
+    ME_REQUIRE(buf_addressable<BM>(p) && p.mask_cols % BN == 0 && BABL == 0 && DEEP == 0, ME_E_BADARG,
+               "me_conv2d_f32: tap masks need cin %% 16 == 0, offsets below 2^31 and a tile width (%d) that divides tap_mask_cols", BN);
   if (!buf_addressable<BM>(p)) return launch_dma<BM, BN, WR, WC, 1, MINW>(p, stream);
   constexpr int BK = 16;
   p.cs = (p.cin + BK - 1) / BK;
@@ -1408,7 +1422,7 @@ int launch_buf(ConvP& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.cout + BN - 1) / BN;
   choose_order<BN>(p);
-  if (BABL) p.kord = 0;  // the ablation kernels exist for the tap-major walk only
+  if (BABL || p.mask_cols) p.kord = 0;  // the ablation kernels exist for the tap-major walk only
   plan_split(p);
   const long long blocks = (long long)p.tiles_m * p.tiles_n;
   ME_REQUIRE(blocks < (1ll << 31), ME_E_TOOBIG, "me_conv2d_f32: grid too large");
@@ -1489,6 +1503,8 @@ int fill_params(const me_conv_desc* d, ConvP& p) {
   p.sps = 0;
   p.counters = d->tile_counters_len > 0 ? d->tile_counters : nullptr;
   p.counters_len = p.counters ? d->tile_counters_len : 0;
+  p.mask_cols = d->tap_mask_cols > 0 ? d->tap_mask_cols : 0;
+  for (int i = 0; i < 4; ++i) p.tapmask[i] = d->tap_mask[i];
   return 0;
 }
 
@@ -1560,6 +1576,26 @@ int me_conv2d_f32(const me_conv_desc* d, void* stream_) {
   ME_REQUIRE(me::aligned16(d->x) && me::aligned16(d->wgt), ME_E_ALIGN, "me_conv2d_f32: x / wgt not 16-byte aligned");
   ME_REQUIRE(!d->res || d->res_pitch >= d->cout, ME_E_BADARG, "me_conv2d_f32: res_pitch < cout");
   ME_REQUIRE(d->split_k >= 0 && d->split_k <= 64, ME_E_BADARG, "me_conv2d_f32: split_k out of range");
+
+  if (p.mask_cols) {  // column-class tap masks (ABI 10): whole tiles of the buffer kernel's tap-major walk
+    const int taps = d->ksize * d->ksize, classes = d->cout / p.mask_cols;
+    ME_REQUIRE(taps <= 16 && d->cout % p.mask_cols == 0 && classes >= 1 && classes <= 4 && d->upsample == 1 && d->split_k <= 1 &&
+                   d->tile >= 0 && d->tile <= 5 && d->cin % 16 == 0, ME_E_BADARG,
+               "me_conv2d_f32: tap masks need ksize^2 <= 16, 1 - 4 column classes, upsample 1, split_k <= 1, tile 0 - 5, cin %% 16 == 0");
+    for (int i = 0; i < classes; ++i)
+      ME_REQUIRE((d->tap_mask[i] & ((1u << taps) - 1u)) != 0, ME_E_BADARG, "me_conv2d_f32: tap_mask[%d] selects no tap", i);
+    p.splitk = 1;
+    p.partial = nullptr;
+    int tile = d->tile;
+    if (tile == 0) tile = p.mask_cols % 128 == 0 ? 1 : p.mask_cols % 64 == 0 ? 2 : 4;
+    switch (tile) {
+      case 1: return launch_buf<128, 128, 2, 2>(p, stream);
+      case 2: return launch_buf<128, 64, 2, 2>(p, stream);
+      case 3: return launch_buf<64, 64, 2, 2>(p, stream);
+      case 4: return launch_buf<128, 32, 4, 1>(p, stream);
+      default: return launch_buf<256, 128, 4, 2, 4>(p, stream);
+    }
+  }
 
   if ((d->tile >= 41 && d->tile <= 45) || d->tile == 47) {  // tail split: split_k = pieces per tile of the last, partial round (0: 4)
     p.splitk = d->split_k > 0 ? d->split_k : 4;

@@ -32,6 +32,8 @@ struct ConvP {
   long long counters_len;
   int bulk;        // tail-split launches: tiles [0, bulk) run whole, tiles [bulk, tiles) cut splitk ways (0 otherwise)
   int store_mode;  // me::store_mode(): output stores of the fast epilogue plain (0) or streaming (nt)
+  unsigned tapmask[4];  // me_conv_desc.tap_mask: set taps of the four column classes (conv_igemm_buf_f32, tap-major walk)
+  int mask_cols;        // output channels per column class, 0 = no masks
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

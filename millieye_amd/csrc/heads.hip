@@ -1063,7 +1063,8 @@ __global__ __launch_bounds__(256) void compact_sort_kernel(const float* __restri
   }
   if (mine)
     for (int c = part; c < cols; c += 16) out[(long long)rank * cols + c] = rows[(long long)i * cols + c];
-  if (i == 0 && part == 0) *count = total;
+  // (system scope: the count word may be pinned host memory that the caller polls)
+  if (i == 0 && part == 0) __hip_atomic_store(count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace

@@ -533,6 +533,152 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const float* __res
     }
 }
 
+// Round 5: conv_wgrad_tile_kernel with D stages of global loads in flight per lane, and a half-wide tile.
+// (a) The 1x1 filters have 2 - 16 output tiles, so their pixel range is cut into many short slices, one or two workgroups per CU,
+//     sixteen 16-pixel stages each - and every stage waited for its own loads (one stage of prefetch = eight MFMAs = 0.2 us of
+//     cover for ~1 us of L2 / ~2 us of HBM latency): 27 - 31 us per layer for 9 us of matrix work (tools/wgrad_bench.py, batch 8).
+//     With D = 4 register sets the loads of stage s + 4 are issued behind stage s's LDS stores.
+// (b) TCI = 32 (cin = 32: 416^2 32 -> 64 / stride 2 and 208^2 32 -> 64): the 64 x 64 tile was half padding (38 TFLOP/s).  The
+//     tile is 64 co x 32 ci; the two waves of a co block split the k-steps of a stage (t < 4 / t >= 4) and add their accumulators
+//     through LDS at the end - four busy waves on a 64 x 32 tile.
+template <int TCO, int TCI, int D>
+__global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(const float* __restrict__ X, long long xp,
+                                                              const float* __restrict__ DY, long long dyp, float* OUT, int n,
+                                                              int h, int w, int cin, int cout, int ks, int stride, int pad,
+                                                              int ho, int wo, int splits, int px_per_split) {
+  constexpr bool KH = TCI == 32;                   // K split across the wave pair instead of two ci blocks
+  constexpr int TCIL = KH ? 64 : TCI;              // LDS row width of the x tile
+  constexpr int MT = TCO / 64, NT = KH ? 1 : TCI / 64;
+  constexpr int YV = TCO / 64, XV = KH ? 1 : TCI / 64;
+  __shared__ __attribute__((aligned(16))) float Ys[2][16][TCO];
+  __shared__ __attribute__((aligned(16))) float Xs[2][16][TCIL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = KH ? 0 : (wave & 1), kh = KH ? (wave & 1) : 0;
+  const int tap = blockIdx.z / splits, split = blockIdx.z - tap * splits;
+  const int ky = tap / ks, kx = tap - ky * ks;
+  const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
+  const int P = n * ho * wo;
+  const int p_begin = split * px_per_split;
+  const int p_end = (p_begin + px_per_split < P) ? p_begin + px_per_split : P;
+  const int hw = ho * wo;
+  const int pp = tid >> 4, cc = (tid & 15) * 4;
+  const int sw = (pp & 1) << 5;
+  const bool x_lane = !KH || cc < 32;
+
+  float4 ry[D][YV], rx[D][XV];
+  int f_img, f_oy, f_ox;
+  {
+    const int p = p_begin + pp;
+    f_img = p / hw;
+    const int rem = p - f_img * hw;
+    f_oy = rem / wo;
+    f_ox = rem - f_oy * wo;
+  }
+  int p_next = p_begin;  // first pixel of the next stage to fetch (stages are fetched in order)
+  auto fetch = [&](float4(&ryd)[YV], float4(&rxd)[XV]) {
+    const int p = p_next + pp;
+#pragma unroll
+    for (int v = 0; v < YV; ++v) ryd[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int v = 0; v < XV; ++v) rxd[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < p_end) {
+      const float* yrow = DY + (long long)p * dyp + co0 + cc;
+      const int iy = f_oy * stride - pad + ky, ix = f_ox * stride - pad + kx;
+      const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+      const float* xrow = X + ((long long)(f_img * h + iy) * w + ix) * xp + ci0 + cc;
+#pragma unroll
+      for (int v = 0; v < YV; ++v)
+        if (co0 + cc + 64 * v < cout) ryd[v] = *reinterpret_cast<const float4*>(yrow + 64 * v);
+      if (inb && x_lane) {
+#pragma unroll
+        for (int v = 0; v < XV; ++v)
+          if (ci0 + cc + 64 * v < cin) rxd[v] = *reinterpret_cast<const float4*>(xrow + 64 * v);
+      }
+    }
+    p_next += 16;
+    f_ox += 16;
+    while (f_ox >= wo) {
+      f_ox -= wo;
+      if (++f_oy == ho) {
+        f_oy = 0;
+        ++f_img;
+      }
+    }
+  };
+
+  wg_f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int i32 = lane & 31, kk = lane >> 5;
+  const int a_base = wr * (TCO / 2) + i32, b_base = (KH ? 0 : wc * (TCI / 2)) + i32, ksw = kk << 5;
+
+#pragma unroll
+  for (int u = 0; u < D; ++u) fetch(ry[u], rx[u]);   // (stages behind the slice's end come back as zeros)
+  int buf = 0;
+  for (int p0 = p_begin; p0 < p_end; p0 += 16 * D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      if (p0 + 16 * u < p_end) {   // (uniform over the workgroup)
+#pragma unroll
+        for (int v = 0; v < YV; ++v) *reinterpret_cast<float4*>(&Ys[buf][pp][(cc + 64 * v) ^ sw]) = ry[u][v];
+        if (x_lane) {
+#pragma unroll
+          for (int v = 0; v < XV; ++v) *reinterpret_cast<float4*>(&Xs[buf][pp][(cc + 64 * v) ^ sw]) = rx[u][v];
+        }
+        __syncthreads();
+        if (p_next < p_end) fetch(ry[u], rx[u]);  // stage s + D, in flight for the next D stages
+#pragma unroll
+        for (int t0 = 0; t0 < (KH ? 4 : 8); ++t0) {
+          const int t = KH ? t0 + 4 * kh : t0;
+          float a[MT], b[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) a[i] = Ys[buf][2 * t + kk][(a_base + 32 * i) ^ ksw];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[j] = Xs[buf][2 * t + kk][(b_base + 32 * j) ^ ksw];
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+      }
+    }
+  }
+  if constexpr (KH) {
+    // the k-halves of a co block meet in LDS: wave (wr, 1) parks its accumulators, wave (wr, 0) adds them (fixed order)
+    __syncthreads();
+    float* park = &Ys[0][0][0];   // 2 waves x 64 lanes x 16 floats * MT <= 2 * 16 * TCO floats
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) park[((wr * MT + i) * 16 + e) * 64 + lane] = acc[i][0][e];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][0][e] += park[((wr * MT + i) * 16 + e) * 64 + lane];
+  }
+  float* out = OUT + (long long)split * cout * ks * ks * cin;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ci = ci0 + (KH ? 0 : wc * (TCI / 2)) + 32 * j + i32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wr * (TCO / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kk;
+        if (co < cout && ci < cin) out[((long long)co * ks * ks + tap) * cin + ci] = acc[i][j][e];
+      }
+    }
+}
+
 // kk_cin > 0: write the sum in the parameter's own OIHW layout (i indexes the OHWI slabs: co, tap, ci) - the autograd result of
 // the detector's training step without a permute + contiguous launch per layer
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* DW, long long count,
@@ -920,6 +1066,86 @@ __global__ __launch_bounds__(256) void affine_bwd_partial_v4_kernel(const float*
   }
 }
 
+// Round 5: the same pass with every workgroup on a CONTIGUOUS range of rows (all channels of a row, up to 1024): the 64-channel
+// column blocks above read 256-byte pieces of every row (a quarter of it at 256 channels, a sixteenth at 1024), half their
+// lanes idle at 32 channels, and the row chunks were sized by rows alone - 13 x 13 x 1024 at batch 8 ran on 80 workgroups.
+// Measured on the Darknet-53 shapes at batch 8 (tools/affine_bench.py): 2.0 TB/s over the 3.7 GB of a step, 1 TB/s on the
+// 52 x 52 x 128 layers.  Here Q = min(C / 4, 256) lanes take the channel quads of a row, the other 256 / Q lane groups take
+// different rows; a lane keeps four rows of y and dy (8 x 16 bytes) in flight; the per-lane sums go through LDS once per
+// workgroup in a fixed order (row lane 0, 1, ...) and leave as one partial row per workgroup, summed by
+// affine_bwd_reduce_kernel in chunk order - deterministic, and bit-identical for a given (rows, C) on every run.
+template <int Q>
+__global__ __launch_bounds__(256) void affine_bwd_rows_kernel(const float* __restrict__ Y, long long ldy,
+                                                              const float* __restrict__ G, long long ldg, int rows, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int act, float* p0, float* p1, int per,
+                                                              const float* __restrict__ scale, float* DC, long long lddc) {
+  constexpr int RL = 256 / Q;  // row lanes
+  __shared__ double s0s[RL][4 * Q], s1s[RL][4 * Q];
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  const int c = blockIdx.x * (4 * Q) + q * 4;   // (blockIdx.x > 0 only beyond 1024 channels)
+  const int chunk = blockIdx.y;
+  const int r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C) {  // C % 4 == 0: the quad is all in or all out
+    float be[4], inv_ga[4], scl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ga = gamma ? gamma[c + j] : 1.f;
+      be[j] = beta ? beta[c + j] : 0.f;
+      inv_ga[j] = (gamma && ga != 0.f) ? 1.f / ga : 0.f;
+      scl[j] = scale ? scale[c + j] : 1.f;
+    }
+    auto one = [&](int r, float4 y4, float4 g4) {
+      float y[4] = {y4.x, y4.y, y4.z, y4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = y[j];
+        if (act == ME_ACT_LEAKY) {
+          g[j] = y[j] > 0.f ? g[j] : 0.1f * g[j];
+          z = y[j] > 0.f ? y[j] : y[j] * 10.f;
+        }
+        s0[j] += g[j];
+        s1[j] += (double)g[j] * ((z - be[j]) * inv_ga[j]);
+        d[j] = scale ? g[j] * scl[j] : g[j];
+      }
+      if (DC) *reinterpret_cast<float4*>(DC + (long long)r * lddc + c) = make_float4(d[0], d[1], d[2], d[3]);
+    };
+    int r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+      float4 yv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        yv[u] = *reinterpret_cast<const float4*>(Y + (long long)(r + RL * u) * ldy + c);
+        gv[u] = *reinterpret_cast<const float4*>(G + (long long)(r + RL * u) * ldg + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(r + RL * u, yv[u], gv[u]);
+    }
+    for (; r < r1; r += RL)
+      one(r, *reinterpret_cast<const float4*>(Y + (long long)r * ldy + c),
+          *reinterpret_cast<const float4*>(G + (long long)r * ldg + c));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s0s[rl][q * 4 + j] = s0[j];
+    s1s[rl][q * 4 + j] = s1[j];
+  }
+  __syncthreads();
+  for (int cl = threadIdx.x; cl < 4 * Q; cl += 256) {
+    const int cg = blockIdx.x * (4 * Q) + cl;
+    if (cg >= C) continue;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) {
+      a += s0s[k][cl];
+      b += s1s[k][cl];
+    }
+    p0[(long long)chunk * C + cg] = (float)a;
+    p1[(long long)chunk * C + cg] = (float)b;
+  }
+}
+
 // second level of the fixed-order reduction: 64 channels x 16 chunk lanes per workgroup (a lane sums the chunks
 // k = lane, lane + 16, ... in double), then a fixed LDS tree - the one-thread-per-channel loop over up to 1024 chunks took 31 us
 __global__ __launch_bounds__(1024) void affine_bwd_reduce_kernel(float* p0, float* p1, int C, int chunks, float* dshift,
@@ -1203,15 +1429,53 @@ int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld
   return me::check_launch("bn_train_bwd");
 }
 
-static int affine_chunks(int rows) {
-  int c = rows / 256;
-  if (c < 1) c = 1;
-  if (c > 1024) c = 1024;
-  return c;
+// Row chunks of the affine backward.  Aligned operands with C % 4 == 0 take affine_bwd_rows_kernel (Q lanes across a row's
+// channel quads, RL = 256 / Q rows side by side): ~8 workgroups per CU (2048), every chunk a multiple of 4 * RL rows and at
+// least 8 * RL of them (two trips of the four-deep load loop), at most 2048 chunks.  The others keep the 64-channel column
+// blocks with rows / 256 chunks.
+static int affine_quads(int channels) {
+  int q = 8;
+  while (q < 256 && q * 4 < channels) q *= 2;
+  return q;  // 8 (<= 32 channels), 16, 32, 64, 128, 256 (>= 1024 channels per column block)
+}
+
+static void affine_plan(int rows, int channels, bool rows_kernel, int* chunks, int* per) {
+  if (!rows_kernel) {
+    int c = rows / 256;
+    if (c < 1) c = 1;
+    if (c > 1024) c = 1024;
+    *chunks = c;
+    *per = (rows + c - 1) / c;
+    return;
+  }
+  const int q = affine_quads(channels), rl = 256 / q;
+  const int groups = (channels + 4 * q - 1) / (4 * q);
+  const int unit = 4 * rl;
+  static const int wgs = getenv("MILLIEYE_AFFINE_WGS") ? atoi(getenv("MILLIEYE_AFFINE_WGS")) : 2048;
+  int want = (wgs + groups - 1) / groups;              // chunks for ~wgs workgroups
+  int p = (rows + want - 1) / want;
+  if (p < 2 * unit) p = 2 * unit;
+  p = (p + unit - 1) / unit * unit;
+  int c = (rows + p - 1) / p;
+  if (c > 2048) {
+    c = 2048;
+    p = ((rows + c - 1) / c + unit - 1) / unit * unit;
+    c = (rows + p - 1) / p;
+  }
+  *chunks = c;
+  *per = p;
+}
+
+// upper bound of the chunk count over both kernels (the workspace does not know the operands' alignment)
+static int affine_chunks_max(int rows, int channels) {
+  int c0, p0, c1, p1;
+  affine_plan(rows, channels, false, &c0, &p0);
+  affine_plan(rows, channels, true, &c1, &p1);
+  return c0 > c1 ? c0 : c1;
 }
 
 int64_t me_affine_bwd_workspace_bytes(int32_t rows, int32_t channels) {
-  return (int64_t)2 * affine_chunks(rows) * channels * (int64_t)sizeof(float);
+  return (int64_t)2 * affine_chunks_max(rows, channels) * channels * (int64_t)sizeof(float);
 }
 
 int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
@@ -1221,12 +1485,30 @@ int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t 
   ME_REQUIRE(y && dy && dc && workspace, ME_E_NULLPTR, "me_affine_act_bwd_f32: null pointer");
   ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_affine_act_bwd_f32: bad dimensions");
   ME_REQUIRE(act == ME_ACT_LINEAR || act == ME_ACT_LEAKY, ME_E_BADARG, "me_affine_act_bwd_f32: activation %d", act);
-  const int chunks = affine_chunks(rows);
-  float* p0 = reinterpret_cast<float*>(workspace);
-  float* p1 = p0 + (long long)chunks * channels;
   const bool v4 = channels % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && lddc % 4 == 0 && me::aligned16(y) &&
                   me::aligned16(dy) && me::aligned16(dc);
-  if (v4)
+  static const int rows_env = getenv("MILLIEYE_AFFINE_ROWS") ? atoi(getenv("MILLIEYE_AFFINE_ROWS")) : 0;  // (A/B: 1 = contiguous rows)
+  const bool rows_kernel = v4 && rows_env != 0;
+  int chunks, per;
+  affine_plan(rows, channels, rows_kernel, &chunks, &per);
+  float* p0 = reinterpret_cast<float*>(workspace);
+  float* p1 = p0 + (long long)chunks * channels;
+  if (rows_kernel) {
+    const int q = affine_quads(channels);
+    const dim3 grid((channels + 4 * q - 1) / (4 * q), chunks);
+#define ME_AFF(Q)                                                                                                         \
+  hipLaunchKernelGGL(affine_bwd_rows_kernel<Q>, grid, dim3(256), 0, stream, y, (long long)ldy, dy, (long long)lddy, rows, \
+                     channels, gamma, beta, act, p0, p1, per, scale, dc, (long long)lddc)
+    switch (q) {
+      case 8: ME_AFF(8); break;
+      case 16: ME_AFF(16); break;
+      case 32: ME_AFF(32); break;
+      case 64: ME_AFF(64); break;
+      case 128: ME_AFF(128); break;
+      default: ME_AFF(256); break;
+    }
+#undef ME_AFF
+  } else if (v4)
     hipLaunchKernelGGL(affine_bwd_partial_v4_kernel, dim3((channels + 63) / 64, chunks), dim3(256), 0, stream, y,
                        (long long)ldy, dy, (long long)lddy, rows, channels, gamma, beta, act, p0, p1, chunks, scale, dc,
                        (long long)lddc);
@@ -1430,13 +1712,31 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
   wgrad_tile(P, cin, cout, ksize, tco, tci);
   if (!vec) tco = tci = 64;  // (the split count was sized for the larger tile: correct, a few workgroups more)
   dim3 grid((cin + tci - 1) / tci, (cout + tco - 1) / tco, ksize * ksize * splits);
+  static const int depth = [] {   // stages of loads in flight per lane (round 5; 0 / 1 = the round-3 kernels, A/B)
+    const char* e = getenv("MILLIEYE_WGRAD_DEPTH");
+    return e ? atoi(e) : 4;
+  }();
   if (done9) {
     // (slabs written by the nine-tap kernel: straight to the reduction)
   } else
 #define ME_WG_TILE(A, B)                                                                                              \
   hipLaunchKernelGGL((conv_wgrad_tile_kernel<A, B>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,           \
                      (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per)
-  if (vec && tco == 128 && tci == 128)
+#define ME_WG_PIPE(A, B, D)                                                                                           \
+  hipLaunchKernelGGL((conv_wgrad_pipe_kernel<A, B, D>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,        \
+                     (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per)
+  if (vec && depth > 1 && cin <= 32 && tco == 64) {
+    grid.x = 1;
+    ME_WG_PIPE(64, 32, 4);   // half-wide tile, the wave pair of a co block splits the k-steps
+  } else if (vec && depth > 4 && tco == 128 && tci == 128)   // (depth 5+: the four-deep pipeline on the full-width tiles, A/B only -
+    ME_WG_PIPE(128, 128, 4);                                  //  measured neutral on the 1x1 filters, slower on 128 x 128)
+  else if (vec && depth > 4 && tco == 128)
+    ME_WG_PIPE(128, 64, 4);
+  else if (vec && depth > 4 && tci == 128)
+    ME_WG_PIPE(64, 128, 4);
+  else if (vec && depth > 4)
+    ME_WG_PIPE(64, 64, 4);
+  else if (vec && tco == 128 && tci == 128)
     ME_WG_TILE(128, 128);
   else if (vec && tco == 128)
     ME_WG_TILE(128, 64);
@@ -1457,6 +1757,7 @@ static int wgrad_mfma(const float* x, int64_t x_pitch, const float* dy, int64_t 
 #undef ME_WG_ABL
   }
 #undef ME_WG_TILE
+#undef ME_WG_PIPE
   else
     hipLaunchKernelGGL(conv_wgrad_mfma_kernel<false>, grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,
                        (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per);

@@ -320,8 +320,13 @@ class DetectorTrainer:
                         # gradient pixel instead of 36 - followed by a pixel shuffle of the cropped result.
                         fresh = cw.parity is not None and cw.parity_stamp == cw._stamp
                         pw = cw.parity if fresh else _parity_weights(cw.wgt)  # (from the step's pack launch when it ran)
+                        # (round 5: 7 of the 16 (class, tap) pairs of that 2x2 filter are structurally zero - class (py, px)
+                        #  has taps only where ky(py, i) and kx(px, j) exist: 1 + 2 + 2 + 4 = 9 of 16 - and the kernel skips
+                        #  them: me_conv_desc.tap_mask, tap t = 2 * i + j)
+                        masks = _PARITY_TAP_MASKS if cin % 32 == 0 and cout % 16 == 0 and _PARITY_MASKS_ON else None
                         dx4 = hip.conv2d_auto(dc, pw, _const_vectors(4 * cin, dev)[0],
-                                              _const_vectors(4 * cin, dev)[1], 2, 1, 1, hip.ACT_LINEAR)
+                                              _const_vectors(4 * cin, dev)[1], 2, 1, 1, hip.ACT_LINEAR,
+                                              tap_masks=(cin, masks) if masks is not None else None)
                         dx = dx4[:, 1:, 1:, :].reshape(n, ho, wo, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(n, h, w, cin)
                         dx = dx.contiguous()
                         res = None  # (accumulated below like any fresh contribution)
@@ -396,6 +401,11 @@ def _side_stream(dev):
 
 
 _PARITY_IDX = {}
+# set taps (bit 2 * i + j) of the four parity classes 2 * py + px of _parity_weights: tap (i, j) of class (py, px) exists when
+# ky(py, i) and kx(px, j) do - (0, 0): i = 0 only; (1, *): both
+_PARITY_TAP_MASKS = tuple(sum(1 << (2 * i + j) for i in (0, 1) for j in (0, 1) if (py == 1 or i == 0) and (px == 1 or j == 0))
+                          for py in (0, 1) for px in (0, 1))   # (0b0001, 0b0011, 0b0101, 0b1111)
+_PARITY_MASKS_ON = os.environ.get("MILLIEYE_PARITY_MASKS", "1") != "0"  # (A/B: 0 = multiply the zero taps like round 3)
 
 
 def _parity_weights(wgt_ohwi):

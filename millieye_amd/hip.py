@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("wgt_tiled", C.c_void_p),
         ("tile_counters", C.c_void_p), ("tile_counters_len", C.c_int64),
+        ("tap_mask", C.c_uint32 * 4), ("tap_mask_cols", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -262,8 +263,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 9:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 9")
+    if lib_.me_abi_version() != 10:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 10")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
@@ -331,10 +332,12 @@ def _nhwc_pitch(t, name):
 
 
 def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-           x_nchw=False, tile=0, split_k=0, wgt_tiled=None, in_launch_reduce=False):
+           x_nchw=False, tile=0, split_k=0, wgt_tiled=None, in_launch_reduce=False, tap_masks=None):
     """x_nhwc: [N,H,W,Cin] contiguous (or NCHW [N,Cin,H,W] when ``x_nchw``).  Returns NHWC
     [N,Ho*up,Wo*up,Cout].  ``in_launch_reduce=True`` hands the library arrival counters: split-K slabs are then summed by the last
-    workgroup of each tile instead of a second launch (same bits; measured slower on MI355X - DESIGN.md section 5 - so off)."""
+    workgroup of each tile instead of a second launch (same bits; measured slower on MI355X - DESIGN.md section 5 - so off).
+    ``tap_masks`` = ``(cols, (m0, m1, ...))``: the output channels are classes of ``cols`` consecutive channels whose filters are
+    all zero on the taps with a clear bit in ``m_class`` - those taps are skipped (``me_conv_desc.tap_mask``, ABI 10)."""
     _require_cuda_f32(x_nhwc, "x")
     if x_nchw:
         n, cin, h, w = x_nhwc.shape
@@ -364,7 +367,12 @@ def conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=N
     if tile >= 100 and wgt_tiled is None and wgt_packed.shape[3] % 16 == 0:
         wgt_tiled = tile_weights_f32(wgt_packed)  # callers that care about time pass their own copy
     d.wgt_tiled = wgt_tiled.data_ptr() if wgt_tiled is not None else None
-    need = lib().me_conv2d_workspace_bytes(C.byref(d))
+    if tap_masks is not None:
+        d.tap_mask_cols = int(tap_masks[0])
+        for i, m in enumerate(tap_masks[1]):
+            d.tap_mask[i] = int(m)
+        d.split_k = 1
+    need = lib().me_conv2d_workspace_bytes(C.byref(d)) if tap_masks is None else 0
     keep = None
     if need > 0:
         ws_ptr, keep = _workspace(need, x_nhwc.device, slot="conv")
@@ -419,7 +427,7 @@ def _conv_auto_save():
 
 
 def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, out=None, x_nchw=False,
-                wgt_tiled=None):
+                wgt_tiled=None, tap_masks=None):
     """:func:`conv2d` with the (tile, split_k) pair measured on this GPU the first time a layer shape is seen (the training
     path's convolutions - forward and data gradient - have no engine plan whose autotuner would do it; the library's cold-start
     guess took 128 x 64 tiles for every data gradient: 7.5 ms of a 42 ms Darknet-53 step where the tuned forward needs 5).
@@ -430,13 +438,15 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
                       wgt_tiled=wgt_tiled)
     _conv_auto_load()
     key = repr((tuple(x_nhwc.shape), x_nhwc.stride(2), wgt_packed.shape[0], ksize, stride, pad, residual is not None,
-                wgt_tiled is not None))
+                wgt_tiled is not None) + ((tap_masks,) if tap_masks is not None else ()))
     hit = _CONV_AUTO.get(key)
     if hit is None:
         cin = wgt_packed.shape[3]
         cands = [(0, 0)] + [(t, sp) for t in (1, 2, 3, 4, 5) for sp in (1, 2, 4)]
         if cin % 16 == 0:
             cands += [(t, sp) for t in (41, 42, 43) for sp in (2, 4)]
+        if tap_masks is not None:  # whole tiles of the buffer kernel only (the library refuses the rest)
+            cands = [(0, 1)] + [(t, 1) for t in (1, 2, 3, 4, 5)]
         scratch = None
         best = (float("inf"), 0, 0)
         torch.cuda.synchronize()  # every stream idle (the weight-gradient stream too): the timings are the candidates' own
@@ -444,12 +454,12 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
             try:
                 for _ in range(2):
                     scratch = conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch,
-                                     tile=tile, split_k=split, wgt_tiled=wgt_tiled)
+                                     tile=tile, split_k=split, wgt_tiled=wgt_tiled, tap_masks=tap_masks)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(3):
                     conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch, tile=tile,
-                           split_k=split, wgt_tiled=wgt_tiled)
+                           split_k=split, wgt_tiled=wgt_tiled, tap_masks=tap_masks)
                 b.record()
                 torch.cuda.synchronize()
                 ms = a.elapsed_time(b) / 3
@@ -461,12 +471,13 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
         _conv_auto_save()
     try:
         return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, tile=hit[0],
-                      split_k=hit[1], wgt_tiled=wgt_tiled)
+                      split_k=hit[1], wgt_tiled=wgt_tiled, tap_masks=tap_masks)
     except MeError:
-        if hit == (0, 0):
+        if hit[0] == 0:
             raise
         _CONV_AUTO[key] = (0, 0)  # a stale entry (a tile this library refuses for the shape): the planner's own choice
-        return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, wgt_tiled=wgt_tiled)
+        return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, wgt_tiled=wgt_tiled,
+                      tap_masks=tap_masks)
 
 
 def tile_weights_f32(wgt_packed):

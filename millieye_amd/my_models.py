@@ -246,6 +246,8 @@ _HEAD_LEAVES = (("refinement_head", "net0", 0), ("refinement_head", "net1", 0), 
                 ("refinement_head", "radar_net", 3), ("ensemble_head", "fc1", 0), ("ensemble_head", "fc2", 0))
 
 
+_COUNT_SPIN = os.environ.get("MILLIEYE_COUNT_SPIN", "0") == "1"  # row count of Network.forward: .item() / polled pinned word (A/B)
+
 _HEAD_BN_PATHS = (("img_cnn_layers", "net", 1), ("radar_cnn_layers", "conv1", 1), ("radar_cnn_layers", "conv2", 1),
                   ("radar_cnn_layers", "conv3", 1), ("refinement_head", "radar_net", 1))
 
@@ -427,6 +429,23 @@ class Network(nn.Module):
         hip.check(hip.lib().me_conv2d_f32(C.byref(d), hip.stream_ptr()), "me_conv2d_f32")
         return out
 
+    def _buf(self, name, shape, dev, dtype=torch.float32):
+        """Scratch tensor of the post-detector tail, kept from call to call (round 5: the tail issued ~18 ``torch.empty`` per
+        forward, 3 - 4 us of host time each, in the one part of a small-batch step where the host is the slower side).  Every
+        launch that reads or writes these buffers is ordered on the forward's main stream or on the side stream behind an event
+        of the main stream, so the next forward's launches queue behind this forward's.  Contents are valid until the next
+        ``forward`` (``self._last`` hands some of them out, like ``plan.tap``).  The returned rows are NOT from this pool."""
+        pool = self.__dict__.get("_tail_bufs")
+        if pool is None:
+            pool = self.__dict__["_tail_bufs"] = {}
+        key = (name, shape, dtype, dev)
+        t = pool.get(key)
+        if t is None:
+            if len(pool) > 96:  # (the RoI capacity follows the number of radar boxes of a call: keep the pool bounded)
+                pool.clear()
+            t = pool[key] = torch.empty(shape, device=dev, dtype=dtype)
+        return t
+
     def _side_stream(self, dev):
         st = self.__dict__.get("_side")
         if st is None or st.device != dev:
@@ -446,10 +465,10 @@ class Network(nn.Module):
         if not (maps.is_cuda and maps.dtype == torch.float32):
             raise hip.MeError("radar maps must be CUDA float32 [N,3,h,w]")
         mh, mw = maps.shape[2], maps.shape[3]
-        t1 = torch.empty((n, mh, mw, 32), **f32)
-        t2 = torch.empty((n, mh, mw, 64), **f32)
-        t3 = torch.empty((n, mh, mw, 128), **f32)
-        radar_score_map = torch.empty((n, mh, mw, 12), **f32)  # 10 channels, pitch 12
+        t1 = self._buf("r1", (n, mh, mw, 32), dev)
+        t2 = self._buf("r2", (n, mh, mw, 64), dev)
+        t3 = self._buf("r3", (n, mh, mw, 128), dev)
+        radar_score_map = self._buf("rmap", (n, mh, mw, 12), dev)  # 10 channels, pitch 12
         self._conv(maps.data_ptr(), 3, True, n, mh, mw, 3, packs["r1"], 3, 1, hip.ACT_LEAKY, t1)
         self._conv(t1.data_ptr(), 32, False, n, mh, mw, 32, packs["r2"], 3, 1, hip.ACT_LEAKY, t2)
         self._conv(t2.data_ptr(), 64, False, n, mh, mw, 64, packs["r3"], 3, 1, hip.ACT_LEAKY, t3)
@@ -466,7 +485,7 @@ class Network(nn.Module):
         tap16 = getattr(plan, "dtype", "f32") != "f32"
         packs[plan.dtype if tap16 else "img"].refresh(dev)
         fh, fw, fc = plan.tap_shape
-        roi_score_map = torch.empty((n, fh, fw, 490), device=dev, dtype=torch.float32)
+        roi_score_map = self._buf("imap", (n, fh, fw, 490), dev)
         if tap16:
             self._conv16(plan.tap_ptr, plan.tap_pitch, n, fh, fw, fc, packs[plan.dtype], 1, 0, hip.ACT_LEAKY, roi_score_map)
         else:
@@ -507,6 +526,9 @@ class Network(nn.Module):
         cb = getattr(self, "_stage_cb", None)
         mark = cb or (lambda _name: None)  # bench.py: per-stage HIP events
         mark("start")
+        tr = self.__dict__.get("_trace_cb") or (lambda _name: None)  # tools/b1_tail_events.py: (host time, HIP event on the
+        # current stream) per point, WITHOUT changing the stream structure (the stage marks above switch the overlap off)
+        tr("entry")
         # The radar CNN needs nothing from the detector: it runs on the side stream beside it (mode 0 / 2 / 3).  Its four launches are
         # ISSUED behind the detector's (the host is the slower side while the detector's ~125 launches go out, and whatever the
         # host does in front of the first one is idle time of the GPU - ~0.1 ms of a 1.8 ms step at batch 1); the side stream only
@@ -524,11 +546,13 @@ class Network(nn.Module):
                 radar_job = self._radar_score_map(maps, n, dev)
             entered = None
         plan, yolo_out = self.base_detector._run(images, nms_conf=float(self.conf_thresh))  # the decode fills the NMS lists
+        tr("detector issued")
         if entered is not None:
             side = self._side_stream(dev)
             side.wait_event(entered)
             with torch.cuda.stream(side):
                 radar_job = self._radar_score_map(maps, n, dev)
+                tr("side: radar CNN issued")
         mark("detector")
         # The score maps (reference :486-487) only need the feature tap, NMS only the decoded rows: NMS keeps 32
         # workgroups busy for ~0.3 ms, so the score-map convolutions run beside it on a second stream (mode 0 / 2 / 3).
@@ -540,21 +564,24 @@ class Network(nn.Module):
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 maps_job = self._score_maps(plan, maps, n, dev, radar_job)
+                tr("side: score map issued")
         det, cnt = hip.nms_batched(yolo_out, float(self.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
                                    writeback_xyxy=False, prepped=plan.nms_prepped == float(self.conf_thresh))
         mark("nms")
+        tr("nms issued")
         num_classes = yolo_out.shape[2] - 5
         cols = 8 + self.class_num
         cap_img = n * _DETECTIONS_PER_IMG
-        img_boxes = torch.empty((cap_img, cols), **f32)
-        n_img_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+        img_boxes = self._buf("img_boxes", (cap_img, cols), dev)
+        n_img_dev = self._buf("n_img", (1,), dev, torch.int32)
         lib = hip.lib()
         hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
                                                 int(self.class_idx), int(self.class_num), img_boxes.data_ptr(),
                                                 n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
         mark("proposals")
+        tr("proposals issued")
         if model_mode == 1:  # yolo only
-            return img_boxes[: int(n_img_dev.item()), :8]
+            return img_boxes[: int(n_img_dev.item()), :8].clone()  # (img_boxes is a pooled scratch buffer: the caller gets its own rows)
         if model_mode == 2:  # radar only: permanent, like the reference (quirk q3)
             self.refine_threshold_img = 1
 
@@ -569,6 +596,7 @@ class Network(nn.Module):
         roi_score_map, radar_score_map, fh, fw, rh_, rw_ = maps_job
         packs = self._get_packs()
         mark("score_maps")
+        tr("joined side stream")
 
         # ---- RoIs: image proposals then radar proposals (reference :490-492)
         if len(radar_boxes_location) > 0:
@@ -576,12 +604,12 @@ class Network(nn.Module):
         n_radar = int(radar_boxes_location.shape[0])
         rb = radar_boxes_location.to(**f32).contiguous() if n_radar else None
         cap = cap_img + n_radar
-        regress = torch.empty((cap, 4), **f32)
-        refine = torch.empty((cap, 2), **f32)
-        mask1 = torch.empty((cap,), **f32)
-        rows = torch.empty((cap, 8), **f32)
-        keep = torch.empty((cap,), device=dev, dtype=torch.uint8)  # (the heads launch clears the slots behind the last RoI)
-        key = torch.empty((cap,), **f32)
+        regress = self._buf("regress", (cap, 4), dev)
+        refine = self._buf("refine", (cap, 2), dev)
+        mask1 = self._buf("mask1", (cap,), dev)
+        rows = self._buf("rows", (cap, 8), dev)
+        keep = self._buf("keep", (cap,), dev, torch.uint8)  # (the heads launch clears the slots behind the last RoI)
+        key = self._buf("key", (cap,), dev)
 
         hw = packs["heads"].refresh(dev)
         d = hip.HeadsDesc()
@@ -599,20 +627,47 @@ class Network(nn.Module):
         d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
         d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
         if not getattr(self, "_fused_heads", False):
-            pooled = torch.empty((cap, 980), **f32)  # the RoI pooling as its own launch (me_heads_desc.pool_scratch)
+            pooled = self._buf("pooled", (cap, 980), dev)  # the RoI pooling as its own launch (me_heads_desc.pool_scratch)
             d.pool_scratch = pooled.data_ptr()
         # (``_fused_heads``: the single-launch VALU kernel with the pooling inside - kept as the cross-check of the two-launch
         # path, tests/test_gpu_network.py)
         hip.check(lib.me_roi_heads_f32(C.byref(d), hip.stream_ptr()), "me_roi_heads_f32")
         mark("roi_heads")
+        tr("heads issued")
         self.refinement_head.count += 1
 
         # ---- keep positives, order by confidence (reference :517-539): one launch, then the one host sync (the row count)
         ordered = torch.empty((cap, 8), **f32)
-        n_out = torch.empty((1,), device=dev, dtype=torch.int32)
-        hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
-                                               n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
-        n_rows = int(n_out.item())
+        if _COUNT_SPIN:
+            # A/B form of the one host sync of the call (round 5): the kernel stores the count straight into a pinned host word
+            # (system-scope store) that the host preset to -1 and polls, instead of ``n_out.item()`` (a 4-byte blocking copy).
+            # tools/b1_tail_events.py suggested ~70 us between the end of the compaction kernel and the count on the host; the
+            # poll showed that gap to be the pick-up latency of the trace's FIRST event on an idle GPU, not a read-back cost:
+            # 1.637 vs 1.628 ms (fp32) and 0.851 vs 0.845 ms (bf16) per batch-1 step with / without the poll - no gain, off.
+            word = self.__dict__.get("_count_word")
+            if word is None:
+                host = torch.zeros((16,), dtype=torch.int32).pin_memory()
+                word = self.__dict__["_count_word"] = (host, C.cast(host.data_ptr(), C.POINTER(C.c_int32)))
+            host, flag = word
+            flag[0] = -1
+            hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
+                                                   host.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+            tr("compaction issued")
+            spins = 0
+            while flag[0] == -1:
+                spins += 1
+                if spins > 20_000_000:  # (seconds: a wedged stream - let the runtime report it)
+                    torch.cuda.current_stream(dev).synchronize()
+                    if flag[0] == -1:
+                        raise hip.MeError("Network.forward: the compaction launch never delivered its row count")
+            n_rows = int(flag[0])
+        else:
+            n_out = self._buf("n_out", (1,), dev, torch.int32)
+            hip.check(lib.me_compact_sort_rows_f32(rows.data_ptr(), keep.data_ptr(), key.data_ptr(), cap, 8, ordered.data_ptr(),
+                                                   n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+            tr("compaction issued")
+            n_rows = int(n_out.item())
+        tr("row count on the host")
         output = ordered[:n_rows]
         mark("output")
         self._last = dict(regress=regress, refine=refine, mask1=mask1, n_img=n_img_dev, img_boxes=img_boxes)

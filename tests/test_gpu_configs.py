@@ -107,6 +107,31 @@ def _match_share(ref, got, px, tol):
     return matched / ref.shape[0]
 
 
+def _iou(a, b):
+    """IoU of one xyxy box with many."""
+    x1, y1 = torch.maximum(a[0], b[:, 0]), torch.maximum(a[1], b[:, 1])
+    x2, y2 = torch.minimum(a[2], b[:, 2]), torch.minimum(a[3], b[:, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter)
+
+
+def _tie_share(ref, got, px=4.0, tol=0.1, iou_min=0.45):
+    """Share of ``ref`` rows with a counterpart in ``got`` when the two tie-breaks of a random-weight detector are allowed for
+    (round 5, tools/bf16_row_diff.py / profiles/r05_bf16_row_diff.txt: every batch-1 row the strict criterion misses in the
+    batch-32 run is one of these - none vanishes at the confidence threshold, none moves by rounding): a counterpart is a row
+    within ``px`` pixels and ``tol`` confidence of ANY class (the class arg-max among near-equal class scores flipped), or a row
+    that overlaps it by IoU >= ``iou_min`` (NMS kept the neighbouring grid cell's near-equal candidate: the row "moves" by one
+    cell = 16 / 32 px)."""
+    if ref.shape[0] == 0 or got.shape[0] == 0:
+        return 1.0 if ref.shape[0] == 0 else 0.0
+    n = 0
+    for row in ref:
+        d = (got[:, 1:5] - row[1:5]).abs().max(dim=1).values
+        near = (d <= px) & ((got[:, 5] - row[5]).abs() <= tol)
+        n += int(bool(near.any()) or bool((_iou(row[1:5], got[:, 1:5]) >= iou_min).any()))
+    return n / ref.shape[0]
+
+
 @pytest.mark.parametrize("dtype,px,tol,bar,floor", [("bf16", 4.0, 0.1, 0.85, 0.70), ("f16", 2.0, 0.02, 0.97, 0.95)])
 def test_module2_batch32_16bit(hip_lib, monkeypatch, tmp_path, dtype, px, tol, bar, floor):
     """(The per-layer tile choice is normally MEASURED on the GPU box, so the roundings - and with them a handful of rows near the

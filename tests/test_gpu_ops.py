@@ -511,3 +511,48 @@ def test_round3_entry_points_refuse_bad_arguments(hip_lib):
     assert lib.me_image_pad_resize_flip_u8_f32(None, 4, 4, p, 8, 1, hip.stream_ptr()) < 0
     assert lib.me_image_pad_resize_flip_u8_f32(p, 0, 4, p, 8, 1, hip.stream_ptr()) < 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cin,cout,h", [(32, 64, 21), (64, 128, 14), (128, 256, 9), (256, 512, 7)])
+def test_conv_tap_masks_skip_the_zero_taps_bit_exactly(hip_lib, cin, cout, h):
+    """ABI 10, ``me_conv_desc.tap_mask``: the 2x2 convolution that computes the four output-parity classes of a 3x3 / stride-2
+    layer's data gradient (detector_train._parity_weights: 7 of its 16 (class, tap) pairs are structurally zero) with the zero
+    taps SKIPPED equals the same launch multiplying them - bit for bit (a skipped tap would have added +0.0), on every tile the
+    library accepts for the class width - and equals torch's transposed convolution; bad masks / tiles are refused."""
+    from millieye_amd import hip
+    from millieye_amd.detector_train import _PARITY_TAP_MASKS, _parity_weights
+    n = 3
+    dev = torch.device("cuda")
+    w = torch.from_numpy(synth.uniform(f"tm/w{cin}", (cout, 3, 3, cin), -1, 1)).to(dev) / (9 * cin) ** 0.5   # forward OHWI
+    dc = torch.from_numpy(synth.uniform(f"tm/dc{cin}", (n, h, h, cout), -1, 1)).to(dev)                    # dL/d(conv output)
+    pw = _parity_weights(w)
+    assert pw.shape == (4 * cin, 2, 2, cout)
+    flat = pw.reshape(4, cin, 4, cout)
+    for cls, mask in enumerate(_PARITY_TAP_MASKS):   # the masks say exactly which taps are zero
+        for t in range(4):
+            assert bool((flat[cls, :, t] == 0).all()) == (not (mask >> t) & 1)
+    ones, zeros = torch.ones(4 * cin, device=dev), torch.zeros(4 * cin, device=dev)
+    plain = hip.conv2d(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=3, split_k=1)
+    seen = 0
+    for tile in (0, 1, 2, 3, 4, 5):
+        try:
+            got = hip.conv2d(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=tile, tap_masks=(cin, _PARITY_TAP_MASKS))
+        except hip.MeError:
+            assert tile != 0, "the automatic tile must exist for every class width"
+            continue   # (a tile wider than the class)
+        base = hip.conv2d(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=tile if tile else 3, split_k=1)
+        assert torch.allclose(got, plain, rtol=1e-5, atol=1e-6), tile
+        if tile:
+            assert torch.equal(got, base), f"tile {tile}: skipping the zero taps changed bits"
+        seen += 1
+    assert seen >= 2
+    # the gradient itself: pixel shuffle of the cropped classes == conv_transpose2d of dc with the forward weights
+    dx = got[:, 1:, 1:, :].reshape(n, h, h, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * h, cin)
+    ref = F.conv_transpose2d(dc.permute(0, 3, 1, 2).cpu(), w.permute(0, 3, 1, 2).cpu(), stride=2, padding=1, output_padding=1)
+    assert_close(dx.permute(0, 3, 1, 2).cpu(), ref, 1e-4, "stride-2 data gradient through the masked parity convolution")
+    with pytest.raises(hip.MeError):
+        hip.conv2d(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tap_masks=(cin, (1, 3, 0, 15)))      # a class without taps
+    with pytest.raises(hip.MeError):
+        hip.conv2d(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tap_masks=(cin + 16, _PARITY_TAP_MASKS))  # cout % cols != 0
+    with pytest.raises(hip.MeError):
+        hip.conv2d(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=43, tap_masks=(cin, _PARITY_TAP_MASKS))  # tail split

@@ -19,7 +19,7 @@ import torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 from millieye_amd import synth  # noqa: E402
-from tests.test_gpu_configs import PLAN, _frame_rows, _m2_net  # noqa: E402
+from tests.test_gpu_configs import PLAN, _frame_rows, _m2_net, _tie_share as tie_share  # noqa: E402
 
 DT = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 
@@ -64,6 +64,8 @@ def main():
             print(f"== frame {f} [{DT}]: batch-1 rows {one.shape[0]}, batch-32 rows {mine.shape[0]}; matched {c['matched']} "
                   f"moved {len(c['moved'])} conf {len(c['conf'])} vanished {len(c['vanished'])} | the other way: matched "
                   f"{back['matched']} moved {len(back['moved'])} conf {len(back['conf'])} vanished {len(back['vanished'])}")
+            print(f"   tie-aware share (any class within 4 px / 0.1, or IoU >= 0.45 with a kept neighbour): "
+                  f"{tie_share(one, mine):.1%} of the batch-1 rows, {tie_share(mine, one):.1%} the other way")
             for row, d, near in c["moved"]:
                 print(f"   moved    {d:7.1f} px  class {int(row[7])} conf {float(row[5]):.3f} (obj {float(row[6]):.3f})  box "
                       f"{[round(float(v), 1) for v in row[1:5]]} nearest {[round(float(v), 1) for v in near[1:5]]}")

@@ -49,7 +49,9 @@ def main():
         else:
             pw = _parity_weights(w)
             o4, z4 = torch.ones(4 * cin, device=dev), torch.zeros(4 * cin, device=dev)
-            dg = timed(lambda: hip.conv2d_auto(dy, pw, o4, z4, 2, 1, 1, hip.ACT_LINEAR))
+            from millieye_amd.detector_train import _PARITY_MASKS_ON, _PARITY_TAP_MASKS
+            masks = (cin, _PARITY_TAP_MASKS) if _PARITY_MASKS_ON and cin % 32 == 0 and cout % 16 == 0 else None  # (what the step does)
+            dg = timed(lambda: hip.conv2d_auto(dy, pw, o4, z4, 2, 1, 1, hip.ACT_LINEAR, tap_masks=masks))
         fl = 2.0 * n * ho * ho * cout * cin * k * k
         print(f"x{cnt} {h:3d}^2 {cin:4d}->{cout:4d} k{k} s{s}: fwd {fwd:7.1f} us {fl / fwd / 1e6:6.1f} TF/s | dgrad {dg:7.1f} us "
               f"{fl / dg / 1e6:6.1f} TF/s")
