@@ -408,7 +408,7 @@ def _conv_auto_load():
         import json
         with open(_conv_auto_file()) as fh:
             for k, v in json.load(fh).items():
-                _CONV_AUTO[k] = (int(v[0]), int(v[1]))
+                _CONV_AUTO[k] = tuple(int(x) for x in v)   # (tile, split_k[, masked])
     except (OSError, ValueError):
         pass
 
@@ -442,42 +442,46 @@ def conv2d_auto(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, resid
     hit = _CONV_AUTO.get(key)
     if hit is None:
         cin = wgt_packed.shape[3]
-        cands = [(0, 0)] + [(t, sp) for t in (1, 2, 3, 4, 5) for sp in (1, 2, 4)]
+        cands = [(0, 0, 0)] + [(t, sp, 0) for t in (1, 2, 3, 4, 5) for sp in (1, 2, 4)]
         if cin % 16 == 0:
-            cands += [(t, sp) for t in (41, 42, 43) for sp in (2, 4)]
-        if tap_masks is not None:  # whole tiles of the buffer kernel only (the library refuses the rest)
-            cands = [(0, 1)] + [(t, 1) for t in (1, 2, 3, 4, 5)]
+            cands += [(t, sp, 0) for t in (41, 42, 43) for sp in (2, 4)]
+        if tap_masks is not None:
+            # the masks are an optimisation (the skipped taps are zero either way): whole tiles of the buffer kernel WITH them
+            # compete against every unmasked candidate - on the small maps one round of tiles lasts as long as its four-tap
+            # class, and the unmasked K splits / tail splits win (tools/dgrad_bench.py, profiles/r05_micro_dgrad_masks.txt)
+            cands += [(0, 1, 1)] + [(t, 1, 1) for t in (1, 2, 3, 4, 5)]
         scratch = None
-        best = (float("inf"), 0, 0)
+        best = (float("inf"), 0, 0, 0)
         torch.cuda.synchronize()  # every stream idle (the weight-gradient stream too): the timings are the candidates' own
-        for tile, split in cands:
+        for tile, split, masked in cands:
+            tm = tap_masks if masked else None
             try:
                 for _ in range(2):
                     scratch = conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch,
-                                     tile=tile, split_k=split, wgt_tiled=wgt_tiled, tap_masks=tap_masks)
+                                     tile=tile, split_k=split, wgt_tiled=wgt_tiled, tap_masks=tm)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(3):
                     conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch, tile=tile,
-                           split_k=split, wgt_tiled=wgt_tiled, tap_masks=tap_masks)
+                           split_k=split, wgt_tiled=wgt_tiled, tap_masks=tm)
                 b.record()
                 torch.cuda.synchronize()
                 ms = a.elapsed_time(b) / 3
             except MeError:
                 continue
             if ms < best[0]:
-                best = (ms, tile, split)
-        hit = _CONV_AUTO[key] = (best[1], best[2])
+                best = (ms, tile, split, masked)
+        hit = _CONV_AUTO[key] = (best[1], best[2], best[3])
         _conv_auto_save()
+    masked = len(hit) > 2 and hit[2]
     try:
         return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, tile=hit[0],
-                      split_k=hit[1], wgt_tiled=wgt_tiled, tap_masks=tap_masks)
+                      split_k=hit[1], wgt_tiled=wgt_tiled, tap_masks=tap_masks if masked else None)
     except MeError:
-        if hit[0] == 0:
+        if hit[0] == 0 and not masked:
             raise
-        _CONV_AUTO[key] = (0, 0)  # a stale entry (a tile this library refuses for the shape): the planner's own choice
-        return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, wgt_tiled=wgt_tiled,
-                      tap_masks=tap_masks)
+        _CONV_AUTO[key] = (0, 0, 0)  # a stale entry (a tile this library refuses for the shape): the planner's own choice
+        return conv2d(x_nhwc, wgt_packed, scale, shift, ksize, stride, pad, act, residual=residual, out=out, wgt_tiled=wgt_tiled)
 
 
 def tile_weights_f32(wgt_packed):

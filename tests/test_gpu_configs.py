@@ -157,15 +157,35 @@ def test_module2_batch32_16bit(hip_lib, monkeypatch, tmp_path, dtype, px, tol, b
         net.base_detector.compute_dtype = dtype
         got, again = net(x), net(x)
         ones = [net(x[f:f + 1]) for f in picks]
+        # At the source - the decoded rows of the detector, before NMS - the batch-32 and batch-1 runs of a frame are close
+        # (round 5, profiles/r05_bf16_row_diff.txt: objectness |d| <= 0.007, boxes of the rows over the threshold <= 0.5 px in
+        # bf16): whatever differs in the output rows is decided by NMS / arg-max tie-breaks downstream, not by rounding
+        _fm, y_all = net.base_detector(x)
+        for f in picks:
+            _fm, y_one = net.base_detector(x[f:f + 1])
+            a, b = y_all[f].float(), y_one[0].float()
+            over = (a[:, 4] >= 0.2) | (b[:, 4] >= 0.2)
+            d_obj = float((a[:, 4] - b[:, 4]).abs().max())
+            d_box = float((a[over, :4] - b[over, :4]).abs().max()) if bool(over.any()) else 0.0
+            print(f"[m2b32 {dtype}] frame {f}: decoded rows batch-32 vs batch-1: objectness |d| {d_obj:.4f}, boxes over the threshold "
+                  f"{d_box:.2f} px")
+            assert d_obj <= (0.03 if dtype == "bf16" else 0.005) and d_box <= (2.0 if dtype == "bf16" else 0.5), (f, d_obj, d_box)
     assert torch.equal(got, again), "not deterministic"
     assert ref32.shape[0] >= 32 and abs(got.shape[0] - ref32.shape[0]) <= max(2, 0.1 * ref32.shape[0]), (got.shape, ref32.shape)
-    found = rows_total = 0
+    found = rows_total = tie_found = 0
     shares = []
     for f, one in zip(picks, ones):
         mine = _frame_rows(got, f)
         assert abs(mine.shape[0] - one.shape[0]) <= max(3, 0.2 * one.shape[0]), (f, mine.shape, one.shape)
         share = _match_share(one, mine, px, tol)
         print(f"[m2b32 {dtype}] frame {f}: {share:.1%} of {one.shape[0]} batch-1 rows found in the batch-32 run")
+        # ... and with the two tie-breaks of a random-weight detector allowed for (a neighbouring cell's near-equal candidate kept
+        # by NMS, the class arg-max flipped among near-equal scores) every row has its counterpart, both ways: measured
+        # 94.7 / 100 / 100 / 100 % (one row of 19 on frame 0), 100 % the other way; a row is 4 - 5 points of a frame
+        t_fwd, t_back = _tie_share(one, mine, px, tol), _tie_share(mine, one, px, tol)
+        print(f"[m2b32 {dtype}] frame {f}: tie-aware {t_fwd:.1%} / {t_back:.1%}")
+        assert min(t_fwd, t_back) >= 0.85, f"{dtype}: frame {f}: tie-aware share {t_fwd:.0%} / {t_back:.0%}"
+        tie_found += t_fwd * one.shape[0]
         shares.append((f, share))
         found += share * one.shape[0]
         rows_total += one.shape[0]
@@ -176,6 +196,7 @@ def test_module2_batch32_16bit(hip_lib, monkeypatch, tmp_path, dtype, px, tol, b
     for f, share in shares:
         assert share >= floor, f"{dtype}: frame {f}: {share:.0%} of the batch-1 rows found in the batch-32 run"
     assert found >= bar * rows_total, f"{dtype}: {found / max(rows_total, 1):.0%} of the batch-1 rows found in the batch-32 run"
+    assert tie_found >= 0.93 * rows_total, f"{dtype}: tie-aware {tie_found / max(rows_total, 1):.0%} (measured 98.8 %)"
     plan_check()
 
 

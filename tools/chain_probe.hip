@@ -110,11 +110,14 @@ __global__ __launch_bounds__(256) void chain_kernel(Args a) {
   __shared__ unsigned s_ticket;
   const unsigned total = (unsigned)a.L * (unsigned)a.T;
   for (;;) {
+    // (the barrier in FRONT of the one-lane ticket draw closes the one-lane publish block at the end of run_tile before the
+    //  back edge: without it hipcc merged the two one-lane regions across the back edge and the lanes of wave 0 met the
+    //  barriers in different iterations - the first version of this probe hung)
+    __syncthreads();
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.head, 1u);
     __syncthreads();
-    const unsigned t = s_ticket;
-    __syncthreads();
-    if (t >= total) return;
+    const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
+    if (t >= total) break;
     run_tile<true>(a, (int)(t / a.T), (int)(t % a.T));
   }
 }
