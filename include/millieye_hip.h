@@ -399,6 +399,15 @@ int64_t me_affine_bwd_workspace_bytes(int32_t rows, int32_t channels);
 int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
                           const float* scale, const float* gamma, const float* beta, int32_t act, float* dc, int64_t lddc,
                           float* dshift, float* dgamma, void* workspace, void* stream);
+/* me_affine_act_bwd_h16 (ABI 10): the same pass in a 16-bit storage mode (half_type 0 = bfloat16, 1 = IEEE half): y, dy and dc are
+ * 16-bit [rows, channels] (channels and pitches % 8 == 0, 16-byte aligned), dc is rounded once (RNE); scale / gamma / beta and the
+ * sums dshift / dgamma stay fp32 (double accumulation, fixed order).  The activation-gradient half of the mixed-precision detector
+ * backward (millieye_amd/detector_train16.py; autograd semantics of yolov3/models.py:22-41,181-267).
+ * workspace: me_affine_bwd_h16_workspace_bytes(rows, channels). */
+int64_t me_affine_bwd_h16_workspace_bytes(int32_t rows, int32_t channels);
+int me_affine_act_bwd_h16(const void* y, int64_t ldy, const void* dy, int64_t lddy, int32_t rows, int32_t channels,
+                          const float* scale, const float* gamma, const float* beta, int32_t act, void* dc, int64_t lddc,
+                          float* dshift, float* dgamma, void* workspace, int32_t half_type, void* stream);
 int me_upsample2_bwd_f32(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n, int32_t h, int32_t w,
                          int32_t c, void* stream);
 int me_maxpool_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n,

@@ -584,7 +584,9 @@ __device__ __forceinline__ void tile_coords(const ConvP& p, int t, int& tile_m, 
 // conv_tail_reduce_f32 sums them in a fixed order and applies the epilogue.
 // DEEP: a longer LDS ring (6 stages tap-major / 9 chunk-major instead of 3: five / eight stages of DMAs in flight) for launches
 // that put one or two workgroups on a CU (batch 1 / 8): there a stage is bound by the latency of its DMAs, not by the matrix pipe.
-template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0, int HYB = 0, int KORD = 0, int DEEP = 0>
+// MASKED: the instance with the column-class tap masks (me_conv_desc.tap_mask, ABI 10).  A separate instance on purpose: the two
+// scalar tests in the tap walk changed the register allocation of the plain kernel (64 x 64 tile: 63 -> 43 VGPRs, another schedule).
+template <int BM, int BN, int WR, int WC, int MINW = 1, int BABL = 0, int HYB = 0, int KORD = 0, int DEEP = 0, int MASKED = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p) {
   constexpr int NW = WR * WC;  // waves per workgroup (4 or 8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
     int tap = 0, cc = 0, ky = 0, kx = 0;
     // Column-class tap masks (me_conv_desc.tap_mask): the K walk of this tile visits only the set taps of its class.
     unsigned tmask = 0xFFFFFFFFu;
-    if (p.mask_cols) {   // (whole tiles only: the host refuses a K split with masks; a class is a multiple of BN columns wide)
+    if constexpr (MASKED) {   // (whole tiles only: the host refuses a K split with masks; a class is a multiple of BN columns wide)
       tmask = p.tapmask[n0 / p.mask_cols] & ((1u << (p.ks * p.ks)) - 1u);
       tap = __builtin_ctz(tmask);
       ky = tap / p.ks;
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
     unsigned a_off = 0, b_off = 0;  // scalar byte offsets of the next stage to issue
     auto enter_tap = [&]() {        // VALU work only here: once per filter tap
 #pragma unroll
-      for (int j = 0; j < LA; ++j) v_cur[j] = (BABL == 1 || ((v_pad[j] >> (tap & 31)) & 1u)) ? kOobOffset : v_base[j];
+      for (int j = 0; j < LA; ++j) v_cur[j] = (BABL == 1 || ((v_pad[j] >> (MASKED ? (tap & 31) : tap)) & 1u)) ? kOobOffset : v_base[j];
       a_off = (unsigned)(ky * p.w + kx) * pitch4;
       b_off = (unsigned)tap * (unsigned)p.cs * b_step;
     };
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_f32(ConvP p
             kx = 0;
             ++ky;
           }
-        } while (tap < p.ks * p.ks && !((tmask >> tap) & 1u));
+        } while (MASKED && tap < p.ks * p.ks && !((tmask >> tap) & 1u));
         enter_tap();
       }
     };
@@ -1385,13 +1387,13 @@ void choose_order(ConvP& p) {
   }
 }
 
-template <int BM, int BN, int WR, int WC, int MINW, int BABL, int HYB, int KORD, int DEEP = 0>
+template <int BM, int BN, int WR, int WC, int MINW, int BABL, int HYB, int KORD, int DEEP = 0, int MASKED = 0>
 int launch_buf_kernel(const ConvP& p, dim3 grid, hipStream_t stream) {
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
   constexpr int NST = DEEP ? (KORD ? 9 : 6) : 3;
   const size_t lds = (size_t)NST * LPW * NW * 256 * sizeof(float);
-  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW, BABL, HYB, KORD, DEEP>;
+  auto kern = conv_igemm_buf_f32<BM, BN, WR, WC, MINW, BABL, HYB, KORD, DEEP, MASKED>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1430,8 +1432,12 @@ int launch_buf(ConvP& p, hipStream_t stream) {
   if (blocks > p.counters_len || p.splitk == 1) p.counters = nullptr;  // in-launch slab reduction needs a counter per tile
   int rc;
   if constexpr (BABL == 0) {
-    rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 1, DEEP>(p, grid, stream)
-                : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 0, DEEP>(p, grid, stream);
+    if (p.mask_cols) {
+      if constexpr (DEEP == 0) rc = launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 0, 0, 1>(p, grid, stream);
+      else rc = ME_E_BADARG;
+    } else
+      rc = p.kord ? launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 1, DEEP>(p, grid, stream)
+                  : launch_buf_kernel<BM, BN, WR, WC, MINW, 0, 0, 0, DEEP>(p, grid, stream);
   } else {
     rc = launch_buf_kernel<BM, BN, WR, WC, MINW, BABL, 0, 0>(p, grid, stream);
   }

@@ -10,6 +10,17 @@
 // bit-identical with that oracle).  Samples that the border rule maps to 0 are skipped by
 // bounding the sample loops to the feature map (adding +0.0f is exact), which also bounds the
 // work for degenerate huge boxes.
+//
+// WHICH KERNELS ARE PRODUCT (three generations live side by side in this file):
+//   inference, stage 3 (Network.forward -> me_roi_heads_f32 with me_heads_desc.pool_scratch set):
+//       roi_pool10_kernel (a thread per bin, ten channels each)  +  roi_heads_mfma_kernel (32 RoIs per workgroup, net0 on the fp32
+//       matrix pipe)  +  compact_sort_kernel.                                                        <- the product path
+//   training, stage 3 (train_path.py: save_* pointers set): roi_heads_kernel (8 RoIs per workgroup, VALU chains; writes the saved
+//       activations the backward needs) and the *_bwd kernels.                                         <- product for training
+//   cross-checks only: roi_heads_kernel as the single fused launch of inference (pool_scratch == NULL; Network._fused_heads,
+//       tests/test_gpu_network.py::test_two_launch_heads_equal_the_fused_launch), roi_pool_kernel (MILLIEYE_POOL10=0: a thread per
+//       pooled value), MILLIEYE_HEADS_MFMA=0 (VALU heads behind the pooling launch).
+//   stage 2 (module2): m2_pool_kernel + m2_heads kernels.
 #include <math.h>
 #include "common.h"
 

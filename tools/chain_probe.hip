@@ -6,6 +6,7 @@
 //   (3) runs an fp32 MFMA chain of CH instructions per wave (the K loop; 64 cycles each),
 //   (4) writes its own 4 KB output.
 // Variant A: one launch per layer (what the engine does: the stream orders the layers).
+// Variant C: B with write-through (sc0 sc1) payload stores and loads on both sides instead of the release / acquire fences.
 // Variant B: ONE launch; workgroups draw (layer, tile) tickets in order from a device-scope counter (placement-independent:
 //   every dependency of a ticket was drawn before it, by a workgroup that is resident or done), prefetch the weight slab into
 //   registers BEFORE waiting (it depends on nothing), then wait for the ND producer tiles' arrival flags of layer - 1
@@ -48,9 +49,22 @@ __device__ __forceinline__ float tile_body(const Args& a, int layer, int tile, c
   return acc[0] * 1e-9f;
 }
 
-// one tile of one layer; `wait` = variant B (flags), else the launch boundary ordered the producers
-template <bool WAIT>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load_wt(const float* p) {   // sc0 sc1: served past this CU's L1 and this XCD's possibly stale L2 lines
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void store_wt(float* p, f32x4 v) {  // write-through: visible to every XCD once vmcnt drains
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// one tile of one layer; MODE 0 = the launch boundary ordered the producers (variant A), 1 = arrival flags with agent-scope
+// release / acquire fences around plain payload accesses (variant B), 2 = arrival flags with write-through (sc0 sc1) payload
+// stores and loads on both sides and no fences (variant C: the guide's other valid form, cheaper per hop)
+template <int MODE>
 __device__ __forceinline__ void run_tile(const Args& a, int layer, int tile) {
+  constexpr bool WAIT = MODE != 0;
   const int tid = threadIdx.x;
   // (1) weights: 16 float4 per lane in flight per round, up to 4 rounds kept in registers (64 KB / 256 lanes = 16 float4)
   float4 wv[16];
@@ -75,14 +89,20 @@ __device__ __forceinline__ void run_tile(const Args& a, int layer, int tile) {
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (MODE == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
   }
   float s = 0.f;
   for (int d = 0; d < a.nd; ++d) {
     const int src = (tile + d) % a.T;
-    const float4 v = reinterpret_cast<const float4*>(in + (long long)src * 1024)[tid];
+    float4 v;
+    if (MODE == 2) {
+      const f32x4 t = load_wt(in + (long long)src * 1024 + tid * 4);
+      v = make_float4(t[0], t[1], t[2], t[3]);
+    } else {
+      v = reinterpret_cast<const float4*>(in + (long long)src * 1024)[tid];
+    }
     // every word of a producer tile carries (layer * 1000 + src + epoch): anything else is a stale or torn read
     const float want = (float)(layer * 1000 + src + a.epoch);
     if (v.x != want || v.y != want || v.z != want || v.w != want) atomicExch(a.err, 1);
@@ -93,19 +113,26 @@ __device__ __forceinline__ void run_tile(const Args& a, int layer, int tile) {
   // (4) output: the value the consumers check (+ r * 0 keeps the chain alive without changing it)
   float* out = a.act + (long long)(layer + 1) * a.T * 1024 + (long long)tile * 1024;
   const float val = (float)((layer + 1) * 1000 + tile + a.epoch) + r * 0.f;
-  reinterpret_cast<float4*>(out)[tid] = make_float4(val, val, val, val);
+  if (MODE == 2) {
+    f32x4 t = {val, val, val, val};
+    store_wt(out + tid * 4, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its own write-through stores in front of the barrier
+  } else {
+    reinterpret_cast<float4*>(out)[tid] = make_float4(val, val, val, val);
+  }
   if (WAIT) {
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (MODE == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(a.flags + (long long)(layer + 1) * a.T + tile, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void layer_kernel(Args a, int layer) { run_tile<false>(a, layer, blockIdx.x); }
+__global__ __launch_bounds__(256) void layer_kernel(Args a, int layer) { run_tile<0>(a, layer, blockIdx.x); }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void chain_kernel(Args a) {
   __shared__ unsigned s_ticket;
   const unsigned total = (unsigned)a.L * (unsigned)a.T;
@@ -118,7 +145,7 @@ __global__ __launch_bounds__(256) void chain_kernel(Args a) {
     __syncthreads();
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= total) break;
-    run_tile<true>(a, (int)(t / a.T), (int)(t % a.T));
+    run_tile<MODE>(a, (int)(t / a.T), (int)(t % a.T));
   }
 }
 
@@ -136,8 +163,8 @@ int main() {
   CK(hipStreamCreate(&st));
   int cus = 0;
   CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-  printf("chain probe: %d layers, %d CUs; us per layer, A = one launch per layer, B = one launch with ticket queue + arrival flags\n", L, cus);
-  printf("%6s %6s %6s %4s | %9s %9s %7s | %s\n", "tiles", "W KB", "mfma", "deps", "A us/lyr", "B us/lyr", "B / A", "errors");
+  printf("chain probe: %d layers, %d CUs; us per layer, A = one launch per layer, B = one launch with ticket queue + arrival flags (release / acquire fences), C = the same with write-through payload instead of fences\n", L, cus);
+  printf("%6s %6s %6s %4s | %9s %9s %9s %6s %6s | %s\n", "tiles", "W KB", "mfma", "deps", "A us/lyr", "B us/lyr", "C us/lyr", "B / A", "C / A", "errors");
   const int Ts[] = {48, 176, 256, 704};
   const int WKBs[] = {16, 64};
   const int CHs[] = {32, 128};   // 32 MFMAs = 0.85 us, 128 = 3.4 us of matrix pipe per wave at 2.4 GHz
@@ -160,14 +187,14 @@ int main() {
         a.w = w; a.act = act; a.flags = flags; a.head = head; a.err = err;
         // resident workgroups of the persistent launch: what fits (occupancy query), at most one per tile slot needed
         int per_cu = 0;
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_kernel, 256, 0));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_kernel<1>, 256, 0));
         if (per_cu > 4) per_cu = 4;
         int grid_b = per_cu * cus;
         if (grid_b > 2 * T) grid_b = 2 * T;   // two layers' worth of tiles in flight is all the chain can use
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        float ms_a = 1e30f, ms_b = 1e30f;
+        float ms_a = 1e30f, ms_b = 1e30f, ms_c = 1e30f;
         int epoch = 0;
         const bool dbg = getenv("CHAIN_DEBUG") != nullptr;
         for (int rep = 0; rep < 12; ++rep) {
@@ -188,16 +215,27 @@ int main() {
           hipLaunchKernelGGL(init_input, dim3(T), dim3(256), 0, st, a);
           CK(hipMemsetAsync(head, 0, 4, st));
           CK(hipEventRecord(e0, st));
-          hipLaunchKernelGGL(chain_kernel, dim3(grid_b), dim3(256), 0, st, a);
+          hipLaunchKernelGGL(chain_kernel<1>, dim3(grid_b), dim3(256), 0, st, a);
           CK(hipEventRecord(e1, st));
           CK(hipStreamSynchronize(st));
           CK(hipEventElapsedTime(&ms, e0, e1));
           if (rep >= 2 && ms < ms_b) ms_b = ms;
+          // C
+          a.epoch = ++epoch;
+          hipLaunchKernelGGL(init_input, dim3(T), dim3(256), 0, st, a);
+          CK(hipMemsetAsync(head, 0, 4, st));
+          CK(hipEventRecord(e0, st));
+          hipLaunchKernelGGL(chain_kernel<2>, dim3(grid_b), dim3(256), 0, st, a);
+          CK(hipEventRecord(e1, st));
+          CK(hipStreamSynchronize(st));
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep >= 2 && ms < ms_c) ms_c = ms;
           if (dbg) printf("  rep %d B %.3f ms\n", rep, ms);
         }
         int herr = 0;
         CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
-        printf("%6d %6d %6d %4d | %9.2f %9.2f %7.2f | %s (B grid %d)\n", T, WKB, CH, a.nd, ms_a * 1e3 / L, ms_b * 1e3 / L, ms_b / ms_a,
+        printf("%6d %6d %6d %4d | %9.2f %9.2f %9.2f %6.2f %6.2f | %s (grid %d)\n", T, WKB, CH, a.nd, ms_a * 1e3 / L, ms_b * 1e3 / L, ms_c * 1e3 / L,
+               ms_b / ms_a, ms_c / ms_a,
                herr == 0 ? "none" : herr == 1 ? "STALE/TORN DATA" : "SPIN LIMIT", grid_b);
         CK(hipFree(w)); CK(hipFree(act)); CK(hipFree(flags)); CK(hipFree(head)); CK(hipFree(err));
       }
