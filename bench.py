@@ -695,9 +695,10 @@ def main():
     # untimed pre-warm: the GPU needs a few hundred ms of sustained load to reach its steady clocks (the first
     # ~100 ms run ~15 % slower, measured with tools/conv_bench.py); serving throughput is the steady state
     if args.dtype != "f32":
-        if args.workload not in ("full", "detector", "module2", "train"):
-            raise SystemExit("--dtype bf16 / f16 applies to inference (workloads full, detector) and to the frozen detector "
-                             "of the stage-3 training step (workload train)")
+        if args.workload not in ("full", "detector", "module2", "train", "detector_train"):
+            raise SystemExit("--dtype bf16 / f16 applies to inference (workloads full, detector, module2), to the frozen detector "
+                             "of the stage-3 training step (workload train) and to the detector training step (detector_train: "
+                             "16-bit activations and activation gradients, fp32 master weights and weight gradients)")
         model.compute_dtype = args.dtype
     t_pre = time.perf_counter() + args.prewarm_seconds
     def lockstep_until(deadline, step=None):
@@ -974,10 +975,12 @@ def main():
             out["config"]["wgrad_stream"] = os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0"  # weight gradients beside the data gradients
             ranks = dist.get_world_size() if dist.is_initialized() else 0
             out["config"]["grad_chunks"] = int(last.get("chunks", 0))
+            mixed = "" if args.dtype == "f32" else (f"{args.dtype} activations and activation gradients, fp32 master weights, weight "
+                                                     "gradients on the fp32 matrix pipe, ")
             out["config"]["workload"] = out["config"]["workload"].replace(
-                "fp32 inference", "fp32 detector training step (forward + HIP backward of every layer, eval-mode BN, "
+                " inference, batch", " detector training step (forward + HIP backward of every layer, eval-mode BN, " + mixed
                 + (f"full-gradient all-reduce in {int(last.get('chunks', 0))} reverse-layer chunks beside the backward, "
-                   if ranks else "all-reduce skipped (1 rank, no process group), ") + "SGD)").replace(
+                   if ranks else "all-reduce skipped (1 rank, no process group), ") + "SGD), batch", 1).replace(
                 "Darknet.forward(x, targets) -> loss.backward() -> all-reduce -> SGD",
                 "Darknet.forward(x, targets) -> loss.backward()" + (" (+ overlapped all-reduce)" if ranks else "") + " -> SGD")
             # this workload's own roofline: the convolution kernels of each pass, timed sequentially on one stream in one
@@ -986,7 +989,9 @@ def main():
             total_flops = sum(v[1] for v in passes.values())
             out["roofline"] = {
                 "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS,
-                "kernel": "conv_igemm_buf_f32 (forward, data gradient) + conv_wgrad_* (weight gradient), fp32 MFMA",
+                "kernel": "conv_igemm_buf_f32 (forward, data gradient) + conv_wgrad_* (weight gradient), fp32 MFMA" if args.dtype == "f32"
+                          else f"me_conv2d_h16 (forward, data gradient; {args.dtype} MFMA) + conv_wgrad_* (weight gradient, fp32 MFMA); "
+                               "frac is against the fp32 peak: the 16-bit passes run above it by construction",
                 "achieved": round(total_flops / (elapsed / args.steps) / 1e12, 2),
                 "frac": round(total_flops / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "note": "achieved / frac: conv FLOPs of the three passes over the WHOLE timed step (affine, pack, loss, SGD "

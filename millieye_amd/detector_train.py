@@ -449,7 +449,11 @@ class _DarknetLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, targets, names, *params):
-        trainer = DetectorTrainer(model)
+        if getattr(model, "compute_dtype", "f32") != "f32":   # 16-bit storage mode: the mixed-precision step (detector_train16.py)
+            from .detector_train16 import DetectorTrainer16
+            trainer = DetectorTrainer16(model)
+        else:
+            trainer = DetectorTrainer(model)
         st = trainer.forward(x)
         loss = 0
         seeds = {}

@@ -1,0 +1,381 @@
+"""Detector forward + backward in a 16-bit storage mode: ``Darknet.forward(x, targets)`` under autograd with
+``model.compute_dtype = "bf16"`` (or ``"f16"``) - the mixed-precision twin of :mod:`millieye_amd.detector_train` (round 5).
+
+Reference: ``module3_our_dataset/yolov3/models.py:181-267`` under autograd (the detector is differentiable in the reference;
+no reference script trains it, ``train.py:170``).  BASELINE north_star names "backbone forward/backward"; the 16-bit storage
+modes were inference only until this round (VERDICT r04 "missing" item 2).
+
+What is stored how:
+
+==========================  ===========================================================================================
+activations (every module)  bfloat16 / IEEE half NHWC, one RNE rounding per stored tensor (``me_conv2d_h16`` epilogue)
+detection maps, YOLO loss   float32 (``y_f32`` output of the three detection convolutions; ``me_yolo_loss_*_f32``)
+activation gradients        16-bit (``me_affine_act_bwd_h16`` and the data-gradient convolutions round once per tensor)
+parameters, their grads     float32 (master weights; ``d gamma`` / ``d beta`` / ``d bias`` summed in double from the 16-bit
+                            tensors, weight gradients by the fp32 matrix kernels on fp32 copies of x and dc - exact products
+                            of 16-bit values, fp32 accumulation, slabs summed in a fixed order)
+matrix work                 forward and data gradient on ``v_mfma_f32_32x32x16_bf16`` / ``_f16`` (16x the fp32 matrix rate),
+                            weight gradient on ``v_mfma_f32_32x32x2_f32``
+==========================  ===========================================================================================
+
+BatchNorm: eval mode only (folded into the convolution, its ``weight`` / ``bias`` still receive gradients, like
+``F.batch_norm(training=False)``); train()-mode BatchNorm stays an fp32 path.  Parity bar (tests/test_gpu_train16.py): the loss
+within 1 % and every parameter gradient at cosine >= 0.99 of the fp32 HIP step's on the same inputs.
+"""
+import os
+
+import torch
+
+from . import hip
+from .detector_train import (_PARITY_IDX, _State, _const_vectors, _conv_flops, _parity_weights, _resolve, _side_stream, _timed,  # noqa: F401
+                             _TIMING)
+
+_HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
+_AUTO16 = {}
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def conv16_auto(x, wgt, scale, shift, ksize, stride, pad, act, residual=None, y_f32=False, x_nchw=False):
+    """``hip.conv2d_h16`` with the (tile, split_k) pair measured the first time a layer shape is seen (the training path has no engine
+    plan whose autotuner would do it).  Candidates: the per-tap tiles with 1 / 2 / 4 K splits and, for 3x3 / stride-1 layers, the
+    patch-resident tiles (their tiled weight copy is made per call: a few microseconds against tens)."""
+    if x_nchw or wgt.shape[3] <= 4:
+        return hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, y_f32=y_f32, x_nchw=x_nchw)
+    key = (tuple(x.shape), x.stride(2), wgt.shape[0], ksize, stride, pad, residual is not None, y_f32, x.dtype)
+    hit = _AUTO16.get(key)
+    if hit is None:
+        cin = wgt.shape[3]
+        cands = [(0, 0)] + [(t, sp) for t in ((1, 2, 3, 4, 11, 12, 13, 14) if cin % 64 == 0 else (1, 2, 3, 4)) for sp in (1, 2, 4)]
+        if ksize == 3 and stride == 1 and pad == 1 and not y_f32 and cin % 32 == 0:
+            cands += [(t, 1) for t in (221, 201, 431, 131, 121, 621)]
+        best = (float("inf"), 0, 0)
+        scratch = None
+        torch.cuda.synchronize()
+        for tile, split in cands:
+            try:
+                wt = hip.tile_weights_h16(wgt) if tile >= 100 else None
+                for _ in range(2):
+                    scratch = hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch,
+                                             y_f32=y_f32, tile=tile, split_k=split, wgt_tiled=wt)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    wt = hip.tile_weights_h16(wgt) if tile >= 100 else None
+                    hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch, y_f32=y_f32,
+                                   tile=tile, split_k=split, wgt_tiled=wt)
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 3
+            except hip.MeError:
+                continue
+            if ms < best[0]:
+                best = (ms, tile, split)
+        hit = _AUTO16[key] = (best[1], best[2])
+    wt = hip.tile_weights_h16(wgt) if hit[0] >= 100 else None
+    return hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, y_f32=y_f32, tile=hit[0], split_k=hit[1],
+                          wgt_tiled=wt)
+
+
+def _add16(a, b, out):
+    c = a.shape[-1]
+    hip.check(hip.lib().me_add_h16(a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), out.data_ptr(), out.stride(-2),
+                                   a.numel() // c, c, hip.HALF_TYPES[a.dtype], hip.stream_ptr()), "me_add_h16")
+
+
+def _copy16(src, dst_ptr, dst_pitch):
+    c = src.shape[-1]
+    hip.check(hip.lib().me_copy_h16(src.data_ptr(), src.stride(-2), dst_ptr, dst_pitch, src.numel() // c, c, hip.stream_ptr()),
+              "me_copy_h16")
+
+
+class _Weights16:
+    """16-bit copies of the packed fp32 weights of every conv block (OHWI, rotated for the data gradient, the parity weights of
+    the stride-2 layers), refreshed by ONE multi-tensor copy per step from the buffers ``DarknetEngine.refresh_train_weights``
+    fills (stable pointers: the destination tensors are allocated once)."""
+
+    def __init__(self):
+        self.dst, self.key = {}, None
+
+    def refresh(self, eng, defs, half, dev):
+        srcs, dsts = [], []
+        for i, d in enumerate(defs):
+            if d["type"] != "convolutional":
+                continue
+            cw = eng._conv_weights(i)
+            for name in ("wgt", "rot", "parity"):
+                src = getattr(cw, name, None)
+                if src is None or src.shape[-1] <= 4 and name == "wgt":
+                    continue
+                slot = (i, name)
+                dst = self.dst.get(slot)
+                if dst is None or dst.shape != src.shape or dst.dtype != half or dst.device != dev:
+                    dst = self.dst[slot] = torch.empty(src.shape, device=dev, dtype=half)
+                srcs.append(src)
+                dsts.append(dst)
+        if srcs:
+            try:
+                torch._foreach_copy_(dsts, srcs)   # fp32 -> 16-bit (RNE), a handful of launches for the whole network
+            except (RuntimeError, AttributeError):   # (a torch without the mixed-dtype multi-tensor copy)
+                for dst, src in zip(dsts, srcs):
+                    dst.copy_(src)
+
+    def get(self, i, name):
+        return self.dst.get((i, name))
+
+
+class DetectorTrainer16:
+    def __init__(self, model):
+        self.m = model
+        self.half = _HALF[model.compute_dtype]
+        w = model.__dict__.get("_weights16")
+        if w is None:
+            w = model.__dict__["_weights16"] = _Weights16()
+        self.w16 = w
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            raise hip.MeError("Darknet training forward needs a 4-D CUDA float32 tensor; there is no CPU fallback")
+        m, lib, half = self.m, hip.lib(), self.half
+        eng = m.engine   # (the fp32 engine owns the packed master weights)
+        x = x.contiguous()
+        defs = m.module_defs
+        outs, raws = [], {}
+        eng.refresh_train_weights(x.device)
+        self.w16.refresh(eng, defs, half, x.device)
+        for i, d in enumerate(defs):
+            t = d["type"]
+            if t == "convolutional":
+                cw = eng._conv_weights(i)
+                cw.refresh(x.device)
+                k, s = int(d["size"]), int(d["stride"])
+                act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
+                src = x if i == 0 else outs[i - 1]
+                seq = m.module_list[i]
+                bn = seq[1] if len(seq) > 1 and isinstance(seq[1], torch.nn.BatchNorm2d) else None
+                if bn is not None and bn.training:
+                    raise NotImplementedError("16-bit detector training: BatchNorm in train() mode is a float32 path "
+                                              "(model.eval() keeps the statistics fixed, as the reference's loops do)")
+                to_yolo = i + 1 < len(defs) and defs[i + 1]["type"] == "yolo"
+                co, ci = cw.wgt.shape[0], cw.wgt.shape[3]
+                if (ci > 4 and ci % 32) or (not to_yolo and co % 32):
+                    raise NotImplementedError(f"16-bit detector training: conv {i} has {ci} -> {co} channels; the 16-bit matrix kernels "
+                                              "want multiples of 32 (Darknet-53 has them; the tiny cfgs' 16-channel stem does not - "
+                                              "train those in float32)")
+                if i == 0 or cw.wgt.shape[3] <= 4:   # stem: fp32 frames and fp32 weights holding 16-bit values
+                    wq = cw.wgt.to(half).float()
+                    with _timed("fwd", _conv_flops(src, cw.wgt, s, i == 0)):
+                        y = hip.conv2d_h16(src, wq, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0), half=half)
+                else:
+                    with _timed("fwd", _conv_flops(src, cw.wgt, s, False)):
+                        y = conv16_auto(src, self.w16.get(i, "wgt"), cw.scale, cw.shift, k, s, (k - 1) // 2, act, y_f32=to_yolo)
+            elif t == "maxpool":
+                raise NotImplementedError("16-bit detector training: [maxpool] layers are a float32 path (no cfg with max-pooling "
+                                          "has 32-multiple channels throughout)")
+            elif t == "upsample":
+                y = hip.upsample_h16(outs[i - 1], int(d["stride"]))
+            elif t == "shortcut":
+                a, b = outs[i - 1], outs[_resolve(d["from"], i)]
+                y = torch.empty_like(a)
+                _add16(a, b, y)
+            elif t == "route":
+                parts = [outs[_resolve(v, i)] for v in d["layers"].split(",")]
+                if len(parts) == 1:
+                    y = parts[0]
+                else:
+                    ct = sum(p.shape[-1] for p in parts)
+                    y = torch.empty(parts[0].shape[:3] + (ct,), device=x.device, dtype=half)
+                    off = 0
+                    for p in parts:
+                        _copy16(p, y.data_ptr() + 2 * off, ct)
+                        off += p.shape[-1]
+            elif t == "yolo":
+                raws[i] = outs[i - 1]
+                y = None
+            else:
+                raise ValueError(f"unsupported cfg block [{t}] at module {i}")
+            outs.append(y)
+        st = _State()
+        st.x, st.outs, st.raws, st.bn_state = x, outs, raws, {}
+        return st
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, st, draws, reducer=None):
+        """``draws``: {yolo module index: d loss / d raw map, float32}.  Returns {parameter name: float32 gradient}."""
+        m, lib, half = self.m, hip.lib(), self.half
+        eng = m.engine
+        defs, outs, x = m.module_defs, st.outs, st.x
+        dev = x.device
+        L = len(defs)
+        dout = [None] * L
+        grads = {}
+        stream = hip.stream_ptr
+        ht = hip.HALF_TYPES[half]
+
+        def contribute(i, g, fresh):
+            """``g``: a 16-bit gradient w.r.t. module i's output (NHWC, dense or a channel slice); ``fresh``: nobody else holds it."""
+            if g.dtype != half:
+                g, fresh = g.to(half), True
+            cur = dout[i]
+            if cur is None:
+                if g.is_contiguous():
+                    dout[i] = (g, bool(fresh))
+                else:  # a channel slice of a wider gradient ([route]): densify once
+                    dense = torch.empty(g.shape, device=dev, dtype=half)
+                    _copy16(g, dense.data_ptr(), g.shape[-1])
+                    dout[i] = (dense, True)
+                return
+            t_cur, owned = cur
+            if owned:
+                _add16(t_cur, g, t_cur)
+            else:
+                total = torch.empty_like(t_cur)
+                _add16(t_cur, g, total)
+                dout[i] = (total, True)
+
+        x_nhwc = None
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0" and _TIMING[0] is None else None
+        for i in reversed(range(L)):
+            d = defs[i]
+            t = d["type"]
+            if t == "yolo":
+                dout[i - 1] = (draws[i], True)   # float32: the detection convolution's output is float32
+                continue
+            if dout[i] is None:
+                continue
+            dy, dy_owned = dout[i]
+            if t == "convolutional":
+                seq = m.module_list[i]
+                bn = seq[1] if len(seq) > 1 and isinstance(seq[1], torch.nn.BatchNorm2d) else None
+                cw = eng._conv_weights(i)
+                k, s = int(d["size"]), int(d["stride"])
+                pad = (k - 1) // 2
+                act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
+                y = outs[i]
+                n, ho, wo, cout = y.shape
+                rows = n * ho * wo
+                dshift = torch.empty(cout, device=dev)
+                dgamma = torch.empty(cout, device=dev) if bn is not None else None
+                gam = bn.weight.detach() if bn is not None else None
+                bet = bn.bias.detach() if bn is not None else None
+                f32_out = y.dtype == torch.float32   # a detection convolution: float32 map, float32 gradient from the loss
+                if f32_out:
+                    dc32 = dy if dy_owned else torch.empty_like(y)
+                    ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
+                    hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
+                                                        cw.scale.data_ptr() if bn is not None else None, _ptr(gam), _ptr(bet), act,
+                                                        dc32.data_ptr(), cout, dshift.data_ptr(), _ptr(dgamma), ws.data_ptr(),
+                                                        stream()), "me_affine_act_bwd_f32")
+                    dc = None
+                else:
+                    if dy.dtype != half or not dy.is_contiguous():
+                        dy = dy.to(half).contiguous()
+                    dc = dy if dy_owned else torch.empty_like(y)
+                    ws = torch.empty(lib.me_affine_bwd_h16_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
+                    hip.check(lib.me_affine_act_bwd_h16(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
+                                                        cw.scale.data_ptr() if bn is not None else None, _ptr(gam), _ptr(bet), act,
+                                                        dc.data_ptr(), cout, dshift.data_ptr(), _ptr(dgamma), ws.data_ptr(), ht,
+                                                        stream()), "me_affine_act_bwd_h16")
+                    dc32 = None
+                if bn is not None:
+                    grads[f"module_list.{i}.batch_norm_{i}.weight"] = dgamma
+                    grads[f"module_list.{i}.batch_norm_{i}.bias"] = dshift
+                else:
+                    grads[f"module_list.{i}.conv_{i}.bias"] = dshift
+                if reducer is not None:
+                    if bn is not None:
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.weight", dgamma, main)
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.bias", dshift, main)
+                    else:
+                        reducer.push(f"module_list.{i}.conv_{i}.bias", dshift, main)
+                # weight gradient: the fp32 matrix kernels on fp32 copies (products of 16-bit values are exact in fp32)
+                if i == 0:
+                    if x_nhwc is None:
+                        x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+                    xin = x_nhwc
+                else:
+                    xin = outs[i - 1]
+                _, h, w, cin = xin.shape
+
+                def wgrad():
+                    x32 = xin if xin.dtype == torch.float32 else xin.float()
+                    d32 = dc32 if dc32 is not None else dc.float()
+                    return hip.conv_wgrad(x32, d32, k, s, pad, oihw=True)
+                if side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        grads[f"module_list.{i}.conv_{i}.weight"] = wgrad()
+                    (dc32 if dc32 is not None else dc).record_stream(side)
+                    xin.record_stream(side)
+                else:
+                    with _timed("wgrad", 2.0 * rows * cout * k * k * cin):
+                        grads[f"module_list.{i}.conv_{i}.weight"] = wgrad()
+                if reducer is not None:
+                    reducer.push(f"module_list.{i}.conv_{i}.weight", grads[f"module_list.{i}.conv_{i}.weight"],
+                                 side if side is not None else main)
+                dout[i] = None
+                if i == 0:
+                    continue
+                # data gradient
+                tm = _timed("dgrad", 2.0 * rows * cout * k * k * cin).__enter__()
+                if f32_out or cout % 32 != 0:
+                    if k != 1 or s != 1:
+                        raise NotImplementedError(f"conv {i}: 16-bit data gradient for cout={cout} needs k=1 (detection convolutions)")
+                    d32 = dc32 if dc32 is not None else dc.float()
+                    dx = torch.empty((n, h, w, cin), device=dev, dtype=torch.float32)
+                    hip.check(lib.me_gemm_f32(0, 0, rows, cin, cout, 1.0, d32.data_ptr(), cout, cw.wgt.data_ptr(), cin, 0.0,
+                                              dx.data_ptr(), cin, stream()), "me_gemm_f32")
+                    contribute(i - 1, dx.to(half), True)
+                else:
+                    ones, zeros = _const_vectors(cin, dev)
+                    parity = s == 2 and k == 3 and pad == 1 and h == 2 * ho and w == 2 * wo and cin % 8 == 0
+                    prev = dout[i - 1]
+                    res = prev[0] if (prev is not None and prev[0].is_contiguous() and prev[0].dtype == half) else None
+                    if s == 1:
+                        rot = self.w16.get(i, "rot")
+                        if rot is None:
+                            rot = cw.wgt.flip(1, 2).permute(3, 1, 2, 0).contiguous().to(half)
+                        dx = conv16_auto(dc, rot, ones, zeros, k, 1, k - 1 - pad, hip.ACT_LINEAR, residual=res)
+                        if res is not None:
+                            dout[i - 1] = (dx, True)
+                        else:
+                            contribute(i - 1, dx, True)
+                    elif parity:
+                        pw = self.w16.get(i, "parity")
+                        if pw is None or cw.parity_stamp != cw._stamp:
+                            pw = _parity_weights(cw.wgt).to(half)
+                        o4, z4 = _const_vectors(4 * cin, dev)
+                        dx4 = conv16_auto(dc, pw, o4, z4, 2, 1, 1, hip.ACT_LINEAR)
+                        dx = dx4[:, 1:, 1:, :].reshape(n, ho, wo, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(n, h, w, cin)
+                        contribute(i - 1, dx.contiguous(), True)
+                    else:
+                        raise NotImplementedError(f"conv {i}: 16-bit data gradient of a {k}x{k} / stride {s} layer on a {h}x{w} map")
+                tm.__exit__()
+                continue
+            elif t == "shortcut":
+                contribute(i - 1, dy, False)
+                contribute(_resolve(d["from"], i), dy, False)
+            elif t == "route":
+                srcs = [_resolve(v, i) for v in d["layers"].split(",")]
+                if len(srcs) == 1:
+                    contribute(srcs[0], dy, dy_owned)
+                else:
+                    off = 0
+                    for sidx in srcs:
+                        c = outs[sidx].shape[-1]
+                        contribute(sidx, dy[..., off:off + c], False)
+                        off += c
+            elif t == "upsample":
+                if int(d["stride"]) != 2:
+                    raise NotImplementedError("upsample backward: stride 2 only")
+                n, h, w, c = outs[i - 1].shape
+                g = dy.float().view(n, h, 2, w, 2, c).sum(dim=(2, 4)).to(half)   # two small layers: fp32 sum of the 2x2 block, one rounding
+                contribute(i - 1, g, True)
+            dout[i] = None
+        if side is not None:
+            main.wait_stream(side)
+        return grads

@@ -363,7 +363,8 @@ class Darknet(nn.Module):
                 layer.grid_size, layer.stride = raw.shape[1], x.shape[2] / raw.shape[1]
             tap = self.engine.tap_module
             if tap is not None and tap < len(st.outs) and st.outs[tap] is not None:
-                self.featuremap = hip.nhwc_to_nchw(st.outs[tap])
+                tap_t = st.outs[tap]
+                self.featuremap = hip.nhwc_to_nchw(tap_t if tap_t.dtype == torch.float32 else tap_t.float())
         if not hasattr(self, "featuremap"):
             raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         return loss, self.featuremap, yolo_outputs

@@ -1,0 +1,142 @@
+"""-m gpu: the detector training step in the 16-bit storage modes (millieye_amd/detector_train16.py, csrc/train_h16.hip):
+16-bit activations and activation gradients, fp32 master weights / weight gradients / per-channel sums.  Bars: the
+activation-gradient kernel against the fp32 kernel on the same 16-bit inputs (one storage ulp; sums 1e-4), and the whole step
+against the fp32 HIP step - which the other suites pin to the oracle and the reference - loss within 1 %, every parameter
+gradient at cosine >= 0.99."""
+import pytest
+import torch
+
+from millieye_amd import synth
+from tests import parity_helpers as ph
+
+pytestmark = pytest.mark.gpu
+HALVES = {"bf16": torch.bfloat16, "f16": torch.float16}
+ULP = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}   # half a storage step, relative
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("rows,c,act,bn", [(2 * 52 * 52, 128, 1, True), (3 * 13 * 13, 1024, 1, True), (1000, 64, 0, False), (77, 32, 1, True)])
+def test_affine_act_bwd_h16_vs_f32_kernel(hip_lib, half, rows, c, act, bn):
+    from millieye_amd import hip
+    dt = HALVES[half]
+    dev = torch.device("cuda")
+    lib = hip.lib()
+    y16 = torch.from_numpy(synth.uniform(f"a16/y{rows}", (rows, c), -2, 2)).to(dev).to(dt)
+    g16 = torch.from_numpy(synth.uniform(f"a16/g{rows}", (rows, c), -1, 1)).to(dev).to(dt)
+    scale = torch.from_numpy(synth.uniform("a16/s", (c,), 0.5, 1.5)).to(dev)
+    gam = torch.from_numpy(synth.uniform("a16/ga", (c,), 0.5, 1.5)).to(dev) if bn else None
+    bet = torch.from_numpy(synth.uniform("a16/be", (c,), -0.5, 0.5)).to(dev) if bn else None
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    # fp32 kernel on the float copies of the SAME 16-bit values
+    y32, g32 = y16.float(), g16.float()
+    dc32, ds32 = torch.empty_like(y32), torch.empty(c, device=dev)
+    dg32 = torch.empty(c, device=dev) if bn else None
+    ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, c), dtype=torch.uint8, device=dev)
+    hip.check(lib.me_affine_act_bwd_f32(y32.data_ptr(), c, g32.data_ptr(), c, rows, c, scale.data_ptr() if bn else None, p(gam), p(bet),
+                                        act, dc32.data_ptr(), c, ds32.data_ptr(), p(dg32), ws.data_ptr(), hip.stream_ptr()), "f32")
+    dc16 = torch.full((rows, c), 7.0, device=dev, dtype=dt)
+    ds16 = torch.empty(c, device=dev)
+    dg16 = torch.empty(c, device=dev) if bn else None
+    ws16 = torch.empty(lib.me_affine_bwd_h16_workspace_bytes(rows, c), dtype=torch.uint8, device=dev)
+    hip.check(lib.me_affine_act_bwd_h16(y16.data_ptr(), c, g16.data_ptr(), c, rows, c, scale.data_ptr() if bn else None, p(gam), p(bet),
+                                        act, dc16.data_ptr(), c, ds16.data_ptr(), p(dg16), ws16.data_ptr(), hip.HALF_TYPES[dt],
+                                        hip.stream_ptr()), "h16")
+    torch.cuda.synchronize()
+    # dc: the fp32 result rounded once to the storage type
+    assert torch.equal(dc16, dc32.to(dt)), f"dc differs from the rounded fp32 result on {int((dc16 != dc32.to(dt)).sum())} elements"
+    torch.testing.assert_close(ds16, ds32, rtol=1e-4, atol=1e-4 * float(ds32.abs().max()))
+    if bn:
+        torch.testing.assert_close(dg16, dg32, rtol=1e-4, atol=1e-4 * float(dg32.abs().max()))
+    # in place (dc aliases dy): same result
+    g_inplace = g16.clone()
+    hip.check(lib.me_affine_act_bwd_h16(y16.data_ptr(), c, g_inplace.data_ptr(), c, rows, c, scale.data_ptr() if bn else None, p(gam),
+                                        p(bet), act, g_inplace.data_ptr(), c, ds16.data_ptr(), p(dg16), ws16.data_ptr(),
+                                        hip.HALF_TYPES[dt], hip.stream_ptr()), "h16 in place")
+    assert torch.equal(g_inplace, dc16)
+    with pytest.raises(hip.MeError):   # channels % 8
+        lib_rc = lib.me_affine_act_bwd_h16(y16.data_ptr(), c, g16.data_ptr(), c, rows, c - 4, None, None, None, act, dc16.data_ptr(), c,
+                                           ds16.data_ptr(), None, ws16.data_ptr(), hip.HALF_TYPES[dt], hip.stream_ptr())
+        hip.check(lib_rc, "bad channels")
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cfg,n,s", [("yolov3", 2, 128)])
+def test_detector_step_16bit_vs_fp32_hip_step(hip_lib, dtype, cfg, n, s):
+    """The mixed-precision step against the fp32 HIP step on the same inputs: Darknet-53 at 128 px (stride-2 parity data
+    gradients, 23 shortcuts, three scales, upsample + route concats; at 64 px the deepest maps are 2 x 2 positions and a weight
+    gradient is the sum of eight products - measured cosine 0.988 on one 13-stage 1x1 filter there)."""
+    name = f"t16/{cfg}"
+    targets = torch.tensor([[0, 0, 0.30, 0.40, 0.20, 0.30], [1, 0, 0.70, 0.60, 0.50, 0.40], [1, 0, 0.52, 0.48, 0.10, 0.15]])
+    if cfg == "yolov3":
+        targets[:, 1] = torch.tensor([3.0, 17.0, 60.0])
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s))).cuda()
+    ref = ph.make_darknet(cfg, tag=name).cuda().eval()
+    loss32, fm32, yo32 = ref(x, targets)
+    loss32.backward()
+    model = ph.make_darknet(cfg, tag=name).cuda().eval()
+    model.compute_dtype = dtype
+    loss16, fm16, yo16 = model(x, targets)
+    assert loss16.requires_grad and fm16.shape == fm32.shape and yo16.shape == yo32.shape and fm16.dtype == torch.float32
+    rel = abs(float(loss16.detach()) - float(loss32.detach())) / abs(float(loss32.detach()))
+    (2.0 * loss16).backward()   # an upstream gradient of 2 must scale every gradient
+    tol_loss, tol_cos = (0.01, 0.99) if dtype == "bf16" else (0.002, 0.999)
+    assert rel <= tol_loss, f"loss {float(loss16):.5f} vs fp32 {float(loss32):.5f}: {rel:.3%}"
+    worst = (1.0, None)
+    seen = 0
+    bad = []
+    for (k, p16), (_k, p32) in zip(model.named_parameters(), ref.named_parameters()):
+        assert p16.grad is not None and p16.grad.dtype == torch.float32 and p16.grad.shape == p32.grad.shape, k
+        assert bool(torch.isfinite(p16.grad).all()), k
+        g16, g32 = p16.grad / 2.0, p32.grad
+        if float(g32.norm()) < 1e-12:
+            continue
+        c = _cos(g16, g32)
+        nr = float(g16.norm() / g32.norm())
+        if c < worst[0]:
+            worst = (c, k)
+        if not (c >= tol_cos and 0.9 <= nr <= 1.1):
+            bad.append(f"{k}: cosine {c:.4f}, norm ratio {nr:.3f}")
+        seen += 1
+    print(f"[{cfg} {dtype}] loss rel {rel:.2e}; worst gradient cosine {worst[0]:.5f} ({worst[1]}); {seen} tensors")
+    assert not bad, "; ".join(bad[:12]) + f" ({len(bad)} of {seen})"
+    assert seen >= 30
+    # deterministic
+    model.zero_grad()
+    l1, _, _ = model(x, targets)
+    l1.backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    l2, _, _ = model(x, targets)
+    l2.backward()
+    assert float(l1.detach()) == float(l2.detach()) and all(torch.equal(g1[k], p.grad) for k, p in model.named_parameters())
+    # an optimizer step on the fp32 master weights lowers the (16-bit forward's) loss; the next forward sees the new weights
+    torch.optim.SGD(model.parameters(), lr=1e-4).step()
+    model.zero_grad()
+    loss_b, _, _ = model(x, targets)
+    assert float(loss_b.detach()) < float(l2.detach())
+
+
+def test_16bit_training_refuses_what_it_cannot_do(hip_lib):
+    """The tiny cfgs (16-channel stem, max-pooling) stay float32 training paths: refused loudly, not computed wrongly."""
+    model = ph.make_darknet("yolov3-tiny-12", tag="t16/tiny").cuda().eval()
+    model.compute_dtype = "bf16"
+    x = torch.from_numpy(synth.uniform("t16/tiny/x", (2, 3, 96, 96))).cuda()
+    with pytest.raises(NotImplementedError):
+        model(x, torch.tensor([[0, 0, 0.5, 0.5, 0.2, 0.2]]))
+    model.compute_dtype = "f32"
+    loss, _, _ = model(x, torch.tensor([[0, 0, 0.5, 0.5, 0.2, 0.2]]))   # (the float32 path still trains it)
+    loss.backward()
+    assert model.module_list[0][0].weight.grad is not None
+
+
+def test_16bit_training_refuses_train_mode_batchnorm(hip_lib):
+    model = ph.make_darknet("yolov3", tag="t16/bn").cuda().train()
+    model.compute_dtype = "bf16"
+    x = torch.from_numpy(synth.uniform("t16/bn/x", (1, 3, 64, 64))).cuda()
+    with pytest.raises(NotImplementedError):
+        model(x, torch.tensor([[0, 0, 0.5, 0.5, 0.2, 0.2]]))
