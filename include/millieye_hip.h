@@ -408,6 +408,14 @@ int64_t me_affine_bwd_h16_workspace_bytes(int32_t rows, int32_t channels);
 int me_affine_act_bwd_h16(const void* y, int64_t ldy, const void* dy, int64_t lddy, int32_t rows, int32_t channels,
                           const float* scale, const float* gamma, const float* beta, int32_t act, void* dc, int64_t lddc,
                           float* dshift, float* dgamma, void* workspace, int32_t half_type, void* stream);
+/* me_conv_wgrad_h16 (ABI 10): dW of y = conv(x, W) from 16-BIT x [n,h,w,cin] and dy [n,ho,wo,cout] (NHWC, pitched; channels and
+ * pitches % 8 == 0, 16-byte aligned) on v_mfma_f32_32x32x16_bf16 / _f16 with fp32 accumulation; dw is FLOAT32, [cout][cin][k][k]
+ * (oihw != 0: the parameter's layout) or [cout][k][k][cin].  Slices of the pixel reduction go through `workspace`
+ * (me_conv_wgrad_workspace_bytes) and are added in a fixed order.  The weight-gradient half of the mixed-precision detector
+ * backward (autograd semantics of yolov3/models.py:22-41,181-267). */
+int me_conv_wgrad_h16(const void* x, int64_t x_pitch, const void* dy, int64_t dy_pitch, float* dw, int32_t n, int32_t h, int32_t w,
+                      int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad, void* workspace, int64_t workspace_bytes,
+                      int32_t oihw, int32_t half_type, void* stream);
 int me_upsample2_bwd_f32(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n, int32_t h, int32_t w,
                          int32_t c, void* stream);
 int me_maxpool_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n,

@@ -679,6 +679,157 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(const float* __res
     }
 }
 
+// Round 5: the per-tap weight gradient on 16-BIT operands (the mixed-precision detector step, millieye_amd/detector_train16.py):
+// x and dc are bfloat16 / IEEE half NHWC, the products go through v_mfma_f32_32x32x16_bf16 / _f16 (16x the fp32 matrix rate), the
+// accumulators and the slabs are fp32 and the slab sums are train.hip's fixed-order reductions - the gradient is float32.
+// A stage is 32 pixels (two MFMA k-steps): 16-byte loads (8 channels), LDS image [pixel][channel] as loaded.  The reduction
+// dimension (pixels) is the STRIDED one of both operands, so an MFMA fragment (8 consecutive pixels of one channel) is eight
+// 2-byte LDS reads packed in registers - the LDS pipe, not the matrix pipe, bounds the kernel (~1/4 - 1/2 of the 16-bit peak,
+// still an order of magnitude over the fp32 kernels); a transposing read (ds_read_b64_tr_b16) is the next step if it matters.
+template <int F16>
+struct WgH16;
+template <>
+struct WgH16<0> {
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ wg_f32x16 mfma(v8 a, v8 b, wg_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct WgH16<1> {
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ wg_f32x16 mfma(v8 a, v8 b, wg_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+template <int TCO, int TCI, int F16>
+__global__ __launch_bounds__(256) void conv_wgrad_tile_h16_kernel(const unsigned short* __restrict__ X, long long xp,
+                                                                  const unsigned short* __restrict__ DY, long long dyp, float* OUT,
+                                                                  int n, int h, int w, int cin, int cout, int ks, int stride, int pad,
+                                                                  int ho, int wo, int splits, int px_per_split) {
+  using v8 = typename WgH16<F16>::v8;
+  constexpr int SP = 32;                          // pixels per stage
+  constexpr int MT = TCO / 64, NT = TCI / 64;     // 32x32 blocks per wave (2 x 2 waves)
+  constexpr int YL = TCO / 64, XL = TCI / 64;     // 16-byte loads per lane and stage: 32 px x T/8 octets over 256 lanes
+  constexpr int YO = TCO / 8, XO = TCI / 8;       // octets per pixel row
+  __shared__ __attribute__((aligned(16))) unsigned short Ys[2][SP][TCO];
+  __shared__ __attribute__((aligned(16))) unsigned short Xs[2][SP][TCI];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tap = blockIdx.z / splits, split = blockIdx.z - tap * splits;
+  const int ky = tap / ks, kx = tap - ky * ks;
+  const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
+  const int P = n * ho * wo;
+  const int p_begin = split * px_per_split;
+  const int p_end = (p_begin + px_per_split < P) ? p_begin + px_per_split : P;
+  const int hw = ho * wo;
+
+  // loader lanes: load v of a lane is pixel row (tid + 256 v) / octets-per-row, channel octet (tid + 256 v) % octets-per-row
+  int x_px[XL], x_oc[XL], f_img[XL], f_oy[XL], f_ox[XL];
+#pragma unroll
+  for (int v = 0; v < XL; ++v) {
+    const int flat = tid + 256 * v;
+    x_px[v] = flat / XO;
+    x_oc[v] = (flat - x_px[v] * XO) * 8;
+    const int p = p_begin + x_px[v];
+    f_img[v] = p / hw;
+    const int rem = p - f_img[v] * hw;
+    f_oy[v] = rem / wo;
+    f_ox[v] = rem - f_oy[v] * wo;
+  }
+  uint4 ry[YL], rx[XL];
+  auto fetch = [&](int p0) {
+#pragma unroll
+    for (int v = 0; v < YL; ++v) {
+      const int flat = tid + 256 * v;
+      const int px = flat / YO, oc = (flat - px * YO) * 8;
+      const int p = p0 + px;
+      ry[v] = make_uint4(0u, 0u, 0u, 0u);
+      if (p < p_end && co0 + oc < cout) ry[v] = *reinterpret_cast<const uint4*>(DY + (long long)p * dyp + co0 + oc);
+    }
+#pragma unroll
+    for (int v = 0; v < XL; ++v) {
+      const int p = p0 + x_px[v];
+      rx[v] = make_uint4(0u, 0u, 0u, 0u);
+      if (p < p_end) {
+        const int iy = f_oy[v] * stride - pad + ky, ix = f_ox[v] * stride - pad + kx;
+        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w && ci0 + x_oc[v] < cin)
+          rx[v] = *reinterpret_cast<const uint4*>(X + ((long long)(f_img[v] * h + iy) * w + ix) * xp + ci0 + x_oc[v]);
+      }
+      f_ox[v] += SP;   // the next stage's pixel
+      while (f_ox[v] >= wo) {
+        f_ox[v] -= wo;
+        if (++f_oy[v] == ho) {
+          f_oy[v] = 0;
+          ++f_img[v];
+        }
+      }
+    }
+  };
+
+  wg_f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int i32 = lane & 31, kk = lane >> 5;
+  const int a_base = wr * (TCO / 2) + i32, b_base = wc * (TCI / 2) + i32;
+
+  // (a fragment = pixels 8 kk .. 8 kk + 7 of a 16-pixel k-step of one channel: eight 16-bit LDS reads, packed in pairs)
+  fetch(p_begin);
+  int buf = 0;
+  for (int p0 = p_begin; p0 < p_end; p0 += SP) {
+#pragma unroll
+    for (int v = 0; v < YL; ++v) {
+      const int flat = tid + 256 * v;
+      const int px = flat / YO, oc = (flat - px * YO) * 8;
+      *reinterpret_cast<uint4*>(&Ys[buf][px][oc]) = ry[v];
+    }
+#pragma unroll
+    for (int v = 0; v < XL; ++v) *reinterpret_cast<uint4*>(&Xs[buf][x_px[v]][x_oc[v]]) = rx[v];
+    __syncthreads();
+    if (p0 + SP < p_end) fetch(p0 + SP);  // in flight while the matrix pipe works
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v8 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        unsigned wd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          wd[q] = (unsigned)Ys[buf][16 * s + 8 * kk + 2 * q][a_base + 32 * i] |
+                  ((unsigned)Ys[buf][16 * s + 8 * kk + 2 * q + 1][a_base + 32 * i] << 16);
+        a[i] = __builtin_bit_cast(v8, make_uint4(wd[0], wd[1], wd[2], wd[3]));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        unsigned wd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          wd[q] = (unsigned)Xs[buf][16 * s + 8 * kk + 2 * q][b_base + 32 * j] |
+                  ((unsigned)Xs[buf][16 * s + 8 * kk + 2 * q + 1][b_base + 32 * j] << 16);
+        b[j] = __builtin_bit_cast(v8, make_uint4(wd[0], wd[1], wd[2], wd[3]));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = WgH16<F16>::mfma(a[i], b[j], acc[i][j]);
+    }
+    buf ^= 1;
+  }
+  float* out = OUT + (long long)split * cout * ks * ks * cin;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ci = ci0 + wc * (TCI / 2) + 32 * j + i32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wr * (TCO / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kk;
+        if (co < cout && ci < cin) out[((long long)co * ks * ks + tap) * cin + ci] = acc[i][j][e];
+      }
+    }
+}
+
 // kk_cin > 0: write the sum in the parameter's own OIHW layout (i indexes the OHWI slabs: co, tap, ci) - the autograd result of
 // the detector's training step without a permute + contiguous launch per layer
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* DW, long long count,
@@ -1787,6 +1938,62 @@ int me_conv_wgrad_mfma_oihw_f32(const float* x, int64_t x_pitch, const float* dy
                                 int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
   return wgrad_mfma(x, x_pitch, dy, dy_pitch, dw, n, h, w, cin, cout, ksize, stride, pad, workspace, workspace_bytes, stream, 1);
+}
+
+// 16-bit operands -> float32 gradient in the parameter's own OIHW layout (or OHWI): conv_wgrad_tile_h16_kernel + the slab sums above.
+int me_conv_wgrad_h16(const void* x_, int64_t x_pitch, const void* dy_, int64_t dy_pitch, float* dw, int32_t n, int32_t h, int32_t w,
+                      int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t pad, void* workspace, int64_t workspace_bytes,
+                      int32_t oihw, int32_t half_type, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const unsigned short* x = reinterpret_cast<const unsigned short*>(x_);
+  const unsigned short* dy = reinterpret_cast<const unsigned short*>(dy_);
+  ME_REQUIRE(x && dy && dw, ME_E_NULLPTR, "me_conv_wgrad_h16: null pointer");
+  ME_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0,
+             ME_E_BADARG, "me_conv_wgrad_h16: bad dimensions");
+  ME_REQUIRE(half_type == 0 || half_type == 1, ME_E_BADARG, "me_conv_wgrad_h16: half_type must be 0 (bf16) or 1 (f16)");
+  ME_REQUIRE(cin % 8 == 0 && cout % 8 == 0 && x_pitch % 8 == 0 && dy_pitch % 8 == 0 && me::aligned16(x) && me::aligned16(dy),
+             ME_E_ALIGN, "me_conv_wgrad_h16: channels and pitches must be multiples of 8 and the tensors 16-byte aligned");
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+  const long long P = (long long)n * ho * wo;
+  ME_REQUIRE(P < (1ll << 31), ME_E_TOOBIG, "me_conv_wgrad_h16: too many output pixels");
+  const long long count = (long long)cout * ksize * ksize * cin;
+  int splits = wgrad_splits(P, cin, cout, ksize);
+  if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * count * (int64_t)sizeof(float))) splits = 1;
+  ME_REQUIRE(!oihw || ksize == 1 || (workspace && workspace_bytes >= count * (int64_t)sizeof(float)), ME_E_BADARG,
+             "me_conv_wgrad_h16: the OIHW form needs a workspace of at least one slab (%lld bytes)", count * 4ll);
+  int per = (int)((P + splits - 1) / splits);
+  per = (per + 31) & ~31;   // whole 32-pixel stages
+  ME_REQUIRE((long long)ksize * ksize * splits < 65536, ME_E_TOOBIG, "me_conv_wgrad_h16: grid too large");
+  const bool via_ws = splits > 1 || (oihw && ksize > 1);
+  float* out = via_ws ? reinterpret_cast<float*>(workspace) : dw;
+  const bool big = cin >= 128 && cout >= 128 && cin % 128 == 0 && cout % 128 == 0;   // 128 x 128: half the LDS reads per product
+  const int tco = big ? 128 : 64, tci = big ? 128 : 64;
+  const dim3 grid((cin + tci - 1) / tci, (cout + tco - 1) / tco, ksize * ksize * splits);
+#define ME_WG16(A, B, F)                                                                                                   \
+  hipLaunchKernelGGL((conv_wgrad_tile_h16_kernel<A, B, F>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,          \
+                     (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per)
+  if (big) {
+    if (half_type) ME_WG16(128, 128, 1);
+    else ME_WG16(128, 128, 0);
+  } else {
+    if (half_type) ME_WG16(64, 64, 1);
+    else ME_WG16(64, 64, 0);
+  }
+#undef ME_WG16
+  int rc = me::check_launch("conv_wgrad_tile_h16_kernel");
+  if (rc || !via_ws) return rc;
+  const float* slabs = reinterpret_cast<const float*>(workspace);
+  if (oihw && ksize > 1 && cout < 65536) {
+    const int kk = ksize * ksize;
+    hipLaunchKernelGGL(conv_wgrad_reduce_oihw_kernel, dim3((cin + 63) / 64, cout), dim3(256), 64 * (kk | 1) * sizeof(float),
+                       stream, slabs, dw, count, splits, kk, cin, ((cin & 3) == 0 && me::aligned16(workspace)) ? 1 : 0);
+  } else if (!(oihw && ksize > 1) && count % 4 == 0 && me::aligned16(dw) && me::aligned16(workspace)) {
+    hipLaunchKernelGGL(conv_wgrad_reduce_v4_kernel, dim3(grid1d(count / 4)), dim3(256), 0, stream, slabs, dw, count / 4, splits);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid1d(count)), dim3(256), 0, stream, slabs, dw, count, splits,
+                       (oihw && ksize > 1) ? ksize * ksize : 0, cin);
+  }
+  return me::check_launch("conv_wgrad_reduce_kernel");
 }
 
 static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w, int32_t c,

@@ -12,10 +12,10 @@ activations (every module)  bfloat16 / IEEE half NHWC, one RNE rounding per stor
 detection maps, YOLO loss   float32 (``y_f32`` output of the three detection convolutions; ``me_yolo_loss_*_f32``)
 activation gradients        16-bit (``me_affine_act_bwd_h16`` and the data-gradient convolutions round once per tensor)
 parameters, their grads     float32 (master weights; ``d gamma`` / ``d beta`` / ``d bias`` summed in double from the 16-bit
-                            tensors, weight gradients by the fp32 matrix kernels on fp32 copies of x and dc - exact products
-                            of 16-bit values, fp32 accumulation, slabs summed in a fixed order)
-matrix work                 forward and data gradient on ``v_mfma_f32_32x32x16_bf16`` / ``_f16`` (16x the fp32 matrix rate),
-                            weight gradient on ``v_mfma_f32_32x32x2_f32``
+                            tensors; weight gradients = exact products of 16-bit values, fp32 accumulation, fp32 slabs
+                            summed in a fixed order: ``me_conv_wgrad_h16``)
+matrix work                 forward, data gradient and weight gradient on ``v_mfma_f32_32x32x16_bf16`` / ``_f16`` (16x the
+                            fp32 matrix rate); the stem's and the detection convolutions' weight gradients on the fp32 pipe
 ==========================  ===========================================================================================
 
 BatchNorm: eval mode only (folded into the convolution, its ``weight`` / ``bias`` still receive gradients, like
@@ -32,6 +32,7 @@ from .detector_train import (_PARITY_IDX, _State, _const_vectors, _conv_flops, _
 
 _HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 _AUTO16 = {}
+_WGRAD16 = os.environ.get("MILLIEYE_WGRAD16", "1") != "0"   # (A/B: 0 = weight gradients by the fp32 kernels on fp32 copies)
 
 
 def _ptr(t):
@@ -302,6 +303,9 @@ class DetectorTrainer16:
                 _, h, w, cin = xin.shape
 
                 def wgrad():
+                    if _WGRAD16 and dc is not None and xin.dtype == half and cin % 8 == 0 and cout % 8 == 0:
+                        return hip.conv_wgrad_h16(xin, dc, k, s, pad, oihw=True)   # 16-bit operands, fp32 accumulators and slabs
+                    # stem (fp32 frames) and the detection convolutions (fp32 gradient, 255 / 51 channels): the fp32 kernels
                     x32 = xin if xin.dtype == torch.float32 else xin.float()
                     d32 = dc32 if dc32 is not None else dc.float()
                     return hip.conv_wgrad(x32, d32, k, s, pad, oihw=True)

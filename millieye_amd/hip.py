@@ -204,6 +204,8 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     "me_affine_bwd_h16_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "me_conv_wgrad_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 8
+                          + [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "me_affine_act_bwd_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p]),
@@ -768,6 +770,21 @@ def roi_align(map_nhwc, rois, pooled=7, spatial_scale=1.0 / 16):
 def ps_roi_align(map_nhwc, rois, pooled=7, spatial_scale=1.0 / 16):
     """torchvision.ops.ps_roi_align(sampling_ratio=-1) on an NHWC map -> [K,C/49,7,7]."""
     return _roi("me_ps_roi_align_f32", map_nhwc, rois, pooled, spatial_scale, True)
+
+
+def conv_wgrad_h16(x_nhwc, dy_nhwc, ksize, stride, pad, oihw=True):
+    """float32 dW from 16-bit ``x`` / ``dy`` (``me_conv_wgrad_h16``: 16-bit MFMA, fp32 accumulation, fixed-order slab sums)."""
+    _require_cuda_bf16(x_nhwc, "x")
+    _require_cuda_bf16(dy_nhwc, "dy")
+    n, h, w, cin = x_nhwc.shape
+    _, ho, wo, cout = dy_nhwc.shape
+    shape = (cout, cin, ksize, ksize) if oihw else (cout, ksize, ksize, cin)
+    dw = torch.empty(shape, device=x_nhwc.device, dtype=torch.float32)
+    need = max(lib().me_conv_wgrad_workspace_bytes(n, ho, wo, cin, cout, ksize), 4 * cout * cin * ksize * ksize)
+    ws_ptr, keep = _workspace(need, x_nhwc.device, slot="wgrad")
+    check(lib().me_conv_wgrad_h16(x_nhwc.data_ptr(), cin, dy_nhwc.data_ptr(), cout, dw.data_ptr(), n, h, w, cin, cout, ksize, stride,
+                                  pad, ws_ptr, need, 1 if oihw else 0, HALF_TYPES[x_nhwc.dtype], stream_ptr()), "me_conv_wgrad_h16")
+    return dw
 
 
 def conv_wgrad(x_nhwc, dy_nhwc, ksize, stride, pad, oihw=False):

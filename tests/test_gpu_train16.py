@@ -59,6 +59,30 @@ def test_affine_act_bwd_h16_vs_f32_kernel(hip_lib, half, rows, c, act, bn):
         hip.check(lib_rc, "bad channels")
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("n,h,cin,cout,k,s", [(2, 26, 64, 128, 3, 1), (2, 26, 128, 256, 3, 2), (3, 13, 256, 128, 1, 1), (1, 20, 32, 64, 3, 1),
+                                              (2, 13, 512, 256, 1, 1), (1, 52, 128, 128, 3, 1)])
+def test_conv_wgrad_h16_vs_fp32_kernel(hip_lib, half, n, h, cin, cout, k, s):
+    """``me_conv_wgrad_h16`` (16-bit operands, 16-bit MFMA, fp32 accumulation) against the fp32 weight-gradient kernels on float
+    copies of the SAME 16-bit values: the products are exact in fp32 either way, only the summation order differs (1e-4 of the
+    tensor's maximum); both the 64 x 64 and the 128 x 128 tile, every tap, stride 2, ragged pixel counts."""
+    from millieye_amd import hip
+    dt = HALVES[half]
+    pad = (k - 1) // 2
+    ho = (h + 2 * pad - k) // s + 1
+    x = torch.from_numpy(synth.uniform(f"w16/x{h}{cin}", (n, h, h, cin), -1, 1)).cuda().to(dt)
+    dy = torch.from_numpy(synth.uniform(f"w16/d{h}{cout}", (n, ho, ho, cout), -1, 1)).cuda().to(dt)
+    ref = hip.conv_wgrad(x.float(), dy.float(), k, s, pad, oihw=True)
+    got = hip.conv_wgrad_h16(x, dy, k, s, pad, oihw=True)
+    assert got.dtype == torch.float32 and got.shape == ref.shape == (cout, cin, k, k)
+    err = float((got - ref).abs().max())
+    assert err <= 1e-4 * float(ref.abs().max()), f"max err {err:.3e} vs max {float(ref.abs().max()):.3e}"
+    got2 = hip.conv_wgrad_h16(x, dy, k, s, pad, oihw=True)
+    assert torch.equal(got, got2)   # fixed-order sums: deterministic
+    ohwi = hip.conv_wgrad_h16(x, dy, k, s, pad, oihw=False)
+    assert torch.equal(ohwi.permute(0, 3, 1, 2).contiguous(), got)
+
+
 def _cos(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))

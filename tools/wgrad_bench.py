@@ -1,5 +1,5 @@
 """Per-layer timing of the weight gradient (me_conv_wgrad_mfma_oihw_f32) over the distinct conv shapes of yolov3.cfg at 416^2.
-usage: python tools/wgrad_bench.py [batch]   (GPU box)"""
+usage: python tools/wgrad_bench.py [batch] [f32|bf16|f16]   (GPU box; 16-bit: me_conv_wgrad_h16 on 16-bit operands)"""
 import os
 import sys
 
@@ -20,6 +20,8 @@ SHAPES = [(1, 416, 3, 32, 3, 1), (1, 416, 32, 64, 3, 2), (1, 208, 64, 32, 1, 1),
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    mode = sys.argv[2] if len(sys.argv) > 2 else "f32"
+    half = {"bf16": torch.bfloat16, "f16": torch.float16}.get(mode)
     dev = torch.device("cuda")
     big = torch.randn((4096, 4096), device=dev)
     for _ in range(30):
@@ -30,12 +32,17 @@ def main():
         ho = (h + 2 * pad - k) // s + 1
         x = torch.randn((n, h, h, cin), device=dev)
         dy = torch.randn((n, ho, ho, cout), device=dev)
+        fn = hip.conv_wgrad
+        if half is not None:
+            if cin % 8 or cout % 8:
+                continue   # (stem / detection convolutions: fp32 kernels in the mixed-precision step)
+            x, dy, fn = x.to(half), dy.to(half), hip.conv_wgrad_h16
         for _ in range(3):
-            hip.conv_wgrad(x, dy, k, s, pad, oihw=True)
+            fn(x, dy, k, s, pad, oihw=True)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(10):
-            hip.conv_wgrad(x, dy, k, s, pad, oihw=True)
+            fn(x, dy, k, s, pad, oihw=True)
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / 10 * 1e3
