@@ -276,7 +276,8 @@ class DarknetEngine:
     def __init__(self, model, dtype="f32"):
         """``dtype``: storage of the activations and MFMA-conv weights between layers - ``"f32"`` (default; the mode the
         1e-3 parity bar is quoted on) or ``"bf16"`` / ``"f16"`` (BASELINE configs[2]/[4]: 16-bit operands, fp32 accumulation and
-        epilogue, fp32 detection maps into the YOLO decode; inference only)."""
+        epilogue, fp32 detection maps into the YOLO decode; the engine plans are inference - the 16-bit training step is
+        millieye_amd/detector_train16.py)."""
         if dtype not in _DTYPES:
             raise ValueError(f"unknown engine dtype {dtype!r} (expected one of {_DTYPES})")
         self.model = model
@@ -423,7 +424,8 @@ class DarknetEngine:
         bf16 = self.dtype in _TORCH_HALF  # any 16-bit storage mode
         half_type = hip.HALF_TYPES[_TORCH_HALF[self.dtype]] if bf16 else 0
         if bf16 and keep_raw:
-            raise NotImplementedError("the 16-bit storage modes are inference only (the YOLO loss / backward run in fp32)")
+            raise NotImplementedError("a 16-bit ENGINE PLAN keeps no raw maps (the loss value of an evaluation call comes from the fp32 engine; "
+                                      "training in a 16-bit storage mode is millieye_amd/detector_train16.py, not an engine plan)")
         act_esize = 2 if bf16 else 4
 
         def new_tensor(hh, ww, cc, esize=None):
