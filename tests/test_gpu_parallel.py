@@ -339,3 +339,8 @@ def test_bench_two_ranks_inference_and_detector_training(hip_lib):
     assert out["n_gpus"] == 2 and out["config"]["grad_chunks"] >= 4
     assert out["config"]["grad_bucket_bytes"] > 30e6 and "reverse-layer chunks" in out["config"]["workload"]
     assert out["config"]["loss_last_step"] == out["config"]["loss_last_step"] and out["roofline"]["by_pass"]["wgrad"]["ms"] > 0
+    # the mixed-precision detector step (round 5) through the same N = 2 flow: float32 gradients leave in chunks like the fp32 step's
+    out = _bench2(["--workload", "detector_train", "--dtype", "bf16", "--cfg", "yolov3", "--size", "64", "--batch", "2", "--chunk-mb", "32"])
+    assert out["n_gpus"] == 2 and out["dtype"] == "bf16" and out["config"]["grad_chunks"] >= 4
+    assert out["config"]["grad_bucket_bytes"] > 240e6 and "bf16 activations and activation gradients" in out["config"]["workload"]
+    assert out["config"]["loss_last_step"] == out["config"]["loss_last_step"] and out["value"] > 0
