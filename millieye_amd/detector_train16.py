@@ -22,6 +22,7 @@ BatchNorm: eval mode only (folded into the convolution, its ``weight`` / ``bias`
 ``F.batch_norm(training=False)``); train()-mode BatchNorm stays an fp32 path.  Parity bar (tests/test_gpu_train16.py): the loss
 within 1 % and every parameter gradient at cosine >= 0.99 of the fp32 HIP step's on the same inputs.
 """
+import ctypes as C
 import os
 
 import torch
@@ -32,6 +33,7 @@ from .detector_train import (_PARITY_IDX, _State, _const_vectors, _conv_flops, _
 
 _HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 _AUTO16 = {}
+_DIRECT = os.environ.get("MILLIEYE_WGRAD16_DIRECT", "1") != "0"   # (A/B: 0 = the weight gradient under torch.cuda.stream(side))
 _WGRAD16 = os.environ.get("MILLIEYE_WGRAD16", "1") != "0"   # (A/B: 0 = weight gradients by the fp32 kernels on fp32 copies)
 
 
@@ -213,7 +215,6 @@ class DetectorTrainer16:
         L = len(defs)
         dout = [None] * L
         grads = {}
-        stream = hip.stream_ptr
         ht = hip.HALF_TYPES[half]
 
         def contribute(i, g, fresh):
@@ -240,6 +241,10 @@ class DetectorTrainer16:
         x_nhwc = None
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0" and _TIMING[0] is None else None
+        side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
+        side_ws = self.m.__dict__.setdefault("_wgrad16_ws", [None])   # slab scratch of the side stream, kept from step to step
+        sp = hip.stream_ptr()   # (the main stream's handle, once: this backward never switches torch's current stream on its hot path)
+        stream = lambda: sp  # noqa: E731
         for i in reversed(range(L)):
             d = defs[i]
             t = d["type"]
@@ -309,7 +314,24 @@ class DetectorTrainer16:
                     x32 = xin if xin.dtype == torch.float32 else xin.float()
                     d32 = dc32 if dc32 is not None else dc.float()
                     return hip.conv_wgrad(x32, d32, k, s, pad, oihw=True)
-                if side is not None:
+                fast16 = _WGRAD16 and dc is not None and xin.dtype == half and cin % 8 == 0 and cout % 8 == 0
+                if side is not None and fast16 and _DIRECT:
+                    # the 16-bit weight gradient straight onto the side stream's handle: no switch of torch's current stream (a
+                    # context manager, two current-stream lookups and a per-stream workspace lookup: ~20 us of host time per layer of
+                    # a step whose host is the slower side), the slab scratch is this backward's own buffer on that stream
+                    side.wait_stream(main)
+                    dwt = torch.empty((cout, cin, k, k), device=dev, dtype=torch.float32)
+                    need = max(int(lib.me_conv_wgrad_workspace_bytes(n, ho, wo, cin, cout, k)), 4 * cout * cin * k * k)
+                    if side_ws[0] is None or side_ws[0].numel() < need + 256:
+                        with torch.cuda.stream(side):
+                            side_ws[0] = torch.empty(max(need + 256, 64 << 20), dtype=torch.uint8, device=dev)
+                    wsp = side_ws[0].data_ptr() + (-side_ws[0].data_ptr()) % 256
+                    hip.check(lib.me_conv_wgrad_h16(xin.data_ptr(), cin, dc.data_ptr(), cout, dwt.data_ptr(), n, h, w, cin, cout, k, s,
+                                                    pad, wsp, need, 1, ht, side_ptr), "me_conv_wgrad_h16")
+                    grads[f"module_list.{i}.conv_{i}.weight"] = dwt
+                    dc.record_stream(side)
+                    xin.record_stream(side)
+                elif side is not None:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         grads[f"module_list.{i}.conv_{i}.weight"] = wgrad()

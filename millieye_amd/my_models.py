@@ -434,11 +434,12 @@ class Network(nn.Module):
         forward, 3 - 4 us of host time each, in the one part of a small-batch step where the host is the slower side).  Every
         launch that reads or writes these buffers is ordered on the forward's main stream or on the side stream behind an event
         of the main stream, so the next forward's launches queue behind this forward's.  Contents are valid until the next
-        ``forward`` (``self._last`` hands some of them out, like ``plan.tap``).  The returned rows are NOT from this pool."""
+        ``forward`` (``self._last`` hands some of them out, like ``plan.tap``).  The returned rows are NOT from this pool.  Keyed by the
+        issuing stream; forwards of one network still run one at a time (the detector's plan arena is per network, not per stream)."""
         pool = self.__dict__.get("_tail_bufs")
         if pool is None:
             pool = self.__dict__["_tail_bufs"] = {}
-        key = (name, shape, dtype, dev)
+        key = (name, shape, dtype, dev, hip.stream_ptr().value)   # (per stream: two forwards of one network on two streams never share scratch)
         t = pool.get(key)
         if t is None:
             if len(pool) > 96:  # (the RoI capacity follows the number of radar boxes of a call: keep the pool bounded)

@@ -210,6 +210,35 @@ def test_two_launch_heads_equal_the_fused_launch(hip_lib, case):
     print(f"two-launch heads vs fused launch ({name}): bit-identical = {bool(torch.equal(split, fused))}")
 
 
+def test_pooled_tail_scratch_and_polled_row_count(hip_lib, monkeypatch):
+    """Round 5: the tail's scratch tensors come from a per-network, per-stream pool - the rows a call returned must survive the
+    next calls (they are never pool memory), a forward issued on another stream gets its own scratch (forwards of ONE network are
+    still one at a time: the detector's plan arena is per network), and the A/B form of the row count
+    (the kernel stores it into a pinned host word that the host polls, MILLIEYE_COUNT_SPIN=1) returns the same rows."""
+    from millieye_amd import my_models
+    name, cfg, n, s, conf = NETWORK_CASES[0]
+    net = _build(name, cfg, conf).eval()
+    net = net.to(net.device)
+    x, maps, rboxes = _inputs(name, n, s)
+    first = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+    keep = first.clone()
+    yolo_only = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 1)
+    keep1 = yolo_only.clone()
+    other = net(x.flip(0).contiguous().cuda(), maps.flip(0).contiguous().cuda(), rboxes.clone().cuda(), 0)
+    assert torch.equal(first, keep) and torch.equal(yolo_only, keep1), "a later forward overwrote rows an earlier one returned"
+    assert other.shape[1] == 8
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        again = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+    side.synchronize()
+    assert torch.equal(again, keep)
+    assert len({k[-1] for k in net._tail_bufs}) >= 3, "scratch is keyed by stream (two caller streams + the network's own side stream)"
+    monkeypatch.setattr(my_models, "_COUNT_SPIN", True)
+    polled = net(x.cuda(), maps.cuda(), rboxes.clone().cuda(), 0)
+    assert torch.equal(polled, keep)
+
+
 def test_bin_major_score_map_follows_weight_updates(hip_lib):
     """The 1x1 score-map convolution runs on row-permuted copies of its packed weights (bin-major channels for the pooling
     launch): an in-place update of the module's parameters must reach them - the rows after the update equal the oracle's on the
