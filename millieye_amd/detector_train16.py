@@ -243,6 +243,7 @@ class DetectorTrainer16:
         side = _side_stream(dev) if os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0" and _TIMING[0] is None else None
         side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
         side_ws = self.m.__dict__.setdefault("_wgrad16_ws", [None])   # slab scratch of the side stream, kept from step to step
+        aff_ws = self.m.__dict__.setdefault("_affine16_ws", [None])
         sp = hip.stream_ptr()   # (the main stream's handle, once: this backward never switches torch's current stream on its hot path)
         stream = lambda: sp  # noqa: E731
         for i in reversed(range(L)):
@@ -281,7 +282,10 @@ class DetectorTrainer16:
                     if dy.dtype != half or not dy.is_contiguous():
                         dy = dy.to(half).contiguous()
                     dc = dy if dy_owned else torch.empty_like(y)
-                    ws = torch.empty(lib.me_affine_bwd_h16_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
+                    need_a = int(lib.me_affine_bwd_h16_workspace_bytes(rows, cout))
+                    if aff_ws[0] is None or aff_ws[0].numel() < need_a:   # one partial-sum scratch for the whole backward (stream-ordered)
+                        aff_ws[0] = torch.empty(max(need_a, 8 << 20), dtype=torch.uint8, device=dev)
+                    ws = aff_ws[0]
                     hip.check(lib.me_affine_act_bwd_h16(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
                                                         cw.scale.data_ptr() if bn is not None else None, _ptr(gam), _ptr(bet), act,
                                                         dc.data_ptr(), cout, dshift.data_ptr(), _ptr(dgamma), ws.data_ptr(), ht,
