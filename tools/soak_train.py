@@ -1,6 +1,6 @@
 """Soak of the detector training step (stream-overlapped backward, device loss, whole-network pack): 30 SGD steps of
 Darknet-53 at 416^2 / batch 8, run twice from the same state - every tensor of the final state_dict must have the same bits.
-usage: python tools/soak_train.py   (GPU box; prints the two last losses and the number of differing tensors)"""
+usage: python tools/soak_train.py [f32|bf16|f16]   (GPU box; prints the two last losses and the number of differing tensors)"""
 import sys, torch, numpy as np
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -9,6 +9,7 @@ from millieye_amd import synth
 def run():
     torch.manual_seed(0)
     model = ph.make_darknet("yolov3", tag="soak").cuda().eval()
+    model.compute_dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"   # 16-bit: the mixed-precision step (detector_train16.py)
     opt = torch.optim.SGD(model.parameters(), lr=1e-6)
     n, s = 8, 416
     rng = np.random.RandomState(3)
