@@ -262,8 +262,9 @@ class Darknet(nn.Module):
 
     def forward(self, x, targets=None):
         """``(featuremap, yolo_outputs)``, or with ``targets`` ``(loss, featuremap, yolo_outputs)`` where
-        ``loss`` is the summed YOLO loss of every scale (reference :261-267).  The loss is a VALUE: the
-        detector backward is not built (no reference script trains the detector)."""
+        ``loss`` is the summed YOLO loss of every scale (reference :261-267).  Under autograd with parameters that require
+        gradients the loss is differentiable (``_forward_train``: millieye_amd/detector_train.py, or - ``compute_dtype`` "bf16" /
+        "f16" - the mixed-precision step of millieye_amd/detector_train16.py); otherwise it is a value."""
         if targets is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(x, targets)
         if self._any_bn_training():
@@ -312,7 +313,7 @@ class Darknet(nn.Module):
     def _forward_batch_stats(self, x, targets):
         """``Darknet.forward`` under ``model.train()`` outside autograd: BatchNorm layers in train() mode normalise with the
         batch statistics and update their running statistics (``me_bn_train_fwd_f32``), the others stay folded; outputs (and,
-        with ``targets``, the loss VALUE) come from that forward.  fp32 only, like every training path of this package."""
+        with ``targets``, the loss VALUE) come from that forward.  fp32 only (the 16-bit training step, detector_train16.py, folds eval-mode BatchNorm)."""
         from ..detector_train import DetectorTrainer
         if self.compute_dtype != "f32":
             raise NotImplementedError("train()-mode BatchNorm: float32 only (the 16-bit storage modes fold BatchNorm)")
