@@ -54,13 +54,19 @@ def parse():
                     help="weak (default): --batch frames PER GPU; strong: --batch frames in total, sharded over the ranks "
                          "(parallel.shard_range).  An N > 1 weak run of an inference workload also times the strong reading "
                          "and reports it as `strong_scaling` in the same line")
+    ap.add_argument("--graph", action="store_true",
+                    help="detector_train: forward + YOLO losses + backward as one captured hipGraph per step "
+                         "(millieye_amd/detector_graph.py; the gradients are exchanged after the replay when N > 1)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1 weak runs: skip the extra strong-scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the extra bf16-storage-mode measurement")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra batch 1 / 8 measurements")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the mAP@0.5-vs-reference leg on the committed mini split")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the CPU baseline leg (the benchmark's batch always gets a warm-up + >= 3 timed passes)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.graph and args.workload != "detector_train":
+        ap.error("--graph applies to --workload detector_train (the inference engines have their own MILLIEYE_GRAPH switch)")
+    return args
 
 
 def spawn_ranks(args):
@@ -598,9 +604,9 @@ def main():
         # N > 1 (or any launcher-made process group): the gradients leave in reverse-layer chunks on a communication stream
         # while the backward of the shallower layers is still running (parallel.GradChunkReducer); without a process
         # group nothing is attached and nothing is exchanged - the workload string below says so
-        reducer = par.overlap_detector_allreduce(model, chunk_bytes=int(args.chunk_mb * 2 ** 20))
+        reducer = None if args.graph else par.overlap_detector_allreduce(model, chunk_bytes=int(args.chunk_mb * 2 ** 20))
 
-        def step():
+        def eager_step():
             loss, _fm, yo = model(x, det_targets)
             loss.backward()
             last["bucket_bytes"] = reducer.bytes_last if reducer is not None else 0
@@ -609,6 +615,21 @@ def main():
             det_opt.zero_grad(set_to_none=True)
             last["loss"] = loss.detach()
             return yo
+        step = eager_step
+        if args.graph:
+            # the same launches as ONE captured hipGraph (forward, the three YOLO losses with their counts kept on the device,
+            # backward of every layer, the weight packing); the step is then: copy frames + targets, replay, all-reduce, SGD
+            from millieye_amd.detector_graph import GraphedDetectorStep
+            graphed = GraphedDetectorStep(model, max_targets=max(64, batch))
+
+            def step():
+                loss = graphed(x, det_targets)
+                det_opt.step()
+                det_opt.zero_grad(set_to_none=True)
+                last["loss"] = loss
+                last["bucket_bytes"] = sum(p.numel() for p in det_params) * 4 if dist.is_initialized() else 0
+                last["chunks"] = 1 if dist.is_initialized() else 0
+                return loss
     elif args.workload == "module2":
         # BASELINE configs[2]: the stage-2 network (module2_mixed/my_models.py: detector + NMS + every-class proposals +
         # PS-RoIAlign + refinement / ensemble heads, no radar branch), batch 32; rows come back on the host like the reference's
@@ -875,7 +896,7 @@ def main():
     det_passes = None
     if args.workload == "detector_train":  # every rank (the step holds collectives when there is a process group)
         from millieye_amd import detector_train as dtr
-        det_passes = dtr.profile_step_passes(step)
+        det_passes = dtr.profile_step_passes(eager_step)   # (the passes' conv launches, sequential: an eager step also under --graph)
     if rank == 0:
         frames = (gbatch if strong else batch * world) * args.steps
         plan = model.engine_for(model.compute_dtype).plan_for(x)
@@ -975,11 +996,16 @@ def main():
             out["config"]["wgrad_stream"] = os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0"  # weight gradients beside the data gradients
             ranks = dist.get_world_size() if dist.is_initialized() else 0
             out["config"]["grad_chunks"] = int(last.get("chunks", 0))
+            out["config"]["captured_graph"] = bool(args.graph)
+            if args.graph:
+                graphed.metrics()   # (the deferred host read: raises if a target of any step was out of range)
             mixed = "" if args.dtype == "f32" else (f"{args.dtype} activations and activation gradients, fp32 master weights, weight "
                                                      "gradients on the fp32 matrix pipe, ")
             out["config"]["workload"] = out["config"]["workload"].replace(
                 " inference, batch", " detector training step (forward + HIP backward of every layer, eval-mode BN, " + mixed
-                + (f"full-gradient all-reduce in {int(last.get('chunks', 0))} reverse-layer chunks beside the backward, "
+                + ("forward + losses + backward replayed as one captured hipGraph, " if args.graph else "")
+                + (("full-gradient all-reduce in one bucket after the replay, " if args.graph else
+                    f"full-gradient all-reduce in {int(last.get('chunks', 0))} reverse-layer chunks beside the backward, ")
                    if ranks else "all-reduce skipped (1 rank, no process group), ") + "SGD), batch", 1).replace(
                 "Darknet.forward(x, targets) -> loss.backward() -> all-reduce -> SGD",
                 "Darknet.forward(x, targets) -> loss.backward()" + (" (+ overlapped all-reduce)" if ranks else "") + " -> SGD")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 10
+#define ME_ABI_VERSION 11
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -426,6 +426,14 @@ int me_yolo_loss_bwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, 
                          const float* tw, const float* th, const float* tcls, const float* tconf, float n_obj,
                          float n_noobj, float obj_scale, float noobj_scale, float grad_scale, float* draw,
                          int64_t dpitch, void* stream);
+/* me_yolo_loss_bwd_dev_f32 (ABI 11): the same pass with n_obj / n_noobj taken from result_device[13] / [14] (the result[16] the
+ * forward wrote) and the upstream gradient from the device float grad_scale_device (NULL = 1): no host value of the step is a
+ * launch argument, so the call can be captured in a hipGraph (millieye_amd/detector_graph.py). */
+int me_yolo_loss_bwd_dev_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                             const uint8_t* obj_mask, const uint8_t* noobj_mask, const float* tx, const float* ty,
+                             const float* tw, const float* th, const float* tcls, const float* tconf,
+                             const float* result_device, float obj_scale, float noobj_scale, const float* grad_scale_device,
+                             float* draw, int64_t dpitch, void* stream);
 
 /* dx = dy * act'(y) from the activation output y (sigmoid / leaky) */
 int me_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx, int64_t lddx, int64_t rows,
@@ -502,6 +510,13 @@ int me_yolo_loss_fwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, 
                          float noobj_scale, uint8_t* obj_mask, uint8_t* noobj_mask, float* tx, float* ty, float* tw, float* th,
                          float* tcls, float* tconf, float* class_mask, float* iou_scores, void* workspace, float* result,
                          void* stream);
+/* me_yolo_loss_fwd_counted_f32 (ABI 11): the same launches over a fixed-capacity target table: `capacity` rows of `targets` are
+ * addressable, the device word *m_device (clamped to [0, capacity]) says how many of them are targets of this step. */
+int me_yolo_loss_fwd_counted_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                                 const float* scaled_anchors_host, const float* targets, int32_t capacity,
+                                 const int32_t* m_device, float ignore_thres, float obj_scale, float noobj_scale, uint8_t* obj_mask,
+                                 uint8_t* noobj_mask, float* tx, float* ty, float* tw, float* th, float* tcls, float* tconf,
+                                 float* class_mask, float* iou_scores, void* workspace, float* result, void* stream);
 /* RoI pooling backward: grad_out [k,c_out,7,7] scattered (atomicAdd) into the zero-filled NHWC grad_map */
 int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
                          int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch, void* stream);

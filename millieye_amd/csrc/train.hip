@@ -1406,7 +1406,14 @@ __global__ __launch_bounds__(256) void yolo_loss_bwd_kernel(const float* __restr
                                                             const float* __restrict__ tw, const float* __restrict__ th,
                                                             const float* __restrict__ tcls, const float* __restrict__ tconf,
                                                             float n_obj, float n_noobj, float obj_scale, float noobj_scale,
-                                                            float gscale, float* draw, long long dpitch) {
+                                                            float gscale, float* draw, long long dpitch,
+                                                            const float* __restrict__ result_dev,
+                                                            const float* __restrict__ gscale_dev) {
+  if (result_dev) {  // me_yolo_loss_bwd_dev_f32: the counts the forward left in result[13] / [14], never read by the host
+    n_obj = result_dev[13];
+    n_noobj = result_dev[14];
+  }
+  if (gscale_dev) gscale = *gscale_dev;
   const int per = nc + 5;
   const long long total = (long long)n * na * g * g * per;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -1707,7 +1714,25 @@ int me_yolo_loss_bwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, 
   const long long work = (long long)n * num_anchors * g * g * (num_classes + 5);
   hipLaunchKernelGGL(yolo_loss_bwd_kernel, dim3(grid1d(work)), dim3(256), 0, stream, raw, (long long)pitch, n, g,
                      num_anchors, num_classes, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf, n_obj, n_noobj,
-                     obj_scale, noobj_scale, grad_scale, draw, (long long)dpitch);
+                     obj_scale, noobj_scale, grad_scale, draw, (long long)dpitch, (const float*)nullptr, (const float*)nullptr);
+  return me::check_launch("yolo_loss_bwd_kernel");
+}
+
+// the same pass with n_obj / n_noobj read from the forward's result[16] in device memory and the upstream gradient of the scalar
+// loss from a device float (NULL = 1): no host value of the step enters the launch (captured step, millieye_amd/detector_graph.py)
+int me_yolo_loss_bwd_dev_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                             const uint8_t* obj_mask, const uint8_t* noobj_mask, const float* tx, const float* ty,
+                             const float* tw, const float* th, const float* tcls, const float* tconf,
+                             const float* result_device, float obj_scale, float noobj_scale, const float* grad_scale_device,
+                             float* draw, int64_t dpitch, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(raw && obj_mask && noobj_mask && tx && ty && tw && th && tcls && tconf && draw && result_device, ME_E_NULLPTR,
+             "me_yolo_loss_bwd_dev_f32: null pointer");
+  ME_REQUIRE(n > 0 && g > 0 && num_anchors > 0 && num_classes > 0, ME_E_BADARG, "me_yolo_loss_bwd_dev_f32: bad dimensions");
+  const long long work = (long long)n * num_anchors * g * g * (num_classes + 5);
+  hipLaunchKernelGGL(yolo_loss_bwd_kernel, dim3(grid1d(work)), dim3(256), 0, stream, raw, (long long)pitch, n, g,
+                     num_anchors, num_classes, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf, 1.f, 1.f,
+                     obj_scale, noobj_scale, 1.f, draw, (long long)dpitch, result_device, grad_scale_device);
   return me::check_launch("yolo_loss_bwd_kernel");
 }
 

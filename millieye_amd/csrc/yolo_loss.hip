@@ -15,7 +15,9 @@
 //                          metric sums; per-block partial sums in double, added in block order by the last block
 //                          (ticket) -> fixed order, deterministic.
 //
-// The dense tensors are what me_yolo_loss_bwd_f32 (train.hip) takes; result[16] (float) is read by the host once.
+// The dense tensors are what me_yolo_loss_bwd_f32 (train.hip) takes; result[16] (float) is read by the host once - or not at all:
+// me_yolo_loss_fwd_counted_f32 + me_yolo_loss_bwd_dev_f32 keep the target count and n_obj / n_noobj in device memory, for the
+// captured training step (millieye_amd/detector_graph.py).
 // Arithmetic: float32 like the reference (sigmoid = 1 / (1 + exp(-x)), BCE with its log clamp at -100); sums in double.
 #include <math.h>
 
@@ -35,6 +37,7 @@ struct YoloLossArgs {
   const float* raw;  // [N,G,G,A*(5+C)] NHWC, pitch floats per pixel
   long long pitch;
   const float* targets;  // [m,6] (image, class, cx, cy, w, h) in [0,1]
+  const int* m_dev;      // or NULL; device word: how many of the m rows are targets (me_yolo_loss_fwd_counted_f32)
   int m, n, g, na, nc;
   float anchors[32];  // scaled anchors (w, h) in grid units, na <= 16
   float ignore_thres, obj_scale, noobj_scale;
@@ -66,7 +69,12 @@ __global__ __launch_bounds__(256) void yolo_targets_init_kernel(YoloLossArgs a) 
 __global__ __launch_bounds__(256) void yolo_targets_scatter_kernel(YoloLossArgs a) {
 #pragma clang fp contract(off)
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.m) return;
+  int m = a.m;
+  if (a.m_dev) {  // a fixed-capacity table (a captured launch): the device word says how many rows count, clamped to [0, m]
+    const int live = *a.m_dev;
+    m = live < 0 ? 0 : (live < m ? live : m);
+  }
+  if (t >= m) return;
   const int per = a.nc + 5;
   auto owner_of = [&](int k, int& b, int& best, int& gi, int& gj, float& gx, float& gy, float& gw, float& gh) {
     const float* row = a.targets + (long long)k * 6;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void yolo_targets_scatter_kernel(YoloLossArgs 
   const int label = (int)a.targets[(long long)t * 6 + 1];
   if (label >= 0 && label < a.nc) a.tcls[cell * a.nc + label] = 1.f; else *a.bad = 1;
   // a later target with the same owner cell overwrites the scalar targets (sequential index_put_ semantics)
-  for (int k = t + 1; k < a.m; ++k) {
+  for (int k = t + 1; k < m; ++k) {
     int b2, best2, gi2, gj2;
     float x2, y2, w2, h2;
     owner_of(k, b2, best2, gi2, gj2, x2, y2, w2, h2);
@@ -264,11 +272,11 @@ extern "C" {
 
 int64_t me_yolo_loss_workspace_bytes(void) { return (int64_t)YL_BLOCKS * YL_SUMS * sizeof(double) + 256; }
 
-int me_yolo_loss_fwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
-                         const float* scaled_anchors_host, const float* targets, int32_t m, float ignore_thres, float obj_scale,
-                         float noobj_scale, uint8_t* obj_mask, uint8_t* noobj_mask, float* tx, float* ty, float* tw, float* th,
-                         float* tcls, float* tconf, float* class_mask, float* iou_scores, void* workspace, float* result,
-                         void* stream_) {
+static int yolo_loss_fwd(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                         const float* scaled_anchors_host, const float* targets, int32_t m, const int32_t* m_device,
+                         float ignore_thres, float obj_scale, float noobj_scale, uint8_t* obj_mask, uint8_t* noobj_mask, float* tx,
+                         float* ty, float* tw, float* th, float* tcls, float* tconf, float* class_mask, float* iou_scores,
+                         void* workspace, float* result, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ME_REQUIRE(raw && scaled_anchors_host && obj_mask && noobj_mask && tx && ty && tw && th && tcls && tconf && class_mask &&
                  iou_scores && workspace && result && (m == 0 || targets),
@@ -277,7 +285,7 @@ int me_yolo_loss_fwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, 
              ME_E_BADARG, "me_yolo_loss_fwd_f32: bad dimensions (at most 16 anchors per scale)");
   ME_REQUIRE(me::aligned16(workspace), ME_E_ALIGN, "me_yolo_loss_fwd_f32: workspace must be 16-byte aligned");
   YoloLossArgs a;
-  a.raw = raw; a.pitch = pitch; a.targets = targets; a.m = m; a.n = n; a.g = g; a.na = num_anchors; a.nc = num_classes;
+  a.raw = raw; a.pitch = pitch; a.targets = targets; a.m_dev = m_device; a.m = m; a.n = n; a.g = g; a.na = num_anchors; a.nc = num_classes;
   for (int i = 0; i < 2 * num_anchors; ++i) a.anchors[i] = scaled_anchors_host[i];
   a.ignore_thres = ignore_thres; a.obj_scale = obj_scale; a.noobj_scale = noobj_scale;
   a.obj = obj_mask; a.noobj = noobj_mask; a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.tcls = tcls; a.tconf = tconf;
@@ -301,6 +309,30 @@ int me_yolo_loss_fwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, 
   if (rb > YL_BLOCKS) rb = YL_BLOCKS;
   hipLaunchKernelGGL(yolo_loss_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, a);
   return me::check_launch("yolo_loss_fwd");
+}
+
+int me_yolo_loss_fwd_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                         const float* scaled_anchors_host, const float* targets, int32_t m, float ignore_thres, float obj_scale,
+                         float noobj_scale, uint8_t* obj_mask, uint8_t* noobj_mask, float* tx, float* ty, float* tw, float* th,
+                         float* tcls, float* tconf, float* class_mask, float* iou_scores, void* workspace, float* result,
+                         void* stream) {
+  return yolo_loss_fwd(raw, pitch, n, g, num_anchors, num_classes, scaled_anchors_host, targets, m, nullptr, ignore_thres, obj_scale,
+                       noobj_scale, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf, class_mask, iou_scores, workspace, result,
+                       stream);
+}
+
+// The same launches over a fixed-capacity target table: `capacity` rows are addressable, the device word *m_device says how many
+// of them are targets.  Nothing about the call depends on the step's target count, so it can sit in a captured hipGraph
+// (millieye_amd/detector_graph.py) that is replayed with another table every step.
+int me_yolo_loss_fwd_counted_f32(const float* raw, int64_t pitch, int32_t n, int32_t g, int32_t num_anchors, int32_t num_classes,
+                                 const float* scaled_anchors_host, const float* targets, int32_t capacity,
+                                 const int32_t* m_device, float ignore_thres, float obj_scale, float noobj_scale, uint8_t* obj_mask,
+                                 uint8_t* noobj_mask, float* tx, float* ty, float* tw, float* th, float* tcls, float* tconf,
+                                 float* class_mask, float* iou_scores, void* workspace, float* result, void* stream) {
+  ME_REQUIRE(m_device != nullptr && capacity > 0, ME_E_NULLPTR, "me_yolo_loss_fwd_counted_f32: needs a device row count and a capacity");
+  return yolo_loss_fwd(raw, pitch, n, g, num_anchors, num_classes, scaled_anchors_host, targets, capacity, m_device, ignore_thres,
+                       obj_scale, noobj_scale, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf, class_mask, iou_scores, workspace,
+                       result, stream);
 }
 
 }  // extern "C"

@@ -215,6 +215,8 @@ SIGNATURES = {
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "me_yolo_loss_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
                              + [C.c_float] * 5 + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_yolo_loss_bwd_dev_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9
+                                 + [C.c_float] * 2 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "me_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                  C.c_int32, C.c_int32, C.c_void_p]),
     "me_conv_wgrad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
@@ -234,6 +236,9 @@ SIGNATURES = {
     "me_yolo_loss_workspace_bytes": (C.c_int64, []),
     "me_yolo_loss_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
                                        C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 13),
+    "me_yolo_loss_fwd_counted_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                               C.POINTER(C.c_float), C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float,
+                                               C.c_float] + [C.c_void_p] * 13),
     "me_pack_conv_plan": (C.c_int64, [C.POINTER(PackDesc), C.c_int32]),
     "me_pack_conv_batch_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "me_ps_roi_align_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -269,8 +274,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 10:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 10")
+    if lib_.me_abi_version() != 11:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 11")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
