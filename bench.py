@@ -609,8 +609,9 @@ def main():
         def eager_step():
             loss, _fm, yo = model(x, det_targets)
             loss.backward()
-            last["bucket_bytes"] = reducer.bytes_last if reducer is not None else 0
-            last["chunks"] = reducer.chunks_last if reducer is not None else 0
+            if not args.graph:   # (under --graph this eager form only serves the per-pass profile; it exchanges nothing)
+                last["bucket_bytes"] = reducer.bytes_last if reducer is not None else 0
+                last["chunks"] = reducer.chunks_last if reducer is not None else 0
             det_opt.step()
             det_opt.zero_grad(set_to_none=True)
             last["loss"] = loss.detach()

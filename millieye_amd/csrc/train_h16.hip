@@ -127,7 +127,9 @@ __global__ __launch_bounds__(1024) void affine_bwd_reduce_h16_kernel(const float
 }
 
 int chunks_of(int rows) {
-  int c = rows / 512;   // 16 rounds of 32 row lanes per chunk
+  // 8 rounds of 32 row lanes per chunk (measured on the Darknet-53 shapes at batch 8, tools/affine_bench.py 8 bf16: 512 rows per
+  // chunk 1.15 ms per step, 256 rows 1.06 - 1.09 ms, 128 rows 1.11 ms: the mid-size layers ran on 84 workgroups)
+  int c = rows / 256;
   if (c < 1) c = 1;
   if (c > 1024) c = 1024;
   return c;

@@ -12,6 +12,8 @@ python bench.py --workload train --dtype bf16 --no-cpu-baseline --steps 20 > $OU
 python bench.py --dtype f16 --size 608 --batch 16 --no-cpu-baseline --no-batch-sweep --steps 20 > $OUT/${TAG}_f16_bench_full_608_b16.json 2>/dev/null
 python bench.py --workload module2 --dtype bf16 --no-cpu-baseline --no-batch-sweep --steps 20 > $OUT/${TAG}_bf16_bench_module2_b32.json 2>/dev/null
 python bench.py --workload detector_train --no-cpu-baseline --steps 20 --warmup 3 > $OUT/${TAG}_bench_detector_train_b8.json 2>/dev/null
+python bench.py --workload detector_train --dtype bf16 --no-cpu-baseline --steps 20 --warmup 3 > $OUT/${TAG}_bf16_bench_detector_train_b8.json 2>/dev/null
+python bench.py --workload detector_train --dtype bf16 --graph --no-cpu-baseline --steps 20 --warmup 3 > $OUT/${TAG}_bf16_bench_detector_train_b8_graph.json 2>/dev/null
 python bench.py --workload allreduce --steps 5 > $OUT/${TAG}_bench_allreduce_1rank_no_pg.json 2>/dev/null
 BENCH_FORCE_SPAWN=1 python bench.py --workload allreduce --steps 5 > $OUT/${TAG}_bench_allreduce_rccl_world1.json 2>/dev/null
 (python tools/affine_bench.py 8; python tools/conv16_bench.py 32; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_probe tools/chain_probe.hip && timeout 300 /tmp/chain_probe) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_microbench.txt
