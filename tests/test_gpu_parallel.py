@@ -237,6 +237,72 @@ def test_dp_detector_hip_step_chunked_allreduce_two_ranks(hip_lib):
     assert checked >= 2 * 30
 
 
+def _det_graph_dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from millieye_amd import parallel as par
+    from millieye_amd.detector_graph import GraphedDetectorStep
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, x, targets = _det_problem()
+    model = model.cuda().eval()
+    lo, hi = par.shard_range(x.shape[0], rank, world)
+    tg = targets[(targets[:, 0] >= lo) & (targets[:, 0] < hi)].clone()
+    tg[:, 0] -= lo
+    step = GraphedDetectorStep(model, max_targets=8)
+    xs = x[lo:hi].contiguous().cuda()
+    out = []
+    for _ in range(2):   # the capture's step and a replay: the same exchanged gradients
+        for p in model.parameters():
+            p.grad = None
+        loss = step(xs, tg)
+        torch.cuda.synchronize()
+        out.append((float(loss), {k: p.grad.cpu().numpy().copy() for k, p in model.named_parameters()}))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_detector_captured_step_exchanges_after_the_replay_two_ranks(hip_lib):
+    """GraphedDetectorStep under a process group (two ranks on the one leased GPU, gloo over CUDA tensors): the replayed graph
+    holds no collective; the gradients are SUM-all-reduced in one bucket after it.  Reference: the two shards' eager steps in
+    one process, added - same kernels, so the sums agree to the shard kernels' own atomics (1e-5 of the tensor's maximum)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_det_graph_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, out = q.get(timeout=900)
+        got[rank] = out
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, x, targets = _det_problem()
+    model = model.cuda().eval()
+    l0, g0 = _det_shard_step(model, x, targets, 0, 2)
+    l1, g1 = _det_shard_step(model, x, targets, 2, 4)
+    checked = 0
+    for rank, want_loss in ((0, l0), (1, l1)):
+        for loss, grads in got[rank]:
+            assert loss == pytest.approx(want_loss, rel=1e-6)
+            for name, a in g0.items():
+                want = (a + g1[name]).cpu()
+                mine = torch.from_numpy(grads[name])
+                assert float((mine - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1e-12), (name, rank)
+                checked += 1
+    assert checked >= 4 * 30
+
+
 def test_bench_allreduce_microbenchmark_runs_through_rccl(hip_lib):
     """``bench.py --workload allreduce``: under a launcher RCCL exchanges the 247.8 MB bucket (world 1
     on this lease); without one the line says that nothing was exchanged."""
