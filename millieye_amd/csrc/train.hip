@@ -699,7 +699,15 @@ struct WgH16<1> {
   static __device__ __forceinline__ wg_f32x16 mfma(v8 a, v8 b, wg_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <int TCO, int TCI, int F16>
+// TR = 1 (round 5, gfx950): the fragments come from ds_read_b64_tr_b16.  Both operands sit in LDS as [pixel][channel] rows (the
+// NHWC order they are stored in) while an MFMA fragment is eight consecutive PIXELS of one channel - the k-strided case the
+// transposed read exists for: per 16-lane group, lane i hands in the address of 4 contiguous channels of pixel row i / 4 and gets
+// back 4 consecutive pixels of channel column (lane & 15).  Two such reads build a fragment (pixels 8 kk .. 8 kk + 7 of channel
+// lane & 31) where the TR = 0 form issues eight 2-byte reads and four pack operations.  Rows are padded by 64 bytes so that the
+// four rows a half-wave touches fall on different banks (pitch 320 B: 80 r mod 64 = 0, 16, 32, 48 dwords; 192 B: 0, 48, 32, 16).
+typedef short wg_v4s __attribute__((ext_vector_type(4)));
+
+template <int TCO, int TCI, int F16, int TR = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_tile_h16_kernel(const unsigned short* __restrict__ X, long long xp,
                                                                   const unsigned short* __restrict__ DY, long long dyp, float* OUT,
                                                                   int n, int h, int w, int cin, int cout, int ks, int stride, int pad,
@@ -709,8 +717,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_h16_kernel(const unsigned
   constexpr int MT = TCO / 64, NT = TCI / 64;     // 32x32 blocks per wave (2 x 2 waves)
   constexpr int YL = TCO / 64, XL = TCI / 64;     // 16-byte loads per lane and stage: 32 px x T/8 octets over 256 lanes
   constexpr int YO = TCO / 8, XO = TCI / 8;       // octets per pixel row
-  __shared__ __attribute__((aligned(16))) unsigned short Ys[2][SP][TCO];
-  __shared__ __attribute__((aligned(16))) unsigned short Xs[2][SP][TCI];
+  constexpr int PY = TCO + (TR ? 32 : 0), PX = TCI + (TR ? 32 : 0);   // LDS row pitches (elements)
+  __shared__ __attribute__((aligned(16))) unsigned short Ys[2][SP][PY];
+  __shared__ __attribute__((aligned(16))) unsigned short Xs[2][SP][PX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tap = blockIdx.z / splits, split = blockIdx.z - tap * splits;
@@ -735,6 +744,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_h16_kernel(const unsigned
     f_ox[v] = rem - f_oy[v] * wo;
   }
   uint4 ry[YL], rx[XL];
+  // (two register sets with the loads issued two stages ahead: measured slower, 47 -> 58 us on the 128 x 128 3x3 layers)
   auto fetch = [&](int p0) {
 #pragma unroll
     for (int v = 0; v < YL; ++v) {
@@ -791,6 +801,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_h16_kernel(const unsigned
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       v8 a[MT], b[NT];
+      if constexpr (TR) {
+        using lds_v4 = __attribute__((address_space(3))) wg_v4s;
+        const int row = 16 * s + 8 * kk + ((lane & 15) >> 2);           // + 4 for the fragment's second half
+        const int col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);        // within the 32-channel block
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const unsigned short* q = &Ys[buf][row][wr * (TCO / 2) + 32 * i + col];
+          const wg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)q);
+          const wg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(q + 4 * PY));
+          a[i] = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const unsigned short* q = &Xs[buf][row][wc * (TCI / 2) + 32 * j + col];
+          const wg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)q);
+          const wg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(q + 4 * PX));
+          b[j] = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         unsigned wd[4];
@@ -808,6 +837,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_h16_kernel(const unsigned
           wd[q] = (unsigned)Xs[buf][16 * s + 8 * kk + 2 * q][b_base + 32 * j] |
                   ((unsigned)Xs[buf][16 * s + 8 * kk + 2 * q + 1][b_base + 32 * j] << 16);
         b[j] = __builtin_bit_cast(v8, make_uint4(wd[0], wd[1], wd[2], wd[3]));
+      }
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -1814,6 +1844,24 @@ static int wgrad_splits(long long P, int cin, int cout, int ks) {
   return (int)s;
 }
 
+// me_conv_wgrad_h16: tile and pixel-slice count.  Measured on the Darknet-53 shapes at batch 8 (tools/wgrad_bench.py 8 bf16 under
+// MILLIEYE_WGRAD_WGS, profiles/r05_wgrad16_wgs_sweep.txt): the 128 x 128 tiles are fastest at ~430 - 580 workgroups (two per CU: the
+// slabs a slice writes and the sum re-reads are a third of the pass), the 64 x 64 tiles at ~1000.
+static bool wgrad_h16_big(int cin, int cout) { return cin >= 128 && cout >= 128 && cin % 128 == 0 && cout % 128 == 0; }
+
+static int wgrad_splits_h16(long long P, int cin, int cout, int ks) {
+  const int t = wgrad_h16_big(cin, cout) ? 128 : 64;
+  const long long tiles = (long long)((cin + t - 1) / t) * ((cout + t - 1) / t) * ks * ks;
+  static const int env = getenv("MILLIEYE_WGRAD16_WGS") ? atoi(getenv("MILLIEYE_WGRAD16_WGS")) : 0;
+  const int target = env > 0 ? env : (t == 128 ? 512 : 1024);
+  long long s = (target + tiles - 1) / tiles;
+  const long long max_s = (P + wgrad_min_px() - 1) / wgrad_min_px();
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
 static bool stem_wgrad_shape(int cin, int cout, int ksize) { return cin == 3 && ksize == 3 && cout % 4 == 0; }
 
 extern "C++" {
@@ -1827,7 +1875,9 @@ int launch(const float* x, long long xp, const float* dy, long long dyp, float* 
 
 int64_t me_conv_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize) {
   if (stem_wgrad_shape(cin, cout, ksize)) return (int64_t)SW_BLOCKS * cout * 27 * (int64_t)sizeof(float);
-  const int s = wgrad_splits((long long)n * ho * wo, cin, cout, ksize);
+  int s = wgrad_splits((long long)n * ho * wo, cin, cout, ksize);
+  const int s16 = wgrad_splits_h16((long long)n * ho * wo, cin, cout, ksize);   // (the 16-bit form slices by its own tiles)
+  if (s16 > s) s = s16;
   int64_t need = s > 1 ? (int64_t)s * cout * ksize * ksize * cin * (int64_t)sizeof(float) : 0;
   if (ksize == 3) {  // the nine-tap kernel (stride 1: the input map is the output map) always goes through slabs
     const int s9 = me_wg9::splits(n, ho, wo, cin, cout, nullptr);
@@ -1982,8 +2032,11 @@ int me_conv_wgrad_h16(const void* x_, int64_t x_pitch, const void* dy_, int64_t 
   const long long P = (long long)n * ho * wo;
   ME_REQUIRE(P < (1ll << 31), ME_E_TOOBIG, "me_conv_wgrad_h16: too many output pixels");
   const long long count = (long long)cout * ksize * ksize * cin;
-  int splits = wgrad_splits(P, cin, cout, ksize);
-  if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * count * (int64_t)sizeof(float))) splits = 1;
+  int splits = wgrad_splits_h16(P, cin, cout, ksize);
+  if (splits > 1) {   // as many pixel slices as the workspace holds slabs for
+    const long long fit = workspace ? workspace_bytes / (count * (int64_t)sizeof(float)) : 0;
+    if (fit < splits) splits = fit < 1 ? 1 : (int)fit;
+  }
   ME_REQUIRE(!oihw || ksize == 1 || (workspace && workspace_bytes >= count * (int64_t)sizeof(float)), ME_E_BADARG,
              "me_conv_wgrad_h16: the OIHW form needs a workspace of at least one slab (%lld bytes)", count * 4ll);
   int per = (int)((P + splits - 1) / splits);
@@ -1991,19 +2044,28 @@ int me_conv_wgrad_h16(const void* x_, int64_t x_pitch, const void* dy_, int64_t 
   ME_REQUIRE((long long)ksize * ksize * splits < 65536, ME_E_TOOBIG, "me_conv_wgrad_h16: grid too large");
   const bool via_ws = splits > 1 || (oihw && ksize > 1);
   float* out = via_ws ? reinterpret_cast<float*>(workspace) : dw;
-  const bool big = cin >= 128 && cout >= 128 && cin % 128 == 0 && cout % 128 == 0;   // 128 x 128: half the LDS reads per product
+  const bool big = wgrad_h16_big(cin, cout);   // 128 x 128: half the LDS reads per product
   const int tco = big ? 128 : 64, tci = big ? 128 : 64;
   const dim3 grid((cin + tci - 1) / tci, (cout + tco - 1) / tco, ksize * ksize * splits);
-#define ME_WG16(A, B, F)                                                                                                   \
-  hipLaunchKernelGGL((conv_wgrad_tile_h16_kernel<A, B, F>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,          \
+  static const int tr_env = getenv("MILLIEYE_WGRAD16_TR") ? atoi(getenv("MILLIEYE_WGRAD16_TR")) : 1;  // (A/B: 0 = 2-byte LDS reads)
+#define ME_WG16(A, B, F, T)                                                                                                \
+  hipLaunchKernelGGL((conv_wgrad_tile_h16_kernel<A, B, F, T>), grid, dim3(256), 0, stream, x, (long long)x_pitch, dy,       \
                      (long long)dy_pitch, out, n, h, w, cin, cout, ksize, stride, pad, ho, wo, splits, per)
+#define ME_WG16_T(A, B, F)     \
+  do {                         \
+    if (tr_env)                \
+      ME_WG16(A, B, F, 1);     \
+    else                       \
+      ME_WG16(A, B, F, 0);     \
+  } while (0)
   if (big) {
-    if (half_type) ME_WG16(128, 128, 1);
-    else ME_WG16(128, 128, 0);
+    if (half_type) ME_WG16_T(128, 128, 1);
+    else ME_WG16_T(128, 128, 0);
   } else {
-    if (half_type) ME_WG16(64, 64, 1);
-    else ME_WG16(64, 64, 0);
+    if (half_type) ME_WG16_T(64, 64, 1);
+    else ME_WG16_T(64, 64, 0);
   }
+#undef ME_WG16_T
 #undef ME_WG16
   int rc = me::check_launch("conv_wgrad_tile_h16_kernel");
   if (rc || !via_ws) return rc;
