@@ -149,9 +149,7 @@ class GraphedDetectorStep:
             with torch.cuda.graph(graph, stream=stream):
                 self.loss, self.results, grads, self._held = self._losses_and_backward()
         torch.cuda.current_stream(dev).wait_stream(stream)
-        missing = [k for k in self.names if k not in grads]
-        self.static_grads = [grads.get(k) for k in self.names]
-        self._missing = missing
+        self.static_grads = [grads.get(k) for k in self.names]   # (None: a parameter the backward produces no gradient for)
         self.graph = graph
         self.bad.zero_()
         self._key = self._signature(x)
