@@ -146,7 +146,9 @@ class GraphedDetectorStep:
                 if d["type"] == "convolutional":
                     eng._conv_weights(i)._stamp = None
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            # thread_local: only THIS thread's calls are checked against the capture - a process group's watchdog thread polls
+            # events of its own streams while a rank captures (the default "global" mode would fail the capture on that)
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 self.loss, self.results, grads, self._held = self._losses_and_backward()
         torch.cuda.current_stream(dev).wait_stream(stream)
         self.static_grads = [grads.get(k) for k in self.names]   # (None: a parameter the backward produces no gradient for)

@@ -410,7 +410,11 @@ def test_bench_two_ranks_inference_and_detector_training(hip_lib):
     assert out["n_gpus"] == 2 and out["dtype"] == "bf16" and out["config"]["grad_chunks"] >= 4
     assert out["config"]["grad_bucket_bytes"] > 240e6 and "bf16 activations and activation gradients" in out["config"]["workload"]
     assert out["config"]["loss_last_step"] == out["config"]["loss_last_step"] and out["value"] > 0
-    # the same step replayed from one captured hipGraph per rank (detector_graph.py): the gradients leave in one bucket after the replay
+
+
+def test_bench_two_ranks_captured_detector_step(hip_lib):
+    """The mixed-precision detector step replayed from one captured hipGraph per rank (detector_graph.py) through the N = 2 flow
+    of bench.py: the gradients leave in one bucket after the replay."""
     out = _bench2(["--workload", "detector_train", "--dtype", "bf16", "--cfg", "yolov3", "--size", "64", "--batch", "2", "--graph"])
     assert out["n_gpus"] == 2 and out["config"]["captured_graph"] is True and out["config"]["grad_bucket_bytes"] > 240e6
     assert "one captured hipGraph" in out["config"]["workload"] and "one bucket after the replay" in out["config"]["workload"]
