@@ -405,6 +405,10 @@ int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t 
  * backward (millieye_amd/detector_train16.py; autograd semantics of yolov3/models.py:22-41,181-267).
  * workspace: me_affine_bwd_h16_workspace_bytes(rows, channels). */
 int64_t me_affine_bwd_h16_workspace_bytes(int32_t rows, int32_t channels);
+/* (ABI 11) me_affine_act_bwd_h16 with dshift == dgamma == NULL writes dc and leaves one row of partial sums per row chunk in
+ * `workspace`; me_affine_bwd_h16_sums adds them in chunk order (the same sums, the same bits) - on any stream that is ordered
+ * behind the first call: the detector backward runs it beside the data gradients (millieye_amd/detector_train16.py). */
+int me_affine_bwd_h16_sums(const void* workspace, int32_t rows, int32_t channels, float* dshift, float* dgamma, void* stream);
 int me_affine_act_bwd_h16(const void* y, int64_t ldy, const void* dy, int64_t lddy, int32_t rows, int32_t channels,
                           const float* scale, const float* gamma, const float* beta, int32_t act, void* dc, int64_t lddc,
                           float* dshift, float* dgamma, void* workspace, int32_t half_type, void* stream);

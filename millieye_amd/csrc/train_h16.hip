@@ -167,9 +167,24 @@ int me_affine_act_bwd_h16(const void* y, int64_t ldy, const void* dy, int64_t ld
   else
     hipLaunchKernelGGL(affine_bwd_partial_h16_kernel<0>, grid, dim3(256), 0, stream, yy, (long long)ldy, gg, (long long)lddy, rows,
                        channels, gamma, beta, act, p0, p1, chunks, scale, dd, (long long)lddc);
+  // dshift == dgamma == NULL: the caller adds the partial rows later (me_affine_bwd_h16_sums, possibly on another stream - the
+  // detector backward's main stream only needs dc to go on)
+  if (dshift || dgamma)
+    hipLaunchKernelGGL(affine_bwd_reduce_h16_kernel, dim3((channels + 63) / 64), dim3(1024), 0, stream, p0, p1, channels, chunks,
+                       dshift, dgamma);
+  return me::check_launch("affine_act_bwd_h16");
+}
+
+int me_affine_bwd_h16_sums(const void* workspace, int32_t rows, int32_t channels, float* dshift, float* dgamma, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(workspace && (dshift || dgamma), ME_E_NULLPTR, "me_affine_bwd_h16_sums: null pointer");
+  ME_REQUIRE(rows > 0 && channels > 0 && channels % 8 == 0, ME_E_BADARG, "me_affine_bwd_h16_sums: bad dimensions");
+  const int chunks = chunks_of(rows);
+  const float* p0 = reinterpret_cast<const float*>(workspace);
+  const float* p1 = p0 + (long long)chunks * channels;
   hipLaunchKernelGGL(affine_bwd_reduce_h16_kernel, dim3((channels + 63) / 64), dim3(1024), 0, stream, p0, p1, channels, chunks,
                      dshift, dgamma);
-  return me::check_launch("affine_act_bwd_h16");
+  return me::check_launch("affine_bwd_h16_sums");
 }
 
 }  // extern "C"

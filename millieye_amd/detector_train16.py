@@ -34,6 +34,7 @@ from .detector_train import (_PARITY_IDX, _State, _const_vectors, _conv_flops, _
 _HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 _AUTO16 = {}
 _DIRECT = os.environ.get("MILLIEYE_WGRAD16_DIRECT", "1") != "0"   # (A/B: 0 = the weight gradient under torch.cuda.stream(side))
+_SUMS_SIDE = os.environ.get("MILLIEYE_AFFINE_SUMS_SIDE", "1") != "0"   # (A/B: 0 = the per-channel sums' second launch on the main stream)
 _WGRAD16 = os.environ.get("MILLIEYE_WGRAD16", "1") != "0"   # (A/B: 0 = weight gradients by the fp32 kernels on fp32 copies)
 
 
@@ -244,6 +245,7 @@ class DetectorTrainer16:
         side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
         side_ws = self.m.__dict__.setdefault("_wgrad16_ws", [None])   # slab scratch of the side stream, kept from step to step
         aff_ws = self.m.__dict__.setdefault("_affine16_ws", [None])
+        aff_layer_ws = self.m.__dict__.setdefault("_affine16_layer_ws", {})
         sp = hip.stream_ptr()   # (the main stream's handle, once: this backward never switches torch's current stream on its hot path)
         stream = lambda: sp  # noqa: E731
         for i in reversed(range(L)):
@@ -278,30 +280,38 @@ class DetectorTrainer16:
                                                         dc32.data_ptr(), cout, dshift.data_ptr(), _ptr(dgamma), ws.data_ptr(),
                                                         stream()), "me_affine_act_bwd_f32")
                     dc = None
+                    sums_ws = None
                 else:
                     if dy.dtype != half or not dy.is_contiguous():
                         dy = dy.to(half).contiguous()
                     dc = dy if dy_owned else torch.empty_like(y)
                     need_a = int(lib.me_affine_bwd_h16_workspace_bytes(rows, cout))
-                    if aff_ws[0] is None or aff_ws[0].numel() < need_a:   # one partial-sum scratch for the whole backward (stream-ordered)
-                        aff_ws[0] = torch.empty(max(need_a, 8 << 20), dtype=torch.uint8, device=dev)
-                    ws = aff_ws[0]
+                    # the second level of the per-channel sums (d gamma / d beta) is not on the data path: when this layer's weight
+                    # gradient goes to the side stream anyway, the sums go with it (me_affine_bwd_h16_sums) and the main stream is
+                    # one launch per layer shorter; the partial rows then need a scratch of the layer's own until the side stream
+                    # has read them (kept on the model: the same addresses every step)
+                    defer_sums = side is not None and _DIRECT and _SUMS_SIDE and _WGRAD16 and i > 0 and outs[i - 1].dtype == half \
+                        and outs[i - 1].shape[-1] % 8 == 0 and cout % 8 == 0
+                    if defer_sums:
+                        ws = aff_layer_ws.get(i)
+                        if ws is None or ws.numel() < need_a:
+                            ws = aff_layer_ws[i] = torch.empty(need_a, dtype=torch.uint8, device=dev)
+                    else:
+                        if aff_ws[0] is None or aff_ws[0].numel() < need_a:   # one partial-sum scratch for the other layers (stream-ordered)
+                            aff_ws[0] = torch.empty(max(need_a, 8 << 20), dtype=torch.uint8, device=dev)
+                        ws = aff_ws[0]
                     hip.check(lib.me_affine_act_bwd_h16(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
                                                         cw.scale.data_ptr() if bn is not None else None, _ptr(gam), _ptr(bet), act,
-                                                        dc.data_ptr(), cout, dshift.data_ptr(), _ptr(dgamma), ws.data_ptr(), ht,
-                                                        stream()), "me_affine_act_bwd_h16")
+                                                        dc.data_ptr(), cout, None if defer_sums else dshift.data_ptr(),
+                                                        None if defer_sums else _ptr(dgamma), ws.data_ptr(), ht, stream()),
+                              "me_affine_act_bwd_h16")
+                    sums_ws = ws if defer_sums else None
                     dc32 = None
                 if bn is not None:
                     grads[f"module_list.{i}.batch_norm_{i}.weight"] = dgamma
                     grads[f"module_list.{i}.batch_norm_{i}.bias"] = dshift
                 else:
                     grads[f"module_list.{i}.conv_{i}.bias"] = dshift
-                if reducer is not None:
-                    if bn is not None:
-                        reducer.push(f"module_list.{i}.batch_norm_{i}.weight", dgamma, main)
-                        reducer.push(f"module_list.{i}.batch_norm_{i}.bias", dshift, main)
-                    else:
-                        reducer.push(f"module_list.{i}.conv_{i}.bias", dshift, main)
                 # weight gradient: the fp32 matrix kernels on fp32 copies (products of 16-bit values are exact in fp32)
                 if i == 0:
                     if x_nhwc is None:
@@ -324,6 +334,9 @@ class DetectorTrainer16:
                     # context manager, two current-stream lookups and a per-stream workspace lookup: ~20 us of host time per layer of
                     # a step whose host is the slower side), the slab scratch is this backward's own buffer on that stream
                     side.wait_stream(main)
+                    if sums_ws is not None:
+                        hip.check(lib.me_affine_bwd_h16_sums(sums_ws.data_ptr(), rows, cout, dshift.data_ptr(), _ptr(dgamma), side_ptr),
+                                  "me_affine_bwd_h16_sums")
                     dwt = torch.empty((cout, cin, k, k), device=dev, dtype=torch.float32)
                     need = max(int(lib.me_conv_wgrad_workspace_bytes(n, ho, wo, cin, cout, k)), 4 * cout * cin * k * k)
                     if side_ws[0] is None or side_ws[0].numel() < need + 256:
@@ -345,6 +358,12 @@ class DetectorTrainer16:
                     with _timed("wgrad", 2.0 * rows * cout * k * k * cin):
                         grads[f"module_list.{i}.conv_{i}.weight"] = wgrad()
                 if reducer is not None:
+                    vec_stream = side if sums_ws is not None else main   # (where d gamma / d beta were finished)
+                    if bn is not None:
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.weight", dgamma, vec_stream)
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.bias", dshift, vec_stream)
+                    else:
+                        reducer.push(f"module_list.{i}.conv_{i}.bias", dshift, vec_stream)
                     reducer.push(f"module_list.{i}.conv_{i}.weight", grads[f"module_list.{i}.conv_{i}.weight"],
                                  side if side is not None else main)
                 dout[i] = None

@@ -53,6 +53,13 @@ def test_affine_act_bwd_h16_vs_f32_kernel(hip_lib, half, rows, c, act, bn):
                                         p(bet), act, g_inplace.data_ptr(), c, ds16.data_ptr(), p(dg16), ws16.data_ptr(),
                                         hip.HALF_TYPES[dt], hip.stream_ptr()), "h16 in place")
     assert torch.equal(g_inplace, dc16)
+    # the two halves apart (the detector backward runs the second one on its side stream): dc first, the sums later - the same bits
+    dc_t, ds_t = torch.full((rows, c), 7.0, device=dev, dtype=dt), torch.full((c,), 3.0, device=dev)
+    dg_t = torch.full((c,), 3.0, device=dev) if bn else None
+    hip.check(lib.me_affine_act_bwd_h16(y16.data_ptr(), c, g16.data_ptr(), c, rows, c, scale.data_ptr() if bn else None, p(gam), p(bet),
+                                        act, dc_t.data_ptr(), c, None, None, ws16.data_ptr(), hip.HALF_TYPES[dt], hip.stream_ptr()), "h16 dc only")
+    hip.check(lib.me_affine_bwd_h16_sums(ws16.data_ptr(), rows, c, ds_t.data_ptr(), p(dg_t), hip.stream_ptr()), "h16 sums")
+    assert torch.equal(dc_t, dc16) and torch.equal(ds_t, ds16) and (not bn or torch.equal(dg_t, dg16))
     with pytest.raises(hip.MeError):   # channels % 8
         lib_rc = lib.me_affine_act_bwd_h16(y16.data_ptr(), c, g16.data_ptr(), c, rows, c - 4, None, None, None, act, dc16.data_ptr(), c,
                                            ds16.data_ptr(), None, ws16.data_ptr(), hip.HALF_TYPES[dt], hip.stream_ptr())
