@@ -399,6 +399,10 @@ int64_t me_affine_bwd_workspace_bytes(int32_t rows, int32_t channels);
 int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
                           const float* scale, const float* gamma, const float* beta, int32_t act, float* dc, int64_t lddc,
                           float* dshift, float* dgamma, void* workspace, void* stream);
+/* (ABI 11) me_affine_act_bwd_f32 with dshift == dgamma == NULL writes dc and leaves one row of partial sums per row chunk in
+ * `workspace`; me_affine_bwd_sums_f32 adds them in chunk order (the same sums, the same bits) on any stream ordered behind the
+ * first call.  vec4: non-zero when the first call's operands were 16-byte aligned with channels and pitches % 4 == 0. */
+int me_affine_bwd_sums_f32(void* workspace, int32_t rows, int32_t channels, int32_t vec4, float* dshift, float* dgamma, void* stream);
 /* me_affine_act_bwd_h16 (ABI 10): the same pass in a 16-bit storage mode (half_type 0 = bfloat16, 1 = IEEE half): y, dy and dc are
  * 16-bit [rows, channels] (channels and pitches % 8 == 0, 16-byte aligned), dc is rounded once (RNE); scale / gamma / beta and the
  * sums dshift / dgamma stay fp32 (double accumulation, fixed order).  The activation-gradient half of the mixed-precision detector

@@ -1704,9 +1704,25 @@ int me_affine_act_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t 
     hipLaunchKernelGGL(affine_bwd_partial_kernel, dim3((channels + 63) / 64, chunks), dim3(256), 0, stream, y,
                        (long long)ldy, dy, (long long)lddy, rows, channels, gamma, beta, act, p0, p1, chunks, scale, dc,
                        (long long)lddc);
+  // dshift == dgamma == NULL: the caller adds the partial rows later (me_affine_bwd_sums_f32, possibly on another stream)
+  if (dshift || dgamma)
+    hipLaunchKernelGGL(affine_bwd_reduce_kernel, dim3((channels + 63) / 64), dim3(1024), 0, stream, p0, p1, channels, chunks,
+                       dshift, dgamma);
+  return me::check_launch("affine_act_bwd");
+}
+
+int me_affine_bwd_sums_f32(void* workspace, int32_t rows, int32_t channels, int32_t vec4, float* dshift, float* dgamma, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ME_REQUIRE(workspace && (dshift || dgamma), ME_E_NULLPTR, "me_affine_bwd_sums_f32: null pointer");
+  ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_affine_bwd_sums_f32: bad dimensions");
+  static const int rows_env = getenv("MILLIEYE_AFFINE_ROWS") ? atoi(getenv("MILLIEYE_AFFINE_ROWS")) : 0;
+  int chunks, per;
+  affine_plan(rows, channels, vec4 != 0 && rows_env != 0, &chunks, &per);   // the first call's plan
+  float* p0 = reinterpret_cast<float*>(workspace);
+  float* p1 = p0 + (long long)chunks * channels;
   hipLaunchKernelGGL(affine_bwd_reduce_kernel, dim3((channels + 63) / 64), dim3(1024), 0, stream, p0, p1, channels, chunks,
                      dshift, dgamma);
-  return me::check_launch("affine_act_bwd");
+  return me::check_launch("affine_bwd_sums");
 }
 
 int me_upsample2_bwd_f32(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t n, int32_t h, int32_t w,

@@ -54,6 +54,7 @@ class _State:
 # forward / data-gradient / weight-gradient convolution is bracketed by HIP events on the launch stream and the weight
 # gradients stay on that stream (a kernel's duration is then its own); outside it the brackets cost nothing.
 _TIMING = [None]
+_SUMS_SIDE = os.environ.get("MILLIEYE_AFFINE_SUMS_SIDE", "1") != "0"   # (A/B: 0 = the per-channel sums' second launch on the main stream)
 
 
 class _timed:
@@ -211,6 +212,7 @@ class DetectorTrainer:
         x_nhwc = None
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if os.environ.get("MILLIEYE_WGRAD_STREAM", "1") != "0" and _TIMING[0] is None else None
+        aff_layer_ws = self.m.__dict__.setdefault("_affine_layer_ws", {})
         for i in reversed(range(L)):
             d = defs[i]
             t = d["type"]
@@ -233,6 +235,7 @@ class DetectorTrainer:
                 rows = n * ho * wo
                 # eval-mode BatchNorm: dc = dy * act'(y) * scale is element-wise - in place when this slot owns its gradient
                 dc = dy if (dy_owned and i not in st.bn_state) else torch.empty_like(y)
+                sums_job = None
                 if i in st.bn_state:  # train-mode BatchNorm: gradient through the batch statistics
                     from .train_path import _bn_bwd
                     c_raw, st_bn = st.bn_state[i]
@@ -242,24 +245,31 @@ class DetectorTrainer:
                 else:
                     dshift = torch.empty(cout, device=dev)
                     dgamma = torch.empty(cout, device=dev) if bn is not None else None
-                    ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
+                    need_a = int(lib.me_affine_bwd_workspace_bytes(rows, cout))
+                    # d gamma / d beta are not on the data path: with the weight gradient on the side stream the second level of
+                    # their sums goes there too (me_affine_bwd_sums_f32) and the main stream is one launch per layer shorter; the
+                    # partial rows then live in a scratch of the layer's own (kept on the model) until the side stream has read them
+                    defer_sums = side is not None and _SUMS_SIDE
+                    if defer_sums:
+                        ws = aff_layer_ws.get(i)
+                        if ws is None or ws.numel() < need_a:
+                            ws = aff_layer_ws[i] = torch.empty(max(need_a, 16), dtype=torch.uint8, device=dev)
+                        sums_job = (ws, rows, cout, int(cout % 4 == 0), dshift, dgamma)
+                    else:
+                        ws = torch.empty(need_a, dtype=torch.uint8, device=dev)
                     gam = bn.weight.detach() if bn is not None else None
                     bet = bn.bias.detach() if bn is not None else None
                     hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,
                                                         cw.scale.data_ptr() if bn is not None else None, _ptr(gam),
-                                                        _ptr(bet), act, dc.data_ptr(), cout, dshift.data_ptr(),
-                                                        _ptr(dgamma), ws.data_ptr(), stream()), "me_affine_act_bwd_f32")
+                                                        _ptr(bet), act, dc.data_ptr(), cout,
+                                                        None if defer_sums else dshift.data_ptr(),
+                                                        None if defer_sums else _ptr(dgamma), ws.data_ptr(), stream()),
+                              "me_affine_act_bwd_f32")
                 if bn is not None:
                     grads[f"module_list.{i}.batch_norm_{i}.weight"] = dgamma
                     grads[f"module_list.{i}.batch_norm_{i}.bias"] = dshift
                 else:
                     grads[f"module_list.{i}.conv_{i}.bias"] = dshift
-                if reducer is not None:
-                    if bn is not None:
-                        reducer.push(f"module_list.{i}.batch_norm_{i}.weight", dgamma, main)
-                        reducer.push(f"module_list.{i}.batch_norm_{i}.bias", dshift, main)
-                    else:
-                        reducer.push(f"module_list.{i}.conv_{i}.bias", dshift, main)
                 # weight gradient, written in the parameter's own OIHW layout by the slab reduction
                 if i == 0:
                     if x_nhwc is None:
@@ -273,6 +283,10 @@ class DetectorTrainer:
                     # same layer (both read dc), so the tails / slab sums of one fill the other's idle CUs
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
+                        if sums_job is not None:
+                            ws_j, rows_j, c_j, v4_j, ds_j, dg_j = sums_job
+                            hip.check(lib.me_affine_bwd_sums_f32(ws_j.data_ptr(), rows_j, c_j, v4_j, ds_j.data_ptr(), _ptr(dg_j),
+                                                                 hip.stream_ptr()), "me_affine_bwd_sums_f32")
                         grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
                     dc.record_stream(side)
                     xin.record_stream(side)
@@ -280,6 +294,12 @@ class DetectorTrainer:
                     with _timed("wgrad", 2.0 * rows * cout * k * k * cin):
                         grads[f"module_list.{i}.conv_{i}.weight"] = hip.conv_wgrad(xin, dc, k, s, pad, oihw=True)
                 if reducer is not None:
+                    vec_stream = side if sums_job is not None else main   # (where d gamma / d beta were finished)
+                    if bn is not None:
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.weight", dgamma, vec_stream)
+                        reducer.push(f"module_list.{i}.batch_norm_{i}.bias", dshift, vec_stream)
+                    else:
+                        reducer.push(f"module_list.{i}.conv_{i}.bias", dshift, vec_stream)
                     reducer.push(f"module_list.{i}.conv_{i}.weight", grads[f"module_list.{i}.conv_{i}.weight"],
                                  side if side is not None else main)
                 dout[i] = None

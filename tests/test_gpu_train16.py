@@ -60,6 +60,12 @@ def test_affine_act_bwd_h16_vs_f32_kernel(hip_lib, half, rows, c, act, bn):
                                         act, dc_t.data_ptr(), c, None, None, ws16.data_ptr(), hip.HALF_TYPES[dt], hip.stream_ptr()), "h16 dc only")
     hip.check(lib.me_affine_bwd_h16_sums(ws16.data_ptr(), rows, c, ds_t.data_ptr(), p(dg_t), hip.stream_ptr()), "h16 sums")
     assert torch.equal(dc_t, dc16) and torch.equal(ds_t, ds16) and (not bn or torch.equal(dg_t, dg16))
+    dc_f, ds_f = torch.full((rows, c), 7.0, device=dev), torch.full((c,), 3.0, device=dev)
+    dg_f = torch.full((c,), 3.0, device=dev) if bn else None
+    hip.check(lib.me_affine_act_bwd_f32(y32.data_ptr(), c, g32.data_ptr(), c, rows, c, scale.data_ptr() if bn else None, p(gam), p(bet),
+                                        act, dc_f.data_ptr(), c, None, None, ws.data_ptr(), hip.stream_ptr()), "f32 dc only")
+    hip.check(lib.me_affine_bwd_sums_f32(ws.data_ptr(), rows, c, int(c % 4 == 0), ds_f.data_ptr(), p(dg_f), hip.stream_ptr()), "f32 sums")
+    assert torch.equal(dc_f, dc32) and torch.equal(ds_f, ds32) and (not bn or torch.equal(dg_f, dg32))
     with pytest.raises(hip.MeError):   # channels % 8
         lib_rc = lib.me_affine_act_bwd_h16(y16.data_ptr(), c, g16.data_ptr(), c, rows, c - 4, None, None, None, act, dc16.data_ptr(), c,
                                            ds16.data_ptr(), None, ws16.data_ptr(), hip.HALF_TYPES[dt], hip.stream_ptr())
