@@ -146,6 +146,10 @@ def test_product_path_has_no_cpu_fallback():
     m = ph.make_darknet("yolov3-tiny-12")
     with pytest.raises(hip.MeError):
         m(ph.frames("cpu", 1, 96))  # CPU tensor -> loud error, never the oracle
+    from millieye_amd.detector_graph import GraphedDetectorStep
+    import torch
+    with pytest.raises(hip.MeError):   # the captured training step: the same rule
+        GraphedDetectorStep(m.eval())(ph.frames("cpu", 1, 96), torch.tensor([[0, 1, 0.5, 0.5, 0.2, 0.2]]))
     src = ""
     for root, _, files in os.walk(os.path.join(ROOT, "millieye_amd")):
         for f in files:

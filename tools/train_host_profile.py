@@ -1,4 +1,4 @@
-"""Where does the host time of a stage-3 training step go?  (tools; GPU box)  python tools/train_host_profile.py"""
+"""Where does the host time of a stage-3 training step go?  (tools; GPU box)  python tools/train_host_profile.py [f32|bf16|f16]"""
 import cProfile, os, pstats, random, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g; g.build()
@@ -10,6 +10,8 @@ batch = 8
 net = Network(Darknet(cfgs.write_cfg("yolov3", "/tmp/thp_cfg")), 0.2).eval()
 synth.fill_network_(net, "bench/yolov3", cls0_bias=3.0, cls_bias=-4.0)
 net = net.cuda()
+if len(sys.argv) > 1 and sys.argv[1] != "f32":
+    net.base_detector.compute_dtype = sys.argv[1]
 x = torch.from_numpy(synth.uniform("bench/frames/0", (batch, 3, 416, 416))).cuda()
 maps_np, boxes_np = synth.radar_inputs("bench/radar/0", batch, 26, boxes_per_image=2)
 maps_d, boxes_d = torch.from_numpy(maps_np).cuda(), torch.from_numpy(boxes_np).cuda()
