@@ -33,6 +33,7 @@ from .detector_train import (_PARITY_IDX, _State, _const_vectors, _conv_flops, _
 
 _HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 _AUTO16 = {}
+_MORE_TILES = os.environ.get("MILLIEYE_TRAIN16_MORE_TILES", "1") != "0"   # (A/B: 0 = the round's first candidate list)
 _DIRECT = os.environ.get("MILLIEYE_WGRAD16_DIRECT", "1") != "0"   # (A/B: 0 = the weight gradient under torch.cuda.stream(side))
 _SUMS_SIDE = os.environ.get("MILLIEYE_AFFINE_SUMS_SIDE", "1") != "0"   # (A/B: 0 = the per-channel sums' second launch on the main stream)
 _WGRAD16 = os.environ.get("MILLIEYE_WGRAD16", "1") != "0"   # (A/B: 0 = weight gradients by the fp32 kernels on fp32 copies)
@@ -55,6 +56,14 @@ def conv16_auto(x, wgt, scale, shift, ksize, stride, pad, act, residual=None, y_
         cands = [(0, 0)] + [(t, sp) for t in ((1, 2, 3, 4, 11, 12, 13, 14) if cin % 64 == 0 else (1, 2, 3, 4)) for sp in (1, 2, 4)]
         if ksize == 3 and stride == 1 and pad == 1 and not y_f32 and cin % 32 == 0:
             cands += [(t, 1) for t in (221, 201, 431, 131, 121, 621)]
+        if _MORE_TILES and not y_f32:
+            # the streaming kernels of the inference plans (the library refuses the shapes they have no instance for): weights in
+            # registers for the pointwise layers without a residual (tile 50), for the 3x3 layers with <= 64 input channels (60)
+            if ksize == 1 and stride == 1 and residual is None:
+                cands.append((50, 1))
+            if ksize == 3 and cin <= 64:
+                cands.append((60, 1))
+            cands += [(15, sp) for sp in (1, 2)]   # 192 x 128
         best = (float("inf"), 0, 0)
         scratch = None
         torch.cuda.synchronize()
