@@ -498,6 +498,15 @@ typedef struct me_pack_desc {
   int32_t cout, cin, ksize;
   float eps;
   int32_t first_block, blocks_x;  /* filled by me_pack_conv_plan */
+  /* ABI 11: 16-bit copies written by the same launch (each NULL = not wanted): the values of ohwi / rot / parity rounded once
+   * (RNE) to bfloat16 (half_type 0) or IEEE half (1) - the weights of the mixed-precision detector step
+   * (millieye_amd/detector_train16.py), which then needs neither the fp32 rot / parity copies nor a conversion pass.  With
+   * ohwi16 set, ohwi may be NULL. */
+  void* ohwi16;
+  void* rot16;
+  void* parity16;
+  int32_t half_type;
+  int32_t reserved0;
 } me_pack_desc;
 int64_t me_pack_conv_plan(me_pack_desc* descs_host, int32_t count);
 int me_pack_conv_batch_f32(const me_pack_desc* descs_device, int32_t count, int64_t total_blocks, int32_t max_ksize,

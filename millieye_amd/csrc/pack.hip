@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "conv16_common.h"
 
 namespace {
 
@@ -54,10 +55,20 @@ __device__ __forceinline__ void pack_block(const PackArgs& a, int bx, int by, fl
   }
   __syncthreads();
   const int lane = t & 31, grp = t >> 5;  // 8 groups of 32 lanes
+  // (ABI 11) 16-bit copies beside (or instead of) the fp32 ones: the same element, rounded once
+  unsigned short* const ohwi16 = reinterpret_cast<unsigned short*>(a.ohwi16);
+  unsigned short* const rot16 = reinterpret_cast<unsigned short*>(a.rot16);
+  unsigned short* const parity16 = reinterpret_cast<unsigned short*>(a.parity16);
+  auto to16 = [&](float v) -> unsigned short { return a.half_type ? H16<1>::to(v) : H16<0>::to(v); };
   // ohwi[o][tap][c]: one (o, tap) row of nc floats per group step
   for (int r = grp; r < no * kk; r += 8) {
     const int o = r / kk, tap = r - o * kk;
-    if (lane < nc) a.ohwi[((long long)(o0 + o) * kk + tap) * a.cin + c0 + lane] = s_w[o * pitch + lane * kk + tap];
+    if (lane < nc) {
+      const float v = s_w[o * pitch + lane * kk + tap];
+      const long long at = ((long long)(o0 + o) * kk + tap) * a.cin + c0 + lane;
+      if (a.ohwi) a.ohwi[at] = v;
+      if (ohwi16) ohwi16[at] = to16(v);
+    }
   }
   if (a.tiled) {  // [tap][chunk][o][16]: cin % 16 == 0 -> nc is a multiple of 16; a group step = 2 o rows of 16 floats
     const int chunks = nc / 16;
@@ -71,10 +82,15 @@ __device__ __forceinline__ void pack_block(const PackArgs& a, int bx, int by, fl
             s_w[o * pitch + (ch * 16 + l) * kk + tap];
     }
   }
-  if (a.rot) {  // rot[c][kk - 1 - tap][o]: one (c, tap) row of no floats per group step
+  if (a.rot || rot16) {  // rot[c][kk - 1 - tap][o]: one (c, tap) row of no floats per group step
     for (int r = grp; r < nc * kk; r += 8) {
       const int c = r / kk, tap = r - c * kk;
-      if (lane < no) a.rot[((long long)(c0 + c) * kk + (kk - 1 - tap)) * a.cout + o0 + lane] = s_w[lane * pitch + c * kk + tap];
+      if (lane < no) {
+        const float v = s_w[lane * pitch + c * kk + tap];
+        const long long at = ((long long)(c0 + c) * kk + (kk - 1 - tap)) * a.cout + o0 + lane;
+        if (a.rot) a.rot[at] = v;
+        if (rot16) rot16[at] = to16(v);
+      }
     }
   }
   if (a.rot_tiled) {  // rott[kk - 1 - tap][o / 16][c][o % 16]: cout % 16 == 0 -> no is a multiple of 16; a group step = 2 c rows
@@ -89,14 +105,17 @@ __device__ __forceinline__ void pack_block(const PackArgs& a, int bx, int by, fl
             s_w[(och * 16 + l) * pitch + c * kk + tap];
     }
   }
-  if (a.parity && kk == 9) {  // parity[(cls * cin + c) * 4 + ij][o]: one (cls, ij, c) row of no floats per group step
+  if ((a.parity || parity16) && kk == 9) {  // parity[(cls * cin + c) * 4 + ij][o]: one (cls, ij, c) row of no floats per group step
     for (int r = grp; r < 16 * nc; r += 8) {
       const int c = r % nc, q = r / nc;  // q = cls * 4 + ij
       const int py = q >> 3, px = (q >> 2) & 1, i = (q >> 1) & 1, j = q & 1;
       const int ky = py ? (i ? 0 : 2) : (i ? -1 : 1), kx = px ? (j ? 0 : 2) : (j ? -1 : 1);
       const float v = (ky < 0 || kx < 0 || lane >= no) ? 0.f : s_w[lane * pitch + c * kk + ky * 3 + kx];
-      if (lane < no)
-        a.parity[(((long long)(q >> 2) * a.cin + c0 + c) * 4 + (q & 3)) * a.cout + o0 + lane] = v;
+      if (lane < no) {
+        const long long at = (((long long)(q >> 2) * a.cin + c0 + c) * 4 + (q & 3)) * a.cout + o0 + lane;
+        if (a.parity) a.parity[at] = v;
+        if (parity16) parity16[at] = to16(v);
+      }
     }
   }
   if (bx == 0 && t < no) {  // the fold, in double like ConvWeights.refresh did on the host side of torch
@@ -149,6 +168,7 @@ int me_pack_conv_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t ksi
   PackArgs a;
   a.w = w_oihw; a.bias = bias; a.gamma = gamma; a.beta = beta; a.mean = mean; a.var = var;
   a.ohwi = ohwi; a.tiled = tiled; a.rot = rot; a.rot_tiled = rot_tiled; a.scale = scale; a.shift = shift; a.parity = nullptr;
+  a.ohwi16 = a.rot16 = a.parity16 = nullptr; a.half_type = 0; a.reserved0 = 0;
   a.cout = cout; a.cin = cin; a.ksize = ksize; a.eps = eps; a.first_block = 0; a.blocks_x = (cin + PC - 1) / PC;
   const size_t lds = (size_t)PO * (PC * ksize * ksize + 1) * sizeof(float);
   ME_REQUIRE(lds <= 64 * 1024, ME_E_TOOBIG, "me_pack_conv_f32: filter too large");
@@ -163,7 +183,8 @@ int64_t me_pack_conv_plan(me_pack_desc* d, int32_t count) {
   long long blocks = 0;
   for (int i = 0; i < count; ++i) {
     me_pack_desc& a = d[i];
-    const bool ok = a.w && a.ohwi && a.scale && a.shift && a.cout > 0 && a.cin > 0 && a.ksize >= 1 &&
+    const bool ok = a.w && (a.ohwi || a.ohwi16) && a.scale && a.shift && a.cout > 0 && a.cin > 0 && a.ksize >= 1 &&
+                    (a.half_type == 0 || a.half_type == 1) && (!a.parity16 || a.ksize == 3) &&
                     (size_t)PO * (PC * a.ksize * a.ksize + 1) * sizeof(float) <= 64 * 1024 &&
                     (!a.gamma || (a.beta && a.mean && a.var)) && (!a.tiled || a.cin % 16 == 0) &&
                     (!a.rot_tiled || (a.cout % 16 == 0 && a.rot)) && (!a.parity || a.ksize == 3);

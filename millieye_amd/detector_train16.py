@@ -34,6 +34,7 @@ from .detector_train import (_PARITY_IDX, _State, _const_vectors, _conv_flops, _
 _HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 _AUTO16 = {}
 _MORE_TILES = os.environ.get("MILLIEYE_TRAIN16_MORE_TILES", "1") != "0"   # (A/B: 0 = the round's first candidate list)
+_PACK16 = os.environ.get("MILLIEYE_PACK16", "1") != "0"   # (A/B: 0 = fp32 pack + a conversion pass)
 _DIRECT = os.environ.get("MILLIEYE_WGRAD16_DIRECT", "1") != "0"   # (A/B: 0 = the weight gradient under torch.cuda.stream(side))
 _SUMS_SIDE = os.environ.get("MILLIEYE_AFFINE_SUMS_SIDE", "1") != "0"   # (A/B: 0 = the per-channel sums' second launch on the main stream)
 _WGRAD16 = os.environ.get("MILLIEYE_WGRAD16", "1") != "0"   # (A/B: 0 = weight gradients by the fp32 kernels on fp32 copies)
@@ -111,6 +112,7 @@ class _Weights16:
 
     def __init__(self):
         self.dst, self.key = {}, None
+        self.direct = False
 
     def refresh(self, eng, defs, half, dev):
         srcs, dsts = [], []
@@ -135,6 +137,62 @@ class _Weights16:
                 for dst, src in zip(dsts, srcs):
                     dst.copy_(src)
 
+    def pack_direct(self, eng, defs, half, dev):
+        """The packed fp32 parameters never exist in this form: ONE ``me_pack_conv_batch_f32`` launch reads the OIHW parameters and
+        writes the 16-bit OHWI / rotated / parity layouts (``me_pack_desc.ohwi16`` / ``rot16`` / ``parity16``, ABI 11), the folded
+        fp32 scale / shift of every block, and fp32 OHWI copies only where this step reads them (the stem's fp32 frames, the
+        detection convolutions' fp32 data gradient).  Against the fp32 pack + the conversion pass: 0.5 GB of traffic instead of 2 GB
+        at the head of every step, where nothing else runs.  Returns False when a block is not plain fp32 on ``dev`` (the caller
+        takes the two-pass path).  The engine's stamps are left alone: its fp32 copies are re-packed when something asks for them."""
+        import ctypes as C
+        cws, rows = [], []
+        for i, d in enumerate(defs):
+            if d["type"] != "convolutional":
+                continue
+            cw = eng._conv_weights(i)
+            s2 = int(d["size"]) == 3 and int(d["stride"]) == 2
+            cw.want_rot = i > 0 and not s2
+            cw.want_parity = i > 0 and s2
+            if cw.cin_pad or cw.cout_pad or cw._prepare_packed_f32(dev) is None:
+                return False
+            to_yolo = i + 1 < len(defs) and defs[i + 1]["type"] == "yolo"
+            cws.append((i, cw, to_yolo))
+        descs = (hip.PackDesc * len(cws))()
+        ht = hip.HALF_TYPES[half]
+        for dsc, (i, cw, to_yolo) in zip(descs, cws):
+            cw._pack_desc(dsc)
+            cout, cin, k, _ = cw.conv.weight.shape
+            fp32_too = cin <= 4 or to_yolo          # the stem (fp32 frames) and the detection convolutions (fp32 gradient)
+            dsc.tiled = dsc.rot = dsc.rot_tiled = dsc.parity = None
+            if not fp32_too:
+                dsc.ohwi = None
+
+            def slot(name, shape):
+                t = self.dst.get((i, name))
+                if t is None or tuple(t.shape) != tuple(shape) or t.dtype != half or t.device != dev:
+                    t = self.dst[(i, name)] = torch.empty(shape, device=dev, dtype=half)
+                return t.data_ptr()
+            dsc.ohwi16 = slot("wgt", (cout, k, k, cin)) if cin > 4 else None
+            dsc.rot16 = slot("rot", (cin, k, k, cout)) if cw.want_rot else None
+            dsc.parity16 = slot("parity", (4 * cin, 2, 2, cout)) if cw.want_parity and k == 3 else None
+            dsc.half_type = ht
+        key = bytes(descs)
+        cached = self.__dict__.get("_table")
+        if cached is None or cached[0] != key:
+            total = int(hip.lib().me_pack_conv_plan(descs, len(cws)))
+            if total <= 0:
+                raise hip.MeError("me_pack_conv_plan: " + hip.lib().me_last_error().decode("utf-8", "replace"))
+            table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+            cached = self._table = (key, table, total, max(int(d.ksize) for d in descs))
+        _, table, total, max_k = cached
+        hip.check(hip.lib().me_pack_conv_batch_f32(table.data_ptr(), len(cws), total, max_k, hip.stream_ptr()),
+                  "me_pack_conv_batch_f32")
+        for _i, cw, _y in cws:   # the fp32 copies of the engine were not (all) written: whoever wants them packs them again
+            cw._stamp = None
+            cw.parity_stamp = None
+        self.direct = True
+        return True
+
     def get(self, i, name):
         return self.dst.get((i, name))
 
@@ -157,13 +215,16 @@ class DetectorTrainer16:
         x = x.contiguous()
         defs = m.module_defs
         outs, raws = [], {}
-        eng.refresh_train_weights(x.device)
-        self.w16.refresh(eng, defs, half, x.device)
+        self.w16.direct = False
+        if not (_PACK16 and self.w16.pack_direct(eng, defs, half, x.device)):
+            eng.refresh_train_weights(x.device)
+            self.w16.refresh(eng, defs, half, x.device)
         for i, d in enumerate(defs):
             t = d["type"]
             if t == "convolutional":
                 cw = eng._conv_weights(i)
-                cw.refresh(x.device)
+                if not self.w16.direct:
+                    cw.refresh(x.device)
                 k, s = int(d["size"]), int(d["stride"])
                 act = hip.ACT_LEAKY if d["activation"] == "leaky" else hip.ACT_LINEAR
                 src = x if i == 0 else outs[i - 1]
@@ -404,7 +465,7 @@ class DetectorTrainer16:
                             contribute(i - 1, dx, True)
                     elif parity:
                         pw = self.w16.get(i, "parity")
-                        if pw is None or cw.parity_stamp != cw._stamp:
+                        if pw is None or (not self.w16.direct and cw.parity_stamp != cw._stamp):
                             pw = _parity_weights(cw.wgt).to(half)
                         o4, z4 = _const_vectors(4 * cin, dev)
                         dx4 = conv16_auto(dc, pw, o4, z4, 2, 1, 1, hip.ACT_LINEAR)

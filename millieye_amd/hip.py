@@ -126,6 +126,7 @@ class PackDesc(C.Structure):
         ("shift", C.c_void_p), ("parity", C.c_void_p),
         ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("eps", C.c_float),
         ("first_block", C.c_int32), ("blocks_x", C.c_int32),
+        ("ohwi16", C.c_void_p), ("rot16", C.c_void_p), ("parity16", C.c_void_p), ("half_type", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

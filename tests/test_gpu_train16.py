@@ -179,3 +179,48 @@ def test_16bit_training_refuses_train_mode_batchnorm(hip_lib):
     x = torch.from_numpy(synth.uniform("t16/bn/x", (1, 3, 64, 64))).cuda()
     with pytest.raises(NotImplementedError):
         model(x, torch.tensor([[0, 0, 0.5, 0.5, 0.2, 0.2]]))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_direct_16bit_weight_pack_equals_the_fp32_pack_rounded(hip_lib, dtype):
+    """me_pack_conv_batch_f32 with 16-bit outputs (me_pack_desc.ohwi16 / rot16 / parity16, ABI 11) against the fp32 pack + one RNE
+    conversion: every OHWI / rotated / parity tensor of Darknet-53 equal, the folded scale / shift and the fp32 copies the step
+    reads (stem, detection convolutions) equal to the fp32 pack's."""
+    from millieye_amd.detector_train16 import _Weights16
+    half = HALVES[dtype]
+    model = ph.make_darknet("yolov3", tag="t16/pack", trained_like=True).cuda().eval()
+    eng, defs, dev = model.engine, model.module_defs, torch.device("cuda", torch.cuda.current_device())
+    two = _Weights16()
+    eng.refresh_train_weights(dev)
+    two.refresh(eng, defs, half, dev)
+    torch.cuda.synchronize()
+    want = {k: v.clone() for k, v in two.dst.items()}
+    convs = [i for i, d in enumerate(defs) if d["type"] == "convolutional"]
+    f32 = {i: (eng._conv_weights(i).wgt.clone(), eng._conv_weights(i).scale.clone(), eng._conv_weights(i).shift.clone()) for i in convs}
+    for i in convs:   # poison what the direct pack must write
+        cw = eng._conv_weights(i)
+        cw.scale.fill_(7.0)
+        cw.shift.fill_(7.0)
+        if cw.wgt.shape[3] <= 4 or (i + 1 < len(defs) and defs[i + 1]["type"] == "yolo"):
+            cw.wgt.fill_(7.0)
+    one = _Weights16()
+    assert one.pack_direct(eng, defs, half, dev) and one.direct
+    torch.cuda.synchronize()
+    assert sorted(one.dst) == sorted(want) and len(want) >= 140
+    for k, v in want.items():
+        assert torch.equal(one.dst[k], v), k
+    for i in convs:
+        cw = eng._conv_weights(i)
+        assert torch.equal(cw.scale, f32[i][1]) and torch.equal(cw.shift, f32[i][2]), i
+        if cw.wgt.shape[3] <= 4 or (i + 1 < len(defs) and defs[i + 1]["type"] == "yolo"):
+            assert torch.equal(cw.wgt, f32[i][0]), i
+        assert cw._stamp is None   # (the engine's fp32 copies are packed again when something asks for them)
+    # ... and something does: the fp32 inference path after the 16-bit pack sees current weights
+    x = torch.from_numpy(synth.uniform("t16/pack/x", (1, 3, 96, 96))).cuda()
+    with torch.no_grad():
+        a = model(x)
+    ref = ph.make_darknet("yolov3", tag="t16/pack", trained_like=True).cuda().eval()
+    with torch.no_grad():
+        b = ref(x)
+    a_rows, b_rows = (a[1] if isinstance(a, tuple) else a), (b[1] if isinstance(b, tuple) else b)
+    assert torch.equal(a_rows, b_rows)
