@@ -1011,20 +1011,22 @@ def main():
                 "Darknet.forward(x, targets) -> loss.backward() -> all-reduce -> SGD",
                 "Darknet.forward(x, targets) -> loss.backward()" + (" (+ overlapped all-reduce)" if ranks else "") + " -> SGD")
             # this workload's own roofline: the convolution kernels of each pass, timed sequentially on one stream in one
-            # extra (untimed) step, against the fp32 matrix peak - not the forward kernel's inference figure
+            # extra (untimed) step, against the matrix peak of the step's arithmetic type - not the forward kernel's inference figure
             passes = det_passes
             total_flops = sum(v[1] for v in passes.values())
+            # (the 16-bit step's three passes all run on the 16-bit matrix pipe since round 5: priced against ITS dense peak)
+            train_peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
             out["roofline"] = {
-                "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS,
+                "bound": "mfma", "unit": "TFLOP/s", "peak": train_peak,
                 "kernel": "conv_igemm_buf_f32 (forward, data gradient) + conv_wgrad_* (weight gradient), fp32 MFMA" if args.dtype == "f32"
-                          else f"me_conv2d_h16 (forward, data gradient; {args.dtype} MFMA) + conv_wgrad_* (weight gradient, fp32 MFMA); "
-                               "frac is against the fp32 peak: the 16-bit passes run above it by construction",
+                          else f"me_conv2d_h16 (forward, data gradient) + conv_wgrad_tile_h16_kernel (weight gradient), {args.dtype} MFMA "
+                               "(v_mfma_f32_32x32x16): batch-8 layers, 32 - 700 workgroups per launch",
                 "achieved": round(total_flops / (elapsed / args.steps) / 1e12, 2),
-                "frac": round(total_flops / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "frac": round(total_flops / (elapsed / args.steps) / 1e12 / train_peak, 4),
                 "note": "achieved / frac: conv FLOPs of the three passes over the WHOLE timed step (affine, pack, loss, SGD "
                         "included); by_pass: each pass's conv launches alone, sequential",
                 "by_pass": {k: {"ms": round(ms, 3), "gflop": round(fl / 1e9, 1), "launches": cnt,
-                                "achieved": round(fl / ms / 1e9, 2), "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                "achieved": round(fl / ms / 1e9, 2), "frac": round(fl / ms / 1e9 / train_peak, 4)}
                             for k, (ms, fl, cnt) in sorted(passes.items())},
                 "traffic": None,
             }
