@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="detector_train: forward + YOLO losses + backward as one captured hipGraph per step "
                          "(millieye_amd/detector_graph.py; the gradients are exchanged after the replay when N > 1)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="train: do not run the frozen detector of the next batch under the current batch's tail "
+                         "(Network.queue_detector_prefetch; A/B)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1 weak runs: skip the extra strong-scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the extra bf16-storage-mode measurement")
@@ -706,6 +709,8 @@ def main():
             opt = torch.optim.Adam(heads, lr=5e-4, fused=True)
 
             def step():  # noqa: F811
+                if not args.no_prefetch:   # the loop's look-ahead (millieye_amd/train.py): the next batch's frames are known here
+                    net.queue_detector_prefetch(x)
                 loss, out_rows, _metric, _att = net(x, maps_d, boxes_d.clone(), targets.clone())
                 loss.backward()
                 last["bucket_bytes"] = par.allreduce_gradients(heads, static_pattern=True)
@@ -1031,6 +1036,10 @@ def main():
                 "traffic": None,
             }
         if args.workload == "train":
+            out["config"]["detector_prefetch"] = not args.no_prefetch
+            if not args.no_prefetch:
+                out["config"]["workload"] += "; the frozen detector + NMS of batch k + 1 are issued on a second stream under the " \
+                                             "host-bound tail of batch k (one detector forward per step, as without it)"
             out["config"]["grad_bucket_bytes"] = int(last.get("bucket_bytes", 0))
             out["config"]["loss_last_step"] = round(float(last["loss"]), 5)
             out["config"]["workload"] = out["config"]["workload"].replace("inference", "training (heads), inference (detector)")

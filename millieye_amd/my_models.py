@@ -500,6 +500,14 @@ class Network(nn.Module):
         radar_score_map, mh, mw = radar_job if radar_job is not None else self._radar_score_map(maps, n, dev)
         return roi_score_map, radar_score_map, fh, fw, mh, mw
 
+    def queue_detector_prefetch(self, images_next):
+        """Training loops with a FROZEN detector (the reference's stage 3, train.py:170): name the next batch's frames in front of the
+        call for the current batch, and that call issues the next batch's detector + NMS + proposal assembly on a second stream as
+        soon as it has its own - the detector of batch k + 1 runs under the host-bound tail of batch k (millieye_amd/train_path.py).
+        Purely an overlap: the next call takes the prefetched result only when frames, thresholds and detector weights are the
+        ones it was computed from, and computes it itself otherwise.  No reference counterpart (a scheduling hint, not an op)."""
+        self.__dict__["_next_images"] = images_next
+
     # ---------------------------------------------------------------------------------- forward
     def forward(self, images, maps, radar_boxes_location, model_mode=0, targets=None):
         """See the reference docstring (my_models.py:434-450).  Returns ``output [m, 8]`` rows

@@ -219,6 +219,97 @@ class _StageThree(torch.autograd.Function):
         return (None,) + tuple(grads.get(n) if n in needed else None for n in names)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The frozen part of the step, one batch ahead (round 5).  Stage-3 training keeps the detector frozen (reference train.py:170), so the
+# detector + NMS + proposal assembly of batch k + 1 depend on nothing batch k's step computes.  The rest of the step is a chain of
+# small launches behind one host read (the RoI count) and is bound by the HOST (2.1 ms of issue time at batch 8 for ~1 ms of kernels,
+# tools/train_host_profile.py): the GPU idles through most of it.  ``Network.queue_detector_prefetch(images_next)`` in front of the
+# call for batch k makes ``forward_train`` issue batch k + 1's frozen part on a second stream right after it has picked up its own -
+# the detector of the next batch runs under the current batch's tail.  Results are private copies (the engine's arena belongs to the
+# prefetch stream while it runs; ``Darknet._run`` waits for a prefetch in flight before anything else touches the engine).
+# ---------------------------------------------------------------------------------------------------------------------------------
+_PREFETCH_STREAMS = {}
+
+
+def _prefetch_stream(dev):
+    key = str(dev)
+    st = _PREFETCH_STREAMS.get(key)
+    if st is None:
+        st = _PREFETCH_STREAMS[key] = torch.cuda.Stream(dev)
+    return st
+
+
+def _frozen_detector_block(net, images):
+    """Detector forward (whatever storage mode ``Darknet.compute_dtype`` names), NMS, per-class proposal rows, an fp32 NHWC copy of the
+    feature tap - everything of the step that has no trainable parameter in it.  Runs on the current stream."""
+    from .my_models import _DETECTIONS_PER_IMG, _NMS_THRESH
+    lib = hip.lib()
+    dev = images.device
+    n = images.shape[0]
+    f32 = dict(device=dev, dtype=torch.float32)
+    plan, yolo_out = net.base_detector._run(images, nms_conf=float(net.conf_thresh))
+    det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
+                               writeback_xyxy=False, prepped=plan.nms_prepped == float(net.conf_thresh))
+    num_classes = yolo_out.shape[2] - 5
+    cols = 8 + net.class_num
+    cap_img = n * _DETECTIONS_PER_IMG
+    img_boxes = torch.empty((cap_img, cols), **f32)
+    n_img_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+    hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
+                                            int(net.class_idx), int(net.class_num), img_boxes.data_ptr(),
+                                            n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
+    if plan.tap is None:
+        raise AttributeError("'Darknet' object has no attribute 'featuremap'")
+    fm = plan.tap.permute(0, 2, 3, 1).float().contiguous()  # fp32 NHWC copy: the arena is reused by the next forward
+    return dict(num_classes=num_classes, cols=cols, cap_img=cap_img, img_boxes=img_boxes, n_img_dev=n_img_dev, fm=fm,
+                tap_shape=tuple(plan.tap_shape))
+
+
+def _prefetch_key(net, images):
+    det = net.base_detector
+    params = net.__dict__.get("_det_param_list")
+    if params is None:
+        params = net.__dict__["_det_param_list"] = [p for p in det.parameters()] + [b for b in det.buffers()]
+    from . import engine as _engine
+    # (this path never differentiates through the detector; whatever else changes its weights - an optimizer that was handed them,
+    #  load_state_dict, engine.invalidate_weights() after a raw-pointer write - moves a version counter or the engine's epoch)
+    return (images.data_ptr(), tuple(images.shape), images._version, float(net.conf_thresh), int(net.class_idx), int(net.class_num),
+            det.compute_dtype, tuple([p._version for p in params]), tuple([p.data_ptr() for p in params[:4]]), _engine._EPOCH[0])
+
+
+def _issue_prefetch(net, images):
+    if not (torch.is_tensor(images) and images.is_cuda and images.dtype == torch.float32 and images.dim() == 4):
+        return
+    key = _prefetch_key(net, images)
+    if key is None or net.base_detector._any_bn_training():
+        return
+    dev = images.device
+    main, side = torch.cuda.current_stream(dev), _prefetch_stream(dev)
+    side.wait_stream(main)   # the frames are there, and whoever ran the engine before is done with it
+    with torch.cuda.stream(side), torch.no_grad():
+        res = _frozen_detector_block(net, images)
+        done = torch.cuda.Event()
+        done.record(side)
+    images.record_stream(side)
+    net.__dict__["_det_prefetch"] = (key, res, done, images)
+    net.base_detector.__dict__["_prefetch_event"] = done   # Darknet._run: nobody else touches the engine before this
+
+
+def _take_prefetch(net, images):
+    rec = net.__dict__.pop("_det_prefetch", None)
+    if rec is None:
+        return None
+    key, res, done, _held = rec
+    main = torch.cuda.current_stream(images.device)
+    main.wait_event(done)
+    if key != _prefetch_key(net, images):
+        return None   # other frames, another threshold, new detector weights: computed again (behind the prefetch, see _run)
+    for t in (res["img_boxes"], res["n_img_dev"], res["fm"]):
+        t.record_stream(main)
+    return res
+
+
 def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0):
     """``targets`` given: returns ``(loss, output, metric, radar_attention)`` like the reference's training call
     (my_models.py:545-641).  ``targets is None``: the inference return of a model left in ``train()`` mode (reference
@@ -249,23 +340,15 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
 
     # ---- frozen detector, NMS, proposal assembly (no grad) -------------------------------------------
     with torch.no_grad():
-        # the detector is frozen here: it runs in whatever storage mode Darknet.compute_dtype names (fp32 by default;
-        # "bf16" / "f16" = BASELINE configs[3]'s "bf16 compute" for the part of the step that is inference)
-        plan, yolo_out = net.base_detector._run(images, nms_conf=float(net.conf_thresh))
-        det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG,
-                                   writeback_xyxy=False, prepped=plan.nms_prepped == float(net.conf_thresh))
-        num_classes = yolo_out.shape[2] - 5
-        cols = 8 + net.class_num
-        cap_img = n * _DETECTIONS_PER_IMG
-        img_boxes = torch.empty((cap_img, cols), **f32)
-        n_img_dev = torch.empty((1,), device=dev, dtype=torch.int32)
-        hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
-                                                int(net.class_idx), int(net.class_num), img_boxes.data_ptr(),
-                                                n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
-        if plan.tap is None:
-            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
-        fh, fw, fc = plan.tap_shape
-        fm = plan.tap.permute(0, 2, 3, 1).float().contiguous()  # fp32 NHWC copy: the arena is reused by the next forward
+        pre = _take_prefetch(net, images)
+        if pre is None:
+            pre = _frozen_detector_block(net, images)
+        num_classes, cols, cap_img = pre["num_classes"], pre["cols"], pre["cap_img"]
+        img_boxes, n_img_dev, fm = pre["img_boxes"], pre["n_img_dev"], pre["fm"]
+        fh, fw, fc = pre["tap_shape"]
+        nxt = net.__dict__.pop("_next_images", None)
+        if nxt is not None:   # (Network.queue_detector_prefetch: the NEXT batch's frozen part, beside this batch's host-bound tail)
+            _issue_prefetch(net, nxt)
         if len(radar_boxes_location) > 0:
             radar_boxes_location[:, 1:] *= size
         n_radar = int(radar_boxes_location.shape[0])

@@ -257,6 +257,9 @@ class Darknet(nn.Module):
     def _run(self, x, keep_raw=False, nms_conf=None):
         """Internal: (plan, yolo_outputs) without cloning the feature tap (used by Network).  ``nms_conf``: see
         ``DarknetEngine.run`` (the decode fills the NMS candidate lists)."""
+        ev = self.__dict__.pop("_prefetch_event", None)
+        if ev is not None:   # train_path._issue_prefetch ran the engine on its own stream: its arena is busy until then
+            torch.cuda.current_stream(x.device).wait_event(ev)
         eng = self.engine if keep_raw else self.engine_for(self.compute_dtype)
         return eng.run(x, keep_raw, nms_conf=nms_conf)
 

@@ -487,3 +487,80 @@ def test_conv_wgrad_pitched_operands(hip_lib, n, h, w, cin, cout, k):
     dw_[..., 8:8 + cout] = dy.permute(0, 2, 3, 1).cuda()
     got = hip.conv_wgrad(xw[..., 4:4 + cin], dw_[..., 8:8 + cout], k, 1, pad, oihw=True)
     assert _rel(got, wt.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_detector_prefetch_is_only_an_overlap(hip_lib, dtype):
+    """Network.queue_detector_prefetch (round 5): the frozen detector + NMS + proposal assembly of the NEXT batch issued on a second
+    stream under the current batch's tail.  Every step must be the plain step: the batch that names a successor, the batch that
+    consumes the prefetched part (loss, RoI count and output rows equal; gradients to the RoI scatters' atomics), and the cases where
+    the prefetched part must NOT be used - other frames, detector weights changed in between."""
+    name, cfg, n, s, conf = "prefetch", "yolov3-tiny-12", 4, 416, 0.2
+    from millieye_amd.my_models import Network, define_yolo
+    net = Network(define_yolo(ph.cfg_path(cfg)), conf)
+    synth.fill_network_(net, name, cls0_bias=3.0, cls_bias=-4.0)
+    net = net.cuda().eval()
+    net.base_detector.compute_dtype = dtype
+    xs = [torch.from_numpy(synth.uniform(f"{name}/x{i}", (n, 3, s, s))).cuda() for i in range(2)]
+    maps, rboxes = synth.radar_inputs(name + "/radar", n, s // 16)
+    maps, rboxes = torch.from_numpy(maps).cuda(), torch.from_numpy(rboxes)
+    with torch.no_grad():
+        det = net(xs[0], maps, rboxes.clone().cuda(), 1).cpu()
+    tg = [[i, 0, 0.5, 0.5, 0.3, 0.3] for i in range(n)]
+    for i in range(n):
+        rows_i = det[det[:, 0] == i]
+        if len(rows_i):
+            b = rows_i[0, 1:5] / s
+            tg.append([i, 0, float((b[0] + b[2]) / 2), float((b[1] + b[3]) / 2), float(b[2] - b[0]) * 1.05, float(b[3] - b[1]) * 0.95])
+    targets = torch.tensor(tg, dtype=torch.float32)
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+
+    def step(x, ahead=None):
+        net.load_state_dict(bn_state, strict=False)   # the same running statistics in front of every step
+        net.train()
+        net.base_detector.eval()
+        for p in net.parameters():
+            p.grad = None
+        random.seed(7)
+        if ahead is not None:
+            net.queue_detector_prefetch(ahead)
+        loss, rows, _metric, _att = net(x, maps, rboxes.clone().cuda(), targets.clone())
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.flatten() for k, p in net.named_parameters()
+                           if not k.startswith("base_detector.") and p.grad is not None]).cpu()
+        return float(loss), int(net._last_train["k"]), rows.detach().cpu(), grads
+
+    def same(a, b, what):
+        assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]), (what, a[0], b[0], a[1], b[1])
+        assert float((a[3] - b[3]).abs().max()) <= 1e-5 * float(b[3].abs().max()), what
+
+    plain = [step(xs[0]), step(xs[1])]
+    assert plain[0][1] > 20 and plain[0][0] != plain[1][0]
+    same(step(xs[0], ahead=xs[1]), plain[0], "the batch that names its successor")
+    assert "_det_prefetch" in net.__dict__
+    same(step(xs[1]), plain[1], "the batch that consumes the prefetched part")
+    assert "_det_prefetch" not in net.__dict__
+    # other frames than the ones announced: computed again, behind the prefetch
+    step(xs[0], ahead=xs[1])
+    same(step(xs[0]), plain[0], "other frames than the prefetched ones")
+    # detector weights changed between the prefetch and the call: the prefetched part is stale and must not be used
+    step(xs[0], ahead=xs[1])
+    w = net.base_detector.module_list[0][0].weight
+    w0 = w.detach().clone()
+    with torch.no_grad():
+        w.mul_(1.5)
+    changed = step(xs[1])
+    assert "_det_prefetch" not in net.__dict__
+    fresh = step(xs[1])            # the plain step on the changed weights
+    same(changed, fresh, "detector weights changed after the prefetch")
+    assert changed[0] != plain[1][0]
+    with torch.no_grad():
+        w.copy_(w0)
+    # the inference path after an unconsumed prefetch waits for it (Darknet._run) and is the plain inference result
+    step(xs[0], ahead=xs[1])
+    net.load_state_dict(bn_state, strict=False)
+    net.eval()
+    with torch.no_grad():
+        again = net(xs[0], maps, rboxes.clone().cuda(), 1).cpu()
+    assert torch.equal(again, det)
