@@ -9,6 +9,10 @@ python bench.py --workload detector_train --no-cpu-baseline --steps 20 --warmup 
 python bench.py --workload detector_train --dtype bf16 --no-cpu-baseline --steps 20 --warmup 3 > $OUT/r05_bf16_bench_detector_train_b8.json 2>/dev/null
 python bench.py --workload detector_train --dtype bf16 --graph --no-cpu-baseline --steps 20 --warmup 3 > $OUT/r05_bf16_bench_detector_train_b8_graph.json 2>/dev/null
 python bench.py --workload detector_train --dtype f16 --graph --no-cpu-baseline --steps 20 --warmup 3 > $OUT/r05_f16_bench_detector_train_b8_graph.json 2>/dev/null
+python bench.py --workload train --no-cpu-baseline --steps 20 > $OUT/r05_bench_train_b8.json 2>/dev/null
+python bench.py --workload train --dtype bf16 --no-cpu-baseline --steps 20 > $OUT/r05_bf16_bench_train_b8.json 2>/dev/null
+python bench.py --workload train --no-prefetch --no-cpu-baseline --steps 20 > $OUT/r05_bench_train_b8_no_prefetch.json 2>/dev/null
+python bench.py --workload train --dtype bf16 --no-prefetch --no-cpu-baseline --steps 20 > $OUT/r05_bf16_bench_train_b8_no_prefetch.json 2>/dev/null
 (python tools/wgrad_bench.py 8 bf16; python tools/affine_bench.py 8 bf16) 2>&1 | grep -v amdgpu > $OUT/r05_backward_microbench_bf16.txt
 DATE=$(date +%Y-%m-%d)
 cd /tmp
