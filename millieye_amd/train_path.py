@@ -287,7 +287,11 @@ def _issue_prefetch(net, images):
     dev = images.device
     main, side = torch.cuda.current_stream(dev), _prefetch_stream(dev)
     side.wait_stream(main)   # the frames are there, and whoever ran the engine before is done with it
-    with torch.cuda.stream(side), torch.no_grad():
+    from . import engine as _engine
+    import contextlib
+    # (the detector as one graph replay: what matters here is the host time of issuing it - the tail this runs under is host-bound)
+    replay = _engine.graph_replay() if os.environ.get("MILLIEYE_PREFETCH_GRAPH", "1") != "0" else contextlib.nullcontext()
+    with torch.cuda.stream(side), torch.no_grad(), replay:
         res = _frozen_detector_block(net, images)
         done = torch.cuda.Event()
         done.record(side)

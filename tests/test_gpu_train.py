@@ -541,6 +541,10 @@ def test_detector_prefetch_is_only_an_overlap(hip_lib, dtype):
     assert "_det_prefetch" in net.__dict__
     same(step(xs[1]), plain[1], "the batch that consumes the prefetched part")
     assert "_det_prefetch" not in net.__dict__
+    # a longer run of look-ahead steps (from the third prefetch on the detector is one captured graph replay, engine.graph_replay)
+    for i in range(6):
+        same(step(xs[i % 2], ahead=xs[(i + 1) % 2]), plain[i % 2], f"look-ahead step {i}")
+    net.__dict__.pop("_det_prefetch", None)
     # other frames than the ones announced: computed again, behind the prefetch
     step(xs[0], ahead=xs[1])
     same(step(xs[0]), plain[0], "other frames than the prefetched ones")
