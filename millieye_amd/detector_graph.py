@@ -109,7 +109,23 @@ class GraphedDetectorStep:
     def _signature(self, x):
         # (the Parameter objects are looked up once per capture: walking the module tree costs more than the rest of this call;
         #  a parameter whose STORAGE moved - .to(), .half(), a re-assigned .data - is seen here and the step is captured again)
-        return (tuple(x.shape), self.m.compute_dtype, tuple([p.data_ptr() for p in self.params]))
+        return (tuple(x.shape), self.m.compute_dtype, tuple([p.data_ptr() for p in self.params]), self._scratch_ptrs())
+
+    def _scratch_ptrs(self):
+        """Addresses of every scratch buffer the captured launches were handed that an EAGER step on the same model (or on the
+        shared side stream) may later outgrow and replace: the model-level slab / partial-sum scratches of the two trainers and
+        the library's per-stream workspaces.  A replaced buffer changes this tuple and the step is captured again instead of
+        replaying launches that point into freed memory."""
+        d = self.m.__dict__
+        out = []
+        for name in ("_wgrad16_ws", "_affine16_ws"):
+            for t in d.get(name) or ():
+                out.append(t.data_ptr() if t is not None else 0)
+        for name in ("_affine16_layer_ws", "_affine_layer_ws"):
+            tab = d.get(name) or {}
+            out.extend((k, tab[k].data_ptr()) for k in sorted(tab))
+        out.extend((k[0], k[2], t.data_ptr()) for k, t in sorted(hip._ws_cache.items(), key=lambda kv: kv[0]) if t is not None)
+        return tuple(out)
 
     def _device(self):
         return next(self.m.parameters()).device

@@ -883,9 +883,24 @@ class DarknetEngine:
                                         device=x.device)
             torch.cuda.synchronize(x.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._launch_all(plan, plan.x_static, plan.y_static)
-            plan.graph = graph
+            try:
+                # thread_local: a DataLoader pin-memory thread or the NCCL watchdog calling into the runtime during the capture
+                # window must not invalidate it (the global mode would) - same choice as detector_graph.GraphedDetectorStep
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    self._launch_all(plan, plan.x_static, plan.y_static)
+            except Exception as exc:  # a failed capture is not fatal and is not retried: this plan stays on eager launches
+                import warnings
+                warnings.warn(f"millieye_amd: hipGraph capture of the detector plan failed ({exc!r}); the plan runs eagerly")
+                plan.graph = False
+                plan.x_static = plan.y_static = None
+                torch.cuda.synchronize(x.device)
+            else:
+                plan.graph = graph
+        if plan.graph is False:
+            yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32, device=x.device)
+            self._launch_all(plan, x, yolo_out)
+            plan.last_input = x
+            return plan, yolo_out
         plan.x_static.copy_(x)
         plan.graph.replay()
         return plan, plan.y_static

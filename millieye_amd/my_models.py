@@ -613,12 +613,15 @@ class Network(nn.Module):
         n_radar = int(radar_boxes_location.shape[0])
         rb = radar_boxes_location.to(**f32).contiguous() if n_radar else None
         cap = cap_img + n_radar
-        regress = self._buf("regress", (cap, 4), dev)
-        refine = self._buf("refine", (cap, 2), dev)
-        mask1 = self._buf("mask1", (cap,), dev)
-        rows = self._buf("rows", (cap, 8), dev)
-        keep = self._buf("keep", (cap,), dev, torch.uint8)  # (the heads launch clears the slots behind the last RoI)
-        key = self._buf("key", (cap,), dev)
+        # the pool is keyed by a capacity BUCKET (multiples of 64 rows): the radar box count changes from frame to frame on real
+        # data, and an exact-shape key would miss the pool on most calls; the launches get leading-row views of ``cap`` rows
+        cap_b = -(-cap // 64) * 64
+        regress = self._buf("regress", (cap_b, 4), dev)[:cap]
+        refine = self._buf("refine", (cap_b, 2), dev)[:cap]
+        mask1 = self._buf("mask1", (cap_b,), dev)[:cap]
+        rows = self._buf("rows", (cap_b, 8), dev)[:cap]
+        keep = self._buf("keep", (cap_b,), dev, torch.uint8)[:cap]  # (the heads launch clears the slots behind the last RoI)
+        key = self._buf("key", (cap_b,), dev)[:cap]
 
         hw = packs["heads"].refresh(dev)
         d = hip.HeadsDesc()
@@ -636,7 +639,7 @@ class Network(nn.Module):
         d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
         d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
         if not getattr(self, "_fused_heads", False):
-            pooled = self._buf("pooled", (cap, 980), dev)  # the RoI pooling as its own launch (me_heads_desc.pool_scratch)
+            pooled = self._buf("pooled", (cap_b, 980), dev)[:cap]  # the RoI pooling as its own launch (me_heads_desc.pool_scratch)
             d.pool_scratch = pooled.data_ptr()
         # (``_fused_heads``: the single-launch VALU kernel with the pooling inside - kept as the cross-check of the two-launch
         # path, tests/test_gpu_network.py)
@@ -679,5 +682,6 @@ class Network(nn.Module):
         tr("row count on the host")
         output = ordered[:n_rows]
         mark("output")
+        # (views of pooled scratch: valid only until the next forward of this network on this stream)
         self._last = dict(regress=regress, refine=refine, mask1=mask1, n_img=n_img_dev, img_boxes=img_boxes)
         return output
