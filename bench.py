@@ -144,27 +144,39 @@ def conv_roofline(model, x, steps):
     timed = {}  # module -> list of (start, end) events; launches stay IN SEQUENCE (real cache state)
     for _ in range(steps):
         for fn, args, _k, name in plan.launches:
-            mfma_conv = (fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_h16) and descs[int(name[4:])].cin > 4
+            mods = _launch_modules(lib, fn, name)   # () for a launch that is not a convolution
+            mfma_conv = bool(mods) and descs[mods[0]].cin > 4
             if mfma_conv:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 fn(*args, stream)
                 b.record()
-                timed.setdefault(int(name[4:]), []).append((a, b))
+                timed.setdefault(mods, []).append((a, b))
             else:
                 fn(*args, stream)
     torch.cuda.synchronize()
     total_ms, total_flops, launches = 0.0, 0, 0
     per_layer = []
-    for mod, evs in timed.items():
+    for mods, evs in timed.items():
         ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-        flops = _conv_flops(descs[mod])
+        flops = sum(_conv_flops(descs[m]) for m in mods)   # a one-launch bottleneck: the ALGORITHMIC flops of its two layers (no halo term)
+        mod = "+".join(str(m) for m in mods)
         per_layer.append((mod, flops, ms))
         total_ms += ms
         total_flops += flops
         launches += 1
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     return achieved, total_ms * 1e3 / launches, launches, total_flops / launches, per_layer
+
+
+def _launch_modules(lib, fn, name):
+    """cfg modules a launch of the engine's list computes: ``(i,)`` for a convolution, ``(i, j)`` for a 1x1 -> 3x3 bottleneck that the
+    16-bit plan runs as one launch (me_bneck_h16: "bneck13+14"), ``()`` for everything else."""
+    if fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_h16:
+        return (int(name[4:]),)
+    if fn is lib.me_bneck_h16:
+        return tuple(int(t) for t in name[5:].split("+"))
+    return ()
 
 
 def _conv_flops(d):
@@ -233,14 +245,15 @@ def stage_roofline(model, net, x, step, rois, reps=5):
         torch.cuda.synchronize()
         for name, fn, a, b in evs:
             ms = a.elapsed_time(b)
-            if fn is lib.me_conv2d_f32 or fn is lib.me_conv2d_h16:
-                d = descs[int(name[4:])]
+            mods = _launch_modules(lib, fn, name)
+            if mods:
+                d = descs[mods[0]]
                 if d.cin <= 4:
                     add("stem conv (cin 3, direct)", ms,
                         bytes=n * (4.0 * d.cin * d.h * d.w + (2.0 if bf16 else 4.0) * d.cout * d.ho * d.wo))
                 else:
                     add("MFMA convs (3x3 / 1x1 + BN + leaky + shortcut/upsample/route epilogues)", ms,
-                        flops=float(_conv_flops(d)))
+                        flops=float(sum(_conv_flops(descs[m]) for m in mods)))
             elif fn is lib.me_yolo_decode_f32:
                 rows_c = plan.rows * (5 + (plan.num_classes or 0))
                 add("YOLO decode", ms, bytes=0.0)  # bytes added once below (the scales share the output tensor)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 11
+#define ME_ABI_VERSION 12
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -610,6 +610,37 @@ typedef struct me_conv16_desc {
 } me_conv16_desc;
 int me_conv2d_h16(const me_conv16_desc* d, void* stream);
 int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d);
+/* ---- one launch for a Darknet bottleneck in the 16-bit storage modes (ABI 12; csrc/bneck_h16.hip) ------------------
+ * Replaces the launch PAIR of a [convolutional] 1x1 block and the [convolutional] 3x3 / stride-1 / pad-1 block behind it
+ * (+ the [shortcut] that adds the pair's input; reference yolov3/models.py:22-41, 258-260 - the eight 52x52 and the two
+ * 104x104 residual blocks of yolov3.cfg and the 1x1 -> 3x3 pairs of its 52x52 head):
+ *     mid = act1(scale1 * conv1x1(x, w1) + shift1)   rounded to the storage type, kept in LDS, never written
+ *     y   = act2(scale2 * conv3x3(mid, w2) + shift2) (+ res)
+ * Same rounding points as the two me_conv2d_h16 launches (mid and y once each, RNE); results equal theirs bit for bit
+ * whenever the two paths sum each dot product in the same order (they do for the whole-tile kernels; tests/test_gpu_h16.py).
+ *   x, res, y  16-bit NHWC, pitches in elements (%% 8), 16-byte aligned;  res may be NULL
+ *   w1_tiled   [cin / 32][cmid][32]        = me_conv16_desc.wgt_tiled of the 1x1 block
+ *   w2_tiled   [9][cmid / 32][cout][32]    = me_conv16_desc.wgt_tiled of the 3x3 block
+ *   tile       1: 192 positions x (cmid 128, cout 256)   3: 512 x (cmid 64, cout 128)   4: 256 x (64, 128)
+ * me_bneck_h16_supported() says whether (tile, channels, map width) has an instance; me_bneck_h16 refuses loudly otherwise. */
+typedef struct me_bneck16_desc {
+  const void* x;
+  const void* w1_tiled;
+  const float* scale1;
+  const float* shift1;
+  const void* w2_tiled;
+  const float* scale2;
+  const float* shift2;
+  const void* res;
+  void* y;
+  int64_t x_pitch, res_pitch, y_pitch;
+  int32_t n, h, w, cin;
+  int32_t cmid, cout, act1, act2;
+  int32_t half_type; /* 0 = bfloat16, 1 = IEEE half */
+  int32_t tile;
+} me_bneck16_desc;
+int me_bneck_h16(const me_bneck16_desc* d, void* stream);
+int me_bneck_h16_supported(const me_bneck16_desc* d);
 /* 16-bit NHWC twins of me_maxpool_f32 / me_upsample_f32 / me_add_f32 / me_copy_f32 (channels and pitches %% 8); upsample
  * and copy move bytes and serve both types */
 int me_maxpool_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int32_t n, int32_t h, int32_t w, int32_t c,

@@ -220,7 +220,8 @@ class ConvWeights:
             realloc = (self.wgt is None or self.wgt.device != device or self.wgt.shape != packed.shape
                        or self.wgt.dtype != packed.dtype)
             tiled = None
-            if packed.dtype in hip.HALF_TYPES and packed.shape[1] == 3 and packed.shape[3] % 32 == 0:
+            if packed.dtype in hip.HALF_TYPES and packed.shape[1] in (1, 3) and packed.shape[3] % 32 == 0:
+                # (3x3: the patch-resident kernels; 1x1: the first half of a one-launch bottleneck, csrc/bneck_h16.hip)
                 tiled = hip.tile_weights_h16(packed)
             elif packed.dtype == torch.float32 and self.dtype == "f32" and packed.shape[3] % 16 == 0:
                 # the fp32 MFMA kernels stream their weight tiles from this copy (a K stage of a tile is contiguous - csrc/conv.hip,
@@ -680,6 +681,8 @@ class DarknetEngine:
                 if bf16:
                     dsc.y_f32 = 1 if y.esize == 4 else 0
                     dsc.half_type = half_type
+                op["launch"] = len(launches)
+                op["desc"] = dsc
                 launches.append((lib.me_conv2d_h16 if bf16 else lib.me_conv2d_f32, (C.byref(dsc),), dsc,
                                  f"conv{op['module']}"))
                 plan.conv_descs.append((op["module"], dsc))
@@ -768,6 +771,9 @@ class DarknetEngine:
         plan.conv_flops = flops
         if _autotune_enabled():
             _autotune(plan, lib)
+        plan.fused_blocks = []
+        if bf16 and _BNECK_MODE != "0":
+            _fuse_bottlenecks(plan, ops, lib)
         if tap_tensor is not None:
             # NCHW view of the feature tap in its storage type (bf16 mode: callers that need fp32 convert at the API
             # boundary - Darknet.forward; Network.forward hands the bf16 tap straight to the score-map conv)
@@ -1203,6 +1209,108 @@ def _autotune(plan, lib):
     agree_on_rank0()
     ensure_workspace(required())
     _tune_save()
+
+
+_BNECK_MODE = os.environ.get("MILLIEYE_BNECK", "1")   # "0": never, "1": where measured faster than the launch pair, "force": wherever an instance exists
+_BNECK_CACHE = {}   # block shape -> bneck tile id, or 0 (the launch pair stays)
+_BNECK_STATS = {"fused": 0, "kept": 0}
+
+
+def _fuse_bottlenecks(plan, ops, lib):
+    """16-bit plans: a ``[convolutional] 1x1`` block whose output is read by nothing but the ``3x3 / stride 1`` block right
+    behind it (+ that block's fused ``[shortcut]``) can run as ONE launch that keeps the mid tensor in LDS (``me_bneck_h16``,
+    csrc/bneck_h16.hip; reference yolov3/models.py:22-41, 258-260 - the residual blocks of yolov3.cfg).  Same rounding points
+    as the pair; which of the two forms runs is decided by MEASUREMENT per block shape (the pair with its tuned tiles against
+    every instance of the one-launch kernel, interleaved, HIP events on the launch stream), cached for the life of the process."""
+    import time
+    stream = hip.stream_ptr()
+    launches = plan.launches
+    conv_ops = [op for op in ops if op["kind"] == "conv"]
+    index = {id(op): k for k, op in enumerate(ops)}
+    pairs = []
+    for a, b in zip(conv_ops, conv_ops[1:]):
+        da, db = a["desc"], b["desc"]
+        if not (index[id(b)] == index[id(a)] + 1 and b["x"] is a["y"]):
+            continue
+        mid = a["y"]
+        if mid.readers != [index[id(b)]] or mid.pinned or mid.parent is not None or mid.padded or mid.esize != 2:
+            continue
+        if not (da.ksize == 1 and da.stride == 1 and da.upsample == 1 and not da.res and not da.y_f32 and not da.x_nchw
+                and db.ksize == 3 and db.stride == 1 and db.pad == 1 and db.upsample == 1 and not db.y_f32
+                and da.wgt_tiled and db.wgt_tiled and da.cout == db.cin and da.y_pitch == db.x_pitch):
+            continue
+        bd = hip.Bneck16Desc()
+        bd.x, bd.x_pitch = da.x, da.x_pitch
+        bd.w1_tiled, bd.scale1, bd.shift1 = da.wgt_tiled, da.scale, da.shift
+        bd.w2_tiled, bd.scale2, bd.shift2 = db.wgt_tiled, db.scale, db.shift
+        bd.res, bd.res_pitch, bd.y, bd.y_pitch = db.res, db.res_pitch, db.y, db.y_pitch
+        bd.n, bd.h, bd.w, bd.cin, bd.cmid, bd.cout = da.n, da.h, da.w, da.cin, da.cout, db.cout
+        bd.act1, bd.act2, bd.half_type = da.act, db.act, da.half_type
+        tiles = []
+        for tile in hip.BNECK_TILES:
+            bd.tile = tile
+            if lib.me_bneck_h16_supported(C.byref(bd)):
+                tiles.append(tile)
+        if tiles:
+            pairs.append((a, b, bd, tiles))
+    if not pairs:
+        return
+
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            if fn() != 0:
+                return None
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    warmed = False
+    for a, b, bd, tiles in pairs:
+        da, db = a["desc"], b["desc"]
+        key = (bd.n, bd.h, bd.w, bd.cin, bd.cmid, bd.cout, int(bool(bd.res)), bd.half_type, bd.act1, bd.act2)
+        choice = _BNECK_CACHE.get(key)
+        if choice is None and _BNECK_MODE == "force":
+            choice = tiles[0]
+        if choice is None:
+            def pair():
+                rc = lib.me_conv2d_h16(C.byref(da), stream)
+                return rc if rc else lib.me_conv2d_h16(C.byref(db), stream)
+            if not warmed:   # clocks up
+                t_end = time.perf_counter() + 0.2
+                while time.perf_counter() < t_end:
+                    timed(pair, 5)
+                warmed = True
+            cands = {0: []}
+            for tile in tiles:
+                cands[tile] = []
+            for _round in range(3):
+                for tile in cands:
+                    if tile == 0:
+                        ms = timed(pair, 6)
+                    else:
+                        bd.tile = tile
+                        ms = timed(lambda: lib.me_bneck_h16(C.byref(bd), stream), 6)
+                    if ms is not None:
+                        cands[tile].append(ms)
+            med = {t: sorted(v)[len(v) // 2] for t, v in cands.items() if v}
+            best = min(med, key=med.get)
+            # the one-launch form has to beat the pair by more than the measurement noise
+            choice = best if (best != 0 and med[best] < 0.98 * med.get(0, float("inf"))) else 0
+            _BNECK_CACHE[key] = choice
+            if os.environ.get("MILLIEYE_TUNE_VERBOSE"):
+                import sys
+                print("[bneck]", key, " ".join(f"{t}:{1e3 * v:.0f}us" for t, v in sorted(med.items())), "->", choice, file=sys.stderr, flush=True)
+        if not choice:
+            _BNECK_STATS["kept"] += 1
+            continue
+        _BNECK_STATS["fused"] += 1
+        bd.tile = choice
+        launches[a["launch"]] = (lib.me_bneck_h16, (C.byref(bd),), bd, f"bneck{a['module']}+{b['module']}")
+        launches[b["launch"]] = None
+        plan.fused_blocks.append((a["module"], b["module"], int(choice)))
+    plan.launches = [entry for entry in launches if entry is not None]
 
 
 def _in_family(cat, p):

@@ -130,7 +130,20 @@ class PackDesc(C.Structure):
     ]
 
 
-_STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights, 6: Conv16Desc, 7: PackDesc}
+class Bneck16Desc(C.Structure):
+    """me_bneck16_desc: a 1x1 -> 3x3 (+ shortcut) bottleneck of the 16-bit storage modes as ONE launch (csrc/bneck_h16.hip)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("w1_tiled", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
+        ("w2_tiled", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
+        ("x_pitch", C.c_int64), ("res_pitch", C.c_int64), ("y_pitch", C.c_int64),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32),
+        ("cmid", C.c_int32), ("cout", C.c_int32), ("act1", C.c_int32), ("act2", C.c_int32),
+        ("half_type", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+_STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights, 6: Conv16Desc, 7: PackDesc,
+            8: Bneck16Desc}
 
 # name -> (restype, argtypes); every symbol include/millieye_hip.h declares
 SIGNATURES = {
@@ -151,6 +164,8 @@ SIGNATURES = {
     "me_compact_sort_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
     "me_conv2d_h16": (C.c_int, [C.POINTER(Conv16Desc), C.c_void_p]),
+    "me_bneck_h16": (C.c_int, [C.POINTER(Bneck16Desc), C.c_void_p]),
+    "me_bneck_h16_supported": (C.c_int, [C.POINTER(Bneck16Desc)]),
     "me_conv2d_h16_workspace_bytes": (C.c_int64, [C.POINTER(Conv16Desc)]),
     "me_maxpool_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 11 + [C.c_void_p]),
     "me_upsample_h16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
@@ -277,8 +292,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 11:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 11")
+    if lib_.me_abi_version() != 12:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 12")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "
@@ -574,6 +589,42 @@ def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=No
 
 
 HALF_TYPES = {torch.bfloat16: 0, torch.float16: 1}  # me_conv16_desc.half_type
+
+
+BNECK_TILES = (1, 3, 4)  # me_bneck16_desc.tile
+
+
+def bneck_h16(x, w1_packed, scale1, shift1, w2_packed, scale2, shift2, residual=None, out=None, tile=1, act1=1, act2=1,
+              w1_tiled=None, w2_tiled=None):
+    """One launch for ``conv1x1 -> conv3x3 (+ residual)`` in a 16-bit storage mode (``me_bneck_h16``): ``x`` 16-bit NHWC
+    [N,H,W,Cin] (or a channel slice), ``w1_packed`` [Cmid,1,1,Cin], ``w2_packed`` [Cout,3,3,Cmid] (16-bit OHWI), scales /
+    shifts fp32.  Equals ``conv2d_h16(conv2d_h16(x, w1...), w2..., residual=residual)`` without the mid tensor in HBM."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in HALF_TYPES):
+        raise MeError("me_bneck_h16: x must be a 16-bit CUDA tensor")
+    n, h, w, cin = x.shape
+    cmid, cout = w1_packed.shape[0], w2_packed.shape[0]
+    if w1_packed.dtype != x.dtype or w2_packed.dtype != x.dtype or tuple(w1_packed.shape[1:]) != (1, 1, cin) \
+            or tuple(w2_packed.shape[1:]) != (3, 3, cmid):
+        raise MeError("me_bneck_h16: weights must be 16-bit OHWI [cmid,1,1,cin] and [cout,3,3,cmid] of x's type")
+    if out is None:
+        out = torch.empty((n, h, w, cout), device=x.device, dtype=x.dtype)
+    if out.dtype != x.dtype or (residual is not None and residual.dtype != x.dtype):
+        raise MeError("me_bneck_h16: out / residual must have x's type")
+    w1_tiled = tile_weights_h16(w1_packed) if w1_tiled is None else w1_tiled
+    w2_tiled = tile_weights_h16(w2_packed) if w2_tiled is None else w2_tiled
+    d = Bneck16Desc()
+    d.x, d.x_pitch = x.data_ptr(), _nhwc_pitch(x, "x")
+    d.w1_tiled, d.scale1, d.shift1 = w1_tiled.data_ptr(), scale1.data_ptr(), shift1.data_ptr()
+    d.w2_tiled, d.scale2, d.shift2 = w2_tiled.data_ptr(), scale2.data_ptr(), shift2.data_ptr()
+    d.res = residual.data_ptr() if residual is not None else None
+    d.res_pitch = _nhwc_pitch(residual, "residual") if residual is not None else 0
+    d.y, d.y_pitch = out.data_ptr(), _nhwc_pitch(out, "out")
+    d.n, d.h, d.w, d.cin, d.cmid, d.cout = n, h, w, cin, cmid, cout
+    d.act1, d.act2, d.half_type, d.tile = act1, act2, HALF_TYPES[x.dtype], tile
+    keep = (w1_tiled, w2_tiled)  # alive across the asynchronous launch
+    check(lib().me_bneck_h16(C.byref(d), stream_ptr()), "me_bneck_h16")
+    del keep
+    return out
 
 
 def _require_cuda_bf16(t, name):

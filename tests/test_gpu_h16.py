@@ -559,3 +559,86 @@ def test_conv_p8_refuses_what_it_cannot_do(hip_lib):
         hip.conv2d_h16(x, w1, one, one, 1, 1, 0, 1, tile=121)          # 1x1
     with pytest.raises(hip.MeError):
         hip.conv2d_h16(x, w3, one[:72], one[:72], 3, 1, 1, 1, tile=121)  # cout % 128 != 0
+
+
+BNECK_CASES = [
+    # name, n, h, w, cin, cmid, cout, tiles, with_res, act2
+    ("52x52 block", 3, 52, 52, 256, 128, 256, (1,), True, 1),
+    ("52x52 head pair (no residual, 384 in)", 2, 52, 52, 384, 128, 256, (1,), False, 1),
+    ("one small image, ragged rows", 1, 7, 11, 64, 128, 256, (1,), True, 0),
+    ("many tiny images (tiles cross several)", 9, 5, 6, 32, 128, 256, (1,), True, 1),
+    ("104x104 block", 2, 104, 104, 128, 64, 128, (3, 4), True, 1),
+    ("rectangular 20x61", 2, 20, 61, 96, 64, 128, (3, 4), True, 1),
+]
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("case", BNECK_CASES, ids=[c[0] for c in BNECK_CASES])
+def test_bottleneck_one_launch_equals_the_two_launches(hip_lib, case, half):
+    """``me_bneck_h16`` (csrc/bneck_h16.hip: 1x1 -> 3x3 (+ shortcut) in one launch, the mid tensor rounded to the storage
+    type but kept in LDS) against (a) the two ``me_conv2d_h16`` launches it replaces - same rounding points and, on the tiles
+    chosen below, the same summation order: the results must be EQUAL bit for bit - and (b) the fp32 CPU convolutions on the same rounded operands with the mid tensor rounded once.  Channel-slice
+    input / output (route buffers), determinism, and the pad rows of the padded-linear space (the 3x3 must see ZEROS there,
+    not leaky(bn1(0)): shift1 is far from zero in these cases)."""
+    from millieye_amd import hip
+    half = HALVES[half]
+    name, n, h, w, cin, cmid, cout, tiles, with_res, act2 = case
+    g = torch.Generator().manual_seed(len(name) * 7 + cin)
+    x = _bf(torch.randn((n, h, w, cin), generator=g), half)
+    w1 = _bf(torch.randn((cmid, cin, 1, 1), generator=g) / cin ** 0.5, half)
+    w2 = _bf(torch.randn((cout, cmid, 3, 3), generator=g) / (9 * cmid) ** 0.5, half)
+    s1, t1 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.5 + 0.7
+    s2, t2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = x if (with_res and cin == cout) else (_bf(torch.randn((n, h, w, cout), generator=g), half) if with_res else None)
+    mid_ref = _ref(x, w1, s1, t1, 1, 1, 0, 1).to(half)
+    ref = _ref(mid_ref, w2, s2, t2, 3, 1, 1, act2, res, 1)
+    p1 = w1.permute(0, 2, 3, 1).contiguous().cuda()
+    p2 = w2.permute(0, 2, 3, 1).contiguous().cuda()
+    xs = x.cuda()
+    rs = None if res is None else (xs if res is x else res.cuda())
+    c = [t.cuda() for t in (s1, t1, s2, t2)]
+    # the pair on a per-tap 1x1 tile and a patch-resident 3x3 tile: both walk K chunk by chunk (3x3: chunk-major, taps inside),
+    # the order the one-launch kernel uses - the results must then be EQUAL (tools/bneck_equal.py: 0 of 2.8 M elements differ;
+    # against the tap-major per-tap 3x3 tiles or the weight-stationary 1x1 tile 0.007 - 0.3 % flip by one ulp, as those do
+    # among themselves)
+    mid = hip.conv2d_h16(xs, p1, c[0], c[1], 1, 1, 0, 1, tile=1, split_k=1)
+    two = hip.conv2d_h16(mid, p2, c[2], c[3], 3, 1, 1, act2, residual=rs, tile=131, split_k=1)
+    def close(got, what):
+        # a composite of two stored layers: a rounding flip of a mid element (one ulp of a value of order 1, a few per dot
+        # product) moves an output by ~1e-4 whatever the output's own size, so the bar is one output ulp PLUS that absolute term
+        got, want = got.float().cpu(), ref.to(half).float()
+        tol = torch.maximum(want.abs(), ref.abs()) * ULP[half] + 2e-3
+        bad = (got - want).abs() > tol
+        assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements off, max {float(((got - want).abs() / tol).max()):.2f} x the bar"
+    close(two, f"{name}: two launches")
+    for tile in tiles:
+        y = hip.bneck_h16(xs, p1, c[0], c[1], p2, c[2], c[3], residual=rs, tile=tile, act2=act2)
+        close(y, f"{name}: one launch, tile {tile}")
+        assert torch.equal(y, two), f"{name} tile {tile}: {int((y != two).sum())} elements differ from the two-launch result"
+        y2 = hip.bneck_h16(xs, p1, c[0], c[1], p2, c[2], c[3], residual=rs, tile=tile, act2=act2)
+        assert torch.equal(y, y2), f"{name} tile {tile}: not deterministic"
+    # channel slices on both sides
+    xw = torch.zeros((n, h, w, cin + 32), dtype=half).cuda()
+    xw[..., 32:] = xs
+    wide = torch.zeros((n, h, w, cout + 48), dtype=half).cuda()
+    r2 = None if rs is None else (xw[..., 32:] if res is x else rs)
+    hip.bneck_h16(xw[..., 32:], p1, c[0], c[1], p2, c[2], c[3], residual=r2, out=wide[..., 16:16 + cout], tile=tiles[0], act2=act2)
+    y0 = hip.bneck_h16(xs, p1, c[0], c[1], p2, c[2], c[3], residual=rs, tile=tiles[0], act2=act2)
+    assert torch.equal(wide[..., 16:16 + cout], y0) and float(wide[..., :16].abs().max()) == 0 \
+        and float(wide[..., 16 + cout:].abs().max()) == 0, f"{name}: pitched operands"
+
+
+def test_bottleneck_one_launch_refuses_what_it_cannot_do(hip_lib):
+    from millieye_amd import hip
+    x = torch.zeros((1, 26, 26, 512), dtype=torch.bfloat16).cuda()
+    w1 = torch.zeros((256, 1, 1, 512), dtype=torch.bfloat16).cuda()
+    w2 = torch.zeros((512, 3, 3, 256), dtype=torch.bfloat16).cuda()
+    f = [torch.zeros(k).cuda() for k in (256, 256, 512, 512)]
+    with pytest.raises(hip.MeError, match="no instance"):   # cmid 256 does not fit the LDS with its patch
+        hip.bneck_h16(x, w1, f[0], f[1], w2, f[2], f[3], tile=1)
+    x = torch.zeros((1, 8, 80, 256), dtype=torch.bfloat16).cuda()   # 80 wide: 192 + 2 * 82 rows > 320
+    w1 = torch.zeros((128, 1, 1, 256), dtype=torch.bfloat16).cuda()
+    w2 = torch.zeros((256, 3, 3, 128), dtype=torch.bfloat16).cuda()
+    f = [torch.zeros(k).cuda() for k in (128, 128, 256, 256)]
+    with pytest.raises(hip.MeError, match="no instance"):
+        hip.bneck_h16(x, w1, f[0], f[1], w2, f[2], f[3], tile=1)
