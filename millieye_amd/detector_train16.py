@@ -18,8 +18,10 @@ matrix work                 forward, data gradient and weight gradient on ``v_mf
                             fp32 matrix rate); the stem's and the detection convolutions' weight gradients on the fp32 pipe
 ==========================  ===========================================================================================
 
-BatchNorm: eval mode only (folded into the convolution, its ``weight`` / ``bias`` still receive gradients, like
-``F.batch_norm(training=False)``); train()-mode BatchNorm stays an fp32 path.  Parity bar (tests/test_gpu_train16.py): the loss
+BatchNorm: eval mode is folded into the convolution (its ``weight`` / ``bias`` still receive gradients, like
+``F.batch_norm(training=False)``); train() mode (round 6) takes float32 batch statistics over the convolution's raw float32 sums
+(``y_f32``), normalises / differentiates in float32 (``me_bn_train_fwd_f32`` / ``_bwd_f32``) and stores the activation and its
+gradient in the 16-bit type - slower than the folded form (float32 intermediates), there for the reference's ``model.train()`` semantics.  Parity bar (tests/test_gpu_train16.py): the loss
 within 1 % and every parameter gradient at cosine >= 0.99 of the fp32 HIP step's on the same inputs.
 """
 import ctypes as C
@@ -214,7 +216,9 @@ class DetectorTrainer16:
         eng = m.engine   # (the fp32 engine owns the packed master weights)
         x = x.contiguous()
         defs = m.module_defs
-        outs, raws = [], {}
+        outs, raws, bn_state = [], {}, {}
+        bn_ws = bn_ws_t = None
+        from .train_path import _bn_fwd
         self.w16.direct = False
         if not (_PACK16 and self.w16.pack_direct(eng, defs, half, x.device)):
             eng.refresh_train_weights(x.device)
@@ -230,16 +234,36 @@ class DetectorTrainer16:
                 src = x if i == 0 else outs[i - 1]
                 seq = m.module_list[i]
                 bn = seq[1] if len(seq) > 1 and isinstance(seq[1], torch.nn.BatchNorm2d) else None
-                if bn is not None and bn.training:
-                    raise NotImplementedError("16-bit detector training: BatchNorm in train() mode is a float32 path "
-                                              "(model.eval() keeps the statistics fixed, as the reference's loops do)")
+                bn_train = bn is not None and bn.training
                 to_yolo = i + 1 < len(defs) and defs[i + 1]["type"] == "yolo"
                 co, ci = cw.wgt.shape[0], cw.wgt.shape[3]
                 if (ci > 4 and ci % 32) or (not to_yolo and co % 32):
                     raise NotImplementedError(f"16-bit detector training: conv {i} has {ci} -> {co} channels; the 16-bit matrix kernels "
                                               "want multiples of 32 (Darknet-53 has them; the tiny cfgs' 16-channel stem does not - "
                                               "train those in float32)")
-                if i == 0 or cw.wgt.shape[3] <= 4:   # stem: fp32 frames and fp32 weights holding 16-bit values
+                if bn_train:
+                    # train()-mode BatchNorm (reference yolov3/models.py:38-40 under model.train()): float32 STATISTICS over the
+                    # convolution of the 16-bit operands - the convolution writes its raw float32 sums (y_f32; the stem on the
+                    # float32 pipe over the frame rounded to the storage type, the values its MFMA form multiplies),
+                    # me_bn_train_fwd_f32 normalises with the batch statistics, updates the running ones and applies the
+                    # activation; the stored activation is that result rounded once, like every other stored activation
+                    if co > 2048:
+                        raise hip.MeError("train-mode BatchNorm: more than 2048 channels")
+                    ones, zeros = _const_vectors(co, x.device)
+                    with _timed("fwd", _conv_flops(src, cw.wgt, s, i == 0)):
+                        if i == 0 or ci <= 4:
+                            wq = cw.wgt.to(half).float()
+                            c_raw = hip.conv2d_auto(src.to(half).float(), wq, ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, x_nchw=(i == 0))
+                        else:
+                            c_raw = conv16_auto(src, self.w16.get(i, "wgt"), ones, zeros, k, s, (k - 1) // 2, hip.ACT_LINEAR, y_f32=True)
+                    y32 = torch.empty_like(c_raw)
+                    if bn_ws is None:
+                        bn_ws_t = torch.empty(int(lib.me_bn_workspace_bytes(2048)) + 256, dtype=torch.uint8, device=x.device)
+                        bn_ws = bn_ws_t.data_ptr() + (-bn_ws_t.data_ptr()) % 256
+                    st_bn = _bn_fwd(c_raw, co, c_raw.numel() // co, co, bn, act, y32, co, bn_ws)
+                    bn_state[i] = (c_raw, st_bn)
+                    y = y32 if to_yolo else y32.to(half)
+                elif i == 0 or cw.wgt.shape[3] <= 4:   # stem: fp32 frames and fp32 weights holding 16-bit values
                     wq = cw.wgt.to(half).float()
                     with _timed("fwd", _conv_flops(src, cw.wgt, s, i == 0)):
                         y = hip.conv2d_h16(src, wq, cw.scale, cw.shift, k, s, (k - 1) // 2, act, x_nchw=(i == 0), half=half)
@@ -273,7 +297,8 @@ class DetectorTrainer16:
                 raise ValueError(f"unsupported cfg block [{t}] at module {i}")
             outs.append(y)
         st = _State()
-        st.x, st.outs, st.raws, st.bn_state = x, outs, raws, {}
+        st.x, st.outs, st.raws, st.bn_state = x, outs, raws, bn_state
+        st.bn_ws = bn_ws_t
         return st
 
     # ------------------------------------------------------------------------------------------ backward
@@ -342,7 +367,20 @@ class DetectorTrainer16:
                 gam = bn.weight.detach() if bn is not None else None
                 bet = bn.bias.detach() if bn is not None else None
                 f32_out = y.dtype == torch.float32   # a detection convolution: float32 map, float32 gradient from the loss
-                if f32_out:
+                if i in st.bn_state:
+                    # train()-mode BatchNorm: the gradient through the batch statistics in float32 (me_bn_train_bwd_f32 on the raw
+                    # float32 sums the forward kept), the activation gradient stored in the 16-bit type like the other layers'
+                    from .train_path import _bn_bwd
+                    c_raw, st_bn = st.bn_state[i]
+                    dy32 = dy.float() if dy.dtype != torch.float32 else dy
+                    dc32_bn = torch.empty_like(c_raw)
+                    ws_b = st.bn_ws.data_ptr() + (-st.bn_ws.data_ptr()) % 256
+                    dgamma, dshift = _bn_bwd(c_raw, cout, dy32.contiguous(), cout, rows, cout, bn, st_bn, act, dc32_bn, cout, ws_b)
+                    dc = dc32_bn.to(half)
+                    dc32 = None
+                    sums_ws = None
+                    f32_out = False
+                elif f32_out:
                     dc32 = dy if dy_owned else torch.empty_like(y)
                     ws = torch.empty(lib.me_affine_bwd_workspace_bytes(rows, cout), dtype=torch.uint8, device=dev)
                     hip.check(lib.me_affine_act_bwd_f32(y.data_ptr(), cout, dy.data_ptr(), cout, rows, cout,

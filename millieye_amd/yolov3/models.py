@@ -316,12 +316,14 @@ class Darknet(nn.Module):
     def _forward_batch_stats(self, x, targets):
         """``Darknet.forward`` under ``model.train()`` outside autograd: BatchNorm layers in train() mode normalise with the
         batch statistics and update their running statistics (``me_bn_train_fwd_f32``), the others stay folded; outputs (and,
-        with ``targets``, the loss VALUE) come from that forward.  fp32 only (the 16-bit training step, detector_train16.py, folds eval-mode BatchNorm)."""
+        with ``targets``, the loss VALUE) come from that forward (either storage mode: detector_train.py / detector_train16.py)."""
         from ..detector_train import DetectorTrainer
-        if self.compute_dtype != "f32":
-            raise NotImplementedError("train()-mode BatchNorm: float32 only (the 16-bit storage modes fold BatchNorm)")
         with torch.no_grad():
-            st = DetectorTrainer(self).forward(x)
+            if self.compute_dtype != "f32":   # 16-bit storage modes: float32 batch statistics over the 16-bit operands' products
+                from ..detector_train16 import DetectorTrainer16
+                st = DetectorTrainer16(self).forward(x)
+            else:
+                st = DetectorTrainer(self).forward(x)
             yolo_outputs = self._decode_state(st, x)
             if targets is None:
                 return self.featuremap, yolo_outputs
@@ -343,7 +345,8 @@ class Darknet(nn.Module):
             layer.grid_size, layer.stride = raw.shape[1], x.shape[2] / raw.shape[1]
         tap = self.engine.tap_module
         if tap is not None and tap < len(st.outs) and st.outs[tap] is not None:
-            self.featuremap = hip.nhwc_to_nchw(st.outs[tap])
+            tap_t = st.outs[tap]
+            self.featuremap = hip.nhwc_to_nchw(tap_t if tap_t.dtype == torch.float32 else tap_t.float())
         if not hasattr(self, "featuremap"):
             raise AttributeError("'Darknet' object has no attribute 'featuremap'")
         return yolo_outputs

@@ -284,30 +284,67 @@ def yolo_loss_terms(raw_nhwc, anchors, num_classes, img_dim, targets, ignore_thr
     return total, metrics, dense
 
 
-def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list.", training=False):
+def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list.", training=False, storage="f32"):
     """Summed YOLO loss of every scale + its gradient w.r.t. every detector parameter.  ``training`` selects the
     BatchNorm mode (False: running statistics, what every reference script uses; True: batch statistics, momentum 0.9).
     Returns ``(loss, {name: grad})`` and, with ``training``, ``{name: updated running statistic}`` as a third item;
-    ``state_dict`` is not modified."""
+    ``state_dict`` is not modified.
+
+    ``storage="bf16"`` / ``"f16"`` restates the build's 16-bit TRAINING step (millieye_amd/detector_train16.py; no reference
+    counterpart - the reference trains in fp32 only, so this mode is pinned to nothing but the fp32 step it approximates): the same
+    fp32 autograd graph with one round-to-nearest-even to the storage type at every point where that path stores 16-bit data -
+    forward: the frame, the weights every convolution multiplies (the fp32 masters receive the gradients: straight-through),
+    every stored activation (after conv + BN + activation; after each [shortcut] add - the training forward keeps every module
+    output, so the add is its own launch and reads ROUNDED operands, unlike the inference plans' fused epilogue); backward: the
+    gradient w.r.t. every stored 16-bit activation (after all its readers' contributions are added) and the gradient w.r.t.
+    every convolution's raw output (``me_affine_act_bwd_h16`` / the converted result of ``me_bn_train_bwd_f32``).  Detection
+    convolutions (read only by a [yolo] block) and the YOLO loss stay fp32, as do all parameter gradients and BatchNorm statistics."""
     blocks = parse_cfg_text(cfg_text)[1:]
     img_dim = x.shape[2]
+    if storage not in ("f32", "bf16", "f16"):
+        raise ValueError(storage)
+    low = storage != "f32"
+    half = torch.float16 if storage == "f16" else torch.bfloat16
+    readers = _readers(blocks)
+
+    def q(t):
+        return t.to(half).to(torch.float32)
+
+    def stored(t):
+        """value rounded to the storage type (straight-through), gradient w.r.t. the stored tensor rounded once"""
+        if not low:
+            return t
+        t = t + (q(t) - t).detach()
+        if t.requires_grad:
+            t.register_hook(q)
+        return t
+
     P = {k: v.detach().clone().requires_grad_(True) for k, v in state_dict.items()
          if v.dtype == torch.float32 and "running_" not in k}
     B = {k: v.detach().clone() for k, v in state_dict.items() if "running_" in k}
     outs = []
     loss = 0
+    if low:
+        x = q(x)
     for i, b in enumerate(blocks):
         kind = b["type"]
         if kind == "convolutional":
             k = int(b["size"])
-            x = F.conv2d(x, P[f"{prefix}{i}.conv_{i}.weight"], P.get(f"{prefix}{i}.conv_{i}.bias"), stride=int(b["stride"]),
-                         padding=(k - 1) // 2)
+            w = P[f"{prefix}{i}.conv_{i}.weight"]
+            detect = bool(readers[i]) and all(blocks[r]["type"] == "yolo" for r in readers[i])
+            if low:
+                w = w + (q(w) - w).detach()
+            x = F.conv2d(x, w, P.get(f"{prefix}{i}.conv_{i}.bias"), stride=int(b["stride"]), padding=(k - 1) // 2)
+            if low and not detect:
+                x.register_hook(q)   # the activation gradient w.r.t. the convolution's raw output is a stored 16-bit tensor
             if int(b["batch_normalize"]):
                 p = f"{prefix}{i}.batch_norm_{i}."
                 x = F.batch_norm(x, B[p + "running_mean"], B[p + "running_var"], P[p + "weight"], P[p + "bias"], training,
                                  0.9, 1e-5)
             if b["activation"] == "leaky":
                 x = F.leaky_relu(x, 0.1)
+            if not detect:
+                x = stored(x)
         elif kind == "maxpool":
             k, s = int(b["size"]), int(b["stride"])
             if k == 2 and s == 1:
@@ -318,7 +355,7 @@ def darknet_train_step(cfg_text, state_dict, x, targets, prefix="module_list.", 
         elif kind == "route":
             x = torch.cat([outs[int(l)] for l in b["layers"].split(",")], 1)
         elif kind == "shortcut":
-            x = outs[-1] + outs[int(b["from"])]
+            x = stored(outs[-1] + outs[int(b["from"])])
         elif kind == "yolo":
             loss = loss + yolo_loss(x, _anchors_of(b), int(b["classes"]), img_dim, targets)
         outs.append(x)

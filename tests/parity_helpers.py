@@ -18,6 +18,49 @@ def cfg_text(name):
     return cfgs.KNOWN[name]()
 
 
+def mini32_cfg_text(classes=4, size=64):
+    """A 20-module detector whose channel counts are all multiples of 32 (what the 16-bit training step wants) with every block
+    kind of yolov3.cfg - stride-2 convolutions, two residual blocks, two scales joined by upsample + route - and a convolution at
+    module 8 (the reference's ``conv_8`` feature tap).  Test-only: shallow enough that rounding noise does not compound through 75
+    normalisations, so a 16-bit step can be compared tensor by tensor."""
+    e = cfgs._Emitter(size)
+    det = 3 * (classes + 5)
+    e.conv(32, 3)            # 0
+    e.conv(64, 3, stride=2)  # 1
+    e.conv(32, 1)            # 2
+    e.conv(64, 3)            # 3
+    e.shortcut(-3)           # 4
+    e.conv(128, 3, stride=2) # 5
+    e.conv(64, 1)            # 6
+    e.conv(128, 3)           # 7
+    e.conv(64, 1)            # 8  (tap)
+    e.conv(128, 3)           # 9
+    e.shortcut(-3)           # 10 (+ module 7)
+    e.conv(det, 1, bn=False, act="linear")  # 11
+    e.yolo((3, 4, 5), cfgs._TINY_ANCHORS, classes, 6)  # 12
+    e.route(-3)              # 13 (= module 10)
+    e.conv(64, 1)            # 14
+    e.upsample(2)            # 15
+    e.route(-1, 4)           # 16: 64 + 64 channels at stride 2
+    e.conv(128, 3)           # 17
+    e.conv(det, 1, bn=False, act="linear")  # 18
+    e.yolo((0, 1, 2), cfgs._TINY_ANCHORS, classes, 6)  # 19
+    return e.text()
+
+
+def make_mini32(tag, size=64):
+    """(Darknet module tree on the mini cfg, its cfg text)."""
+    from millieye_amd.yolov3.models import Darknet
+    text = mini32_cfg_text(size=size)
+    os.makedirs(CFG_DIR, exist_ok=True)
+    path = os.path.join(CFG_DIR, "mini32.cfg")
+    with open(path, "w") as fh:
+        fh.write(text)
+    model = Darknet(path).eval()
+    synth.fill_darknet_(model, tag)
+    return model, text
+
+
 def make_darknet(name, tag=None, trained_like=False):
     """Product-side Darknet module tree with deterministic weights (CPU tensors)."""
     from millieye_amd.yolov3.models import Darknet

@@ -173,12 +173,135 @@ def test_16bit_training_refuses_what_it_cannot_do(hip_lib):
     assert model.module_list[0][0].weight.grad is not None
 
 
-def test_16bit_training_refuses_train_mode_batchnorm(hip_lib):
-    model = ph.make_darknet("yolov3", tag="t16/bn").cuda().train()
-    model.compute_dtype = "bf16"
-    x = torch.from_numpy(synth.uniform("t16/bn/x", (1, 3, 64, 64))).cuda()
-    with pytest.raises(NotImplementedError):
-        model(x, torch.tensor([[0, 0, 0.5, 0.5, 0.2, 0.2]]))
+def _step_errors(named_params, scale, ref32, rst):
+    """Per parameter tensor: the HIP gradient's relative L2 distance from the fp32 oracle, the restatement's distance from the
+    fp32 oracle, and the cosine of the HIP gradient with the restatement's."""
+    rows = []
+    for k, p in named_params:
+        g = (p.grad / scale).cpu().double()
+        a, r = ref32[k].double(), rst[k].double()
+        if float(a.norm()) < 1e-12:
+            continue
+        rows.append((k, float((g - a).norm() / a.norm()), float((r - a).norm() / a.norm()), _cos(g, r), _cos(g, a)))
+    return rows
+
+
+@pytest.mark.parametrize("dtype,n,s", [("bf16", 2, 128), ("f16", 2, 128), ("bf16", 8, 416)])
+def test_detector_step_16bit_vs_oracle_restatement(hip_lib, dtype, n, s):
+    """The 16-bit training step against an INDEPENDENT check (until round 6 it was compared with the fp32 HIP
+    step only): ``oracle.darknet_ref.darknet_train_step(storage=...)`` = fp32 CPU autograd through a forward rounded at this
+    path's rounding points, with the activation gradients rounded where ``detector_train16.py`` stores them, and the plain fp32
+    oracle step (pinned to the reference's autograd by ``yololoss_*.npz``).  Darknet-53, trained-like weights, 128 px batch 2 in
+    both formats and the bench's shape (416 px, batch 8) in bf16.  Bars:
+      * the storage format, not the kernels, sets the error: the mean over the 222 parameter tensors of the HIP gradient's
+        relative distance from the fp32 oracle is within 1.25 x + 1e-4 of the restatement's own distance (the bar of
+        ``test_detector_bf16``), and so is the loss;
+      * HIP and restatement agree tensor by tensor: at the bench's shape every cosine >= 0.998 (measured worst 0.99846: the 1x1
+        convolution in front of the second upsample), median >= 0.9999 (measured 0.99997); at 128 px the deepest maps are 4 x 4
+        positions x 2 frames and a rounding flip of one activation moves a whole filter's gradient, so the per-tensor bar there is
+        0.98 (bf16; measured worst 0.9886 on a 512-channel BatchNorm weight) / 0.997 (f16) and the median is >= 0.995 (bf16, measured 0.9972 - 0.9988 from run to run: the layer tiles are tuned per process) / 0.999 (f16, 0.9997 - 0.9999)."""
+    import os
+    from millieye_amd import cfgs
+    from oracle import darknet_ref
+    name = f"t16r/{n}/{s}"
+    cpu_model = ph.make_darknet("yolov3", tag=name, trained_like=True)
+    targets = torch.tensor([[i % n, (3 * i) % 80, 0.3 + 0.04 * (i % 8), 0.4 + 0.03 * (i % 5), 0.2, 0.3] for i in range(max(n, 3))],
+                           dtype=torch.float32)
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    torch.set_num_threads(min(64, len(os.sched_getaffinity(0))))
+    text, sd = cfgs.KNOWN["yolov3"](), cpu_model.state_dict()
+    loss32, g32 = darknet_ref.darknet_train_step(text, sd, x, targets)
+    loss_r, g_r = darknet_ref.darknet_train_step(text, sd, x, targets, storage=dtype)
+    model = ph.make_darknet("yolov3", tag=name, trained_like=True).cuda().eval()
+    model.compute_dtype = dtype
+    loss, _fm, _yo = model(x.cuda(), targets)
+    loss.backward()
+    torch.cuda.synchronize()
+    rel_h = abs(float(loss.detach()) - float(loss32)) / abs(float(loss32))
+    rel_r = abs(float(loss_r) - float(loss32)) / abs(float(loss32))
+    rows = _step_errors(list(model.named_parameters()), 1.0, g32, g_r)
+    assert len(rows) == 222
+    e_h = sum(r[1] for r in rows) / len(rows)
+    e_r = sum(r[2] for r in rows) / len(rows)
+    cos = sorted(r[3] for r in rows)
+    worst = min(rows, key=lambda r: r[3])
+    print(f"[{dtype} {n}x{s}] loss: HIP {rel_h:.2e} / restatement {rel_r:.2e} from fp32; gradients: mean distance from fp32 HIP {e_h:.3e} / "
+          f"restatement {e_r:.3e}; cosine HIP vs restatement: median {cos[len(cos) // 2]:.5f}, worst {worst[3]:.5f} ({worst[0]})")
+    assert rel_h <= 1.25 * rel_r + (1e-3 if dtype == "f16" else 5e-3), (rel_h, rel_r)
+    assert e_h <= 1.25 * e_r + 1e-4, f"HIP gradients {e_h:.3e} from the fp32 oracle, the restatement {e_r:.3e}"
+    per_tensor = 0.998 if s >= 416 else (0.98 if dtype == "bf16" else 0.997)
+    bad = [f"{r[0]}: {r[3]:.4f}" for r in rows if r[3] < per_tensor]
+    assert not bad, "; ".join(bad[:10]) + f" ({len(bad)} of {len(rows)} below {per_tensor})"
+    assert cos[len(cos) // 2] >= (0.9999 if s >= 416 else 0.995 if dtype == "bf16" else 0.999)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cfg", ["mini32", "yolov3"])
+def test_16bit_training_with_train_mode_batchnorm(hip_lib, dtype, cfg):
+    """``model.train()`` in a 16-bit storage mode (refused until round 6): float32 batch statistics over the raw float32 sums of
+    the 16-bit convolution, normalisation / its gradient in float32 (``me_bn_train_fwd_f32`` / ``_bwd_f32``), activations and
+    activation gradients stored in the 16-bit type - against the oracle's restatement of exactly that
+    (``darknet_train_step(training=True, storage=...)``) and against the fp32 oracle step that
+    ``yololoss_tiny12_s96_n2_bntrain.npz`` pins to the reference's own ``model.train()`` run: loss, every gradient, every running
+    statistic (momentum 0.9), ``num_batches_tracked``, and the no-autograd form (``Darknet.forward(x)`` under ``model.train()``).
+
+    Batch-statistics BatchNorm subtracts the mean and the xhat-component of every activation gradient; the YOLO loss's gradient is
+    mostly such a common component (``noobj_scale`` 100 over every cell), so what is left carries the 16-bit rounding noise many
+    times amplified: against fp32 the RESTATEMENT's own gradients sit at cosine ~0.97 (bf16) on a 20-module cfg and lose all
+    resemblance over Darknet-53's 72 normalisations (measured mean distance 0.74 bf16 / 0.30 f16, HIP and restatement alike).
+    So: tensor-by-tensor agreement of HIP with the restatement on the shallow ``mini32`` cfg (tests/parity_helpers.py: every
+    block kind of yolov3.cfg, 32-multiple channels); on Darknet-53 the format-sets-the-error bar, the loss and the statistics."""
+    import os
+    from millieye_amd import cfgs
+    from oracle import darknet_ref
+    mini = cfg == "mini32"
+    name, n, s = f"t16bn/{cfg}", 4, (64 if mini else 128)
+    if mini:
+        cpu_model, text = ph.make_mini32(name, size=s)
+        targets = torch.tensor([[0, 1, 0.30, 0.40, 0.20, 0.30], [1, 2, 0.70, 0.60, 0.50, 0.40], [3, 0, 0.52, 0.48, 0.10, 0.15]])
+    else:
+        cpu_model, text = ph.make_darknet("yolov3", tag=name), cfgs.KNOWN["yolov3"]()
+        targets = torch.tensor([[0, 3, 0.30, 0.40, 0.20, 0.30], [1, 17, 0.70, 0.60, 0.50, 0.40], [3, 60, 0.52, 0.48, 0.10, 0.15]])
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s)))
+    torch.set_num_threads(min(64, len(os.sched_getaffinity(0))))
+    sd = cpu_model.state_dict()
+    loss32, g32, b32 = darknet_ref.darknet_train_step(text, sd, x, targets, training=True)
+    loss_r, g_r, b_r = darknet_ref.darknet_train_step(text, sd, x, targets, training=True, storage=dtype)
+    model = (ph.make_mini32(name, size=s)[0] if mini else ph.make_darknet("yolov3", tag=name)).cuda().train()
+    model.compute_dtype = dtype
+    loss, fm, yo = model(x.cuda(), targets)
+    assert loss.requires_grad and fm.dtype == torch.float32 and fm.shape[0] == n
+    loss.backward()
+    torch.cuda.synchronize()
+    rel_h = abs(float(loss.detach()) - float(loss32)) / abs(float(loss32))
+    rel_r = abs(float(loss_r) - float(loss32)) / abs(float(loss32))
+    rows = _step_errors(list(model.named_parameters()), 1.0, g32, g_r)
+    e_h = sum(r[1] for r in rows) / len(rows)
+    e_r = sum(r[2] for r in rows) / len(rows)
+    cos = sorted(r[3] for r in rows)
+    worst = min(rows, key=lambda r: r[3])
+    print(f"[bn-train {cfg} {dtype}] loss: HIP {rel_h:.2e} / restatement {rel_r:.2e} from fp32; gradients: HIP {e_h:.3e} / restatement {e_r:.3e} "
+          f"from fp32; cosine HIP vs restatement: median {cos[len(cos) // 2]:.5f}, worst {worst[3]:.5f} ({worst[0]})")
+    assert rel_h <= 1.25 * rel_r + (2e-3 if dtype == "f16" else 1e-2), (rel_h, rel_r)
+    assert e_h <= 1.25 * e_r + 1e-3, f"HIP gradients {e_h:.3e} from the fp32 oracle, the restatement {e_r:.3e}"
+    if mini:
+        bar = 0.97 if dtype == "bf16" else 0.9995   # measured worst 0.979 / 0.99994, medians 0.992 / 0.99998
+        bad = [f"{r[0]}: {r[3]:.4f}" for r in rows if r[3] < bar]
+        assert not bad, "; ".join(bad[:10]) + f" ({len(bad)} of {len(rows)} below {bar})"
+    got = model.state_dict()
+    for k, v in b_r.items():
+        ref = v.double()
+        err = float((got[k].cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+        assert err <= (2e-2 if dtype == "bf16" else 3e-3) * (1 if mini else 5), f"{k}: running statistic {err:.3e} from the restatement"   # (Darknet-53, measured worst 4.6e-2 / 6.3e-3: the variance of a 64-sample channel 78 layers deep)
+        err32 = float((got[k].cpu().double() - b32[k].double()).abs().max() / b32[k].double().abs().max().clamp_min(1e-6))
+        assert err32 <= (5e-2 if dtype == "bf16" else 1e-2) * (1 if mini else 4), f"{k}: running statistic {err32:.3e} from the fp32 oracle"
+    assert all(int(v) == 1 for k, v in got.items() if k.endswith("num_batches_tracked"))
+    # no autograd: the batch-statistics forward of the same storage mode (running statistics move again)
+    before = {k: v.clone() for k, v in got.items() if "running_mean" in k}
+    with torch.no_grad():
+        fm2, yo2 = model(x.cuda())
+    assert yo2.shape == yo.shape and bool(torch.isfinite(yo2).all())
+    assert any(not torch.equal(model.state_dict()[k], v) for k, v in before.items())
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
