@@ -156,17 +156,63 @@ def conv_roofline(model, x, steps):
                 fn(*args, stream)
     torch.cuda.synchronize()
     total_ms, total_flops, launches = 0.0, 0, 0
-    per_layer = []
+    per_layer, per_layer_descs = [], []
     for mods, evs in timed.items():
         ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
         flops = sum(_conv_flops(descs[m]) for m in mods)   # a one-launch bottleneck: the ALGORITHMIC flops of its two layers (no halo term)
         mod = "+".join(str(m) for m in mods)
         per_layer.append((mod, flops, ms))
+        per_layer_descs.append(([descs[m] for m in mods], flops, ms))
         total_ms += ms
         total_flops += flops
         launches += 1
     achieved = total_flops / (total_ms * 1e-3) / 1e12
+    conv_roofline.by_class = _by_class(per_layer_descs, half=plan.dtype != "f32")
     return achieved, total_ms * 1e3 / launches, launches, total_flops / launches, per_layer
+
+
+def _conv_bytes(d, esize):
+    """SURVEY 8(d) algorithmic bytes of one conv launch: input + output activations once (+ the residual it adds), weights once."""
+    out_es = 4 if getattr(d, "y_f32", 0) else esize
+    act = d.n * (d.h * d.w * d.cin * esize + d.ho * d.wo * d.upsample * d.upsample * d.cout * out_es)
+    if d.res:
+        act += d.n * d.ho * d.wo * d.cout * out_es
+    return act + d.cout * d.ksize * d.ksize * d.cin * esize
+
+
+def _by_class(rows, half):
+    """SURVEY 8(d)'s roofline classes for the conv launches of one step: a launch whose arithmetic intensity (algorithmic flops /
+    algorithmic bytes) is above the ridge (matrix peak / 8 TB/s: 314 flop/B in the 16-bit modes, 20 in fp32) is priced against
+    the MFMA peak, one below it against HBM - the single MFMA number of ``roofline`` hides that the 16-bit 1x1 bottlenecks (AI ~ 85)
+    are traffic problems.  ``rows``: (descs of the launch, flops, ms)."""
+    peak = BF16_MFMA_PEAK_TFLOPS if half else FP32_MFMA_PEAK_TFLOPS
+    esize = 2 if half else 4
+    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    acc = {}
+    for descs, flops, ms in rows:
+        nbytes = sum(_conv_bytes(d, esize) for d in descs)
+        if len(descs) == 2:   # a one-launch bottleneck: the mid tensor is neither written nor read
+            nbytes -= 2 * descs[0].n * descs[0].ho * descs[0].wo * descs[0].cout * esize
+        ai = flops / nbytes
+        k = max(d.ksize for d in descs)
+        name = ("3x3" if k == 3 else "1x1") + (" (MFMA-bound: AI above the ridge)" if ai >= ridge else " (HBM-bound: AI below the ridge)")
+        e = acc.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, bound="mfma" if ai >= ridge else "hbm"))
+        e["ms"] += ms
+        e["flops"] += flops
+        e["bytes"] += nbytes
+        e["launches"] += 1
+    out = []
+    for name, e in sorted(acc.items(), key=lambda kv: -kv[1]["ms"]):
+        row = {"class": name, "bound": e["bound"], "launches": e["launches"], "ms": round(e["ms"], 4),
+               "arithmetic_intensity": round(e["flops"] / e["bytes"], 1)}
+        if e["bound"] == "mfma":
+            a = e["flops"] / (e["ms"] * 1e-3) / 1e12
+            row.update(achieved=round(a, 2), peak=peak, unit="TFLOP/s", frac=round(a / peak, 4))
+        else:
+            a = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+            row.update(achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4), algorithmic_bytes=int(e["bytes"]))
+        out.append(row)
+    return {"ridge_flop_per_byte": round(ridge, 1), "classes": out}
 
 
 def _launch_modules(lib, fn, name):
@@ -335,13 +381,22 @@ def conv_traffic(args, batch, half=False):
     be read from inside this process, so the committed measurement is reported ONLY when it was taken on this
     configuration (cfg, size, batch, workload, storage type) and this kernel generation (source hash); otherwise
     ``traffic`` is null and ``traffic_source`` says why.  Returns (bytes or None, source string)."""
-    name = "conv_traffic_bf16.json" if half else "conv_traffic.json"
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        with open(path) as fh:
-            t = json.load(fh)
-    except (OSError, ValueError):
-        return None, f"no committed PMC measurement (profiles/{name} missing)"
+    dt = ("bf16" if half else "f32") if args.dtype == "f32" else args.dtype
+    # one file per measured line: conv_traffic_<workload>_<dtype>[_<size>][_graph].json (tools/profile_r06.sh), the two batch-32
+    # inference lines under their old names
+    names = [f"conv_traffic_{args.workload}_{dt}_{args.size}" + ("_graph" if getattr(args, "graph", False) else "") + ".json",
+             f"conv_traffic_{args.workload}_{dt}" + ("_graph" if getattr(args, "graph", False) else "") + ".json",
+             "conv_traffic_bf16.json" if half else "conv_traffic.json"]
+    t = name = None
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                t = json.load(fh)
+            break
+        except (OSError, ValueError):
+            continue
+    if t is None:
+        return None, f"no committed PMC measurement (profiles/{names[0]} missing)"
     want = dict(cfg=args.cfg, size=args.size, batch=batch, workload=args.workload,
                 dtype=("bf16" if half else "f32") if args.dtype == "f32" else args.dtype,
                 kernel_generation=kernel_generation(half))
@@ -825,7 +880,7 @@ def main():
             alt = {"e": e16}
             if rank == 0:
                 ach16, avg16, n16, _f16, _pl = conv_roofline(model, x, max(3, min(args.steps, 10)))
-                alt.update(ach=ach16, avg_us=avg16, launches=n16)
+                alt.update(ach=ach16, avg_us=avg16, launches=n16, by_class=conv_roofline.by_class)
             model.compute_dtype = "f32"
         except Exception as exc:  # the extra line must never take the fp32 measurement down with it
             alt = {"error": f"{type(exc).__name__}: {exc}"}
@@ -976,6 +1031,7 @@ def main():
                 "launches_per_step": launches,
                 "avg_launch_us": round(avg_us, 2),
                 "gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                "by_class": conv_roofline.by_class,
             },
         }
         if sweep:
@@ -997,7 +1053,8 @@ def main():
                              "frac": round(alt["ach"] / BF16_MFMA_PEAK_TFLOPS, 4),
                              "traffic": conv_traffic(args, batch, half=True)[0],
                              "traffic_source": conv_traffic(args, batch, half=True)[1],
-                             "launches_per_step": alt["launches"], "avg_launch_us": round(alt["avg_us"], 2)},
+                             "launches_per_step": alt["launches"], "avg_launch_us": round(alt["avg_us"], 2),
+                             "by_class": alt.get("by_class")},
             }
         if not args.no_cpu_baseline and world == 1 and args.workload not in ("train", "detector_train", "module2"):
             from millieye_amd.engine import pick_tap_module
@@ -1046,7 +1103,10 @@ def main():
                 "by_pass": {k: {"ms": round(ms, 3), "gflop": round(fl / 1e9, 1), "launches": cnt,
                                 "achieved": round(fl / ms / 1e9, 2), "frac": round(fl / ms / 1e9 / train_peak, 4)}
                             for k, (ms, fl, cnt) in sorted(passes.items())},
-                "traffic": None,
+                # (per launch of the step's convolution kernels - forward, data gradient, weight gradient - from this workload's own
+                #  PMC passes: profiles/conv_traffic_detector_train_<dtype>[_graph].json)
+                "traffic": conv_traffic(args, batch, half=args.dtype != "f32")[0],
+                "traffic_source": conv_traffic(args, batch, half=args.dtype != "f32")[1],
             }
         if args.workload == "train":
             out["config"]["detector_prefetch"] = not args.no_prefetch

@@ -328,6 +328,14 @@ int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t 
 int me_linear_f32(const float* x, int64_t ldx, int64_t rows, int32_t in_features, const float* w, const float* bias,
                   int32_t out_features, int32_t act, float* y, int64_t ldy, void* stream);
 int me_mask_scale_f32(const float* x, const uint8_t* mask, float scale, int64_t count, float* y, void* stream);
+/* me_m2_pairs_f32 (ABI 12): the ensemble head's input x2 [k * c1, 2] = (refinement_vector, yolo_vector) pairs
+ *   (module2_mixed/my_models.py:333-339; yolo_vector = columns 5, 8 .. of the proposal rows).
+ * me_m2_rows_f32 (ABI 12): the tail of the stage-2 forward (:341-364) per proposal - masks = softmax(o) [k,2], keep = masks[:,1] >
+ *   threshold, box_regress, rows [k,8] = (image_i, x1,y1,x2,y2, masks[:,1], cls_score, cls_pred), key = masks[:,1]; order the kept
+ *   rows with me_compact_sort_rows_f32 (= torch.sort(descending, stable)). */
+int me_m2_pairs_f32(const float* refine, const float* boxes, int32_t box_cols, int32_t k, int32_t c1, float* x2, void* stream);
+int me_m2_rows_f32(const float* o, const float* regress, const float* boxes, int32_t box_cols, int32_t k, float threshold,
+                   float* masks, float* rows, uint8_t* keep, float* key, void* stream);
 int me_m2_loss_f32(const float* o, const float* refine, int32_t c1, const float* regress, const float* boxes,
                    int32_t box_cols, const float* target_location, const float* class_label, const uint8_t* pos,
                    const uint8_t* sample, int32_t k, float alpha, float lambda0, float lambda1, float grad_scale,

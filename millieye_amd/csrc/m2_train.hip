@@ -122,9 +122,74 @@ __global__ __launch_bounds__(256) void m2_loss_kernel(const float* __restrict__ 
   d_o[2ll * i + 1] = gscale * go1;
 }
 
+// Tail of the stage-2 forward (my_models.py:341-364), one thread per proposal:
+//   masks = softmax(o)  (two logits);  keep = masks[:,1] > threshold;  box_regress (:222-236) on the kept boxes;
+//   row = (image_i, x1', y1', x2', y2', masks[:,1], cls_score, cls_pred);  key = masks[:,1]  ->  me_compact_sort_rows_f32.
+__global__ __launch_bounds__(256) void m2_rows_kernel(const float* __restrict__ O, const float* __restrict__ REG,
+                                                      const float* __restrict__ boxes, int box_cols, int k, float thr,
+                                                      float* masks, float* rows, unsigned char* keep, float* key) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const float o0 = O[2ll * i], o1 = O[2ll * i + 1];
+  const float m = fmaxf(o0, o1);
+  const float e0 = expf(o0 - m), e1 = expf(o1 - m);
+  const float s = e0 + e1;
+  const float p0 = e0 / s, p1 = e1 / s;
+  masks[2ll * i] = p0;
+  masks[2ll * i + 1] = p1;
+  const float* b = boxes + (long long)i * box_cols;
+  const float* rp = REG + 4ll * i;
+  const float cx = (b[1] + b[3]) / 2, cy = (b[2] + b[4]) / 2, bw = b[3] - b[1], bh = b[4] - b[2];
+  const float nx = rp[0] * bw + cx, ny = rp[1] * bh + cy, nw = expf(rp[2]) * bw, nh = expf(rp[3]) * bh;
+  float* r = rows + 8ll * i;
+  r[0] = b[0];
+  r[1] = nx - nw / 2;
+  r[2] = ny - nh / 2;
+  r[3] = nx + nw / 2;
+  r[4] = ny + nh / 2;
+  r[5] = p1;
+  r[6] = b[6];
+  r[7] = b[7];
+  keep[i] = p1 > thr ? 1 : 0;
+  key[i] = p1;
+}
+
+// Input of the ensemble head (my_models.py:333-339): x2[i * c1 + c] = (refinement_vector[i][c], yolo_vector[i][c]) with
+// yolo_vector = (object confidence, class scores) = columns 5, 8 .. 8 + class_num - 1 of the proposal rows.
+__global__ __launch_bounds__(256) void m2_pairs_kernel(const float* __restrict__ R, const float* __restrict__ boxes, int box_cols,
+                                                       int k, int c1, float* x2) {
+  const long long total = (long long)k * c1;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % c1);
+    const long long i = idx / c1;
+    x2[2 * idx] = R[idx];
+    x2[2 * idx + 1] = boxes[i * box_cols + (c == 0 ? 5 : 7 + c)];
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int me_m2_rows_f32(const float* o, const float* regress, const float* boxes, int32_t box_cols, int32_t k, float threshold,
+                   float* masks, float* rows, uint8_t* keep, float* key, void* stream) {
+  if (k == 0) return 0;
+  ME_REQUIRE(o && regress && boxes && masks && rows && keep && key, ME_E_NULLPTR, "me_m2_rows_f32: null pointer");
+  ME_REQUIRE(k > 0 && box_cols >= 8, ME_E_BADARG, "me_m2_rows_f32: bad dimensions");
+  hipLaunchKernelGGL(m2_rows_kernel, dim3((k + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, regress, boxes, box_cols, k,
+                     threshold, masks, rows, keep, key);
+  return me::check_launch("m2_rows_kernel");
+}
+
+int me_m2_pairs_f32(const float* refine, const float* boxes, int32_t box_cols, int32_t k, int32_t c1, float* x2, void* stream) {
+  if (k == 0) return 0;
+  ME_REQUIRE(refine && boxes && x2, ME_E_NULLPTR, "me_m2_pairs_f32: null pointer");
+  ME_REQUIRE(k > 0 && c1 >= 2 && box_cols >= 7 + c1, ME_E_BADARG, "me_m2_pairs_f32: bad dimensions");
+  hipLaunchKernelGGL(m2_pairs_kernel, dim3(grid_for((long long)k * c1)), dim3(256), 0, (hipStream_t)stream, refine, boxes,
+                     box_cols, k, c1, x2);
+  return me::check_launch("m2_pairs_kernel");
+}
+
 
 int me_linear_f32(const float* x, int64_t ldx, int64_t rows, int32_t in_features, const float* w, const float* bias,
                   int32_t out_features, int32_t act, float* y, int64_t ldy, void* stream) {

@@ -100,6 +100,15 @@ class Network(nn.Module):
         self.refinement_head = refinement_head((490, 256, self.class_num + 1))
         self.ensemble_head = ensemble_head((2, 32, 32 * (self.class_num + 1), 2))
         object.__setattr__(self, "_packs", None)
+        # "cpu": nn.Dropout's mask of the training step from torch's CPU generator (reproducible against the reference's CPU run, the
+        # goldens); "device": from the GPU's generator (what the reference does when it runs on a CUDA machine; faster)
+        self.dropout_generator = "cpu"
+
+    def queue_detector_prefetch(self, images_next):
+        """The stage-3 Network's look-ahead hint (millieye_amd/my_models.py) for the stage-2 loop: the detector is frozen here too
+        (module2_mixed/train.py:129 ``model.base_detector.eval()``, its parameters are not handed to the optimizer), so the next
+        batch's detector + NMS + proposal rows can run under this batch's host-bound tail.  Purely an overlap."""
+        self.__dict__["_next_images"] = images_next
 
     def forward(self, images, targets=None):
         if targets is not None or self.fcn_layers.net[1].training or self.refinement_head.training:

@@ -55,10 +55,22 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
         model.base_detector.eval()
         start_time = time.time()
         parallel.begin_epoch(dataloader, epoch, device)  # equal batch counts on every rank + the sampler's epoch
-        for batch_i, (_, imgs, targets) in enumerate(dataloader):
+        # one batch of look-ahead, as in the stage-3 loop (millieye_amd/train.py): the frozen detector's part of batch k + 1 runs
+        # under the host-bound tail of batch k (Network.queue_detector_prefetch; MILLIEYE_DETECTOR_PREFETCH=0 = the plain loop).
+        # Same batches, same order, same results.
+        batches = iter(dataloader)
+        upcoming = next(batches, None)
+        imgs_ahead, batch_i = None, -1
+        while upcoming is not None:
+            batch_i += 1
+            (_, imgs, targets), upcoming = upcoming, next(batches, None)
             batches_done = len(dataloader) * epoch + batch_i
             epoch_batches_left = len(dataloader) - (batch_i + 1)
-            imgs = imgs.to(device)
+            imgs = imgs_ahead if imgs_ahead is not None else imgs.to(device)
+            imgs_ahead = None
+            if upcoming is not None and os.environ.get("MILLIEYE_DETECTOR_PREFETCH", "1") != "0" and hasattr(model, "queue_detector_prefetch"):
+                imgs_ahead = upcoming[1].to(device)
+                model.queue_detector_prefetch(imgs_ahead)
             targets.requires_grad = False
 
             output, loss, metric = model(imgs, targets)  # imgs on the device, targets on the host

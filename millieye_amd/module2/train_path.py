@@ -21,7 +21,8 @@ import torch
 
 from .. import hip
 from ..my_models import _DETECTIONS_PER_IMG, _NMS_THRESH
-from ..train_path import _bn_bwd, _bn_fwd, _colsum, _conv, _f32, _gemm, _ptr, iou_labels_vectorized
+from ..train_path import (_bn_bwd, _bn_fwd, _colsum, _conv, _f32, _frozen_detector_block, _gemm, _issue_prefetch, _ptr, _take_prefetch,
+                          iou_labels_vectorized)
 from ..utils.utils import xywh2xyxy
 
 LEAKY, SIGMOID, LINEAR = hip.ACT_LEAKY, hip.ACT_SIGMOID, hip.ACT_LINEAR
@@ -80,23 +81,22 @@ def forward_train(net, images, targets):
     c1 = net.class_num + 1
 
     with torch.no_grad():
-        plan, yolo_out = net.base_detector._run(images)  # frozen detector: Darknet.compute_dtype applies
-        det, cnt = hip.nms_batched(yolo_out, float(net.conf_thresh), _NMS_THRESH, _DETECTIONS_PER_IMG, writeback_xyxy=False)
-        num_classes = yolo_out.shape[2] - 5
-        cols, cap = 8 + net.class_num, n * _DETECTIONS_PER_IMG
-        boxes = torch.empty((cap, cols), **f32)
-        n_dev = torch.empty((1,), device=dev, dtype=torch.int32)
-        hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes, -1,
-                                                net.class_num, boxes.data_ptr(), n_dev.data_ptr(), hip.stream_ptr()),
-                  "me_gather_class_boxes_f32")
+        # frozen detector -> NMS -> all-class proposal rows -> fp32 NHWC copy of the feature tap: the stage-3 path's block
+        # (millieye_amd/train_path.py), taken from the look-ahead when the training loop named this batch one call early
+        pre = _take_prefetch(net, images)
+        if pre is None:
+            pre = _frozen_detector_block(net, images)
+        nxt = net.__dict__.pop("_next_images", None)
+        if nxt is not None:   # (Network.queue_detector_prefetch: the NEXT batch's frozen part beside this batch's host-bound tail)
+            _issue_prefetch(net, nxt)
+        cols, cap = pre["cols"], pre["cap_img"]
+        boxes, n_dev = pre["img_boxes"], pre["n_img_dev"]
         k = int(n_dev.item())
         if k == 0:
             raise hip.MeError("module-2 training step: the detector produced no proposal for this batch")
-        boxes = boxes[:k].contiguous()
-        if plan.tap is None:
-            raise AttributeError("'Darknet' object has no attribute 'featuremap'")
-        fh, fw, fc = plan.tap_shape
-        fm = plan.tap.permute(0, 2, 3, 1).float().contiguous()
+        boxes = boxes[:k]   # (leading rows of a contiguous buffer: contiguous)
+        fh, fw, fc = pre["tap_shape"]
+        fm = pre["fm"]
         pix = n * fh * fw
         ws_t = torch.empty(int(lib.me_bn_workspace_bytes(512)) + 256, dtype=torch.uint8, device=dev)
         ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256
@@ -122,27 +122,35 @@ def forward_train(net, images, targets):
         e2w, e2b = eh.fc2[0].weight.detach().contiguous(), eh.fc2[0].bias.detach().contiguous()
         t_act = _linear(feat, 490, k, 490, w0, b0, LEAKY, _f32(dev, k, 256), 256)
         # nn.Dropout(0.5), train mode: aten's CPU path draws empty_like(t).bernoulli_(1 - p) from the default generator
-        mask = torch.empty((k, 256)).bernoulli_(0.5).to(torch.uint8).to(dev)
+        if getattr(net, "dropout_generator", "cpu") == "device":
+            # opt-in (Network.dropout_generator = "device"): the mask from torch's generator of the GPU, what the reference's own run
+            # on a CUDA machine does - 11 ms of host time per step less at 1600 proposals; not reproducible against a CPU run
+            mask = torch.empty((k, 256), device=dev).bernoulli_(0.5).to(torch.uint8)
+        else:
+            mask = torch.empty((k, 256)).bernoulli_(0.5).to(torch.uint8).to(dev)
         hidden = _f32(dev, k, 256)
         hip.check(lib.me_mask_scale_f32(t_act.data_ptr(), mask.data_ptr(), 2.0, k * 256, hidden.data_ptr(), hip.stream_ptr()),
                   "me_mask_scale_f32")
         regress = _linear(hidden, 256, k, 256, w1, b1, LINEAR, _f32(dev, k, 4), 4)
         refine = _linear(hidden, 256, k, 256, w2, b2, SIGMOID, _f32(dev, k, c1), c1)
-        yolo_vec = torch.cat((boxes[:, 5:6], boxes[:, 8:8 + net.class_num]), 1)
-        x2 = torch.stack((refine, yolo_vec), -1).reshape(k * c1, 2).contiguous()       # [K*(C+1), 2]
+        x2 = _f32(dev, k * c1, 2)                                                      # [K*(C+1), 2] = (refine, yolo_vector) pairs
+        hip.check(lib.me_m2_pairs_f32(refine.data_ptr(), boxes.data_ptr(), cols, k, c1, x2.data_ptr(), hip.stream_ptr()),
+                  "me_m2_pairs_f32")
         h1 = _linear(x2, 2, k * c1, 2, e1w, e1b, LEAKY, _f32(dev, k * c1, 32), 32)      # -> flatten [K, 32*(C+1)]
         o = _linear(h1, 32 * c1, k, 32 * c1, e2w, e2b, LEAKY, _f32(dev, k, 2), 2)
-        masks = torch.softmax(o, dim=1)
 
-        # output rows (reference :349-357)
-        positive = masks[:, 1] > net.refine_threshold
-        bx = boxes[positive]
-        rp = regress[positive]
-        cx, cy, bw, bh = (bx[:, 1] + bx[:, 3]) / 2, (bx[:, 2] + bx[:, 4]) / 2, bx[:, 3] - bx[:, 1], bx[:, 4] - bx[:, 2]
-        nx, ny, nw, nh = rp[:, 0] * bw + cx, rp[:, 1] * bh + cy, torch.exp(rp[:, 2]) * bw, torch.exp(rp[:, 3]) * bh
-        output = torch.stack((bx[:, 0], nx - nw / 2, ny - nh / 2, nx + nw / 2, ny + nh / 2, masks[positive, 1], bx[:, 6],
-                              bx[:, 7]), 1)
-        output = output[torch.sort(output[:, 5], descending=True, stable=True).indices].cpu()
+        # masks = softmax(o), output rows (reference :341-364): one launch + the compaction / ordering launch of stage 3
+        masks, rows_all, key = _f32(dev, k, 2), _f32(dev, k, 8), _f32(dev, k)
+        keep = torch.empty((k,), device=dev, dtype=torch.uint8)
+        hip.check(lib.me_m2_rows_f32(o.data_ptr(), regress.data_ptr(), boxes.data_ptr(), cols, k, float(net.refine_threshold),
+                                     masks.data_ptr(), rows_all.data_ptr(), keep.data_ptr(), key.data_ptr(), hip.stream_ptr()),
+                  "me_m2_rows_f32")
+        ordered = _f32(dev, k, 8)
+        n_out = torch.empty((1,), device=dev, dtype=torch.int32)
+        hip.check(lib.me_compact_sort_rows_f32(rows_all.data_ptr(), keep.data_ptr(), key.data_ptr(), k, 8, ordered.data_ptr(),
+                                               n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
+        output = ordered[:int(n_out.item())].cpu()
+        positive = keep.bool()
         if targets is None:
             # train() mode without targets (reference :299-364 in train mode): batch statistics in fcn_layers (running
             # statistics updated above), Dropout active, no loss

@@ -241,7 +241,8 @@ def _prefetch_stream(dev):
 
 
 def _frozen_detector_block(net, images):
-    """Detector forward (whatever storage mode ``Darknet.compute_dtype`` names), NMS, per-class proposal rows, an fp32 NHWC copy of the
+    """Detector forward (whatever storage mode ``Darknet.compute_dtype`` names), NMS, per-class proposal rows (stage 3: the rows of
+    ``net.class_idx``; stage 2 - module2/my_models.py has no ``class_idx`` - the rows of every class), an fp32 NHWC copy of the
     feature tap - everything of the step that has no trainable parameter in it.  Runs on the current stream."""
     from .my_models import _DETECTIONS_PER_IMG, _NMS_THRESH
     lib = hip.lib()
@@ -257,7 +258,7 @@ def _frozen_detector_block(net, images):
     img_boxes = torch.empty((cap_img, cols), **f32)
     n_img_dev = torch.empty((1,), device=dev, dtype=torch.int32)
     hip.check(lib.me_gather_class_boxes_f32(det.data_ptr(), cnt.data_ptr(), n, _DETECTIONS_PER_IMG, num_classes,
-                                            int(net.class_idx), int(net.class_num), img_boxes.data_ptr(),
+                                            int(getattr(net, "class_idx", -1)), int(net.class_num), img_boxes.data_ptr(),
                                             n_img_dev.data_ptr(), hip.stream_ptr()), "me_gather_class_boxes_f32")
     if plan.tap is None:
         raise AttributeError("'Darknet' object has no attribute 'featuremap'")
@@ -274,7 +275,7 @@ def _prefetch_key(net, images):
     from . import engine as _engine
     # (this path never differentiates through the detector; whatever else changes its weights - an optimizer that was handed them,
     #  load_state_dict, engine.invalidate_weights() after a raw-pointer write - moves a version counter or the engine's epoch)
-    return (images.data_ptr(), tuple(images.shape), images._version, float(net.conf_thresh), int(net.class_idx), int(net.class_num),
+    return (images.data_ptr(), tuple(images.shape), images._version, float(net.conf_thresh), int(getattr(net, "class_idx", -1)), int(net.class_num),
             det.compute_dtype, tuple([p._version for p in params]), tuple([p.data_ptr() for p in params[:4]]), _engine._EPOCH[0])
 
 
