@@ -606,7 +606,7 @@ typedef struct me_conv16_desc {
   int32_t x_nchw;
   int32_t y_f32;
   int32_t half_type; /* 0 = bfloat16, 1 = IEEE half (x, wgt, res / y unless y_f32) */
-  int32_t tile;    /* 0 = auto; 1..4 = 128x128 / 128x64 / 64x64 / 256x128; 11..14 = single sub-stage variants; 5 / 15 = 192x128; >= 100: patch-resident big tiles (conv_p8_h16.hip; need wgt_tiled) */
+  int32_t tile;    /* 0 = auto; 1..4 = 128x128 / 128x64 / 64x64 / 256x128; 11..14 = single sub-stage variants; 5 / 15 = 192x128; 40 / 41 = small-batch tiles 32x32 / 32x64 with the K split over the eight waves of a workgroup (one launch, no slabs; conv_kw_h16.hip); >= 100: patch-resident big tiles (conv_p8_h16.hip; need wgt_tiled) */
   int32_t split_k; /* as me_conv_desc */
   void* workspace;
   int64_t workspace_bytes;

@@ -35,6 +35,8 @@ bool ws1x1_eligible(const Conv16P& p);      // conv1x1_ws_h16.hip: tile id 50, w
 int launch_ws1x1(const Conv16P& p, hipStream_t stream);
 bool ws3x3_eligible(const Conv16P& p);      // conv3x3_ws_h16.hip: tile id 60, weight-stationary 3x3 for cin 32 / 64
 int launch_ws3x3(const Conv16P& p, hipStream_t stream);
+// conv_kw_h16.hip: small-batch kernel, K split over the eight waves of a workgroup (tile ids 40 / 41)
+int launch_kw(const Conv16P& p, int tile, hipStream_t stream);
 bool stem_mfma_eligible(const Conv16P& p);  // stem_mfma_h16.hip
 int launch_stem_mfma(const Conv16P& p, hipStream_t stream);
 }  // namespace me16
@@ -660,6 +662,7 @@ int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d) {
   if (!d || fill16(d, p) != 0 || d->cin <= 4) return 0;
   int tile, split;
   if (d->tile >= 100) return me16::p8_workspace_bytes(p, d->tile, d->split_k);  // patch tiles: split only when asked to
+  if (d->tile == 40 || d->tile == 41) return 0;  // the K split lives inside the workgroup: no slabs
   plan16(p, d->split_k > 0 ? d->split_k : kMaxSplit16, &tile, &split);
   if (d->split_k > 0) split = d->split_k;
   return split > 1 ? (int64_t)split * p.M * p.cout * (int64_t)sizeof(float) : 0;
@@ -729,6 +732,7 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   p.splitk = split;
   p.partial = reinterpret_cast<float*>(d->workspace);
   if (tile >= 100) return me16::launch_p8_tile(p, tile, stream);
+  if (tile == 40 || tile == 41) return me16::launch_kw(p, tile, stream);
   if (tile == 50) return me16::launch_ws1x1(p, stream);
   if (tile == 60) return me16::launch_ws3x3(p, stream);
   const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows

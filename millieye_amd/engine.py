@@ -397,6 +397,16 @@ class DarknetEngine:
         self._fast_stamp = stamp
         return True
 
+    def weight_stamp(self, device):
+        """``(data_ptr, _version)`` of every tensor the packed weights are built from, read through the modules' LIVE parameter /
+        buffer dicts (a re-assigned ``nn.Parameter`` is seen), + the device and the invalidation epoch: the identity of the detector's
+        weights, one pass over ~370 dict entries (what ``refresh_weights`` compares in front of every forward)."""
+        fast = self.__dict__.get("_fast_sources")
+        if fast is None:
+            self.refresh_weights(device)
+            fast = self._fast_sources
+        return tuple([(t.data_ptr(), t._version) for t in [dct[key] for dct, key in fast[0]]]) + (str(device), _EPOCH[0])
+
     # ---------------------------------------------------------------------------------- planning
     def _build(self, n, h, w, device, keep_raw=False):
         defs = self.model.module_defs
@@ -944,8 +954,10 @@ _TUNE_STATS = {"measured": 0, "synced": 0}  # layer shapes whose candidates were
 _TUNE_TILES = (1, 2, 3, 4, 5)  # (7 / 47 = 64x64 with a 6 / 9-stage LDS ring: no gain at batch 1 / 8 - a lone wave per SIMD is bound by its
 # own MFMA chain, not by DMA latency - so they stay forced-only ids)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8)
+_KW_MAX_POSITIONS = 6144   # tiles 40 / 41 are offered to layers with at most this many output positions (batch 1 up to 52 x 52)
 _TUNE_TILES_BF16 = (1, 2, 3, 4, 11, 12, 13, 14, 15)  # 1x = one 32-channel sub-stage per pipeline stage (more workgroups / CU)
-_TILE_SHAPES_BF16 = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
+_TILE_SHAPES_BF16 = {40: (32, 32), 41: (32, 64),   # small-batch tiles: the K split over the waves of one workgroup (csrc/conv_kw_h16.hip)
+                     1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128),
                      11: (128, 128), 12: (128, 64), 13: (64, 64), 14: (256, 128), 15: (192, 128),
                      # patch-resident big tiles (csrc/conv_p8_h16.hip; 3x3 stride 1 only, no split-K): 1xx one workgroup per
                      # CU with register-pipelined fragments, 2xx two workgroups per CU
@@ -1139,6 +1151,8 @@ def _autotune(plan, lib):
                 tiles = tiles + (50,)  # refused by the library unless one of its (cin, cout) instances fits
             if d.ksize == 3 and d.cin <= 64 and d.upsample == 1 and not d.y_f32 and "60" not in no_ws:
                 tiles = tiles + (60,)
+            if d.n * d.ho * d.wo <= _KW_MAX_POSITIONS and os.environ.get("MILLIEYE_NO_KW", "0") != "1":
+                tiles = tiles + (40, 41)  # round 6: one launch instead of split-K slabs + a reduce launch (batch-1 layers)
         else:
             if d.cin % 16 == 0 and os.environ.get("MILLIEYE_TUNE_TAIL", "1") != "0":
                 tiles = tiles + _TUNE_TILES_TAIL
@@ -1163,7 +1177,7 @@ def _autotune(plan, lib):
             # (patch tiles can be cut along K - split_k > 1, compact fp32 slabs + a reduce launch - but the slabs are twice the
             #  fp32 size of the layer's output: 60 -> 76 us at 13x13, tools/p8_bench.py 32 121,121/2; not offered to the tuner)
             p8_split = False
-            for split in (_TUNE_SPLITS[1:] if tail else (1,) if tile in (50, 60) else _TUNE_SPLITS if tile < 100
+            for split in (_TUNE_SPLITS[1:] if tail else (1,) if tile in (50, 60) or (bf16 and tile in (40, 41)) else _TUNE_SPLITS if tile < 100
                           else (1, 2, 3, 4) if p8_split else (1,)):
                 d.tile, d.split_k = tile, split
                 if tail or (tile >= 100 and split > 1):

@@ -267,22 +267,21 @@ def _frozen_detector_block(net, images):
                 tap_shape=tuple(plan.tap_shape))
 
 
-def _prefetch_key(net, images):
+def _prefetch_key(net, images, wstamp=None):
+    """What a look-ahead result was computed from: the frames, the thresholds, the storage mode and the detector's weights - the
+    engine's own weight stamp (live ``(data_ptr, _version)`` of every source tensor + the invalidation epoch) and the identity of
+    the detector module.  ``wstamp``: a stamp the caller computed a moment ago (one pass over the ~370 tensors per step, not two)."""
     det = net.base_detector
-    params = net.__dict__.get("_det_param_list")
-    if params is None:
-        params = net.__dict__["_det_param_list"] = [p for p in det.parameters()] + [b for b in det.buffers()]
-    from . import engine as _engine
-    # (this path never differentiates through the detector; whatever else changes its weights - an optimizer that was handed them,
-    #  load_state_dict, engine.invalidate_weights() after a raw-pointer write - moves a version counter or the engine's epoch)
-    return (images.data_ptr(), tuple(images.shape), images._version, float(net.conf_thresh), int(getattr(net, "class_idx", -1)), int(net.class_num),
-            det.compute_dtype, tuple([p._version for p in params]), tuple([p.data_ptr() for p in params[:4]]), _engine._EPOCH[0])
+    if wstamp is None:
+        wstamp = det.engine.weight_stamp(images.device)
+    return (images.data_ptr(), tuple(images.shape), images._version, float(net.conf_thresh), int(getattr(net, "class_idx", -1)),
+            int(net.class_num), det.compute_dtype, id(det), wstamp)
 
 
-def _issue_prefetch(net, images):
+def _issue_prefetch(net, images, wstamp=None):
     if not (torch.is_tensor(images) and images.is_cuda and images.dtype == torch.float32 and images.dim() == 4):
         return
-    key = _prefetch_key(net, images)
+    key = _prefetch_key(net, images, wstamp)
     if key is None or net.base_detector._any_bn_training():
         return
     dev = images.device
@@ -301,14 +300,14 @@ def _issue_prefetch(net, images):
     net.base_detector.__dict__["_prefetch_event"] = done   # Darknet._run: nobody else touches the engine before this
 
 
-def _take_prefetch(net, images):
+def _take_prefetch(net, images, wstamp=None):
     rec = net.__dict__.pop("_det_prefetch", None)
     if rec is None:
         return None
     key, res, done, _held = rec
     main = torch.cuda.current_stream(images.device)
     main.wait_event(done)
-    if key != _prefetch_key(net, images):
+    if key != _prefetch_key(net, images, wstamp):
         return None   # other frames, another threshold, new detector weights: computed again (behind the prefetch, see _run)
     for t in (res["img_boxes"], res["n_img_dev"], res["fm"]):
         t.record_stream(main)
@@ -345,15 +344,17 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
 
     # ---- frozen detector, NMS, proposal assembly (no grad) -------------------------------------------
     with torch.no_grad():
-        pre = _take_prefetch(net, images)
+        nxt = net.__dict__.pop("_next_images", None)
+        look_ahead = nxt is not None or "_det_prefetch" in net.__dict__
+        wstamp = net.base_detector.engine.weight_stamp(images.device) if look_ahead else None   # once per step, for both uses
+        pre = _take_prefetch(net, images, wstamp)
         if pre is None:
             pre = _frozen_detector_block(net, images)
         num_classes, cols, cap_img = pre["num_classes"], pre["cols"], pre["cap_img"]
         img_boxes, n_img_dev, fm = pre["img_boxes"], pre["n_img_dev"], pre["fm"]
         fh, fw, fc = pre["tap_shape"]
-        nxt = net.__dict__.pop("_next_images", None)
         if nxt is not None:   # (Network.queue_detector_prefetch: the NEXT batch's frozen part, beside this batch's host-bound tail)
-            _issue_prefetch(net, nxt)
+            _issue_prefetch(net, nxt, wstamp)
         if len(radar_boxes_location) > 0:
             radar_boxes_location[:, 1:] *= size
         n_radar = int(radar_boxes_location.shape[0])

@@ -642,3 +642,46 @@ def test_bottleneck_one_launch_refuses_what_it_cannot_do(hip_lib):
     f = [torch.zeros(k).cuda() for k in (128, 128, 256, 256)]
     with pytest.raises(hip.MeError, match="no instance"):
         hip.bneck_h16(x, w1, f[0], f[1], w2, f[2], f[3], tile=1)
+
+
+KW_CASES = CASES + [
+    ("detection conv fp32 out, 255 channels", 1, 13, 13, 1024, 255, 1, 1, 0, False, 1),
+    ("13x13 deep 3x3", 1, 13, 13, 512, 1024, 3, 1, 1, True, 1),
+    ("52x52 1x1", 1, 52, 52, 256, 128, 1, 1, 1, False, 1),
+    ("K steps not a multiple of 8 (two idle waves)", 2, 9, 7, 32, 40, 3, 1, 1, False, 1),
+]
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("tile", [40, 41])
+@pytest.mark.parametrize("case", KW_CASES, ids=[c[0] for c in KW_CASES])
+def test_conv_small_batch_tiles_k_split_over_the_waves(hip_lib, case, tile, half):
+    """Tile ids 40 / 41 (csrc/conv_kw_h16.hip): one workgroup per 32 x 32 / 32 x 64 output tile, its eight waves take an eighth
+    of the K steps each, the partial tiles are added in LDS in wave order and go through the fused epilogue - the one-launch
+    form of a split-K layer (no slabs, no reduce launch).  Every filter size / stride, residual, 2x upsample, ragged output
+    channels, the fp32 detection output; against the fp32 CPU convolution under the bar of the other tiles, deterministic."""
+    from millieye_amd import hip
+    half = HALVES[half]
+    name, n, h, w, cin, cout, k, s, act, with_res, ups = case
+    y_f32 = "fp32 out" in name
+    g = torch.Generator().manual_seed(len(name) * 13 + cin + tile)
+    pad = (k - 1) // 2
+    x = _bf(torch.randn((n, h, w, cin), generator=g), half)
+    wgt = _bf(torch.randn((cout, cin, k, k), generator=g) / (k * k * cin) ** 0.5, half)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ho = (h + 2 * pad - k) // s + 1
+    res = _bf(torch.randn((n, ho, ho if h == w else (w + 2 * pad - k) // s + 1, cout), generator=g), half) if with_res else None
+    ref = _ref(x, wgt, scale, shift, k, s, pad, act, res, ups)
+    packed = wgt.permute(0, 2, 3, 1).contiguous().cuda()
+    y = hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), k, s, pad, act, residual=res.cuda() if res is not None else None,
+                       upsample=ups, y_f32=y_f32, tile=tile, split_k=1)
+    if y_f32:
+        assert y.dtype == torch.float32
+        err = float((y.cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= 1e-3, f"{name} tile {tile}: fp32 output {err:.2e}"
+    else:
+        _check_bf16(y, ref, f"{name} tile {tile}")
+    y2 = hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), k, s, pad, act, residual=res.cuda() if res is not None else None,
+                        upsample=ups, y_f32=y_f32, tile=tile, split_k=1)
+    assert torch.equal(y, y2), "not deterministic"

@@ -29,8 +29,14 @@ net.train(); net.base_detector.eval()
 heads = head_parameters(net)
 opt = torch.optim.Adam(heads, lr=5e-4, fused=True)
 random.seed(1)
+x2 = x.clone()
+flip = [0]
 def step():
-    loss, out_rows, _m, _a = net(x, maps_d, boxes_d.clone(), targets.clone())
+    cur, nxt = (x, x2) if flip[0] == 0 else (x2, x)
+    flip[0] ^= 1
+    if os.environ.get("PREFETCH", "1") != "0":
+        net.queue_detector_prefetch(nxt)
+    loss, out_rows, _m, _a = net(cur, maps_d, boxes_d.clone(), targets.clone())
     loss.backward()
     par.allreduce_gradients(heads)
     opt.step(); opt.zero_grad(set_to_none=True)
