@@ -79,8 +79,11 @@ def _bn_eval(x, sd, prefix, eps=1e-5):
                         sd[prefix + "bias"], False, 0.1, eps)
 
 
-def img_cnn(sd, fm):
-    x = F.conv2d(fm, sd["img_cnn_layers.net.conv_0.weight"], sd["img_cnn_layers.net.conv_0.bias"])
+def img_cnn(sd, fm, storage="f32"):
+    w = sd["img_cnn_layers.net.conv_0.weight"]
+    if storage != "f32":  # 16-bit storage modes: the score-map convolution multiplies the 16-bit tap with 16-bit weights (fp32 sums, fp32 out)
+        w = w.to(torch.float16 if storage == "f16" else torch.bfloat16).float()
+    x = F.conv2d(fm, w, sd["img_cnn_layers.net.conv_0.bias"])
     return F.leaky_relu(_bn_eval(x, sd, "img_cnn_layers.net.batch_norm_0."), 0.1)
 
 
@@ -124,13 +127,16 @@ def box_regress(regress_param, roi_location):
 
 
 def network_forward(cfg_text, sd, images, maps, radar_boxes, model_mode=0, conf_thresh=0.2, thr_img=0.0,
-                    thr_radar=0.0, class_idx=0, class_num=1, tap_module=8, return_internals=False):
+                    thr_radar=0.0, class_idx=0, class_num=1, tap_module=8, return_internals=False, storage="f32"):
     """Inference branch of Network.forward (targets=None).  ``sd``: state dict of the whole
     Network (detector keys prefixed ``base_detector.``).  ``radar_boxes`` [r,5] in [0,1] units is
-    NOT modified (the reference scales it in place; the scaled copy is returned in internals)."""
+    NOT modified (the reference scales it in place; the scaled copy is returned in internals).
+    ``storage="bf16"`` / ``"f16"``: the build's 16-bit storage modes - the detector restated by ``darknet_forward(storage=...)``
+    (16-bit activations and weights, fp32 detection maps), the score-map convolution on the 16-bit tap with 16-bit weights,
+    everything behind it fp32 as in the HIP path.  No reference counterpart (the reference is fp32)."""
     det_sd = {k[len("base_detector."):]: v for k, v in sd.items() if k.startswith("base_detector.")}
     with torch.no_grad():
-        feature_map, output_tensor = darknet_ref.darknet_forward(cfg_text, det_sd, images, tap_module=tap_module)
+        feature_map, output_tensor = darknet_ref.darknet_forward(cfg_text, det_sd, images, tap_module=tap_module, storage=storage)
         detections = nms_cpp(output_tensor, conf_thresh)
         img_boxes = []
         for image_i, det in enumerate(detections):
@@ -147,7 +153,7 @@ def network_forward(cfg_text, sd, images, maps, radar_boxes, model_mode=0, conf_
             return img_boxes[:, :8]
         if model_mode == 2:
             thr_img = 1
-        roi_score_map = img_cnn(sd, feature_map)
+        roi_score_map = img_cnn(sd, feature_map, storage)
         radar_score_map = radar_cnn(sd, maps)
         radar_boxes = radar_boxes.clone()
         if len(radar_boxes) > 0:
