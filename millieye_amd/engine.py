@@ -782,8 +782,8 @@ class DarknetEngine:
         if _autotune_enabled():
             _autotune(plan, lib)
         plan.fused_blocks = []
-        if bf16 and _BNECK_MODE != "0":
-            _fuse_bottlenecks(plan, ops, lib)
+        if bf16 and _bneck_mode() != "0" and (_autotune_enabled() or _bneck_mode() == "force"):
+            _fuse_bottlenecks(plan, ops, lib)   # (a measured choice, like the tiles: not without the autotuner - pinned plans stay pinned)
         if tap_tensor is not None:
             # NCHW view of the feature tap in its storage type (bf16 mode: callers that need fp32 convert at the API
             # boundary - Darknet.forward; Network.forward hands the bf16 tap straight to the score-map conv)
@@ -1225,7 +1225,11 @@ def _autotune(plan, lib):
     _tune_save()
 
 
-_BNECK_MODE = os.environ.get("MILLIEYE_BNECK", "1")   # "0": never, "1": where measured faster than the launch pair, "force": wherever an instance exists
+def _bneck_mode():
+    """MILLIEYE_BNECK: "0" never, "1" (default) where measured faster than the launch pair, "force" wherever an instance exists."""
+    return os.environ.get("MILLIEYE_BNECK", "1")
+
+
 _BNECK_CACHE = {}   # block shape -> bneck tile id, or 0 (the launch pair stays)
 _BNECK_STATS = {"fused": 0, "kept": 0}
 
@@ -1285,7 +1289,7 @@ def _fuse_bottlenecks(plan, ops, lib):
         da, db = a["desc"], b["desc"]
         key = (bd.n, bd.h, bd.w, bd.cin, bd.cmid, bd.cout, int(bool(bd.res)), bd.half_type, bd.act1, bd.act2)
         choice = _BNECK_CACHE.get(key)
-        if choice is None and _BNECK_MODE == "force":
+        if choice is None and _bneck_mode() == "force":
             choice = tiles[0]
         if choice is None:
             def pair():

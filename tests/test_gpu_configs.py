@@ -76,6 +76,7 @@ def _pin_plan(monkeypatch, tmp_path):
     shutil.copy(PLAN, local)
     monkeypatch.setenv("MILLIEYE_TUNE_CACHE", str(local))
     monkeypatch.setenv("MILLIEYE_AUTOTUNE", "1")
+    monkeypatch.setenv("MILLIEYE_BNECK", "0")   # (the one-launch bottleneck is a measured choice too: the pinned plan keeps the launch pairs)
     saved = dict(engine._TUNE_CACHE), engine._TUNE_FILE_LOADED[0]
     engine._TUNE_CACHE.clear()
     engine._TUNE_FILE_LOADED[0] = False

@@ -685,3 +685,42 @@ def test_conv_small_batch_tiles_k_split_over_the_waves(hip_lib, case, tile, half
     y2 = hip.conv2d_h16(x.cuda(), packed, scale.cuda(), shift.cuda(), k, s, pad, act, residual=res.cuda() if res is not None else None,
                         upsample=ups, y_f32=y_f32, tile=tile, split_k=1)
     assert torch.equal(y, y2), "not deterministic"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_detector_plan_with_one_launch_bottlenecks(hip_lib, monkeypatch, dtype):
+    """The engine's plan with every eligible 1x1 -> 3x3 (+ shortcut) pair of Darknet-53 replaced by ``me_bneck_h16``
+    (``MILLIEYE_BNECK=force``: the 52 x 52 and 104 x 104 residual blocks and the 52 x 52 head pairs) against the plan that keeps
+    the launch pairs (``MILLIEYE_BNECK=0``): the same decoded rows up to the one-ulp flips of another summation order in the
+    layers whose tuned pair tiles walk K tap-major (measured: objectness |d| <= 0.01, boxes <= 0.5 px; bit-equal when the tuner
+    picked chunk-major tiles), the same feature tap, deterministic, and the default mode (measured choice) equals one of the two."""
+    from tests import parity_helpers as ph
+    x = ph.frames(f"bneckplan/{dtype}", 2, 416).cuda()
+    outs = {}
+    for mode in ("0", "force"):
+        monkeypatch.setenv("MILLIEYE_BNECK", mode)
+        model = ph.make_darknet("yolov3", tag="bneckplan", trained_like=True).cuda()
+        model.compute_dtype = dtype
+        with torch.no_grad():
+            fm, y = model(x)
+            fm2, y2 = model(x)
+        assert torch.equal(y, y2) and torch.equal(fm, fm2)
+        plan = model.engine_for(dtype).plan_for(x)
+        outs[mode] = (fm, y, list(plan.fused_blocks), len(plan.launches))
+    assert outs["0"][2] == [] and len(outs["force"][2]) >= 10, outs["force"][2]
+    assert outs["force"][3] == outs["0"][3] - len(outs["force"][2])   # one launch less per block
+    a, b = outs["0"][1].float(), outs["force"][1].float()
+    over = (a[..., 4] >= 0.2) | (b[..., 4] >= 0.2)
+    d_obj = float((a[..., 4] - b[..., 4]).abs().max())
+    d_box = float(((a[over][:, :4] - b[over][:, :4]).abs() / a[over][:, 2:4].abs().clamp_min(16.0).repeat(1, 2)).max()) if bool(over.any()) else 0.0
+    # ... and neither form is further from the fp32 run than the other: the storage format, not the launch structure, sets the error
+    monkeypatch.setenv("MILLIEYE_BNECK", "0")
+    model = ph.make_darknet("yolov3", tag="bneckplan", trained_like=True).cuda()
+    with torch.no_grad():
+        fm32, y32 = model(x)
+    e_pair, _ = _err(outs["0"][1].cpu(), y32.cpu())
+    e_one, _ = _err(outs["force"][1].cpu(), y32.cpu())
+    print(f"[bneck plan {dtype}] {len(outs['force'][2])} blocks in one launch each; pair vs one launch: objectness |d| {d_obj:.4f}, boxes over the "
+          f"threshold {d_box:.2%} of their size; mean error vs fp32: pair {e_pair:.3e}, one launch {e_one:.3e}")
+    assert d_obj <= (0.03 if dtype == "bf16" else 0.005) and d_box <= (0.03 if dtype == "bf16" else 0.005)
+    assert e_one <= 1.25 * e_pair + 1e-4
