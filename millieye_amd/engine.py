@@ -1288,9 +1288,7 @@ def _fuse_bottlenecks(plan, ops, lib):
     for a, b, bd, tiles in pairs:
         da, db = a["desc"], b["desc"]
         key = (bd.n, bd.h, bd.w, bd.cin, bd.cmid, bd.cout, int(bool(bd.res)), bd.half_type, bd.act1, bd.act2)
-        choice = _BNECK_CACHE.get(key)
-        if choice is None and _bneck_mode() == "force":
-            choice = tiles[0]
+        choice = tiles[0] if _bneck_mode() == "force" else _BNECK_CACHE.get(key)
         if choice is None:
             def pair():
                 rc = lib.me_conv2d_h16(C.byref(da), stream)
