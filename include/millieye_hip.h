@@ -548,6 +548,27 @@ int me_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, in
 int me_ps_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w,
                             int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
                             void* stream);
+/* ---- row counts from device memory (ABI 12): the stage-3 backward as ONE captured hipGraph (millieye_amd/train_path.py) --------
+ * The number of proposals changes from step to step (n_img from the NMS + the radar boxes), and every launch argument of a captured
+ * graph is fixed; these forms take the buffers' CAPACITY as the launch size and the live row count from a device word: rows behind it
+ * produce zeros (so the dense gradient products over the whole capacity add exact zeros) and cost nothing in the scatter kernels.
+ *   me_heads_tail_bwd_dev_f32     me_heads_tail_bwd_f32 over `cap` rows, zeros behind *k_dev
+ *   me_bn_train_bwd_dev_f32       me_bn_train_bwd_f32 with the statistics' row count = min(*rows_dev, rows_cap), dx = 0 behind it
+ *   me_[ps_]roi_align_bwd_dev_f32 the RoI scatters over min(*k_dev, k_cap) RoIs */
+int me_heads_tail_bwd_dev_f32(const me_heads_desc* d, const float* small, const float* refine, const float* mask1,
+                              const float* seed_p, const float* seed_conf, int32_t cap, const int32_t* k_dev, float* g_o,
+                              float* g_hpre, float* h_act, float* xin, float* g_z2, float* g_rl, float* rl, float* g_rlogit,
+                              void* stream);
+int me_bn_train_bwd_dev_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, int32_t rows_cap, const int32_t* rows_dev,
+                            int32_t channels, const float* gamma, const float* beta, const float* save_mean,
+                            const float* save_rstd, int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                            void* workspace, void* stream);
+int me_roi_align_bwd_dev_f32(const float* grad_out, const float* rois, int32_t k_cap, const int32_t* k_dev, int32_t n, int32_t h,
+                             int32_t w, int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
+                             void* stream);
+int me_ps_roi_align_bwd_dev_f32(const float* grad_out, const float* rois, int32_t k_cap, const int32_t* k_dev, int32_t n, int32_t h,
+                                int32_t w, int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
+                                void* stream);
 
 /* stand-alone RoI ops (tests, training path): out [k, c_out, 7, 7] dense */
 int me_roi_align_f32(const float* map, int64_t pitch, int32_t n, int32_t h, int32_t w, int32_t c,

@@ -973,9 +973,16 @@ __global__ __launch_bounds__(256) void heads_tail_bwd_kernel(me_heads_desc d, co
                                                              const float* mask1, const float* seed_p,
                                                              const float* seed_conf, int k, float* g_o, float* g_hpre,
                                                              float* h_act, float* xin, float* g_z2, float* g_rl,
-                                                             float* rl_out, float* g_rlogit) {
+                                                             float* rl_out, float* g_rlogit, const int* k_dev) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= k) return;
+  if (k_dev && i >= *k_dev) {   // captured step (k = the buffers' capacity, the live row count in device memory): zeros behind it
+    for (int u = 0; u < 64; ++u) { g_hpre[64ll * i + u] = 0.f; h_act[64ll * i + u] = 0.f; }
+    xin[4 * i + 0] = xin[4 * i + 1] = xin[4 * i + 2] = xin[4 * i + 3] = 0.f;
+    g_o[2 * i] = g_o[2 * i + 1] = g_z2[2 * i] = g_z2[2 * i + 1] = g_rlogit[i] = 0.f;
+    for (int o = 0; o < C_OUT; ++o) { g_rl[10ll * i + o] = 0.f; rl_out[10ll * i + o] = 0.f; }
+    return;
+  }
   const int n_img = *d.n_img;
   const float* sm = small + 16ll * i;
   const float conf = refine[2 * i], cls1 = refine[2 * i + 1];
@@ -1214,10 +1221,10 @@ int me_heads_loss_f32(const float* mask1, const float* refine, const uint8_t* la
   return me::check_launch("heads_loss_kernel");
 }
 
-int me_heads_tail_bwd_f32(const me_heads_desc* d, const float* small, const float* refine, const float* mask1,
-                          const float* seed_p, const float* seed_conf, int32_t k, float* g_o, float* g_hpre,
-                          float* h_act, float* xin, float* g_z2, float* g_rl, float* rl, float* g_rlogit,
-                          void* stream_) {
+static int launch_heads_tail_bwd(const me_heads_desc* d, const float* small, const float* refine, const float* mask1,
+                                 const float* seed_p, const float* seed_conf, int32_t k, const int32_t* k_dev, float* g_o,
+                                 float* g_hpre, float* h_act, float* xin, float* g_z2, float* g_rl, float* rl, float* g_rlogit,
+                                 void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ME_REQUIRE(k >= 0, ME_E_BADARG, "me_heads_tail_bwd_f32: negative k");
   if (k == 0) return 0;
@@ -1225,8 +1232,25 @@ int me_heads_tail_bwd_f32(const me_heads_desc* d, const float* small, const floa
                  rl && g_rlogit && d->n_img && d->img_boxes,
              ME_E_NULLPTR, "me_heads_tail_bwd_f32: null pointer");
   hipLaunchKernelGGL(heads_tail_bwd_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, *d, small, refine, mask1,
-                     seed_p, seed_conf, k, g_o, g_hpre, h_act, xin, g_z2, g_rl, rl, g_rlogit);
+                     seed_p, seed_conf, k, g_o, g_hpre, h_act, xin, g_z2, g_rl, rl, g_rlogit, k_dev);
   return me::check_launch("heads_tail_bwd_kernel");
+}
+
+int me_heads_tail_bwd_f32(const me_heads_desc* d, const float* small, const float* refine, const float* mask1,
+                          const float* seed_p, const float* seed_conf, int32_t k, float* g_o, float* g_hpre,
+                          float* h_act, float* xin, float* g_z2, float* g_rl, float* rl, float* g_rlogit,
+                          void* stream) {
+  return launch_heads_tail_bwd(d, small, refine, mask1, seed_p, seed_conf, k, nullptr, g_o, g_hpre, h_act, xin, g_z2, g_rl, rl,
+                               g_rlogit, stream);
+}
+
+int me_heads_tail_bwd_dev_f32(const me_heads_desc* d, const float* small, const float* refine, const float* mask1,
+                              const float* seed_p, const float* seed_conf, int32_t cap, const int32_t* k_dev, float* g_o,
+                              float* g_hpre, float* h_act, float* xin, float* g_z2, float* g_rl, float* rl, float* g_rlogit,
+                              void* stream) {
+  ME_REQUIRE(k_dev != nullptr, ME_E_NULLPTR, "me_heads_tail_bwd_dev_f32: null row count");
+  return launch_heads_tail_bwd(d, small, refine, mask1, seed_p, seed_conf, cap, k_dev, g_o, g_hpre, h_act, xin, g_z2, g_rl, rl,
+                               g_rlogit, stream);
 }
 
 int me_compact_sort_rows_f32(const float* rows, const uint8_t* keep, const float* key, int32_t cap, int32_t cols, float* out,

@@ -127,12 +127,14 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                                                          const float* __restrict__ G, long long ldg,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, float* p0, float* p1) {
+                                                         int act, float* p0, float* p1, const int* rows_dev = nullptr) {
   // forward use (G == nullptr): p0 = sum x, p1 = sum x^2 over this block's row chunk
   // backward use: p0 = sum g, p1 = sum g * xhat with g = dy * act'(bn output)
+  // rows_dev (captured steps): the live row count in device memory, `rows` is then the buffers' capacity
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int chunk = blockIdx.y;
   if (c >= C) return;
+  if (rows_dev) rows = *rows_dev < rows ? *rows_dev : rows;
   const int per = (rows + BN_CHUNKS - 1) / BN_CHUNKS;
   const int r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
   double s0 = 0.0, s1 = 0.0;
@@ -197,12 +199,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int C, const float* mean, const float* rstd,
                                                            const float* gamma, const float* beta, int act,
                                                            const float* p0, const float* p1, float* dgamma,
-                                                           float* dbeta, float* DX, long long lddx) {
+                                                           float* dbeta, float* DX, long long lddx, const int* rows_dev = nullptr) {
   // p0[c] / p1[c] hold the channel sums (bn_reduce_partials_kernel folded the chunk partials, fixed order)
-  const long long total = (long long)rows * C;
+  const long long total = (long long)rows * C;   // (the capacity when rows_dev is given: rows behind the live count get dx = 0)
+  if (rows_dev) rows = *rows_dev < rows ? *rows_dev : rows;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int c = (int)(idx % C);
     const long long r = idx / C;
+    if (r >= rows) {
+      if (DX) DX[r * lddx + c] = 0.f;
+      continue;
+    }
     const double s0 = p0[c], s1 = p1[c];
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
     const float xh = (X[r * ld + c] - mu) * rs;
@@ -1085,8 +1092,9 @@ __device__ __forceinline__ void scatter_bilinear(float* gmap, long long pitch, i
 
 __global__ __launch_bounds__(256) void roi_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois,
                                                       int k, int c, int h, int w, float scale, float* gmap,
-                                                      long long pitch, int ps) {
+                                                      long long pitch, int ps, const int* k_dev = nullptr) {
   // gout: [k, c_out, 7, 7] with c_out = ps ? c/49 : c
+  if (k_dev) k = *k_dev < k ? *k_dev : k;   // (captured steps: k = capacity, the live RoI count in device memory)
   const int cout = ps ? c / 49 : c;
   const long long total = (long long)k * cout * 49;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -1597,10 +1605,32 @@ int me_bn_train_fwd_f32(const float* x, int64_t ldx, int32_t rows, int32_t chann
   return me::check_launch("bn_train_fwd");
 }
 
+static int launch_bn_train_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int32_t rows, const int32_t* rows_dev,
+                               int32_t channels, const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_rstd, int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                               void* workspace, void* stream_);
+
 int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, int32_t rows, int32_t channels,
                         const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
                         int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* workspace,
-                        void* stream_) {
+                        void* stream) {
+  return launch_bn_train_bwd(x, ldx, dy, lddy, rows, nullptr, channels, gamma, beta, save_mean, save_rstd, act, dx, lddx, dgamma,
+                             dbeta, workspace, stream);
+}
+
+int me_bn_train_bwd_dev_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, int32_t rows_cap, const int32_t* rows_dev,
+                            int32_t channels, const float* gamma, const float* beta, const float* save_mean,
+                            const float* save_rstd, int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                            void* workspace, void* stream) {
+  ME_REQUIRE(rows_dev != nullptr, ME_E_NULLPTR, "me_bn_train_bwd_dev_f32: null row count");
+  return launch_bn_train_bwd(x, ldx, dy, lddy, rows_cap, rows_dev, channels, gamma, beta, save_mean, save_rstd, act, dx, lddx,
+                             dgamma, dbeta, workspace, stream);
+}
+
+static int launch_bn_train_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int32_t rows, const int32_t* rows_dev,
+                               int32_t channels, const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_rstd, int32_t act, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                               void* workspace, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ME_REQUIRE(x && dy && gamma && beta && save_mean && save_rstd && workspace, ME_E_NULLPTR,
              "me_bn_train_bwd_f32: null pointer");
@@ -1609,11 +1639,11 @@ int me_bn_train_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld
   float* p1 = p0 + (long long)BN_CHUNKS * channels;
   const unsigned cb = (channels + 255) / 256;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
-                     dy, (long long)lddy, save_mean, save_rstd, gamma, beta, act, p0, p1);
+                     dy, (long long)lddy, save_mean, save_rstd, gamma, beta, act, p0, p1, rows_dev);
   hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, channels);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d((long long)rows * channels)), dim3(256), 0, stream, x,
                      (long long)ldx, dy, (long long)lddy, rows, channels, save_mean, save_rstd, gamma, beta, act, p0,
-                     p1, dgamma, dbeta, dx, (long long)lddx);
+                     p1, dgamma, dbeta, dx, (long long)lddx, rows_dev);
   return me::check_launch("bn_train_bwd");
 }
 
@@ -2100,7 +2130,8 @@ int me_conv_wgrad_h16(const void* x_, int64_t x_pitch, const void* dy_, int64_t 
 }
 
 static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32_t n, int32_t h, int32_t w, int32_t c,
-                          int32_t pooled, float scale, float* gmap, int64_t pitch, void* stream_, int ps) {
+                          int32_t pooled, float scale, float* gmap, int64_t pitch, void* stream_, int ps,
+                          const int32_t* k_dev = nullptr) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ME_REQUIRE(gmap && (k == 0 || (gout && rois)), ME_E_NULLPTR, "me_roi_align_bwd_f32: null pointer");
   ME_REQUIRE(pooled == 7 && n > 0 && h > 0 && w > 0 && c > 0 && pitch >= c && k >= 0, ME_E_BADARG,
@@ -2109,7 +2140,7 @@ static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32
   if (k == 0) return 0;
   const long long total = (long long)k * (ps ? c / 49 : c) * 49;
   hipLaunchKernelGGL(roi_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, stream, gout, rois, k, c, h, w, scale, gmap,
-                     (long long)pitch, ps);
+                     (long long)pitch, ps, k_dev);
   return me::check_launch("roi_bwd_kernel");
 }
 
@@ -2123,6 +2154,20 @@ int me_ps_roi_align_bwd_f32(const float* grad_out, const float* rois, int32_t k,
                             int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
                             void* stream) {
   return launch_roi_bwd(grad_out, rois, k, n, h, w, c, pooled, spatial_scale, grad_map, pitch, stream, 1);
+}
+
+int me_roi_align_bwd_dev_f32(const float* grad_out, const float* rois, int32_t k_cap, const int32_t* k_dev, int32_t n, int32_t h,
+                             int32_t w, int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
+                             void* stream) {
+  ME_REQUIRE(k_dev != nullptr, ME_E_NULLPTR, "me_roi_align_bwd_dev_f32: null RoI count");
+  return launch_roi_bwd(grad_out, rois, k_cap, n, h, w, c, pooled, spatial_scale, grad_map, pitch, stream, 0, k_dev);
+}
+
+int me_ps_roi_align_bwd_dev_f32(const float* grad_out, const float* rois, int32_t k_cap, const int32_t* k_dev, int32_t n, int32_t h,
+                                int32_t w, int32_t c, int32_t pooled, float spatial_scale, float* grad_map, int64_t pitch,
+                                void* stream) {
+  ME_REQUIRE(k_dev != nullptr, ME_E_NULLPTR, "me_ps_roi_align_bwd_dev_f32: null RoI count");
+  return launch_roi_bwd(grad_out, rois, k_cap, n, h, w, c, pooled, spatial_scale, grad_map, pitch, stream, 1, k_dev);
 }
 
 }  // extern "C"

@@ -208,6 +208,14 @@ SIGNATURES = {
     "me_heads_loss_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "me_heads_tail_bwd_f32": (C.c_int, [C.POINTER(HeadsDesc)] + [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 9),
+    "me_heads_tail_bwd_dev_f32": (C.c_int, [C.POINTER(HeadsDesc)] + [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 10),
+    "me_bn_train_bwd_dev_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "me_roi_align_bwd_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "me_ps_roi_align_bwd_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "me_gemm_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
                               C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "me_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

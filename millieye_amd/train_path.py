@@ -57,13 +57,28 @@ def _f32(dev, *shape):
     return torch.empty(shape, device=dev, dtype=torch.float32)
 
 
+_CONSTS = {}
+
+
+def _const(dev, c, value):
+    """A cached read-only vector of ``c`` ones / zeros (per-channel scale / shift of a plain convolution): the step asked torch for a
+    fresh one - an allocation and a fill launch - eight times per call."""
+    key = (str(dev), int(c), float(value))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full((int(c),), float(value), device=dev, dtype=torch.float32)
+    return t
+
+
 class _BnState:
-    def __init__(self, c, dev):
-        self.mean, self.var, self.rstd = _f32(dev, c), _f32(dev, c), _f32(dev, c)
+    def __init__(self, c, dev, buf=None):
+        if buf is None:
+            buf = torch.empty((3, c), device=dev, dtype=torch.float32)   # (one allocation for the three vectors)
+        self.mean, self.var, self.rstd = buf[0], buf[1], buf[2]
 
 
-def _bn_fwd(x, ldx, rows, c, bn, act, y, ldy, ws):
-    st = _BnState(c, x.device)
+def _bn_fwd(x, ldx, rows, c, bn, act, y, ldy, ws, buf=None):
+    st = _BnState(c, x.device, buf)   # (``buf``: a [3, c] arena buffer - the captured backward reads the statistics from fixed addresses)
     if rows == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, {c}]")
     hip.check(hip.lib().me_bn_train_fwd_f32(_ptr(x), ldx, rows, c, _ptr(bn.weight), _ptr(bn.bias), float(bn.eps),
@@ -74,12 +89,17 @@ def _bn_fwd(x, ldx, rows, c, bn, act, y, ldy, ws):
     # scale/shift caches (engine.ConvWeights, my_models._HeadPack) re-fold them at the next eval-mode forward
     torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
     with torch.no_grad():
-        bn.num_batches_tracked += 1
+        bn._buffers["num_batches_tracked"].add_(1)   # (in place on the buffer: `bn.num_batches_tracked += 1` goes through Module.__setattr__)
     return st
 
 
-def _bn_bwd(x, ldx, dy, lddy, rows, c, bn, st, act, dx, lddx, ws):
+def _bn_bwd(x, ldx, dy, lddy, rows, c, bn, st, act, dx, lddx, ws, rows_dev=None):
     dg, db = _f32(x.device, c), _f32(x.device, c)
+    if rows_dev is not None:   # captured step: ``rows`` is the buffers' capacity, the live row count is the device word
+        hip.check(hip.lib().me_bn_train_bwd_dev_f32(_ptr(x), ldx, _ptr(dy), lddy, rows, rows_dev.data_ptr(), c, _ptr(bn.weight),
+                                                    _ptr(bn.bias), _ptr(st.mean), _ptr(st.rstd), act, _ptr(dx), lddx, _ptr(dg),
+                                                    _ptr(db), ws, hip.stream_ptr()), "me_bn_train_bwd_dev_f32")
+        return dg, db
     hip.check(hip.lib().me_bn_train_bwd_f32(_ptr(x), ldx, _ptr(dy), lddy, rows, c, _ptr(bn.weight), _ptr(bn.bias),
                                             _ptr(st.mean), _ptr(st.rstd), act, _ptr(dx), lddx, _ptr(dg), _ptr(db), ws,
                                             hip.stream_ptr()), "me_bn_train_bwd_f32")
@@ -202,6 +222,94 @@ def _head_names(net):
     return list(_head_named(net)[0])
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The backward of the step as ONE captured hipGraph (round 6).  The step is host-bound (profiles/r06_host_profile_train16_tottime.txt:
+# 0.9 ms of the 2.4 ms step issues the ~45 launches of ``_backward``), but its launch arguments change from step to step with the
+# number of proposals k.  Captured form: every tensor the backward reads lives in a per-network ARENA of fixed-capacity buffers
+# (capacity rows = 200 N + the radar boxes rounded up to 16; same addresses every step - ``forward_train`` writes them eagerly, with
+# the true k), the launches run over the CAPACITY and the four kernels whose arithmetic depends on the row count read it from a device
+# word (``me_heads_tail_bwd_dev_f32``, ``me_bn_train_bwd_dev_f32``, ``me_[ps_]roi_align_bwd_dev_f32``: zeros behind the live rows, so the
+# dense products over the capacity add exact zeros).  The first two backwards of a signature run eagerly, the third is captured,
+# later ones are one copy of the upstream gradient + one replay + one clone of the flat gradient buffer.  MILLIEYE_TRAIN_GRAPH=0: off.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _train_graph_enabled():
+    return os.environ.get("MILLIEYE_TRAIN_GRAPH", "1") != "0"
+
+
+class _Arena:
+    """Named fixed-shape device buffers of one Network's training step, zero-filled when first asked for and kept."""
+
+    def __init__(self):
+        self.t = {}
+        self.graphs = {}
+
+    def get(self, name, shape, dev, dtype=torch.float32):
+        key = (name, tuple(int(v) for v in shape), dtype, str(dev))
+        t = self.t.get(key)
+        if t is None:
+            if len(self.t) > 512:   # (shapes follow the batch geometry: bounded in any real loop; never let it grow without limit)
+                self.t.clear()
+                self.graphs.clear()
+            t = self.t[key] = torch.zeros(key[1], device=dev, dtype=dtype)
+        return t
+
+
+def _arena(net):
+    a = net.__dict__.get("_train_arena")
+    if a is None:
+        a = net.__dict__["_train_arena"] = _Arena()
+    return a
+
+
+class _BackwardGraph:
+    def __init__(self):
+        self.runs = 0
+        self.graph = None
+        self.g_in = None
+        self.flat = None
+        self.layout = None   # [(name, shape, offset, numel)]
+
+
+def _graphed_backward(S, grad_out, needed):
+    arena = S["arena"]
+    sig = S["graph_sig"] + (tuple(sorted(needed)) if needed is not None else None,)
+    rec = arena.graphs.get(sig)
+    if rec is None:
+        rec = arena.graphs[sig] = _BackwardGraph()
+    if rec.graph is False or torch.cuda.is_current_stream_capturing():
+        return _backward(S, grad_out, needed)
+    rec.runs += 1
+    if rec.graph is None and rec.runs <= 2:
+        return _backward(S, grad_out, needed)   # eager warm-up: lazy one-time state (workspaces, kernel attributes) settles
+    dev = S["fm"].device
+    if rec.graph is None:
+        rec.g_in = torch.zeros((), device=dev, dtype=torch.float32)
+        rec.g_in.copy_(grad_out.reshape(()))
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                G = _backward(S, rec.g_in, needed, rows=S["cap_rows"], k_dev=S["k_dev"])
+                names = sorted(G)
+                rec.flat = torch.cat([G[nm].reshape(-1) for nm in names])
+            off, layout = 0, []
+            for nm in names:
+                layout.append((nm, tuple(G[nm].shape), off, G[nm].numel()))
+                off += G[nm].numel()
+            rec.layout, rec.graph = layout, graph
+        except Exception as exc:   # a failed capture is not fatal and is not retried: this signature stays eager
+            import warnings
+            warnings.warn(f"millieye_amd: hipGraph capture of the stage-3 backward failed ({exc!r}); it runs eagerly")
+            rec.graph = False
+            torch.cuda.synchronize(dev)
+            return _backward(S, grad_out, needed)
+    else:
+        rec.g_in.copy_(grad_out.reshape(()))
+    rec.graph.replay()
+    fresh = rec.flat.clone()   # the caller's gradients must not alias the graph's static buffer (accumulation over several batches)
+    return {nm: fresh[off:off + cnt].view(shape) for nm, shape, off, cnt in rec.layout}
+
+
 class _StageThree(torch.autograd.Function):
     @staticmethod
     def forward(ctx, state, *params):
@@ -215,7 +323,7 @@ class _StageThree(torch.autograd.Function):
         # score-map conv / BatchNorm frozen, the largest GEMMs of the step (490 x 256 over every pixel, the PS-RoIAlign
         # scatter, the BatchNorm backward over N*h*w x 490) are skipped altogether
         needed = {n for n, need in zip(names, ctx.needs_input_grad[1:]) if need}
-        grads = _backward(ctx.state, grad_out, needed)
+        grads = _graphed_backward(ctx.state, grad_out, needed) if ctx.state.get("arena") is not None else _backward(ctx.state, grad_out, needed)
         return (None,) + tuple(grads.get(n) if n in needed else None for n in names)
 
 
@@ -343,6 +451,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         net.refine_threshold_img = 1
 
     # ---- frozen detector, NMS, proposal assembly (no grad) -------------------------------------------
+    grad_on = torch.is_grad_enabled()
     with torch.no_grad():
         nxt = net.__dict__.pop("_next_images", None)
         look_ahead = nxt is not None or "_det_prefetch" in net.__dict__
@@ -360,19 +469,41 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         n_radar = int(radar_boxes_location.shape[0])
         rb = radar_boxes_location.to(**f32).contiguous() if n_radar else torch.zeros((0, 5), **f32)
         pix = n * fh * fw
-        ws_t = torch.empty(int(lib.me_bn_workspace_bytes(512)) + 256, dtype=torch.uint8, device=dev)
+        # captured backward (_graphed_backward): everything the backward reads is allocated from the network's arena - fixed capacity,
+        # the same addresses every step.  Only for the plain training configuration; everything else keeps per-step tensors.
+        arena = _arena(net) if (_train_graph_enabled() and targets is not None and bn_train and model_mode == 0 and grad_on) else None
+        r_cap = -(-max(n_radar, 1) // 16) * 16
+        cap_rows = cap_img + r_cap
+
+        def A(name, *shape, dtype=torch.float32):
+            return arena.get(name, shape, dev, dtype) if arena is not None else torch.empty(shape, device=dev, dtype=dtype)
+
+        def stbuf(name, c):
+            return arena.get(name, (3, c), dev) if arena is not None else None
+
+        if arena is not None:   # the prefetched block's results are per-step tensors: into the arena (three small copies)
+            ib_a, nd_a, fm_a = A("img_boxes", cap_img, cols), A("n_img", 1, dtype=torch.int32), A("fm", n, fh, fw, fc)
+            ib_a.copy_(img_boxes)
+            nd_a.copy_(n_img_dev)
+            fm_a.copy_(fm)
+            img_boxes, n_img_dev, fm = ib_a, nd_a, fm_a
+            rb_a = A("rb", r_cap, 5)
+            if n_radar:
+                rb_a[:n_radar].copy_(rb)
+            rb = rb_a[:n_radar]
+        ws_t = A("bn_ws", int(lib.me_bn_workspace_bytes(512)) + 256, dtype=torch.uint8)
         ws = ws_t.data_ptr() + (-ws_t.data_ptr()) % 256
 
         # ---- image score map: conv1x1 (+bias) -> BN(train) -> leaky ---------------------------------
         icl = net.img_cnn_layers.net
         w_img = icl[0].weight.detach().reshape(490, fc).contiguous()
-        ones490, b_img = torch.ones(490, **f32), icl[0].bias.detach().contiguous()
-        a1 = _f32(dev, pix, 490)
+        ones490, b_img = _const(dev, 490, 1.0), icl[0].bias.detach().contiguous()
+        a1 = A("a1", pix, 490)
         if bn_train:
-            z1 = _f32(dev, pix, 490)
+            z1 = A("z1", pix, 490)
             _conv(fm, fc, n, fh, fw, fc, w_img.view(490, 1, 1, fc), ones490, b_img, 1, 0, hip.ACT_LINEAR,
                   z1.view(n, fh, fw, 490))
-            st_img = _bn_fwd(z1, 490, pix, 490, icl[1], hip.ACT_LEAKY, a1, 490, ws)
+            st_img = _bn_fwd(z1, 490, pix, 490, icl[1], hip.ACT_LEAKY, a1, 490, ws, stbuf("st_img", 490))
         else:  # folded affine + LeakyReLU in the conv epilogue; the backward recovers the pre-activation from a1
             z1, st_img = None, _BnEval(icl[1], dev)
             _conv(fm, fc, n, fh, fw, fc, w_img.view(490, 1, 1, fc), st_img.scale, st_img.with_bias(b_img), 1, 0,
@@ -383,19 +514,23 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         maps = maps.to(**f32)
         mh, mw = maps.shape[2], maps.shape[3]  # may differ from (fh, fw): the demos feed the raw 32 x 32 map (quirk q15)
         pix_r = n * mh * mw
-        x0 = maps.permute(0, 2, 3, 1).contiguous()  # NHWC, 3 channels
+        if arena is not None:
+            x0 = A("x0", n, mh, mw, 3)
+            x0.copy_(maps.permute(0, 2, 3, 1))
+        else:
+            x0 = maps.permute(0, 2, 3, 1).contiguous()  # NHWC, 3 channels
         radar = {"x0": x0}
         prev, prev_c = x0, 3
         for li, seq in enumerate((rc.conv1, rc.conv2, rc.conv3), start=1):
             conv, bn = seq[0], seq[1]
             cout = conv.weight.shape[0]
             wp = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
-            r_act = _f32(dev, n, mh, mw, cout)
+            r_act = A(f"r{li}", n, mh, mw, cout)
             if bn_train:
-                c_raw = _f32(dev, n, mh, mw, cout)
-                _conv(prev, prev_c, n, mh, mw, prev_c, wp, torch.ones(cout, **f32), conv.bias.detach().contiguous(), 3, 1,
+                c_raw = A(f"c{li}", n, mh, mw, cout)
+                _conv(prev, prev_c, n, mh, mw, prev_c, wp, _const(dev, cout, 1.0), conv.bias.detach().contiguous(), 3, 1,
                       hip.ACT_LINEAR, c_raw)
-                st = _bn_fwd(c_raw, cout, pix_r, cout, bn, hip.ACT_LEAKY, r_act, cout, ws)
+                st = _bn_fwd(c_raw, cout, pix_r, cout, bn, hip.ACT_LEAKY, r_act, cout, ws, stbuf(f"st{li}", cout))
             else:
                 c_raw, st = None, _BnEval(bn, dev)
                 _conv(prev, prev_c, n, mh, mw, prev_c, wp, st.scale, st.with_bias(conv.bias), 3, 1, hip.ACT_LEAKY, r_act)
@@ -403,19 +538,21 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
             prev, prev_c = r_act, cout
         conv4 = rc.conv3[3]
         w4 = conv4.weight.detach().reshape(10, 128).contiguous()
-        r4 = _f32(dev, n, mh, mw, 10)
-        _conv(prev, 128, n, mh, mw, 128, w4.view(10, 1, 1, 128), torch.ones(10, **f32), conv4.bias.detach().contiguous(),
+        r4 = A("r4", n, mh, mw, 10)
+        _conv(prev, 128, n, mh, mw, 128, w4.view(10, 1, 1, 128), _const(dev, 10, 1.0), conv4.bias.detach().contiguous(),
               1, 0, hip.ACT_SIGMOID, r4)
         radar["r4"] = r4
 
         # ---- heads, part A: pooling + net0 + small dot products (saved for backward) -----------------
         wts = dict(
-            w0t=rh.net0[0].weight.detach().t().contiguous(), b0=rh.net0[0].bias.detach().contiguous(),
+            w0t=(A("w0t", 490, 256).copy_(rh.net0[0].weight.detach().t()) if arena is not None
+                 else rh.net0[0].weight.detach().t().contiguous()), b0=rh.net0[0].bias.detach().contiguous(),
             w1=rh.net1[0].weight.detach().contiguous(), b1=rh.net1[0].bias.detach().contiguous(),
             w2=rh.net2[0].weight.detach().contiguous(), b2=rh.net2[0].bias.detach().contiguous(),
             rw=rh.radar_net[0].weight.detach().reshape(10, 490).contiguous(),
             rb=rh.radar_net[0].bias.detach().contiguous(),
-            rscale=torch.ones(10, **f32), rshift=torch.zeros(10, **f32),
+            rscale=(A("rscale", 10) if arena is not None else torch.ones(10, **f32)),
+            rshift=(A("rshift", 10) if arena is not None else torch.zeros(10, **f32)),
             rw2=rh.radar_net[3].weight.detach().reshape(10).contiguous(),
             rb2=rh.radar_net[3].bias.detach().reshape(1).contiguous(),
             e1w=eh.fc1[0].weight.detach().contiguous(), e1b=eh.fc1[0].bias.detach().contiguous(),
@@ -426,12 +563,12 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         # GPU has already gone idle (the step's second half is bound by the host).
         n_img = int(n_img_dev.item())
         k = n_img + n_radar
-        cap = max(k, 1)
-        feat_img, feat_rad = _f32(dev, cap, 490), _f32(dev, cap, 490)
-        hidden, small = _f32(dev, cap, 256), _f32(dev, cap, 16)
-        regress, refine, mask1 = _f32(dev, cap, 4), _f32(dev, cap, 2), _f32(dev, cap)
-        rows, key = _f32(dev, cap, 8), _f32(dev, cap)
-        keep = torch.zeros((cap,), device=dev, dtype=torch.uint8)
+        cap = max(k, 1) if arena is None else cap_rows
+        feat_img, feat_rad = A("feat_img", cap, 490), A("feat_rad", cap, 490)
+        hidden, small = A("hidden", cap, 256), A("small", cap, 16)
+        regress, refine, mask1 = A("regress", cap, 4), A("refine", cap, 2), A("mask1", cap)
+        rows, key = A("rows", cap, 8), A("key", cap)
+        keep = A("keep", cap, dtype=torch.uint8).zero_() if arena is not None else torch.zeros((cap,), device=dev, dtype=torch.uint8)
         d = hip.HeadsDesc()
         d.img_map, d.radar_map, d.img_pitch, d.radar_pitch = a1.data_ptr(), r4.data_ptr(), 490, 10
         d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16
@@ -456,9 +593,11 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         if k > 0:
             if bn_train:
                 dummy = _f32(dev, k, 10)
-                st_r = _bn_fwd(small[:, 6:], 16, k, 10, bn_r, hip.ACT_LINEAR, dummy, 10, ws)
+                st_r = _bn_fwd(small[:, 6:], 16, k, 10, bn_r, hip.ACT_LINEAR, dummy, 10, ws, stbuf("st_r", 10))
                 rscale = bn_r.weight.detach() * st_r.rstd
                 rshift = bn_r.bias.detach() - st_r.mean * rscale
+                if arena is not None:   # (fixed addresses: the descriptor the captured backward holds points at them)
+                    rscale, rshift = wts["rscale"].copy_(rscale), wts["rshift"].copy_(rshift)
             else:
                 st_r = _BnEval(bn_r, dev)
                 rscale, rshift = st_r.scale, st_r.shift
@@ -514,7 +653,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         lab_d, foc_d, cnf_d = masks_d[0], masks_d[1], masks_d[2]
 
         # ---- loss terms + gradient seeds ----------------------------------------------------------------
-        terms, seed_p, seed_c = _f32(dev, cap, 2), _f32(dev, cap), _f32(dev, cap)
+        terms, seed_p, seed_c = A("terms", cap, 2), A("seed_p", cap), A("seed_c", cap)
         sums = torch.zeros(2, **f32)
         if k > 0:
             hip.check(lib.me_heads_loss_f32(mask1.data_ptr(), refine.data_ptr(), lab_d.data_ptr(), foc_d.data_ptr(),
@@ -530,16 +669,31 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
                  n_radar=n_radar, fm=fm, z1=z1, a1=a1, st_img=st_img, radar=radar, feat_img=feat_img,
                  feat_rad=feat_rad, hidden=hidden, small=small, refine=refine, mask1=mask1, seed_p=seed_p,
                  seed_c=seed_c, desc=d, keepalive=(wts, img_boxes, n_img_dev, rb, regress, rows, keep, key), st_r=st_r,
-                 ws=(ws, ws_t), w_img=w_img, w4=w4, rois=torch.cat((ib[:, :5], rb), 0).contiguous(),
+                 ws=(ws, ws_t), w_img=w_img, w4=w4, rois=None,
                  losses=dict(masks_loss=sums[0], conf_loss=sums[1]))
+    with torch.no_grad():
+        if arena is None:
+            state["rois"] = torch.cat((ib[:, :5], rb), 0).contiguous()
+        else:
+            rois = A("rois", cap_rows, 5)
+            if n_img:
+                rois[:n_img].copy_(ib[:, :5])
+            if n_radar:
+                rois[n_img:k].copy_(rb)
+            k_dev = A("k_dev", 1, dtype=torch.int32)
+            torch.add(n_img_dev, n_radar, out=k_dev)
+            state.update(rois=rois, arena=arena if k > 0 else None, cap_rows=cap_rows, k_dev=k_dev,
+                         graph_sig=(n, fh, fw, fc, mh, mw, cap_rows, cols, str(dev), tuple(p.data_ptr() for p in head_parameters(net))))
     loss = _StageThree.apply(state, *head_parameters(net))
     net._last_train = state
     return loss, output, metric, radar_attention
 
 
-def _backward(S, grad_out, needed=None):
+def _backward(S, grad_out, needed=None, rows=None, k_dev=None):
     """Manual backward of the stage-3 graph; returns {parameter name: gradient}.  ``needed``: names whose gradient the
-    caller wants (None = all); whole branches whose every consumer is frozen are skipped."""
+    caller wants (None = all); whole branches whose every consumer is frozen are skipped.  ``rows`` / ``k_dev`` (the captured
+    form, ``_graphed_backward``): every launch runs over ``rows`` = the capacity of the arena buffers and the kernels whose
+    arithmetic depends on the proposal count read it from the device word ``k_dev``."""
     net, dev = S["net"], S["fm"].device
     lib = hip.lib()
     f32 = dict(device=dev, dtype=torch.float32)
@@ -550,37 +704,47 @@ def _backward(S, grad_out, needed=None):
     ws = S["ws"][0]
     G = {}
     with torch.no_grad():
-        if k == 0:
+        if k == 0 and rows is None:
             return G
+        if rows is not None:
+            k = rows
         g = grad_out.to(**f32).reshape(())
         seed_p, seed_c = S["seed_p"][:k] * g, S["seed_c"][:k] * g
         d = S["desc"]
         g_o, g_hpre, h_act, xin = _f32(dev, k, 2), _f32(dev, k, 64), _f32(dev, k, 64), _f32(dev, k, 4)
         g_z2, g_rl, rl, g_rlogit = _f32(dev, k, 2), _f32(dev, k, 10), _f32(dev, k, 10), _f32(dev, k, 1)
-        hip.check(lib.me_heads_tail_bwd_f32(C.byref(d), S["small"].data_ptr(), S["refine"].data_ptr(),
-                                            S["mask1"].data_ptr(), seed_p.data_ptr(), seed_c.data_ptr(), k,
-                                            g_o.data_ptr(), g_hpre.data_ptr(), h_act.data_ptr(), xin.data_ptr(),
-                                            g_z2.data_ptr(), g_rl.data_ptr(), rl.data_ptr(), g_rlogit.data_ptr(),
-                                            hip.stream_ptr()), "me_heads_tail_bwd_f32")
+        if k_dev is not None:
+            hip.check(lib.me_heads_tail_bwd_dev_f32(C.byref(d), S["small"].data_ptr(), S["refine"].data_ptr(),
+                                                    S["mask1"].data_ptr(), seed_p.data_ptr(), seed_c.data_ptr(), k, k_dev.data_ptr(),
+                                                    g_o.data_ptr(), g_hpre.data_ptr(), h_act.data_ptr(), xin.data_ptr(),
+                                                    g_z2.data_ptr(), g_rl.data_ptr(), rl.data_ptr(), g_rlogit.data_ptr(),
+                                                    hip.stream_ptr()), "me_heads_tail_bwd_dev_f32")
+        else:
+            hip.check(lib.me_heads_tail_bwd_f32(C.byref(d), S["small"].data_ptr(), S["refine"].data_ptr(),
+                                                S["mask1"].data_ptr(), seed_p.data_ptr(), seed_c.data_ptr(), k,
+                                                g_o.data_ptr(), g_hpre.data_ptr(), h_act.data_ptr(), xin.data_ptr(),
+                                                g_z2.data_ptr(), g_rl.data_ptr(), rl.data_ptr(), g_rlogit.data_ptr(),
+                                                hip.stream_ptr()), "me_heads_tail_bwd_f32")
         # ---- ensemble head ------------------------------------------------------------------------------
-        dw = torch.zeros((2, 64), **f32); _gemm(1, 0, 2, 64, k, g_o, 2, h_act, 64, dw, 64)
+        # (me_gemm_f32 with beta = 0 never reads C: the full-size weight gradients need no zero fill)
+        dw = torch.empty((2, 64), **f32); _gemm(1, 0, 2, 64, k, g_o, 2, h_act, 64, dw, 64)
         db = _f32(dev, 2); _colsum(g_o, 2, k, 2, db)
         G["ensemble_head.fc2.0.weight"], G["ensemble_head.fc2.0.bias"] = dw, db
-        dw = torch.zeros((32, 2), **f32); _gemm(1, 0, 32, 2, 2 * k, g_hpre, 32, xin, 2, dw, 2)
+        dw = torch.empty((32, 2), **f32); _gemm(1, 0, 32, 2, 2 * k, g_hpre, 32, xin, 2, dw, 2)
         db = _f32(dev, 32); _colsum(g_hpre, 32, 2 * k, 32, db)
         G["ensemble_head.fc1.0.weight"], G["ensemble_head.fc1.0.bias"] = dw, db
         # ---- radar_net: 1x1, BN over RoIs (+leaky), 7x7 conv ---------------------------------------------
-        dw = torch.zeros((1, 10), **f32); _gemm(1, 0, 1, 10, k, g_rlogit, 1, rl, 10, dw, 10)
+        dw = torch.empty((1, 10), **f32); _gemm(1, 0, 1, 10, k, g_rlogit, 1, rl, 10, dw, 10)
         db = _f32(dev, 1); _colsum(g_rlogit, 1, k, 1, db)
         G["refinement_head.radar_net.3.weight"], G["refinement_head.radar_net.3.bias"] = dw.view(1, 10, 1, 1), db
         bn_r = rh.radar_net[1]
         g_rconv = _f32(dev, k, 10)
         if S["bn_train"]:
-            dg, dbt = _bn_bwd(S["small"][:, 6:], 16, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10, ws)
+            dg, dbt = _bn_bwd(S["small"][:, 6:], 16, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10, ws, rows_dev=k_dev)
         else:  # rl = leaky(rscale * small + rshift), the stored activated value
             dg, dbt = _bn_eval_bwd(rl, 10, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10)
         G["refinement_head.radar_net.1.weight"], G["refinement_head.radar_net.1.bias"] = dg, dbt
-        dw = torch.zeros((10, 490), **f32); _gemm(1, 0, 10, 490, k, g_rconv, 10, S["feat_rad"], 490, dw, 490)
+        dw = torch.empty((10, 490), **f32); _gemm(1, 0, 10, 490, k, g_rconv, 10, S["feat_rad"], 490, dw, 490)
         db = _f32(dev, 10); _colsum(g_rconv, 10, k, 10, db)
         G["refinement_head.radar_net.0.weight"], G["refinement_head.radar_net.0.bias"] = dw.view(10, 10, 7, 7), db
         wr = rh.radar_net[0].weight.detach().reshape(10, 490).contiguous()
@@ -594,7 +758,7 @@ def _backward(S, grad_out, needed=None):
         g_pre = _f32(dev, k, 256)
         hip.check(lib.me_act_bwd_f32(S["hidden"].data_ptr(), 256, dt.data_ptr(), 256, g_pre.data_ptr(), 256, k, 256,
                                      hip.ACT_LEAKY, hip.stream_ptr()), "me_act_bwd_f32")
-        dw0 = torch.zeros((256, 490), **f32); _gemm(1, 0, 256, 490, k, g_pre, 256, S["feat_img"], 490, dw0, 490)
+        dw0 = torch.empty((256, 490), **f32); _gemm(1, 0, 256, 490, k, g_pre, 256, S["feat_img"], 490, dw0, 490)
         db0 = _f32(dev, 256); _colsum(g_pre, 256, k, 256, db0)
         G["refinement_head.net0.0.weight"], G["refinement_head.net0.0.bias"] = dw0, db0
         img_names = ("img_cnn_layers.net.batch_norm_0.weight", "img_cnn_layers.net.batch_norm_0.bias",
@@ -609,10 +773,18 @@ def _backward(S, grad_out, needed=None):
         d_r4 = torch.zeros((pix_r, 10), **f32)
         if want_img:
             d_a1 = torch.zeros((pix, 490), **f32)
-            hip.check(lib.me_ps_roi_align_bwd_f32(d_pimg.data_ptr(), rois.data_ptr(), k, n, fh, fw, 490, 7, 1.0 / 16,
-                                                  d_a1.data_ptr(), 490, hip.stream_ptr()), "me_ps_roi_align_bwd_f32")
-        hip.check(lib.me_roi_align_bwd_f32(d_prad.data_ptr(), rois.data_ptr(), k, n, mh, mw, 10, 7, 1.0 / 16,
-                                           d_r4.data_ptr(), 10, hip.stream_ptr()), "me_roi_align_bwd_f32")
+            if k_dev is not None:
+                hip.check(lib.me_ps_roi_align_bwd_dev_f32(d_pimg.data_ptr(), rois.data_ptr(), k, k_dev.data_ptr(), n, fh, fw, 490, 7,
+                                                          1.0 / 16, d_a1.data_ptr(), 490, hip.stream_ptr()), "me_ps_roi_align_bwd_dev_f32")
+            else:
+                hip.check(lib.me_ps_roi_align_bwd_f32(d_pimg.data_ptr(), rois.data_ptr(), k, n, fh, fw, 490, 7, 1.0 / 16,
+                                                      d_a1.data_ptr(), 490, hip.stream_ptr()), "me_ps_roi_align_bwd_f32")
+        if k_dev is not None:
+            hip.check(lib.me_roi_align_bwd_dev_f32(d_prad.data_ptr(), rois.data_ptr(), k, k_dev.data_ptr(), n, mh, mw, 10, 7, 1.0 / 16,
+                                                   d_r4.data_ptr(), 10, hip.stream_ptr()), "me_roi_align_bwd_dev_f32")
+        else:
+            hip.check(lib.me_roi_align_bwd_f32(d_prad.data_ptr(), rois.data_ptr(), k, n, mh, mw, 10, 7, 1.0 / 16,
+                                               d_r4.data_ptr(), 10, hip.stream_ptr()), "me_roi_align_bwd_f32")
         # ---- image score map: BN(+leaky) backward, 1x1 conv weight / bias gradient -------------------------
         if want_img:
             icl = net.img_cnn_layers.net
@@ -622,7 +794,7 @@ def _backward(S, grad_out, needed=None):
             else:
                 dg, dbt = _bn_eval_bwd(S["a1"], 490, d_a1, 490, pix, 490, icl[1], S["st_img"], hip.ACT_LEAKY, dz1, 490)
             G["img_cnn_layers.net.batch_norm_0.weight"], G["img_cnn_layers.net.batch_norm_0.bias"] = dg, dbt
-            dw = torch.zeros((490, fc), **f32); _gemm(1, 0, 490, fc, pix, dz1, 490, S["fm"], fc, dw, fc)
+            dw = torch.empty((490, fc), **f32); _gemm(1, 0, 490, fc, pix, dz1, 490, S["fm"], fc, dw, fc)
             db = _f32(dev, 490); _colsum(dz1, 490, pix, 490, db)
             G["img_cnn_layers.net.conv_0.weight"], G["img_cnn_layers.net.conv_0.bias"] = dw.view(490, fc, 1, 1), db
         # ---- radar CNN ---------------------------------------------------------------------------------------
@@ -630,7 +802,7 @@ def _backward(S, grad_out, needed=None):
         dc4 = _f32(dev, pix_r, 10)
         hip.check(lib.me_act_bwd_f32(R["r4"].data_ptr(), 10, d_r4.data_ptr(), 10, dc4.data_ptr(), 10, pix_r, 10,
                                      hip.ACT_SIGMOID, hip.stream_ptr()), "me_act_bwd_f32")
-        dw = torch.zeros((10, 128), **f32); _gemm(1, 0, 10, 128, pix_r, dc4, 10, R["r3"], 128, dw, 128)
+        dw = torch.empty((10, 128), **f32); _gemm(1, 0, 10, 128, pix_r, dc4, 10, R["r3"], 128, dw, 128)
         db = _f32(dev, 10); _colsum(dc4, 10, pix_r, 10, db)
         G["radar_cnn_layers.conv3.3.weight"], G["radar_cnn_layers.conv3.3.bias"] = dw.view(10, 128, 1, 1), db
         d_act = _f32(dev, pix_r, 128); _gemm(0, 0, pix_r, 128, 10, dc4, 10, S["w4"], 128, d_act, 128)
@@ -650,7 +822,7 @@ def _backward(S, grad_out, needed=None):
             if li > 1:  # data gradient = the forward conv kernel on the rotated, transposed weights
                 wd = conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()  # [cin][ky][kx][cout]
                 d_prev = _f32(dev, n, mh, mw, cin)
-                _conv(dc, cout, n, mh, mw, cout, wd, torch.ones(cin, **f32), torch.zeros(cin, **f32), 3, 1,
+                _conv(dc, cout, n, mh, mw, cout, wd, _const(dev, cin, 1.0), _const(dev, cin, 0.0), 3, 1,
                       hip.ACT_LINEAR, d_prev)
                 d_act = d_prev.view(pix_r, cin)
     return G
