@@ -15,7 +15,7 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-MAIN = ("conv_igemm", "conv3x3_p8", "conv1x1_ws", "conv3x3_ws")
+MAIN = ("conv_igemm", "conv3x3_p8", "conv1x1_ws", "conv3x3_ws", "conv_kw")
 SECOND = ("conv_tail_reduce", "conv_splitk_reduce")
 
 
