@@ -128,3 +128,35 @@ def test_metrics_host_code_matches_reference():
     assert U.compute_ap(np.array([0.1, 0.4, 0.4, 0.9]), np.array([1.0, 0.8, 0.6, 0.5])) == float(g["ap_simple"])
     # known-answer: 3-point PR curve by hand: (0.5-0)*1 + (1-0.5)*0.5 = 0.75
     assert abs(U.compute_ap(np.array([0.5, 1.0]), np.array([1.0, 0.5])) - 0.75) < 1e-12
+
+
+def test_oracle_16bit_training_restatement_is_a_rounding_of_the_fp32_step():
+    """``darknet_train_step(storage=...)`` (the checker of the 16-bit HIP training step, tests/test_gpu_train16.py) on the mini32
+    cfg: the fp32 mode is untouched by the storage plumbing (same loss and gradients as the default call, bit for bit - the call
+    the reference's ``yololoss_*.npz`` goldens pin), the 16-bit modes are roundings of it (loss within 1 %, every gradient at
+    cosine >= 0.97 in bf16 / 0.999 in f16 with eval-mode BatchNorm), f16 closer than bf16, and ``training=True`` returns the
+    updated running statistics in every mode."""
+    from oracle import darknet_ref
+    from tests import parity_helpers as ph
+    model, text = ph.make_mini32("oracle16", size=64)
+    sd = model.state_dict()
+    x = torch.from_numpy(synth.uniform("oracle16/x", (2, 3, 64, 64)))
+    targets = torch.tensor([[0, 1, 0.30, 0.40, 0.20, 0.30], [1, 2, 0.70, 0.60, 0.50, 0.40]])
+    l0, g0 = darknet_ref.darknet_train_step(text, sd, x, targets)
+    l1, g1 = darknet_ref.darknet_train_step(text, sd, x, targets, storage="f32")
+    assert float(l0) == float(l1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+    worst = {}
+    for mode, bar in (("bf16", 0.97), ("f16", 0.999)):
+        l, g = darknet_ref.darknet_train_step(text, sd, x, targets, storage=mode)
+        assert abs(float(l) - float(l0)) <= 1e-2 * abs(float(l0)), (mode, float(l), float(l0))
+        cos = []
+        for k in g0:
+            a, b = g0[k].double().flatten(), g[k].double().flatten()
+            if float(a.norm()) > 1e-12:
+                cos.append(float(a @ b / (a.norm() * b.norm())))
+        worst[mode] = min(cos)
+        assert worst[mode] >= bar, (mode, worst[mode])
+    assert worst["f16"] >= worst["bf16"]
+    out = darknet_ref.darknet_train_step(text, sd, x, targets, training=True, storage="bf16")
+    assert len(out) == 3 and any(not torch.equal(v, sd[k]) for k, v in out[2].items())
+    assert all(torch.equal(sd[k], model.state_dict()[k]) for k in sd), "state_dict must not be modified"
