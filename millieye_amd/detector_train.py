@@ -254,7 +254,10 @@ class DetectorTrainer:
                         ws = aff_layer_ws.get(i)
                         if ws is None or ws.numel() < need_a:
                             ws = aff_layer_ws[i] = torch.empty(max(need_a, 16), dtype=torch.uint8, device=dev)
-                        sums_job = (ws, rows, cout, int(cout % 4 == 0), dshift, dgamma)
+                        # (the flag must be the predicate me_affine_act_bwd_f32 derives for ITS plan - channels, pitches and
+                        #  16-byte alignment of y / dy / dc - or the two calls could disagree on the chunk count)
+                        v4 = cout % 4 == 0 and y.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and dc.data_ptr() % 16 == 0
+                        sums_job = (ws, rows, cout, int(v4), dshift, dgamma)
                     else:
                         ws = torch.empty(need_a, dtype=torch.uint8, device=dev)
                     gam = bn.weight.detach() if bn is not None else None

@@ -34,10 +34,22 @@ def main():
             keys[k] = int(keys[k])
     import os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import bench
     keys["kernel_generation"] = bench.kernel_generation(half=keys.get("dtype", "f32") != "f32")
-    f, nf = per_launch(fetch_db, "FETCH_SIZE", match)
-    w, nw = per_launch(write_db, "WRITE_SIZE", match)
+    last = int(keys.pop("last_forward", 0))
+    if last:
+        # only the conv launches of the LAST whole detector forward of each pass (tools/pmc_layers.py's rule: behind the last stem
+        # launch; slab-reduce launches charged to their conv launch) - the plain average below also counts whatever else the process
+        # launched with a matching name (autotuning candidates, the measured pair-vs-one-launch choice), which inflated the 16-bit figure
+        import pmc_layers
+        fl = pmc_layers.launches(fetch_db, "FETCH_SIZE", last)
+        wl = pmc_layers.launches(write_db, "WRITE_SIZE", last)
+        f, nf, w, nw = sum(v for _n, v, _d in fl), len(fl), sum(v for _n, v, _d in wl), len(wl)
+        match = f"last forward: {last} conv launches (+ their slab-reduce launches)"
+    else:
+        f, nf = per_launch(fetch_db, "FETCH_SIZE", match)
+        w, nw = per_launch(write_db, "WRITE_SIZE", match)
     fetch_bytes = 2.0 * f * 1024.0 / max(nf, 1)
     write_bytes = w * 1024.0 / max(nw, 1)
     print(json.dumps({
