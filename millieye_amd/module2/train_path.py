@@ -21,7 +21,8 @@ import torch
 
 from .. import hip
 from ..my_models import _DETECTIONS_PER_IMG, _NMS_THRESH
-from ..train_path import (_bn_bwd, _bn_fwd, _colsum, _conv, _f32, _frozen_detector_block, _gemm, _issue_prefetch, _ptr, _take_prefetch,
+from ..train_path import (_bn_bwd, _bn_fwd, _colsum, _conv, _f32, _frozen_detector_block, _gemm, _head_named, _issue_prefetch, _ptr,
+                          _take_prefetch,
                           iou_labels_vectorized)
 from ..utils.utils import xywh2xyxy
 
@@ -124,10 +125,13 @@ def forward_train(net, images, targets):
         # nn.Dropout(0.5), train mode: aten's CPU path draws empty_like(t).bernoulli_(1 - p) from the default generator
         if getattr(net, "dropout_generator", "cpu") == "device":
             # opt-in (Network.dropout_generator = "device"): the mask from torch's generator of the GPU, what the reference's own run
-            # on a CUDA machine does - 11 ms of host time per step less at 1600 proposals; not reproducible against a CPU run
+            # on a CUDA machine does - 3.6 ms of host time per step less at 1600 proposals; not reproducible against a CPU run
             mask = torch.empty((k, 256), device=dev).bernoulli_(0.5).to(torch.uint8)
         else:
-            mask = torch.empty((k, 256)).bernoulli_(0.5).to(torch.uint8).to(dev)
+            # (the float mask goes to the device as it is and is narrowed THERE: the float -> uint8 conversion of 400 K elements on the
+            #  host runs through a 128-thread parallel region on the GPU boxes' CPUs - 34 ms against 3.6 for the draw itself,
+            #  tools/bernoulli_probe.py - same values either way)
+            mask = torch.empty((k, 256)).bernoulli_(0.5).to(dev).to(torch.uint8)
         hidden = _f32(dev, k, 256)
         hip.check(lib.me_mask_scale_f32(t_act.data_ptr(), mask.data_ptr(), 2.0, k * 256, hidden.data_ptr(), hip.stream_ptr()),
                   "me_mask_scale_f32")
@@ -192,8 +196,8 @@ def forward_train(net, images, targets):
         _colsum(terms, 5, k, 5, sums)
         loss_val = sums[0] + (sums[1] + sums[2]) / net.loss_lambda[0] + (sums[3] + sums[4]) / net.loss_lambda[1]
 
-    names = [name for name, _ in net.named_parameters() if not name.startswith("base_detector.")]
-    params = [p for name, p in net.named_parameters() if not name.startswith("base_detector.")]
+    names, params = _head_named(net)   # (cached walk: two named_parameters() passes over ~370 tensors were 6 ms of host time per step)
+    names, params = list(names), list(params)
     state = dict(loss=loss_val, names=names, net=net, n=n, fh=fh, fw=fw, fc=fc, pix=pix, k=k, c1=c1, ws_t=ws_t, ws=ws, fm=fm,
                  z1=z1, a1=a1, st_img=st_img, rois=rois, feat=feat, t_act=t_act, mask=mask, hidden=hidden, refine=refine, x2=x2,
                  h1=h1, o=o, d_o=d_o, d_ref=d_ref, d_reg=d_reg, w0=w0, w1=w1, w2=w2, e1w=e1w, e2w=e2w, w_img=w_img,
@@ -247,7 +251,7 @@ def _backward(S, grad_out):
         dbc = _f32(dev, 490)
         _colsum(dz1, 490, pix, 490, dbc)
         grads["fcn_layers.net.conv_0.weight"], grads["fcn_layers.net.conv_0.bias"] = dw.view(490, fc, 1, 1), dbc
-    for name, p in net.named_parameters():
+    for name, p in zip(*_head_named(net)):
         if name in grads and not p.requires_grad:
             grads[name] = None
     return grads
