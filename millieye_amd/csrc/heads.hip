@@ -793,6 +793,14 @@ __global__ __launch_bounds__(256) void roi_heads_mfma_kernel(me_heads_desc d, in
   }
   __syncthreads();
   if (stop == 4) return;
+  if (d.save_small) {  // training mode (round 6): keep what the backward pass needs - the pooled features already sit in pool_scratch
+    for (int idx = t; idx < nr * HID; idx += 256) d.save_hidden[(long long)(k0 + idx / HID) * HID + idx % HID] = s_hid[(idx / HID) * HP + idx % HID];
+    for (int idx = t; idx < nr * 16; idx += 256) {
+      const int r = idx / 16, j = idx % 16;
+      d.save_small[(long long)(k0 + r) * 16 + j] = s_small[r * 16 + j] + (j >= 6 ? d.wts.rb[j - 6] : 0.f);
+    }
+    return;   // (the tail runs separately, once the RoI-wise BatchNorm statistics are known: me_heads_tail_f32)
+  }
   // phase D: one thread per RoI - scalar tail (its weights from LDS)
   if (t < nr)
     tail_one(d, s_small + t * 16, s_roi + t * 5, k0 + t, n_img,
@@ -1143,8 +1151,9 @@ int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
              ME_E_BADARG, "me_roi_heads_f32: bad dimensions");
   ME_REQUIRE(d->img_pitch >= FEAT && d->radar_pitch >= C_OUT, ME_E_BADARG, "me_roi_heads_f32: map pitch too small");
   const bool train = d->save_small || d->save_feat_img || d->save_feat_rad || d->save_hidden;
-  ME_REQUIRE(!train || (d->save_small && d->save_feat_img && d->save_feat_rad && d->save_hidden && w.rb), ME_E_NULLPTR,
-             "me_roi_heads_f32: training mode needs all four save_* pointers and wts.rb");
+  // (with pool_scratch the pooled features ARE the feature saves: [cap][980] = image half | radar half, pitch 980)
+  ME_REQUIRE(!train || (d->save_small && d->save_hidden && w.rb && (d->pool_scratch || (d->save_feat_img && d->save_feat_rad))), ME_E_NULLPTR,
+             "me_roi_heads_f32: training mode needs save_small, save_hidden, wts.rb and either pool_scratch or both save_feat_* pointers");
   const int cap = d->n_img_cap + d->n_radar;
   if (cap == 0) return 0;
   if (d->pool_scratch) {
@@ -1155,7 +1164,7 @@ int me_roi_heads_f32(const me_heads_desc* d, void* stream_) {
     if (rc) return rc;
   }
   static const int mfma_env = getenv("MILLIEYE_HEADS_MFMA") ? atoi(getenv("MILLIEYE_HEADS_MFMA")) : 1;
-  if (mfma_env && d->pool_scratch && !d->save_small) {  // inference on pooled rows: net0 on the matrix pipe, 32 RoIs per workgroup
+  if (mfma_env && d->pool_scratch) {  // pooled rows (inference, and training since round 6): net0 on the matrix pipe, 32 RoIs per workgroup
     static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_heads_mfma_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHeadsMfmaLds);
     ME_HIP(attr);

@@ -564,7 +564,14 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         n_img = int(n_img_dev.item())
         k = n_img + n_radar
         cap = max(k, 1) if arena is None else cap_rows
-        feat_img, feat_rad = A("feat_img", cap, 490), A("feat_rad", cap, 490)
+        # pooled features [cap, 980] = image half | radar half (me_heads_desc.pool_scratch): the RoI pooling as its own launch and net0
+        # on the matrix pipe, as in inference (same operations in the same order: the same bits as the fused launch); the halves are
+        # the backward's feature operands, pitch 980
+        pooled = A("pooled", cap, 980)
+        feat_img, feat_rad, feat_ld = pooled[:, :490], pooled[:, 490:], 980
+        if os.environ.get("MILLIEYE_TRAIN_HEADS_MFMA", "1") == "0":   # (A/B: the fused VALU launch with separate feature saves)
+            pooled = None
+            feat_img, feat_rad, feat_ld = A("feat_img", cap, 490), A("feat_rad", cap, 490), 490
         hidden, small = A("hidden", cap, 256), A("small", cap, 16)
         regress, refine, mask1 = A("regress", cap, 4), A("refine", cap, 2), A("mask1", cap)
         rows, key = A("rows", cap, 8), A("key", cap)
@@ -581,7 +588,10 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
             setattr(d.wts, name, t.data_ptr())
         d.regress_out, d.refine_out, d.mask1_out = regress.data_ptr(), refine.data_ptr(), mask1.data_ptr()
         d.out_rows, d.keep, d.sort_key = rows.data_ptr(), keep.data_ptr(), key.data_ptr()
-        d.save_feat_img, d.save_feat_rad = feat_img.data_ptr(), feat_rad.data_ptr()
+        if pooled is not None:
+            d.pool_scratch = pooled.data_ptr()
+        else:
+            d.save_feat_img, d.save_feat_rad = feat_img.data_ptr(), feat_rad.data_ptr()
         d.save_hidden, d.save_small = hidden.data_ptr(), small.data_ptr()
         if k > 0:
             hip.check(lib.me_roi_heads_f32(C.byref(d), hip.stream_ptr()), "me_roi_heads_f32")
@@ -667,7 +677,7 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
     state = dict(net=net, names=_head_names(net), loss=loss_value, bn_train=bn_train, n=n, fh=fh, fw=fw, fc=fc, pix=pix, k=k, n_img=n_img,
                  mh=mh, mw=mw,
                  n_radar=n_radar, fm=fm, z1=z1, a1=a1, st_img=st_img, radar=radar, feat_img=feat_img,
-                 feat_rad=feat_rad, hidden=hidden, small=small, refine=refine, mask1=mask1, seed_p=seed_p,
+                 feat_rad=feat_rad, feat_ld=feat_ld, hidden=hidden, small=small, refine=refine, mask1=mask1, seed_p=seed_p,
                  seed_c=seed_c, desc=d, keepalive=(wts, img_boxes, n_img_dev, rb, regress, rows, keep, key), st_r=st_r,
                  ws=(ws, ws_t), w_img=w_img, w4=w4, rois=None,
                  losses=dict(masks_loss=sums[0], conf_loss=sums[1]))
@@ -744,7 +754,7 @@ def _backward(S, grad_out, needed=None, rows=None, k_dev=None):
         else:  # rl = leaky(rscale * small + rshift), the stored activated value
             dg, dbt = _bn_eval_bwd(rl, 10, g_rl, 10, k, 10, bn_r, S["st_r"], hip.ACT_LEAKY, g_rconv, 10)
         G["refinement_head.radar_net.1.weight"], G["refinement_head.radar_net.1.bias"] = dg, dbt
-        dw = torch.empty((10, 490), **f32); _gemm(1, 0, 10, 490, k, g_rconv, 10, S["feat_rad"], 490, dw, 490)
+        dw = torch.empty((10, 490), **f32); _gemm(1, 0, 10, 490, k, g_rconv, 10, S["feat_rad"], S["feat_ld"], dw, 490)
         db = _f32(dev, 10); _colsum(g_rconv, 10, k, 10, db)
         G["refinement_head.radar_net.0.weight"], G["refinement_head.radar_net.0.bias"] = dw.view(10, 10, 7, 7), db
         wr = rh.radar_net[0].weight.detach().reshape(10, 490).contiguous()
@@ -758,7 +768,7 @@ def _backward(S, grad_out, needed=None, rows=None, k_dev=None):
         g_pre = _f32(dev, k, 256)
         hip.check(lib.me_act_bwd_f32(S["hidden"].data_ptr(), 256, dt.data_ptr(), 256, g_pre.data_ptr(), 256, k, 256,
                                      hip.ACT_LEAKY, hip.stream_ptr()), "me_act_bwd_f32")
-        dw0 = torch.empty((256, 490), **f32); _gemm(1, 0, 256, 490, k, g_pre, 256, S["feat_img"], 490, dw0, 490)
+        dw0 = torch.empty((256, 490), **f32); _gemm(1, 0, 256, 490, k, g_pre, 256, S["feat_img"], S["feat_ld"], dw0, 490)
         db0 = _f32(dev, 256); _colsum(g_pre, 256, k, 256, db0)
         G["refinement_head.net0.0.weight"], G["refinement_head.net0.0.bias"] = dw0, db0
         img_names = ("img_cnn_layers.net.batch_norm_0.weight", "img_cnn_layers.net.batch_norm_0.bias",
