@@ -131,31 +131,43 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   // forward use (G == nullptr): p0 = sum x, p1 = sum x^2 over this block's row chunk
   // backward use: p0 = sum g, p1 = sum g * xhat with g = dy * act'(bn output)
   // rows_dev (captured steps): the live row count in device memory, `rows` is then the buffers' capacity
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  // Round 6: a block = 64 channels x 4 row lanes (a wave reads 64 consecutive channels of one row; the four lanes of a channel walk
+  // rows r0 + lane, + 4, ... and meet in LDS in a fixed order).  The first form gave every channel ONE thread per chunk: the ten
+  // channels of the RoI-wise / radar BatchNorms ran on ten threads per workgroup, 85 dependent loads each (22 us per launch,
+  // ten launches per stage-3 step).
+  __shared__ double s0s[4][64], s1s[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int chunk = blockIdx.y;
-  if (c >= C) return;
   if (rows_dev) rows = *rows_dev < rows ? *rows_dev : rows;
   const int per = (rows + BN_CHUNKS - 1) / BN_CHUNKS;
   const int r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
   double s0 = 0.0, s1 = 0.0;
-  if (G == nullptr) {
-    for (int r = r0; r < r1; ++r) {
-      const float x = X[(long long)r * ld + c];
-      s0 += x;
-      s1 += (double)x * x;
-    }
-  } else {
-    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
-    for (int r = r0; r < r1; ++r) {
-      const float xh = (X[(long long)r * ld + c] - mu) * rs;
-      float g = G[(long long)r * ldg + c];
-      if (act == ME_ACT_LEAKY) g = (xh * ga + be > 0.f) ? g : 0.1f * g;
-      s0 += g;
-      s1 += (double)g * xh;
+  if (c < C) {
+    if (G == nullptr) {
+      for (int r = r0 + rl; r < r1; r += 4) {
+        const float x = X[(long long)r * ld + c];
+        s0 += x;
+        s1 += (double)x * x;
+      }
+    } else {
+      const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+      for (int r = r0 + rl; r < r1; r += 4) {
+        const float xh = (X[(long long)r * ld + c] - mu) * rs;
+        float g = G[(long long)r * ldg + c];
+        if (act == ME_ACT_LEAKY) g = (xh * ga + be > 0.f) ? g : 0.1f * g;
+        s0 += g;
+        s1 += (double)g * xh;
+      }
     }
   }
-  p0[(long long)chunk * C + c] = (float)s0;
-  p1[(long long)chunk * C + c] = (float)s1;
+  s0s[rl][cl] = s0;
+  s1s[rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    p0[(long long)chunk * C + c] = (float)(((s0s[0][cl] + s0s[1][cl]) + s0s[2][cl]) + s0s[3][cl]);
+    p1[(long long)chunk * C + c] = (float)(((s1s[0][cl] + s1s[1][cl]) + s1s[2][cl]) + s1s[3][cl]);
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const float* p0, const float* p1, int rows, int C,
@@ -1092,17 +1104,25 @@ __device__ __forceinline__ void scatter_bilinear(float* gmap, long long pitch, i
 
 __global__ __launch_bounds__(256) void roi_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois,
                                                       int k, int c, int h, int w, float scale, float* gmap,
-                                                      long long pitch, int ps, const int* k_dev = nullptr) {
+                                                      long long pitch, int ps, const int* k_dev = nullptr, int xsplit = 0) {
   // gout: [k, c_out, 7, 7] with c_out = ps ? c/49 : c
+  // xsplit (round 6, batches of >= 4 frames): the RoIs of frame b are scattered by the workgroups of XCD b % 8 only (workgroup ids
+  // are dealt round-robin over the eight XCDs).  The proposals of a frame pile up on the same few objects, so their atomics hit the
+  // same lines of the gradient map; with the RoIs dealt over all XCDs those lines migrated between the eight L2s for every add
+  // (120 us per launch at ~300 RoIs); within one XCD they stay in its L2.  Every XCD's workgroups scan all indices and keep their frames'.
   if (k_dev) k = *k_dev < k ? *k_dev : k;   // (captured steps: k = capacity, the live RoI count in device memory)
   const int cout = ps ? c / 49 : c;
   const long long total = (long long)k * cout * 49;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+  const int xcd = blockIdx.x & 7;
+  const long long first = xsplit ? (long long)(blockIdx.x >> 3) * 256 + threadIdx.x : (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = xsplit ? (long long)(gridDim.x >> 3) * 256 : (long long)gridDim.x * 256;
+  for (long long idx = first; idx < total; idx += stride) {
     const int pw = (int)(idx % P7), ph = (int)((idx / P7) % P7);
     const int cc = (int)((idx / 49) % cout);
     const int r = (int)(idx / (49ll * cout));
     const float* roi = rois + 5 * r;
     const int b = (int)roi[0];
+    if (xsplit && (b & 7) != xcd) continue;
     const float off = ps ? 0.5f : 0.0f;
     const float sw = roi[1] * scale - off, sh = roi[2] * scale - off;
     const float ew = roi[3] * scale - off, eh = roi[4] * scale - off;
@@ -1595,7 +1615,7 @@ int me_bn_train_fwd_f32(const float* x, int64_t ldx, int32_t rows, int32_t chann
   float* p0 = reinterpret_cast<float*>(workspace);
   float* p1 = p0 + (long long)BN_CHUNKS * channels;
   const unsigned cb = (channels + 255) / 256;
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((channels + 63) / 64, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
                      (const float*)nullptr, 0ll, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, 0, p0, p1);
   hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, rows, channels, eps, momentum,
@@ -1638,7 +1658,7 @@ static int launch_bn_train_bwd(const float* x, int64_t ldx, const float* dy, int
   float* p0 = reinterpret_cast<float*>(workspace);
   float* p1 = p0 + (long long)BN_CHUNKS * channels;
   const unsigned cb = (channels + 255) / 256;
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((channels + 63) / 64, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
                      dy, (long long)lddy, save_mean, save_rstd, gamma, beta, act, p0, p1, rows_dev);
   hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, channels);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d((long long)rows * channels)), dim3(256), 0, stream, x,
@@ -2139,8 +2159,16 @@ static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32
   ME_REQUIRE(!ps || c % 49 == 0, ME_E_BADARG, "me_ps_roi_align_bwd_f32: channels %% 49 != 0");
   if (k == 0) return 0;
   const long long total = (long long)k * (ps ? c / 49 : c) * 49;
-  hipLaunchKernelGGL(roi_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, stream, gout, rois, k, c, h, w, scale, gmap,
-                     (long long)pitch, ps, k_dev);
+  static const int xs_env = getenv("MILLIEYE_ROI_BWD_XSPLIT") ? atoi(getenv("MILLIEYE_ROI_BWD_XSPLIT")) : 1;   // (A/B: 0 = off)
+  const int xsplit = (xs_env && n >= 4) ? 1 : 0;
+  unsigned grid = grid1d(total);
+  if (xsplit) {   // eight groups of workgroups, each scanning every index: a group needs total / 256 workgroup passes of its own
+    long long per = (total + 255) / 256;
+    if (per > 1024) per = 1024;
+    grid = 8u * (unsigned)(per < 1 ? 1 : per);
+  }
+  hipLaunchKernelGGL(roi_bwd_kernel, dim3(grid), dim3(256), 0, stream, gout, rois, k, c, h, w, scale, gmap,
+                     (long long)pitch, ps, k_dev, xsplit);
   return me::check_launch("roi_bwd_kernel");
 }
 
