@@ -576,6 +576,19 @@ def forward_train(net, images, maps, radar_boxes_location, targets, model_mode=0
         regress, refine, mask1 = A("regress", cap, 4), A("refine", cap, 2), A("mask1", cap)
         rows, key = A("rows", cap, 8), A("key", cap)
         keep = A("keep", cap, dtype=torch.uint8).zero_() if arena is not None else torch.zeros((cap,), device=dev, dtype=torch.uint8)
+        if arena is not None:
+            # rows [k, previous k) of the feature operands still hold the last step's values.  The captured backward multiplies them by
+            # exact zeros - harmless for finite values, but a degenerate proposal pools NaN (0 / 0, like the library) and NaN x 0 would
+            # poison every later weight gradient: clear what this step does not overwrite
+            prev_k = arena.t.get(("prev_k", cap), 0)
+            if prev_k > k:
+                hidden[k:prev_k].zero_()
+                if pooled is not None:
+                    pooled[k:prev_k].zero_()
+                else:
+                    feat_img[k:prev_k].zero_()
+                    feat_rad[k:prev_k].zero_()
+            arena.t[("prev_k", cap)] = k
         d = hip.HeadsDesc()
         d.img_map, d.radar_map, d.img_pitch, d.radar_pitch = a1.data_ptr(), r4.data_ptr(), 490, 10
         d.n, d.fh, d.fw, d.spatial_scale = n, fh, fw, 1.0 / 16
