@@ -922,7 +922,9 @@ class DarknetEngine:
         return plan, plan.y_static
 
 
-_GRAPH_SCOPE = [0]
+import threading
+
+_GRAPH_SCOPE = threading.local()   # (per thread: a `with graph_replay()` block of one thread must not switch another thread's engine runs)
 
 
 class graph_replay:
@@ -931,11 +933,11 @@ class graph_replay:
     host-bound (train_path._issue_prefetch) - one copy + one graph launch instead of ~130 launches (0.4 ms of issue time)."""
 
     def __enter__(self):
-        _GRAPH_SCOPE[0] += 1
+        _GRAPH_SCOPE.depth = getattr(_GRAPH_SCOPE, "depth", 0) + 1
         return self
 
     def __exit__(self, *exc):
-        _GRAPH_SCOPE[0] -= 1
+        _GRAPH_SCOPE.depth = getattr(_GRAPH_SCOPE, "depth", 1) - 1
         return False
 
 
@@ -944,7 +946,7 @@ def _graphs_enabled():
     batch 1, 1508 vs 1514 at batch 8 with / without the graph - the GPU side of the path is bound by the kernels' own latency, not by
     launches, so the eager sequence stays the default."""
     import os
-    return _GRAPH_SCOPE[0] > 0 or os.environ.get("MILLIEYE_HIPGRAPH", "0") in ("1", "true", "on")
+    return getattr(_GRAPH_SCOPE, "depth", 0) > 0 or os.environ.get("MILLIEYE_HIPGRAPH", "0") in ("1", "true", "on")
 
 
 # ------------------------------------------------------------------------------------------ autotuner
