@@ -244,6 +244,11 @@ struct YoloCand {
 // spread over the whole chip.
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v);  // (DPP network, defined with the select kernel)
 
+__global__ __launch_bounds__(256) void zero_ints_kernel(int* p, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) p[i] = 0;
+}
+
 template <int RPW>
 __global__ __launch_bounds__(256) void yolo_decode_cand_kernel(YoloCand d, NmsWs w) {
 #pragma clang fp contract(off)
@@ -1149,7 +1154,15 @@ int me_yolo_decode_cand_multi_f32(const me_yolo_desc* const* ys, int32_t count, 
   }
   const int n = ys[0]->n;
   NmsWs w = carve(nms_workspace, n, ys[0]->rows_total);
-  if (first) ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * n, stream));
+  if (first) {
+    // a kernel, not hipMemsetAsync: this launch sequence is captured into hipGraphs (engine._run_graph), and on this ROCm (7.2) a
+    // captured hipMemsetAsync of 64 bytes or more clears the words on the FIRST replay only - later replays write a pointer-like
+    // pattern instead (tools/memset_graph_probe.py, profiles/r06_memset_graph_probe.txt; 8 bytes are fine).  The counts then
+    // started at garbage and the lists overran: a memory fault on the second replay (round 6).
+    hipLaunchKernelGGL(zero_ints_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, stream, w.cand_count, 4 * n);
+    const int rc0 = me::check_launch("zero_ints_kernel");
+    if (rc0) return rc0;
+  }
   // rows per wave: 16 when that still leaves >= 2048 workgroups, else 4, else 1 (batch 1: 10 647 rows over 2 662 workgroups)
   const long long wg16 = rows_all * n / 64;
   const int rpw = wg16 >= 2048 ? 16 : (wg16 >= 512 ? 4 : 1);
@@ -1185,7 +1198,8 @@ static int nms_batched(const me_nms_desc* d, void* stream_, int prepped) {
   NmsWs w = carve(d->workspace, d->n, d->rows);
   int rc = 0;
   if (!prepped) {
-    ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int) * d->n, stream));  // counts, max-coordinate bits, NaN / fallback flags
+    // counts, max-coordinate bits, NaN / fallback flags (a kernel: see me_yolo_decode_cand_multi_f32 on captured memsets)
+    hipLaunchKernelGGL(zero_ints_kernel, dim3((4 * d->n + 255) / 256), dim3(256), 0, stream, w.cand_count, 4 * d->n);
     hipLaunchKernelGGL(nms_prep_kernel, dim3((d->rows + 255) / 256, d->n), dim3(256), 0, stream, d->pred, d->rows,
                        d->num_classes, d->conf_thresh, d->writeback_xyxy, w);
     rc = me::check_launch("nms_prep_kernel");
@@ -1219,7 +1233,7 @@ int me_nms_boxes_f32(const float* boxes, const float* scores, const float* label
   ME_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, ME_E_ALIGN,
              "me_nms_boxes_f32: workspace not 256-byte aligned");
   NmsWs w = carve(workspace, 1, m);
-  ME_HIP(hipMemsetAsync(w.cand_count, 0, 4 * sizeof(int), stream));
+  hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, stream, w.cand_count, 4);
   hipLaunchKernelGGL(nms_prep_boxes_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, boxes, scores, labels, m, w);
   int rc = me::check_launch("nms_prep_boxes_kernel");
   if (rc) return rc;

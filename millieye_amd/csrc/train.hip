@@ -1150,6 +1150,95 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// The same scatter through LDS (round 6).  A stage-3 step of 8 frames has ~1200 proposals piled on a few objects: the kernel
+// above issued 2.4-9 M global float atomics on the same few hundred lines (126 us per launch in the step's trace).  Here a
+// workgroup owns one frame and a slice of the gradient map small enough for LDS, scatters into it with LDS atomics and writes
+// the slice out once:
+//   PS  (ps_roi_align): output channel (cc*7+ph)*7+pw is fed by bin (ph, pw) only, so workgroup (bin, frame) owns the c/49
+//       channels of that bin in all h*w cells - exclusively: one add per non-zero cell, no two workgroups on an address;
+//   !PS (roi_align): workgroup (split, frame) takes every split-th RoI of the frame on the whole [h, w, c] map and adds its
+//       non-zero cells to the global map with atomics (gridDim.x adds per cell at most).
+// The RoIs of the frame are compacted into an LDS list first (2048 candidates per round).  Summation order within a cell is
+// the order the LDS atomics retire in - not fixed, like the global atomics of the kernel above.
+constexpr int ROI_LDS_LIST = 2048;
+constexpr int ROI_LDS_THREADS = 512;
+
+template <bool PS>
+__global__ __launch_bounds__(ROI_LDS_THREADS) void roi_bwd_lds_kernel(const float* __restrict__ gout,
+                                                                       const float* __restrict__ rois, int k, int c, int h,
+                                                                       int w, float scale, float* gmap, long long pitch,
+                                                                       const int* k_dev) {
+  extern __shared__ float s_map[];   // [h*w][cl]: cl = c/49 channels of one bin (PS) or all c channels (!PS)
+  __shared__ int s_list[ROI_LDS_LIST];
+  __shared__ int s_n;
+  if (k_dev) k = *k_dev < k ? *k_dev : k;
+  const int b = blockIdx.y;
+  const int cout = PS ? c / 49 : c;   // channels of grad_out
+  const int cl = cout;                // channels of the LDS slice
+  const int cells = h * w * cl;
+  for (int i = threadIdx.x; i < cells; i += ROI_LDS_THREADS) s_map[i] = 0.f;
+  const int bin = PS ? (int)blockIdx.x : 0;
+  const int bph = bin / P7, bpw = bin % P7;
+  const int split = PS ? 0 : (int)blockIdx.x, nsplit = PS ? 1 : (int)gridDim.x;
+  const int per_roi = PS ? cout : cout * 49;   // scatter items per RoI handled by this workgroup
+  for (int base = 0; base < k; base += ROI_LDS_LIST) {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int lim = (base + ROI_LDS_LIST < k) ? base + ROI_LDS_LIST : k;
+    for (int r = base + threadIdx.x; r < lim; r += ROI_LDS_THREADS) {
+      if ((int)rois[5 * r] == b && (r % nsplit) == split) s_list[atomicAdd(&s_n, 1)] = r;
+    }
+    __syncthreads();
+    const int items = s_n * per_roi;
+    for (int it = threadIdx.x; it < items; it += ROI_LDS_THREADS) {
+      // lanes of a wave: channel fastest, then RoI, the bin slowest - 64 lanes are ~6 RoIs x all channels of ONE bin, so two lanes
+      // meet on an LDS address only where two RoIs overlap (with the bin fastest the 49 bins of a small RoI fell into two or three
+      // cells of the same channel: 20-way same-address adds, 80 us per launch at 1200 RoIs)
+      int r, cc, ph, pw;
+      if (PS) {
+        r = s_list[it / per_roi];
+        cc = it % per_roi; ph = bph; pw = bpw;
+      } else {
+        const int nr = s_n, b49 = it / (nr * cout), rem = it - b49 * (nr * cout);
+        r = s_list[rem / cout];
+        cc = rem % cout; ph = b49 / P7; pw = b49 % P7;
+      }
+      const float* roi = rois + 5 * r;
+      const float off = PS ? 0.5f : 0.0f;
+      const float sw = roi[1] * scale - off, sh = roi[2] * scale - off;
+      const float ew = roi[3] * scale - off, eh = roi[4] * scale - off;
+      float roi_w = ew - sw, roi_h = eh - sh;
+      if (!PS) {
+        roi_w = roi_w > 1.f ? roi_w : 1.f;
+        roi_h = roi_h > 1.f ? roi_h : 1.f;
+      }
+      const float bin_h = roi_h / (float)P7, bin_w = roi_w / (float)P7;
+      const int gh = grid_of7(roi_h), gw = grid_of7(roi_w);
+      if (gh <= 0 || gw <= 0 || gh > 4096 || gw > 4096) continue;
+      const float count = (float)(gh * gw);
+      const float g = gout[((long long)r * cout + cc) * 49 + ph * P7 + pw];
+      const float ybase = PS ? ((float)ph * bin_h + sh) : (sh + ph * bin_h);
+      const float xbase = PS ? ((float)pw * bin_w + sw) : (sw + pw * bin_w);
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = ybase + ((float)(iy + .5f)) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = xbase + ((float)(ix + .5f)) * bin_w / (float)gw;
+          scatter_bilinear(s_map, cl, h, w, cc, yy, xx, g / count);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* gimg = gmap + (long long)b * h * w * pitch;
+  for (int i = threadIdx.x; i < cells; i += ROI_LDS_THREADS) {
+    const float v = s_map[i];
+    if (v == 0.f) continue;   // (NaN compares unequal and is written)
+    const int cell = i / cl, cc = i - cell * cl;
+    // (PS: this workgroup alone owns the element; the add without return value does not wait for the memory round trip)
+    atomicAdd(gimg + (long long)cell * pitch + (PS ? (cc * P7 + bph) * P7 + bpw : cc), v);
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // detector backward building blocks (Darknet.forward(x, targets) -> loss.backward(), eval-mode BatchNorm)
@@ -2161,6 +2250,25 @@ static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32
   const long long total = (long long)k * (ps ? c / 49 : c) * 49;
   static const int xs_env = getenv("MILLIEYE_ROI_BWD_XSPLIT") ? atoi(getenv("MILLIEYE_ROI_BWD_XSPLIT")) : 1;   // (A/B: 0 = off)
   const int xsplit = (xs_env && n >= 4) ? 1 : 0;
+  // the scatter through LDS when a frame's slice of the map fits (MILLIEYE_ROI_BWD_LDS=0: the global-atomics kernel)
+  static const int lds_env = getenv("MILLIEYE_ROI_BWD_LDS") ? atoi(getenv("MILLIEYE_ROI_BWD_LDS")) : 1;
+  const long long slice = (long long)h * w * (ps ? c / 49 : c) * (long long)sizeof(float);
+  if (lds_env && slice <= 48 * 1024) {
+    if (ps) {
+      hipLaunchKernelGGL(roi_bwd_lds_kernel<true>, dim3(49, n), dim3(ROI_LDS_THREADS), (size_t)slice, stream, gout, rois, k, c, h,
+                         w, scale, gmap, (long long)pitch, k_dev);
+    } else {
+      static const int ns_env = getenv("MILLIEYE_ROI_BWD_SPLITS") ? atoi(getenv("MILLIEYE_ROI_BWD_SPLITS")) : 0;
+      // one workgroup walks its RoIs' items in a chain of dependent loads (list -> RoI -> gradient): the time of a launch follows
+      // the items per workgroup (1200 RoIs, 8 frames: 136 / 79 / 43 / 31 us at 4 / 8 / 16 / 32 slices per frame), so enough slices
+      // to put a workgroup on every CU; a slice's write-out is at most h*w*c adds
+      int nsplit = ns_env > 0 ? ns_env : 256 / n;
+      nsplit = nsplit < 1 ? 1 : (nsplit > 64 ? 64 : nsplit);
+      hipLaunchKernelGGL(roi_bwd_lds_kernel<false>, dim3(nsplit, n), dim3(ROI_LDS_THREADS), (size_t)slice, stream, gout, rois, k,
+                         c, h, w, scale, gmap, (long long)pitch, k_dev);
+    }
+    return me::check_launch("roi_bwd_lds_kernel");
+  }
   unsigned grid = grid1d(total);
   if (xsplit) {   // eight groups of workgroups, each scanning every index: a group needs total / 256 workgroup passes of its own
     long long per = (total + 255) / 256;

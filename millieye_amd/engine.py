@@ -833,24 +833,27 @@ class DarknetEngine:
             self.refresh_weights(x.device)
             plan = self.plan_for(x, keep_raw)
             if _graphs_enabled() and not torch.cuda.is_current_stream_capturing():
-                plan.nms_prepped = None
-                return self._run_graph(plan, x)
+                return self._run_graph(plan, x, self._nms_candidates(plan, x, nms_conf))
         while True:
             yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
                                    device=x.device)
-            cand = None
-            plan.nms_prepped = None
-            if nms_conf is not None and plan.yolo_descs and 5 + (plan.num_classes or 0) <= 128 and plan.rows <= 32768 \
-                    and plan.n <= 65535:
-                ws_ptr, _keep = hip.nms_workspace(plan.n, plan.rows, x.device)
-                cand = (float(nms_conf), ws_ptr)
-                plan.nms_prepped = float(nms_conf)
+            cand = self._nms_candidates(plan, x, nms_conf)
+            plan.nms_prepped = cand[0] if cand is not None else None
             self._launch_all(plan, x, yolo_out, cand)
             plan.last_input = x  # keep the caller's tensor alive until the stream has consumed it
             if not early or not self.refresh_weights(x.device):
                 return plan, yolo_out
             early = False  # a parameter changed since the last run: again, on the fresh weights (and a fresh plan if they moved)
             plan = self.plan_for(x, keep_raw)
+
+    @staticmethod
+    def _nms_candidates(plan, x, nms_conf):
+        """``(threshold, workspace pointer)`` when the [yolo] decodes of this run are to fill the NMS candidate lists (the caller's
+        stream's workspace: ``hip.nms_batched`` on the same stream finds them there), else None."""
+        if nms_conf is None or not plan.yolo_descs or 5 + (plan.num_classes or 0) > 128 or plan.rows > 32768 or plan.n > 65535:
+            return None
+        ws_ptr, _keep = hip.nms_workspace(plan.n, plan.rows, x.device)
+        return (float(nms_conf), ws_ptr)
 
     @staticmethod
     def _launch_all(plan, x, yolo_out, cand=None):
@@ -879,31 +882,45 @@ class DarknetEngine:
             if rc != 0:
                 hip.check(rc, name)
 
-    def _run_graph(self, plan, x):
+    def _run_graph(self, plan, x, cand=None):
         """hipGraph replay of the plan's launch sequence (80-110 kernels): the first two runs of a plan are eager (lazy
         one-time state such as kernel attributes settles), the third is captured with ``torch.cuda.graph`` into static
         input / output buffers, later runs are one device-to-device copy of the frames + one graph launch.  Descriptors
         are passed to the kernels by value, so the capture holds everything; a plan rebuild (weight reallocation, new
         shape) drops the graph with the plan.  ``yolo_outputs`` is then a static buffer that the next run of the same
-        plan overwrites (``Darknet.forward`` hands out a copy; ``Network.forward`` consumes it immediately)."""
-        if plan.graph is None:
-            plan.eager_runs = getattr(plan, "eager_runs", 0) + 1
-            if plan.eager_runs <= 2:
-                yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
-                                       device=x.device)
-                self._launch_all(plan, x, yolo_out)
+        plan overwrites (``Darknet.forward`` hands out a copy; ``Network.forward`` consumes it immediately).
+        ``cand`` (``_nms_candidates``): the decodes also fill the NMS candidate lists, like the eager run with ``nms_conf``.  The
+        threshold and the workspace pointer are baked into the capture, so a plan holds one graph per ``cand`` value (round 6: the
+        stage-3 loop's look-ahead detector is a replay - without this it paid the separate decode + candidate pass, 96 us per
+        step at batch 8); a workspace that was replaced by a bigger one gives a new key and a new capture."""
+        shape = (plan.n, plan.rows, 5 + (plan.num_classes or 0))
+        plan.nms_prepped = cand[0] if cand is not None else None
+        rec = None
+        if plan.graph is not False:   # (False: a capture failed; None: no graph run yet; else the dict {cand: record})
+            if plan.graph is None:
+                plan.graph = {}
+            rec = plan.graph.get(cand)
+            if rec is None:
+                if len(plan.graph) >= 4:   # thresholds that keep changing: drop the oldest capture
+                    plan.graph.pop(next(iter(plan.graph)))
+                rec = plan.graph[cand] = {"eager": 0, "graph": None}
+        if rec is not None and rec["graph"] is None:
+            rec["eager"] += 1
+            if rec["eager"] <= 2:
+                yolo_out = torch.empty(shape, dtype=torch.float32, device=x.device)
+                self._launch_all(plan, x, yolo_out, cand)
                 plan.last_input = x
                 return plan, yolo_out
-            plan.x_static = torch.empty_like(x)
-            plan.y_static = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32,
-                                        device=x.device)
+            if getattr(plan, "x_static", None) is None:
+                plan.x_static = torch.empty_like(x)
+                plan.y_static = torch.empty(shape, dtype=torch.float32, device=x.device)
             torch.cuda.synchronize(x.device)
             graph = torch.cuda.CUDAGraph()
             try:
                 # thread_local: a DataLoader pin-memory thread or the NCCL watchdog calling into the runtime during the capture
                 # window must not invalidate it (the global mode would) - same choice as detector_graph.GraphedDetectorStep
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    self._launch_all(plan, plan.x_static, plan.y_static)
+                    self._launch_all(plan, plan.x_static, plan.y_static, cand)
             except Exception as exc:  # a failed capture is not fatal and is not retried: this plan stays on eager launches
                 import warnings
                 warnings.warn(f"millieye_amd: hipGraph capture of the detector plan failed ({exc!r}); the plan runs eagerly")
@@ -911,14 +928,14 @@ class DarknetEngine:
                 plan.x_static = plan.y_static = None
                 torch.cuda.synchronize(x.device)
             else:
-                plan.graph = graph
+                rec["graph"] = graph
         if plan.graph is False:
-            yolo_out = torch.empty((plan.n, plan.rows, 5 + (plan.num_classes or 0)), dtype=torch.float32, device=x.device)
-            self._launch_all(plan, x, yolo_out)
+            yolo_out = torch.empty(shape, dtype=torch.float32, device=x.device)
+            self._launch_all(plan, x, yolo_out, cand)
             plan.last_input = x
             return plan, yolo_out
         plan.x_static.copy_(x)
-        plan.graph.replay()
+        rec["graph"].replay()
         return plan, plan.y_static
 
 

@@ -148,6 +148,50 @@ def test_roi_backward_vs_oracle(hip_lib):
         assert _rel(gmap.permute(0, 3, 1, 2), m.grad) < 1e-4
 
 
+
+@pytest.mark.parametrize("n,h,k,lds", [(8, 26, 2500, True), (1, 26, 300, True), (2, 40, 60, False)])
+def test_roi_backward_through_lds_on_clustered_proposals(hip_lib, n, h, k, lds):
+    """The stage-3 shape of the scatter: proposals of a frame piled on a few objects.  Maps whose per-frame slice fits LDS take
+    roi_bwd_lds_kernel (one workgroup per bin and frame / per RoI slice and frame; 2500 RoIs = two rounds of its RoI list), larger
+    ones the global-atomics kernel; both against oracle/tv_ops.c's backward, and the device-count entry points with a capacity
+    above the live count against the host-count ones."""
+    from millieye_amd import hip
+    from oracle import tv_ops
+    size = 16.0 * h
+    g = np.random.RandomState(7)
+    centres = g.uniform(0.15 * size, 0.85 * size, size=(n, 3, 2))
+    rois = np.zeros((k, 5), dtype=np.float32)
+    for i in range(k):
+        b = i * n // k
+        c = centres[b, g.randint(3)] + g.uniform(-6, 6, size=2)
+        wh = g.uniform(40, 0.3 * size, size=2)
+        rois[i] = [b, c[0] - wh[0] / 2, c[1] - wh[1] / 2, c[0] + wh[0] / 2, c[1] + wh[1] / 2]
+    rois = torch.from_numpy(rois)
+    assert ((h * h * 10 * 4) <= 48 * 1024) == lds
+    for ps, ch in ((False, 10), (True, 490)):
+        m = torch.zeros((n, ch, h, h), requires_grad=True)
+        out = (tv_ops.ps_roi_align if ps else tv_ops.roi_align)(m, rois, (7, 7), 1 / 16)
+        go = _t(f"rlg{ch}{k}", tuple(out.shape))
+        out.backward(go)
+        gd, rd = go.cuda(), rois.cuda()
+        gmap = torch.zeros((n, h, h, ch)).cuda()
+        fn = hip.lib().me_ps_roi_align_bwd_f32 if ps else hip.lib().me_roi_align_bwd_f32
+        hip.check(fn(gd.data_ptr(), rd.data_ptr(), k, n, h, h, ch, 7, 1.0 / 16, gmap.data_ptr(), ch, hip.stream_ptr()), "roi bwd")
+        torch.cuda.synchronize()
+        assert _rel(gmap.permute(0, 3, 1, 2), m.grad) < 1e-4, (ps, _rel(gmap.permute(0, 3, 1, 2), m.grad))
+        # capacity above the live count: rows behind the count hold garbage that must not be scattered
+        cap = k + 100
+        gd2 = torch.cat([gd, torch.full((100,) + tuple(gd.shape[1:]), 1e6, device="cuda")])
+        rd2 = torch.cat([rd, rd[:100]])
+        kd = torch.tensor([k], dtype=torch.int32, device="cuda")
+        gmap2 = torch.zeros_like(gmap)
+        fn2 = hip.lib().me_ps_roi_align_bwd_dev_f32 if ps else hip.lib().me_roi_align_bwd_dev_f32
+        hip.check(fn2(gd2.data_ptr(), rd2.data_ptr(), cap, kd.data_ptr(), n, h, h, ch, 7, 1.0 / 16, gmap2.data_ptr(), ch,
+                      hip.stream_ptr()), "roi bwd dev")
+        torch.cuda.synchronize()
+        assert _rel(gmap2, gmap) < 1e-5
+
+
 def _build(name, cfg, conf):
     from millieye_amd.my_models import Network, define_yolo
     net = Network(define_yolo(ph.cfg_path(cfg)), conf)
@@ -545,6 +589,10 @@ def test_detector_prefetch_is_only_an_overlap(hip_lib, dtype):
     for i in range(6):
         same(step(xs[i % 2], ahead=xs[(i + 1) % 2]), plain[i % 2], f"look-ahead step {i}")
     net.__dict__.pop("_det_prefetch", None)
+    # ... and that replay carries the NMS candidate pass (one capture per (threshold, workspace), engine._run_graph)
+    plans = net.base_detector.engine_for(dtype)._plans.values()
+    assert any(isinstance(p.graph, dict) and any(k is not None and k[0] == conf and r["graph"] is not None for k, r in p.graph.items())
+               for p in plans), "the look-ahead detector never ran as a captured graph with the candidate decode"
     # other frames than the ones announced: computed again, behind the prefetch
     step(xs[0], ahead=xs[1])
     same(step(xs[0]), plain[0], "other frames than the prefetched ones")
