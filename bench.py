@@ -774,7 +774,11 @@ def main():
             net.train()
             net.base_detector.eval()
             heads = head_parameters(net)
-            opt = torch.optim.Adam(heads, lr=5e-4, fused=True)
+            if os.environ.get("MILLIEYE_TORCH_ADAM", "0") == "1":   # A/B: torch's fused implementation
+                opt = torch.optim.Adam(heads, lr=5e-4, fused=True)
+            else:
+                from millieye_amd.optim import Adam   # the loop's default optimizer (millieye_amd/train.py): one launch per step
+                opt = Adam(heads, lr=5e-4)
 
             def step():  # noqa: F811
                 if not args.no_prefetch:   # the loop's look-ahead (millieye_amd/train.py): the next batch's frames are known here

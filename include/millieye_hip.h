@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 12
+#define ME_ABI_VERSION 13
 
 #define ME_E_BADARG (-1)   /* inconsistent / unsupported descriptor            */
 #define ME_E_NULLPTR (-2)  /* required pointer is NULL                          */
@@ -681,8 +681,39 @@ int me_add_h16(const void* a, int64_t a_pitch, const void* b, int64_t b_pitch, v
                int32_t c, int32_t half_type, void* stream);
 int me_copy_h16(const void* x, int64_t x_pitch, void* y, int64_t y_pitch, int64_t pixels, int32_t c, void* stream);
 
+/* ---- optimizer step (ABI 13; csrc/optim.hip) -------------------------------------------------------------------------
+ * optimizer.step() of the reference's training loops - torch.optim.Adam(lr=5e-4) in module3_our_dataset/train.py:161,196-197,
+ * torch.optim.AdamW(lr=1e-4) in module2/train.py:122,150-151 - for up to ME_ADAM_MAX_TENSORS fp32 tensors in ONE launch, the
+ * arithmetic of torch/optim/adam.py:_single_tensor_adam element by element (amsgrad / maximize off), every product, quotient and
+ * sum rounded on its own like the sequence of tensor operations:
+ *   decoupled != 0 (AdamW): p = p * decay;     decoupled == 0 and weight_decay != 0 (Adam): g = g + weight_decay * p
+ *   m = m + one_minus_beta1 * (g - m)                       (lerp_)
+ *   v = v * beta2;  v = v + (one_minus_beta2 * g) * g       (mul_, addcmul_)
+ *   p = p + (neg_step_size * m) / (sqrt(v) / bias_correction2_sqrt + eps)      (addcdiv_)
+ * The scalars are what the Python code of the torch class computes in double and hands to the tensor ops, rounded to fp32 once
+ * by the caller: one_minus_beta1 = 1 - beta1 (< 0.5: lerp_'s first formula), one_minus_beta2 = 1 - beta2,
+ * decay = 1 - lr * weight_decay, neg_step_size = -(lr / (1 - beta1^t)), bias_correction2_sqrt = sqrt(1 - beta2^t), t = the step
+ * count after this step (>= 1).  first_chunk[i] = sum over j < i of ceil(numel[j] / me_adam_chunk()): the workgroups of tensor
+ * i.  grad is read only; param, exp_avg, exp_avg_sq are updated in place. */
+#define ME_ADAM_MAX_TENSORS 64
+typedef struct me_adam_desc {
+  float* param[ME_ADAM_MAX_TENSORS];
+  const float* grad[ME_ADAM_MAX_TENSORS];
+  float* exp_avg[ME_ADAM_MAX_TENSORS];
+  float* exp_avg_sq[ME_ADAM_MAX_TENSORS];
+  int64_t numel[ME_ADAM_MAX_TENSORS];
+  int32_t first_chunk[ME_ADAM_MAX_TENSORS];
+  int32_t count;
+  int32_t decoupled;
+  float beta2, eps, weight_decay, decay;
+  float one_minus_beta1, one_minus_beta2;
+  float neg_step_size, bias_correction2_sqrt;
+} me_adam_desc;
+int me_adam_step_f32(const me_adam_desc* d, void* stream);
+int32_t me_adam_chunk(void);
+
 /* sizes of the descriptor structs, so a binding can assert its mirror layout */
-int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights, 6 conv16 */
+int32_t me_sizeof(int32_t which); /* 0 conv, 1 pool, 2 yolo, 3 nms, 4 heads, 5 heads_weights, 6 conv16, 7 pack, 8 bneck16, 9 adam */
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,7 @@ int32_t me_sizeof(int32_t which) {
     case 6: return (int32_t)sizeof(me_conv16_desc);
     case 7: return (int32_t)sizeof(me_pack_desc);
     case 8: return (int32_t)sizeof(me_bneck16_desc);
+    case 9: return (int32_t)sizeof(me_adam_desc);
     default: return -1;
   }
 }

@@ -1687,6 +1687,10 @@ int me_colsum_f32(const float* x, int64_t ld, int32_t rows, int32_t cols, float*
   ME_REQUIRE(rows >= 0 && cols > 0, ME_E_BADARG, "me_colsum_f32: bad dimensions");
   int cw = 1;
   while (cw < cols && cw < 64) cw <<= 1;
+  // tall matrices: narrower column groups, so that a row lane walks <= ~16 rows (two rounds of its eight partial sums) and the
+  // launch has more workgroups - [5408 x 490] was 8 workgroups of 338 rows per lane (a chain of 42 dependent load rounds); down
+  // to 8 columns (32 B per row and lane group) the reads still fill half a 64-byte sector
+  while (cw > 8 && (long long)rows * cw > 16 * 1024) cw >>= 1;
   hipLaunchKernelGGL(colsum_kernel, dim3((cols + cw - 1) / cw), dim3(1024), 0, stream, x, (long long)ld, rows, cols, cw, out);
   return me::check_launch("colsum_kernel");
 }

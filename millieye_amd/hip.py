@@ -142,8 +142,24 @@ class Bneck16Desc(C.Structure):
     ]
 
 
+ADAM_MAX_TENSORS = 64
+
+
+class AdamDesc(C.Structure):
+    """me_adam_desc: one optimizer step over up to 64 fp32 tensors (csrc/optim.hip)."""
+    _fields_ = [
+        ("param", C.c_void_p * ADAM_MAX_TENSORS), ("grad", C.c_void_p * ADAM_MAX_TENSORS),
+        ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS),
+        ("numel", C.c_int64 * ADAM_MAX_TENSORS), ("first_chunk", C.c_int32 * ADAM_MAX_TENSORS),
+        ("count", C.c_int32), ("decoupled", C.c_int32),
+        ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("decay", C.c_float),
+        ("one_minus_beta1", C.c_float), ("one_minus_beta2", C.c_float),
+        ("neg_step_size", C.c_float), ("bias_correction2_sqrt", C.c_float),
+    ]
+
+
 _STRUCTS = {0: ConvDesc, 1: PoolDesc, 2: YoloDesc, 3: NmsDesc, 4: HeadsDesc, 5: HeadsWeights, 6: Conv16Desc, 7: PackDesc,
-            8: Bneck16Desc}
+            8: Bneck16Desc, 9: AdamDesc}
 
 # name -> (restype, argtypes); every symbol include/millieye_hip.h declares
 SIGNATURES = {
@@ -151,6 +167,8 @@ SIGNATURES = {
     "me_last_error": (C.c_char_p, []),
     "me_device_query": (C.c_int, [C.POINTER(C.c_int32)] * 3),
     "me_sizeof": (C.c_int32, [C.c_int32]),
+    "me_adam_step_f32": (C.c_int, [C.POINTER(AdamDesc), C.c_void_p]),
+    "me_adam_chunk": (C.c_int32, []),
     "me_batch_statistics_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                           C.c_void_p, C.c_void_p]),
     "me_image_pad_resize_u8_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -303,8 +321,8 @@ def load(path=None):
             raise MeError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib_.me_abi_version() != 12:
-        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 12")
+    if lib_.me_abi_version() != 13:
+        raise MeError(f"ABI version mismatch: library {lib_.me_abi_version()}, binding 13")
     for which, struct in _STRUCTS.items():
         if lib_.me_sizeof(which) != C.sizeof(struct):
             raise MeError(f"struct layout mismatch for {struct.__name__}: C {lib_.me_sizeof(which)} vs "

@@ -44,7 +44,12 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
     device = getattr(model, "device", torch.device("cuda"))
     os.makedirs(checkpoint_dir, exist_ok=True)
     if optimizer is None:
-        optimizer = torch.optim.AdamW(model.parameters(), lr=1e-4)
+        params = list(model.parameters())   # AdamW(lr=1e-4) over all parameters (reference module2/train.py:122)
+        if params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            from ..optim import AdamW   # one launch per step (millieye_amd/optim.py), torch.optim.AdamW's state and update rule
+            optimizer = AdamW(params, lr=1e-4)
+        else:
+            optimizer = torch.optim.AdamW(params, lr=1e-4)
     distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
     rank = torch.distributed.get_rank() if distributed else 0
     history = dict(losses=[], steps=[], checkpoints=[], evaluations=[])

@@ -69,10 +69,15 @@ def train_loop(model, dataloader, *, epochs, gradient_accumulations=2, checkpoin
     device = getattr(model, "device", torch.device("cuda"))
     os.makedirs(checkpoint_dir, exist_ok=True)
     if optimizer is None:
-        # same update rule as the reference's Adam(lr=5e-4); the fused implementation is one launch instead of a dozen
-        # multi-tensor launches + 2 host reads per parameter
+        # the reference's Adam(lr=5e-4) (train.py:161): on the GPU the one-launch step of millieye_amd/optim.py (same state, same
+        # update rule element by element, checkpoints interchangeable with torch.optim.Adam); a model that is not on the GPU (the
+        # host-logic tests) gets the torch class itself
         params = list(model.parameters())
-        optimizer = torch.optim.Adam(params, lr=5e-4, fused=all(p.is_cuda for p in params))
+        if params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            from .optim import Adam
+            optimizer = Adam(params, lr=5e-4)
+        else:
+            optimizer = torch.optim.Adam(params, lr=5e-4)
     distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
     rank = torch.distributed.get_rank() if distributed else 0
     history = dict(losses=[], steps=[], checkpoints=[], evaluations=[])

@@ -135,7 +135,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     loaded = hip.load()
-    assert loaded.me_abi_version() == 12
+    assert loaded.me_abi_version() == 13
     for which, struct in hip._STRUCTS.items():
         assert loaded.me_sizeof(which) == ctypes.sizeof(struct)
     assert loaded.me_nms_workspace_bytes(2, 2535) > 0

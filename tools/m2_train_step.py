@@ -26,7 +26,8 @@ def main():
     net.base_detector.compute_dtype = dtype
     net.dropout_generator = os.environ.get("M2_DROPOUT", "cpu")
     params = [p for k, p in net.named_parameters() if not k.startswith("base_detector.")]
-    opt = torch.optim.Adam(params, lr=5e-4, fused=True)
+    from millieye_amd.optim import AdamW   # the stage-2 loop's default optimizer (module2/train.py)
+    opt = AdamW(params, lr=1e-4)
     frames = [torch.from_numpy(synth.uniform(f"m2step/x{i}", (n, 3, 416, 416))).cuda() for i in range(4)]
     targets = torch.tensor([[i % n, (3 * i) % 12, 0.3 + 0.04 * (i % 8), 0.4 + 0.03 * (i % 5), 0.3, 0.4] for i in range(2 * n)], dtype=torch.float32)
     random.seed(0)
