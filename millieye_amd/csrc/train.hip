@@ -170,16 +170,27 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
+// the 64 chunk partials of one channel, summed in double by the 64 lanes of one wave (xor butterfly: every lane ends with the same
+// sum, the association order is fixed).  Round 6: the two finishing kernels below ran a thread per channel through 64 dependent
+// loads - 7-8 us per launch, ten launches per stage-3 step.
+__device__ __forceinline__ void wave_sum2(double& s0, double& s1) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    s0 += __shfl_xor(s0, m, 64);
+    s1 += __shfl_xor(s1, m, 64);
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const float* p0, const float* p1, int rows, int C,
                                                               float eps, float momentum, float* mean, float* var,
                                                               float* rstd, float* running_mean, float* running_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  static_assert(BN_CHUNKS == 64, "one lane per chunk");
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);   // a wave per channel
   if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < BN_CHUNKS; ++k) {
-    s0 += p0[(long long)k * C + c];
-    s1 += p1[(long long)k * C + c];
-  }
+  double s0 = p0[(long long)lane * C + c], s1 = p1[(long long)lane * C + c];
+  wave_sum2(s0, s1);
+  if (lane != 0) return;
   const double mu = s0 / rows;
   double v = s1 / rows - mu * mu;
   if (v < 0.0) v = 0.0;
@@ -236,15 +247,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(float* p0, float* p1, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < BN_CHUNKS; ++k) {
-    s0 += p0[(long long)k * C + c];
-    s1 += p1[(long long)k * C + c];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);   // a wave per channel; rows 1.. of the partials are read before row 0 is
+  if (c >= C) return;                                  // written, and only by this wave
+  double s0 = p0[(long long)lane * C + c], s1 = p1[(long long)lane * C + c];
+  wave_sum2(s0, s1);
+  if (lane == 0) {
+    p0[c] = (float)s0;
+    p1[c] = (float)s1;
   }
-  p0[c] = (float)s0;
-  p1[c] = (float)s1;
 }
 
 // elementwise activation backward: dx = dy * act'(y) given the activation OUTPUT y
@@ -1707,7 +1718,7 @@ int me_bn_train_fwd_f32(const float* x, int64_t ldx, int32_t rows, int32_t chann
   ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_bn_train_fwd_f32: bad dimensions");
   float* p0 = reinterpret_cast<float*>(workspace);
   float* p1 = p0 + (long long)BN_CHUNKS * channels;
-  const unsigned cb = (channels + 255) / 256;
+  const unsigned cb = (channels + 3) / 4;   // the finishing kernels: a wave per channel
   hipLaunchKernelGGL(bn_partial_kernel, dim3((channels + 63) / 64, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
                      (const float*)nullptr, 0ll, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, 0, p0, p1);
@@ -1750,7 +1761,7 @@ static int launch_bn_train_bwd(const float* x, int64_t ldx, const float* dy, int
   ME_REQUIRE(rows > 0 && channels > 0, ME_E_BADARG, "me_bn_train_bwd_f32: bad dimensions");
   float* p0 = reinterpret_cast<float*>(workspace);
   float* p1 = p0 + (long long)BN_CHUNKS * channels;
-  const unsigned cb = (channels + 255) / 256;
+  const unsigned cb = (channels + 3) / 4;   // the finishing kernels: a wave per channel
   hipLaunchKernelGGL(bn_partial_kernel, dim3((channels + 63) / 64, BN_CHUNKS), dim3(256), 0, stream, x, (long long)ldx, rows, channels,
                      dy, (long long)lddy, save_mean, save_rstd, gamma, beta, act, p0, p1, rows_dev);
   hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cb), dim3(256), 0, stream, p0, p1, channels);
