@@ -320,7 +320,10 @@ int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t 
 /* ---- stage-2 training building blocks (module2_mixed/my_models.py:96-164 heads, :366-459 objective) ------------------
  * me_linear_f32: y [rows,out] = act(x [rows,in] . w[out,in]^T + bias) (nn.Linear + Linear / LeakyReLU / Sigmoid).
  * me_mask_scale_f32: y = mask ? x * scale : 0 (nn.Dropout(0.5) in train mode, forward and backward; the mask is drawn
- *   by the caller with torch's CPU generator, like the reference's run).
+ *   by the caller - with torch's CPU generator like the reference's CPU run, or by me_dropout_mask_u8).
+ * me_dropout_mask_u8 (ABI 13): the keep mask of nn.Dropout(1 - keep_prob) on the device - Philox4x32-10 (the generator family
+ *   of torch's CUDA dropout) keyed by `seed`, counter = element index / 4, one 32-bit word per element: keep iff
+ *   (word >> 8) / 2^24 < keep_prob.  Same (seed, count) -> same mask; the caller draws a fresh seed per step.
  * me_m2_loss_f32: per-RoI terms [k,5] = (focal on softmax(o), confidence BCE, category BCE, SmoothL1 xy, SmoothL1 wh) and
  *   the gradients d_o [k,2], d_refine [k,c1], d_regress [k,4] of
  *   focal + (conf + category)/lambda0 + (xy + wh)/lambda1, times grad_scale; pos / sample are the IoU-positive and the
@@ -328,6 +331,7 @@ int me_m2_heads_f32(const float* img_map, int64_t img_pitch, int32_t n, int32_t 
 int me_linear_f32(const float* x, int64_t ldx, int64_t rows, int32_t in_features, const float* w, const float* bias,
                   int32_t out_features, int32_t act, float* y, int64_t ldy, void* stream);
 int me_mask_scale_f32(const float* x, const uint8_t* mask, float scale, int64_t count, float* y, void* stream);
+int me_dropout_mask_u8(uint64_t seed, float keep_prob, int64_t count, uint8_t* mask, void* stream);
 /* me_m2_pairs_f32 (ABI 12): the ensemble head's input x2 [k * c1, 2] = (refinement_vector, yolo_vector) pairs
  *   (module2_mixed/my_models.py:333-339; yolo_vector = columns 5, 8 .. of the proposal rows).
  * me_m2_rows_f32 (ABI 12): the tail of the stage-2 forward (:341-364) per proposal - masks = softmax(o) [k,2], keep = masks[:,1] >

@@ -2,6 +2,7 @@
 // stage-2 objective.  Reference: module2_mixed/my_models.py:96-164 (heads), :366-459 (losses).  Everything here is tiny
 // next to the detector (K <= 200 * N RoIs): one thread per output element, fixed-order sums (bit-reproducible).
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -42,6 +43,94 @@ __global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict
                                                          float scale, long long count, float* Y) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
     Y[i] = M[i] ? X[i] * scale : 0.f;
+}
+
+// The same nn.Linear through LDS tiles (round 6).  linear_kernel above reads W with a stride of in_f floats across the lanes of a
+// wave (64 cache lines per load) and walks one dependent chain per thread: 400 us for the [1600 x 490] x [490 x 256] layer of a
+// batch-8 step, 626 us per step over the five layers.  Here a workgroup stages a TM x 16 tile of X and a 16 x TN tile of W^T in
+// LDS and every thread owns 4 x 4 outputs; each output is still ONE fmaf chain over i = 0 .. in_f - 1 in ascending order, so the
+// results equal linear_kernel's bit for bit.  TM x TN = 64 x 64 for the wide layers, 256 x 16 for out_f <= 16.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void linear_tiled_kernel(const float* __restrict__ X, long long ldx, long long rows, int in_f,
+                                                           const float* __restrict__ W, const float* __restrict__ B, int out_f,
+                                                           int act, float* Y, long long ldy) {
+  static_assert((TM / 4) * (TN / 4) == 256, "4 x 4 outputs per thread");
+  __shared__ float Xs[16][TM + 1];
+  __shared__ float Ws[16][TN + 1];
+  constexpr int NX = TN / 4;   // threads along the outputs
+  const int tx = threadIdx.x % NX, ty = threadIdx.x / NX;
+  const long long m0 = (long long)blockIdx.y * TM;
+  const int n0 = blockIdx.x * TN;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < in_f; k0 += 16) {
+    const int kn = in_f - k0 < 16 ? in_f - k0 : 16;
+    for (int idx = threadIdx.x; idx < 16 * TM; idx += 256) {   // X[m][k]: k fastest (16 consecutive floats of a row)
+      const int kk = idx % 16, mm = idx / 16;
+      const long long m = m0 + mm;
+      Xs[kk][mm] = (m < rows && kk < kn) ? X[m * ldx + k0 + kk] : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < 16 * TN; idx += 256) {   // W[n][k]
+      const int kk = idx % 16, nn = idx / 16;
+      const int n = n0 + nn;
+      Ws[kk][nn] = (n < out_f && kk < kn) ? W[(long long)n * in_f + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    for (int kk = 0; kk < kn; ++kk) {   // (the tail is NOT padded with zero terms: fmaf(0, 0, -0.f) would flip a negative zero)
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Xs[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Ws[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long m = m0 + ty * 4 + i;
+      const int n = n0 + tx * 4 + j;
+      if (m < rows && n < out_f) Y[m * ldy + n] = act_fwd(acc[i][j] + (B ? B[n] : 0.f), act);
+    }
+}
+
+// nn.Dropout's keep mask on the device: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the
+// generator of torch's CUDA dropout too) keyed by a 64-bit seed the caller draws per step, counter = element quad index; one 32-bit
+// word per element, keep iff its top 24 bits / 2^24 < keep_prob.
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+  const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned long long seed, float keep_prob, long long count,
+                                                           unsigned char* mask) {
+  const long long quads = (count + 3) / 4;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
+    unsigned c0 = (unsigned)q, c1 = (unsigned)((unsigned long long)q >> 32), c2 = 0u, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c0, c1, c2, c3, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    const unsigned w[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long i = 4 * q + j;
+      if (i < count) mask[i] = ((float)(w[j] >> 8) * (1.0f / 16777216.0f) < keep_prob) ? 1 : 0;
+    }
+  }
 }
 
 // Per-RoI terms of the stage-2 loss and their gradients (my_models.py:411-456).
@@ -198,9 +287,30 @@ int me_linear_f32(const float* x, int64_t ldx, int64_t rows, int32_t in_features
   ME_REQUIRE(rows > 0 && in_features > 0 && out_features > 0 && ldx >= in_features && ldy >= out_features, ME_E_BADARG,
              "me_linear_f32: bad dimensions");
   ME_REQUIRE(act >= 0 && act <= 2, ME_E_BADARG, "me_linear_f32: unknown activation %d", act);
-  hipLaunchKernelGGL(linear_kernel, dim3(grid_for((long long)rows * out_features)), dim3(256), 0, (hipStream_t)stream, x,
-                     (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y, (long long)ldy);
+  static const int naive = getenv("MILLIEYE_M2_LINEAR_NAIVE") ? atoi(getenv("MILLIEYE_M2_LINEAR_NAIVE")) : 0;   // (A/B, same bits)
+  if (naive) {
+    hipLaunchKernelGGL(linear_kernel, dim3(grid_for((long long)rows * out_features)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y, (long long)ldy);
+  } else if (out_features <= 16) {
+    ME_REQUIRE((rows + 255) / 256 <= 65535, ME_E_TOOBIG, "me_linear_f32: too many rows");
+    hipLaunchKernelGGL((linear_tiled_kernel<256, 16>), dim3(1, (unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y, (long long)ldy);
+  } else {
+    ME_REQUIRE((rows + 63) / 64 <= 65535, ME_E_TOOBIG, "me_linear_f32: too many rows");
+    hipLaunchKernelGGL((linear_tiled_kernel<64, 64>), dim3((out_features + 63) / 64, (unsigned)((rows + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, x, (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y,
+                       (long long)ldy);
+  }
   return me::check_launch("linear_kernel");
+}
+
+int me_dropout_mask_u8(uint64_t seed, float keep_prob, int64_t count, uint8_t* mask, void* stream) {
+  if (count == 0) return 0;
+  ME_REQUIRE(mask != nullptr, ME_E_NULLPTR, "me_dropout_mask_u8: null pointer");
+  ME_REQUIRE(count > 0 && keep_prob >= 0.f && keep_prob <= 1.f, ME_E_BADARG, "me_dropout_mask_u8: bad arguments");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned long long)seed, keep_prob, (long long)count, mask);
+  return me::check_launch("dropout_mask_kernel");
 }
 
 int me_mask_scale_f32(const float* x, const uint8_t* mask, float scale, int64_t count, float* y, void* stream) {

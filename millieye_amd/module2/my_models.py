@@ -100,9 +100,11 @@ class Network(nn.Module):
         self.refinement_head = refinement_head((490, 256, self.class_num + 1))
         self.ensemble_head = ensemble_head((2, 32, 32 * (self.class_num + 1), 2))
         object.__setattr__(self, "_packs", None)
-        # "cpu": nn.Dropout's mask of the training step from torch's CPU generator (reproducible against the reference's CPU run, the
-        # goldens); "device": from the GPU's generator (what the reference does when it runs on a CUDA machine; faster)
-        self.dropout_generator = "cpu"
+        # where nn.Dropout's keep mask of the training step comes from (module2/train_path.py): "philox" - drawn on the device by
+        # me_dropout_mask_u8 from one CPU-generator seed per step (default; reproducible under torch.manual_seed); "device" - torch's
+        # GPU generator (what the reference does on a CUDA machine); "cpu" - torch's CPU generator element by element (the reference's
+        # CPU run bit for bit: the goldens and the oracle comparisons; 3.6 ms of host time per step)
+        self.dropout_generator = "philox"
 
     def queue_detector_prefetch(self, images_next):
         """The stage-3 Network's look-ahead hint (millieye_amd/my_models.py) for the stage-2 loop: the detector is frozen here too

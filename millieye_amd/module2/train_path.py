@@ -7,8 +7,9 @@ autograd sees one :class:`torch.autograd.Function` over the head parameters:
 
 forward   frozen detector -> NMS -> all-class proposals (as in inference); ``me_conv2d_f32`` + ``me_bn_train_fwd_f32``
           (fcn_layers, batch statistics); ``me_ps_roi_align_f32``; ``me_linear_f32`` for net0 (+ LeakyReLU), the Dropout mask
-          (drawn with torch's CPU generator exactly like aten's CPU dropout: ``empty_like(t).bernoulli_(0.5)``) through
-          ``me_mask_scale_f32``; ``me_linear_f32`` for net1 / net2 (sigmoid) / fc1 / fc2 (LeakyReLU); host-side IoU labels and
+          (``Network.dropout_generator``: ``me_dropout_mask_u8`` on the device by default; "cpu" draws it with torch's CPU generator
+          exactly like aten's CPU dropout - ``empty_like(t).bernoulli_(0.5)`` - for the comparisons with the reference's CPU run)
+          through ``me_mask_scale_f32``; ``me_linear_f32`` for net1 / net2 (sigmoid) / fc1 / fc2 (LeakyReLU); host-side IoU labels and
           python-``random`` negative sampling (host-side in the reference too); ``me_m2_loss_f32`` = focal + confidence +
           category + SmoothL1 terms and the gradient seeds.
 backward  ``me_act_bwd_f32`` + ``me_gemm_f32`` / MFMA weight gradient / ``me_colsum_f32`` per Linear, the Dropout mask again,
@@ -122,16 +123,25 @@ def forward_train(net, images, targets):
         e1w, e1b = eh.fc1[0].weight.detach().contiguous(), eh.fc1[0].bias.detach().contiguous()
         e2w, e2b = eh.fc2[0].weight.detach().contiguous(), eh.fc2[0].bias.detach().contiguous()
         t_act = _linear(feat, 490, k, 490, w0, b0, LEAKY, _f32(dev, k, 256), 256)
-        # nn.Dropout(0.5), train mode: aten's CPU path draws empty_like(t).bernoulli_(1 - p) from the default generator
-        if getattr(net, "dropout_generator", "cpu") == "device":
-            # opt-in (Network.dropout_generator = "device"): the mask from torch's generator of the GPU, what the reference's own run
-            # on a CUDA machine does - 3.6 ms of host time per step less at 1600 proposals; not reproducible against a CPU run
+        # nn.Dropout(0.5), train mode.  Network.dropout_generator names where the keep mask comes from:
+        gen = getattr(net, "dropout_generator", "philox")
+        if gen == "philox":
+            # (default) me_dropout_mask_u8: Philox4x32-10 on the device, keyed by ONE 64-bit draw from torch's CPU generator per step -
+            # reproducible under torch.manual_seed, no host work that grows with the proposal count
+            seed = int(torch.empty((), dtype=torch.int64).random_())
+            mask = torch.empty((k, 256), device=dev, dtype=torch.uint8)
+            hip.check(lib.me_dropout_mask_u8(seed, 0.5, k * 256, mask.data_ptr(), hip.stream_ptr()), "me_dropout_mask_u8")
+        elif gen == "device":
+            # the mask from torch's generator of the GPU - what the reference's own run on a CUDA machine does
             mask = torch.empty((k, 256), device=dev).bernoulli_(0.5).to(torch.uint8)
-        else:
+        elif gen == "cpu":
+            # aten's CPU dropout draws empty_like(t).bernoulli_(1 - p) from the default generator: the reference's CPU run (the goldens)
+            # bit for bit, at 3.6 ms of host time per step at 1600 proposals - the whole step was bound by it (5.8 ms at batch 8).
             # (the float mask goes to the device as it is and is narrowed THERE: the float -> uint8 conversion of 400 K elements on the
-            #  host runs through a 128-thread parallel region on the GPU boxes' CPUs - 34 ms against 3.6 for the draw itself,
-            #  tools/bernoulli_probe.py - same values either way)
+            #  host runs through a 128-thread parallel region on the GPU boxes' CPUs - 34 ms, tools/bernoulli_probe.py)
             mask = torch.empty((k, 256)).bernoulli_(0.5).to(dev).to(torch.uint8)
+        else:
+            raise ValueError(f"Network.dropout_generator = {gen!r}: expected 'philox', 'device' or 'cpu'")
         hidden = _f32(dev, k, 256)
         hip.check(lib.me_mask_scale_f32(t_act.data_ptr(), mask.data_ptr(), 2.0, k * 256, hidden.data_ptr(), hip.stream_ptr()),
                   "me_mask_scale_f32")

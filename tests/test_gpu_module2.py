@@ -156,3 +156,102 @@ def test_module2_forward_in_16bit_storage_modes(hip_lib, dtype, px, tol, share):
         j = int(d.argmin())
         matched += int(float(d[j]) <= px and abs(float(cand[j, 5] - row[5])) <= tol)
     assert matched >= share * ref.shape[0], f"{dtype}: {matched} of {ref.shape[0]} fp32 rows have a counterpart"
+
+
+def test_dropout_mask_kernel_is_the_philox_restatement(hip_lib):
+    """me_dropout_mask_u8 (the stage-2 step's default mask source) bit for bit against oracle/philox_ref.py - itself pinned to the
+    Random123 known-answer vectors - for counts around the quad boundary, several seeds and keep probabilities."""
+    from millieye_amd import hip
+    from oracle import philox_ref
+    for seed, keep, count in [(0x0123456789abcdef, 0.5, 1600 * 256), (1, 0.5, 1), (2 ** 63 - 1, 0.5, 1023), (77, 0.8, 4097),
+                              (0, 0.25, 6), (0xffffffff00000001, 0.5, 70001)]:
+        mask = torch.full((count + 8,), 9, dtype=torch.uint8, device="cuda")
+        hip.check(hip.lib().me_dropout_mask_u8(seed, keep, count, mask.data_ptr(), hip.stream_ptr()), "me_dropout_mask_u8")
+        got = mask.cpu().numpy()
+        assert np.array_equal(got[:count], philox_ref.dropout_mask(seed, keep, count)), (seed, keep, count)
+        assert (got[count:] == 9).all(), "wrote behind the mask"
+
+
+def test_linear_through_lds_tiles_equals_the_thread_per_output_kernel(hip_lib, tmp_path):
+    """me_linear_f32 stages X / W tiles through LDS (round 6) but keeps ONE ascending fmaf chain per output: the same bits as the
+    thread-per-output kernel (MILLIEYE_M2_LINEAR_NAIVE=1, read once per process - hence the two child processes), on the five layer
+    shapes of a batch-8 step and odd ones; and within fp32 rounding of torch's own linear."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from millieye_amd import hip
+out = {}
+for i, (rows, fin, fout, act, ld) in enumerate([(1600, 490, 256, 1, 0), (1600, 256, 4, 0, 0), (1600, 256, 13, 2, 0), (20800, 2, 32, 1, 0),
+                                                (1600, 416, 2, 1, 0), (37, 19, 70, 1, 5), (1, 1, 1, 0, 0), (300, 33, 16, 2, 3), (65, 16, 17, 0, 0)]):
+    g = np.random.RandomState(i)
+    x = torch.from_numpy(g.standard_normal((rows, fin + ld)).astype(np.float32)).cuda()
+    w = torch.from_numpy(g.standard_normal((fout, fin)).astype(np.float32)).cuda()
+    b = torch.from_numpy(g.standard_normal((fout,)).astype(np.float32)).cuda()
+    y = torch.full((rows, fout + ld), 7.0, device="cuda")
+    hip.check(hip.lib().me_linear_f32(x.data_ptr(), fin + ld, rows, fin, w.data_ptr(), b.data_ptr() if i %% 4 != 3 else None, fout, act,
+                                      y.data_ptr(), fout + ld, hip.stream_ptr()), "me_linear_f32")
+    ref = torch.nn.functional.linear(x[:, :fin].double(), w.double(), b.double() if i %% 4 != 3 else None)
+    ref = torch.nn.functional.leaky_relu(ref, 0.1) if act == 1 else (torch.sigmoid(ref) if act == 2 else ref)
+    err = float((y[:, :fout].double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+    assert err < 1e-5, (i, err)
+    assert bool((y[:, fout:] == 7.0).all()), "wrote into the row padding"
+    out[str(i)] = y.cpu()
+torch.save(out, sys.argv[1])
+''' % root
+    paths = []
+    for naive in ("0", "1"):
+        path = str(tmp_path / f"linear_{naive}.pt")
+        env = dict(os.environ, MILLIEYE_M2_LINEAR_NAIVE=naive)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+        paths.append(path)
+    a, b = torch.load(paths[0]), torch.load(paths[1])
+    assert a.keys() == b.keys() and len(a) == 9
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"case {k}: the tiled kernel's bits differ from the thread-per-output kernel's"
+
+
+def test_module2_training_step_with_the_device_mask(hip_lib):
+    """Network.dropout_generator = "philox" (the default): the step is reproducible under torch.manual_seed, consumes ONE draw of the
+    CPU generator, another seed gives another mask (another loss), and its loss stays close to the CPU-mask step's (same network,
+    same proposals, a different Bernoulli(0.5) sample)."""
+    import random
+    from millieye_amd.module2.my_models import Network, define_yolo
+    from tests.golden.make_golden import M2_TRAIN_CASE, m2_train_fill_
+    name, cfg, n, s, conf, seed = M2_TRAIN_CASE
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    x = torch.from_numpy(synth.uniform(name + "/x", (n, 3, s, s))).cuda()
+    targets = torch.from_numpy(g["targets"])
+    assert Network(define_yolo(cfg_path(cfg)), conf).dropout_generator == "philox"
+    net = m2_train_fill_(Network(define_yolo(cfg_path(cfg)), conf), name)
+    net = net.to(net.device).train()
+    net.base_detector.eval()
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+
+    def step(mode, sd):
+        net.load_state_dict(bn_state, strict=False)
+        net.dropout_generator = mode
+        for p in net.parameters():
+            p.grad = None
+        random.seed(seed)
+        torch.manual_seed(sd)
+        _out, loss, _metric = net(x, targets.clone())
+        after = torch.empty((), dtype=torch.int64).random_()   # the CPU generator's next draw: tells how much the step consumed
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.flatten() for k, p in net.named_parameters() if not k.startswith("base_detector.") and p.grad is not None])
+        return float(loss.detach()), grads.cpu(), int(after)
+
+    a, b, c = step("philox", 11), step("philox", 11), step("philox", 12)
+    assert a[0] == b[0], "same seed, same mask, same loss"
+    assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max()), "same seed, same step (up to the RoI scatter's atomics)"
+    assert c[0] != a[0], "another seed, another mask"
+    torch.manual_seed(11)
+    torch.empty((), dtype=torch.int64).random_()
+    assert a[2] == int(torch.empty((), dtype=torch.int64).random_()), "the step draws exactly one number from the CPU generator"
+    cpu = step("cpu", 11)
+    assert np.isfinite(a[0]) and abs(a[0] - cpu[0]) <= 0.25 * abs(cpu[0]) + 1e-3, (a[0], cpu[0])
+    with pytest.raises(ValueError):
+        step("nope", 11)

@@ -160,3 +160,22 @@ def test_oracle_16bit_training_restatement_is_a_rounding_of_the_fp32_step():
     out = darknet_ref.darknet_train_step(text, sd, x, targets, training=True, storage="bf16")
     assert len(out) == 3 and any(not torch.equal(v, sd[k]) for k, v in out[2].items())
     assert all(torch.equal(sd[k], model.state_dict()[k]) for k in sd), "state_dict must not be modified"
+
+
+def test_philox_restatement_against_the_random123_known_answers():
+    """oracle/philox_ref.py (the generator behind me_dropout_mask_u8) against the three philox4x32-10 known-answer vectors of the
+    Random123 distribution (kat_vectors: zero, all-ones and the digits-of-pi inputs), and the mask convention on top of it."""
+    from oracle import philox_ref as p
+
+    def kat(counter, key):
+        return [int(v) for v in p.philox4x32_10(np.array(counter, dtype=np.uint32), key)]
+
+    assert kat([0, 0, 0, 0], (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert kat([0xffffffff] * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert kat([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    m = p.dropout_mask(0x0123456789abcdef, 0.5, 400003)
+    assert m.dtype == np.uint8 and m.shape == (400003,) and abs(float(m.mean()) - 0.5) < 0.004
+    assert np.array_equal(m[:1001], p.dropout_mask(0x0123456789abcdef, 0.5, 1001)), "element i depends on (seed, i) only"
+    assert abs(float(p.dropout_mask(7, 0.8, 200000).mean()) - 0.8) < 0.004
+    assert p.dropout_mask(7, 0.0, 64).sum() == 0 and p.dropout_mask(7, 1.0, 64).sum() == 64

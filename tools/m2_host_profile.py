@@ -1,7 +1,7 @@
-"""Host profile of steady-state stage-2 training steps (tools; GPU box): python tools/m2_host_profile.py [cpu|device]"""
+"""Host profile of steady-state stage-2 training steps (tools; GPU box): python tools/m2_host_profile.py [philox|cpu|device]"""
 import cProfile, os, pstats, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-os.environ.setdefault("M2_DROPOUT", sys.argv[1] if len(sys.argv) > 1 else "cpu")
+os.environ.setdefault("M2_DROPOUT", sys.argv[1] if len(sys.argv) > 1 else "philox")
 import tools.m2_train_step as t  # noqa: E402
 sys.argv = ["m2", "10", "8", "bf16", "1"]
 t.main()                      # warm: plans, autotuning, first-call costs

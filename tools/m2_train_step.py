@@ -24,7 +24,7 @@ def main():
     net = net.cuda().train()
     net.base_detector.eval()
     net.base_detector.compute_dtype = dtype
-    net.dropout_generator = os.environ.get("M2_DROPOUT", "cpu")
+    net.dropout_generator = os.environ.get("M2_DROPOUT", "philox")
     params = [p for k, p in net.named_parameters() if not k.startswith("base_detector.")]
     from millieye_amd.optim import AdamW   # the stage-2 loop's default optimizer (module2/train.py)
     opt = AdamW(params, lr=1e-4)
