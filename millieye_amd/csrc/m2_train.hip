@@ -48,55 +48,83 @@ __global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict
 // The same nn.Linear through LDS tiles (round 6).  linear_kernel above reads W with a stride of in_f floats across the lanes of a
 // wave (64 cache lines per load) and walks one dependent chain per thread: 400 us for the [1600 x 490] x [490 x 256] layer of a
 // batch-8 step, 626 us per step over the five layers.  Here a workgroup stages a TM x 16 tile of X and a 16 x TN tile of W^T in
-// LDS and every thread owns 4 x 4 outputs; each output is still ONE fmaf chain over i = 0 .. in_f - 1 in ascending order, so the
-// results equal linear_kernel's bit for bit.  TM x TN = 64 x 64 for the wide layers, 256 x 16 for out_f <= 16.
-template <int TM, int TN>
+// LDS and every thread owns RM x 4 outputs; each output is still ONE fmaf chain over i = 0 .. in_f - 1 in ascending order, so the
+// results equal linear_kernel's bit for bit.  TM x TN = 64 x 64 (4 x 4 outputs per thread) for the wide layers, 64 x 16 (1 x 4) for
+// out_f <= 16 - the narrow layers have few outputs to spread, so small row tiles keep the launch wide.
+template <int TM, int TN, int RM>
 __global__ __launch_bounds__(256) void linear_tiled_kernel(const float* __restrict__ X, long long ldx, long long rows, int in_f,
                                                            const float* __restrict__ W, const float* __restrict__ B, int out_f,
                                                            int act, float* Y, long long ldy) {
-  static_assert((TM / 4) * (TN / 4) == 256, "4 x 4 outputs per thread");
+  static_assert((TM / RM) * (TN / 4) == 256, "RM x 4 outputs per thread");
   __shared__ float Xs[16][TM + 1];
   __shared__ float Ws[16][TN + 1];
   constexpr int NX = TN / 4;   // threads along the outputs
   const int tx = threadIdx.x % NX, ty = threadIdx.x / NX;
   const long long m0 = (long long)blockIdx.y * TM;
   const int n0 = blockIdx.x * TN;
-  float acc[4][4];
+  float acc[RM][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  // the loads are unconditional (clamped addresses, the value dropped afterwards: behind a branch each of them waited for its own
+  // round trip - 2.3 us per K step) and run one K step ahead of the arithmetic (registers -> LDS behind the barrier)
+  float xv[16 * TM / 256], wv[(16 * TN + 255) / 256];
+  auto fetch = [&](int k0) {
+    const int kn = in_f - k0 < 16 ? in_f - k0 : 16;
+#pragma unroll
+    for (int u = 0; u < 16 * TM / 256; ++u) {   // X[m][k]: k fastest (16 consecutive floats of a row)
+      const int idx = threadIdx.x + 256 * u, kk = idx % 16, mm = idx / 16;
+      const long long m = m0 + mm;
+      xv[u] = X[(m < rows ? m : rows - 1) * ldx + k0 + (kk < kn ? kk : kn - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < (16 * TN + 255) / 256; ++u) {   // W[n][k]
+      const int idx = threadIdx.x + 256 * u, kk = idx % 16, nn = (idx / 16) % TN;
+      const int n = n0 + nn;
+      wv[u] = W[(long long)(n < out_f ? n : out_f - 1) * in_f + k0 + (kk < kn ? kk : kn - 1)];
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < in_f; k0 += 16) {
     const int kn = in_f - k0 < 16 ? in_f - k0 : 16;
-    for (int idx = threadIdx.x; idx < 16 * TM; idx += 256) {   // X[m][k]: k fastest (16 consecutive floats of a row)
-      const int kk = idx % 16, mm = idx / 16;
-      const long long m = m0 + mm;
-      Xs[kk][mm] = (m < rows && kk < kn) ? X[m * ldx + k0 + kk] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16 * TM / 256; ++u) {
+      const int idx = threadIdx.x + 256 * u;
+      Xs[idx % 16][idx / 16] = xv[u];
     }
-    for (int idx = threadIdx.x; idx < 16 * TN; idx += 256) {   // W[n][k]
-      const int kk = idx % 16, nn = idx / 16;
-      const int n = n0 + nn;
-      Ws[kk][nn] = (n < out_f && kk < kn) ? W[(long long)n * in_f + k0 + kk] : 0.f;
+#pragma unroll
+    for (int u = 0; u < (16 * TN + 255) / 256; ++u) {
+      const int idx = threadIdx.x + 256 * u;
+      if (idx < 16 * TN) Ws[idx % 16][idx / 16] = wv[u];
     }
     __syncthreads();
-    for (int kk = 0; kk < kn; ++kk) {   // (the tail is NOT padded with zero terms: fmaf(0, 0, -0.f) would flip a negative zero)
-      float a[4], b[4];
+    if (k0 + 16 < in_f) fetch(k0 + 16);
+    // (the tail step is NOT padded with zero terms: fmaf(0, 0, -0.f) would flip a negative zero)
+    auto fma_step = [&](int kk) {
+      float a[RM], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = Xs[kk][ty * 4 + i];
+      for (int i = 0; i < RM; ++i) a[i] = Xs[kk][ty * RM + i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = Ws[kk][tx * 4 + j];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    };
+    if (kn == 16) {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) fma_step(kk);
+    } else {
+      for (int kk = 0; kk < kn; ++kk) fma_step(kk);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const long long m = m0 + ty * 4 + i;
+      const long long m = m0 + ty * RM + i;
       const int n = n0 + tx * 4 + j;
       if (m < rows && n < out_f) Y[m * ldy + n] = act_fwd(acc[i][j] + (B ? B[n] : 0.f), act);
     }
@@ -292,12 +320,12 @@ int me_linear_f32(const float* x, int64_t ldx, int64_t rows, int32_t in_features
     hipLaunchKernelGGL(linear_kernel, dim3(grid_for((long long)rows * out_features)), dim3(256), 0, (hipStream_t)stream, x,
                        (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y, (long long)ldy);
   } else if (out_features <= 16) {
-    ME_REQUIRE((rows + 255) / 256 <= 65535, ME_E_TOOBIG, "me_linear_f32: too many rows");
-    hipLaunchKernelGGL((linear_tiled_kernel<256, 16>), dim3(1, (unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+    ME_REQUIRE((rows + 63) / 64 <= 65535, ME_E_TOOBIG, "me_linear_f32: too many rows");
+    hipLaunchKernelGGL((linear_tiled_kernel<64, 16, 1>), dim3(1, (unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
                        (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y, (long long)ldy);
   } else {
     ME_REQUIRE((rows + 63) / 64 <= 65535, ME_E_TOOBIG, "me_linear_f32: too many rows");
-    hipLaunchKernelGGL((linear_tiled_kernel<64, 64>), dim3((out_features + 63) / 64, (unsigned)((rows + 63) / 64)), dim3(256), 0,
+    hipLaunchKernelGGL((linear_tiled_kernel<64, 64, 4>), dim3((out_features + 63) / 64, (unsigned)((rows + 63) / 64)), dim3(256), 0,
                        (hipStream_t)stream, x, (long long)ldx, (long long)rows, in_features, w, bias, out_features, act, y,
                        (long long)ldy);
   }
