@@ -42,19 +42,33 @@ def _act_bwd(y, dy, rows, c, act):
     return dx
 
 
-def _linear_bwd(x, rows, in_f, w, dz, need_dx=True):
+def _linear_bwd(x, rows, in_f, w, dz, need_dx=True, dx_into=None):
     """Gradients of z = x . w^T + b given dz [rows,out]: (dw [out,in], db [out], dx [rows,in] | None)."""
     out_f = w.shape[0]
     dev = x.device
-    dw = torch.zeros((out_f, in_f), device=dev, dtype=torch.float32)
+    dw = _f32(dev, out_f, in_f)   # (beta = 0: the products never read C, no zero fill)
     _gemm(1, 0, out_f, in_f, rows, dz, out_f, x, in_f, dw, in_f)
     db = _f32(dev, out_f)
     _colsum(dz, out_f, rows, out_f, db)
     dx = None
-    if need_dx:
+    if dx_into is not None:   # dx += dz . w into the gradient another consumer of x has already written
+        dx = dx_into
+        _gemm(0, 0, rows, in_f, out_f, dz, out_f, w, in_f, dx, in_f, beta=1.0)
+    elif need_dx:
         dx = _f32(dev, rows, in_f)
         _gemm(0, 0, rows, in_f, out_f, dz, out_f, w, in_f, dx, in_f)
     return dw, db, dx
+
+
+_LOSS_W = {}
+
+
+def _loss_weights(dev, l0, l1):
+    key = (str(dev), l0, l1)
+    w = _LOSS_W.get(key)
+    if w is None:
+        w = _LOSS_W[key] = torch.tensor([1.0, 1.0 / l0, 1.0 / l0, 1.0 / l1, 1.0 / l1], dtype=torch.float32).to(dev)
+    return w
 
 
 class _StageTwo(torch.autograd.Function):
@@ -163,8 +177,7 @@ def forward_train(net, images, targets):
         n_out = torch.empty((1,), device=dev, dtype=torch.int32)
         hip.check(lib.me_compact_sort_rows_f32(rows_all.data_ptr(), keep.data_ptr(), key.data_ptr(), k, 8, ordered.data_ptr(),
                                                n_out.data_ptr(), hip.stream_ptr()), "me_compact_sort_rows_f32")
-        output = ordered[:int(n_out.item())].cpu()
-        positive = keep.bool()
+        output = ordered.cpu()[:int(n_out.item())]   # (whole buffers to the host, sliced there: no slicing / casting launches)
         if targets is None:
             # train() mode without targets (reference :299-364 in train mode): batch statistics in fcn_layers (running
             # statistics updated above), Dropout active, no loss
@@ -174,13 +187,17 @@ def forward_train(net, images, targets):
         # labels + sampling on the host (reference :369-420)
         targets[:, 2:] = xywh2xyxy(targets[:, 2:])
         targets[:, 2:] *= size
-        boxes_cpu = torch.cat((boxes[:, :1], boxes[:, 7:8], boxes[:, 1:5]), 1).cpu()
+        # (host-side slicing through numpy: torch's CPU indexing kernels enter an intra-op parallel region, which costs milliseconds on
+        #  the many-core hosts of the GPU boxes - 21 ms per step when these three lines were torch ops)
+        boxes_np = boxes.cpu().numpy()
+        boxes_cpu = torch.from_numpy(np.ascontiguousarray(boxes_np[:, [0, 7, 1, 2, 3, 4]]))
         iou_labels, target_location = iou_labels_vectorized(boxes_cpu, targets.cpu())
         pos_filter = (iou_labels > net.iou_thresh[1]).flatten()
         neg_filter = (iou_labels < net.iou_thresh[0]).flatten()
         flat = iou_labels.flatten()
-        conf_1, conf_2 = boxes[:, 5].cpu(), masks[:, 1].cpu()
-        positive_cpu = positive.cpu()
+        conf_1 = torch.from_numpy(np.ascontiguousarray(boxes_np[:, 5]))
+        conf_2 = torch.from_numpy(np.ascontiguousarray(masks.cpu().numpy()[:, 1]))
+        positive_cpu = torch.from_numpy(keep.cpu().numpy().astype(np.bool_))
         metric = dict(total=len(iou_labels), true=pos_filter.sum(), positive=positive_cpu.sum(),
                       tp=(positive_cpu * pos_filter).sum().float(),
                       conf=dict(conf_1_pos=conf_1[flat > 0.5], conf_1_neg=conf_1[flat < 0.5], conf_2_pos=conf_2[flat > 0.5],
@@ -204,7 +221,10 @@ def forward_train(net, images, targets):
                                      d_o.data_ptr(), d_ref.data_ptr(), d_reg.data_ptr(), hip.stream_ptr()), "me_m2_loss_f32")
         sums = _f32(dev, 5)
         _colsum(terms, 5, k, 5, sums)
-        loss_val = sums[0] + (sums[1] + sums[2]) / net.loss_lambda[0] + (sums[3] + sums[4]) / net.loss_lambda[1]
+        # focal + (conf + category) / lambda0 + (xy + wh) / lambda1 (reference :456-458) as one [1 x 5] . [5 x 1] product
+        loss_val = _f32(dev, 1)
+        _gemm(0, 0, 1, 1, 5, sums, 5, _loss_weights(dev, float(net.loss_lambda[0]), float(net.loss_lambda[1])), 1, loss_val, 1)
+        loss_val = loss_val.view(())
 
     names, params = _head_named(net)   # (cached walk: two named_parameters() passes over ~370 tensors were 6 ms of host time per step)
     names, params = list(names), list(params)
@@ -230,16 +250,18 @@ def _backward(S, grad_out):
         grads["ensemble_head.fc2.0.weight"], grads["ensemble_head.fc2.0.bias"] = dw, db
         # ensemble fc1 over the K*(C+1) (refine, yolo) pairs
         dz = _act_bwd(S["h1"], d_h1.view(k * c1, 32), k * c1, 32, LEAKY)
-        dw, db, d_x2 = _linear_bwd(S["x2"], k * c1, 2, S["e1w"], dz)
+        dw, db, _none = _linear_bwd(S["x2"], k * c1, 2, S["e1w"], dz, need_dx=False)
         grads["ensemble_head.fc1.0.weight"], grads["ensemble_head.fc1.0.bias"] = dw, db
-        # refinement_vector: direct loss gradient + the ensemble path (column 0 of every pair); then the sigmoid
-        d_ref = scale(S["d_ref"]) + d_x2.view(k, c1, 2)[:, :, 0]
-        dz2 = _act_bwd(S["refine"], d_ref.contiguous(), k, c1, SIGMOID)
+        # refinement_vector: direct loss gradient + the ensemble path - column 0 of every (refine, yolo) pair: d_x2[:, 0] = dz . e1w[:, 0],
+        # accumulated onto the loss gradient by the product itself (n = 1, ldb = 2 walks column 0; the yolo column feeds the frozen
+        # detector and is not computed); then the sigmoid
+        d_ref = scale(S["d_ref"]).clone()
+        _gemm(0, 0, k * c1, 1, 32, dz, 32, S["e1w"], 2, d_ref, 1, beta=1.0)
+        dz2 = _act_bwd(S["refine"], d_ref, k, c1, SIGMOID)
         dw, db, d_hid = _linear_bwd(S["hidden"], k, 256, S["w2"], dz2)
         grads["refinement_head.net2.0.weight"], grads["refinement_head.net2.0.bias"] = dw, db
-        dw, db, d_hid1 = _linear_bwd(S["hidden"], k, 256, S["w1"], scale(S["d_reg"]).contiguous())
+        dw, db, d_hid = _linear_bwd(S["hidden"], k, 256, S["w1"], scale(S["d_reg"]).contiguous(), dx_into=d_hid)
         grads["refinement_head.net1.0.weight"], grads["refinement_head.net1.0.bias"] = dw, db
-        d_hid = d_hid + d_hid1
         # Dropout, LeakyReLU, net0
         d_t = _f32(dev, k, 256)
         hip.check(lib.me_mask_scale_f32(d_hid.data_ptr(), S["mask"].data_ptr(), 2.0, k * 256, d_t.data_ptr(), hip.stream_ptr()),
@@ -256,7 +278,7 @@ def _backward(S, grad_out):
         dz1 = _f32(dev, pix, 490)
         dg, dbt = _bn_bwd(S["z1"], 490, d_a1, 490, pix, 490, bn, S["st_img"], LEAKY, dz1, 490, S["ws"])
         grads["fcn_layers.net.batch_norm_0.weight"], grads["fcn_layers.net.batch_norm_0.bias"] = dg, dbt
-        dw = torch.zeros((490, fc), device=dev, dtype=torch.float32)
+        dw = _f32(dev, 490, fc)
         _gemm(1, 0, 490, fc, pix, dz1, 490, S["fm"], fc, dw, fc)
         dbc = _f32(dev, 490)
         _colsum(dz1, 490, pix, 490, dbc)
