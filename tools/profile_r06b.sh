@@ -29,3 +29,21 @@ for f in ("r06_bench_full_b32.json", "r06_bf16_bench_full_b32.json"):
     print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], (d.get("bf16_storage_mode") or {}).get("value"),
           ((d.get("bf16_storage_mode") or {}).get("roofline") or {}).get("traffic"))
 PY
+# second half of the round: micro-benchmarks and per-step kernel tables of the two training steps
+(for e in 0 1; do MILLIEYE_ROI_BWD_LDS=$e python tools/roi_bwd_bench.py 1200 8; done
+ for s in 4 8 16 32 64; do echo "slices per frame: $s"; MILLIEYE_ROI_BWD_SPLITS=$s python tools/roi_bwd_bench.py 1200 8 | tail -n 1; done
+ MILLIEYE_ROI_BWD_LDS=0 python tools/roi_bwd_bench.py 200 1; python tools/roi_bwd_bench.py 200 1) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_micro_roi_bwd_lds.txt
+(python tools/linear_bench.py; MILLIEYE_M2_LINEAR_NAIVE=1 python tools/linear_bench.py) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_micro_linear.txt
+python tools/memset_graph_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_memset_graph_probe.txt
+(for m in philox cpu; do for p in 1 0; do M2_DROPOUT=$m python tools/m2_train_step.py 40 8 bf16 $p 2>&1 | grep "stage-2" | sed "s/\$/  [mask: $m]/"; done; done) > $OUT/${TAG}_m2_train_prefetch_ab.txt
+cd /tmp
+TR="python $R/bench.py --workload train --dtype bf16 --no-cpu-baseline --warmup 4"
+rocprofv3 --kernel-trace --stats -d /tmp/ts_a -o k -- $TR --steps 10 > /tmp/ts_a.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/ts_b -o k -- $TR --steps 50 > /tmp/ts_b.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/m2_a -o k -- python $R/tools/m2_train_step.py 10 8 bf16 1 > /tmp/m2_a.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/m2_b -o k -- python $R/tools/m2_train_step.py 40 8 bf16 1 > /tmp/m2_b.log 2>&1
+cd $R/tools
+python prof_diff.py /tmp/ts_a/k_results.db /tmp/ts_b/k_results.db heads_tail_bwd 2>&1 | head -n 70 > $OUT/${TAG}_train_step_per_step_kernels.txt
+python prof_diff.py /tmp/m2_a/k_results.db /tmp/m2_b/k_results.db 30 2>&1 | head -n 70 > $OUT/${TAG}_m2_train_step_per_step_kernels.txt
+cd $R
+head -n 3 $OUT/${TAG}_train_step_per_step_kernels.txt $OUT/${TAG}_m2_train_step_per_step_kernels.txt; cat $OUT/${TAG}_m2_train_prefetch_ab.txt
