@@ -192,6 +192,45 @@ def test_roi_backward_through_lds_on_clustered_proposals(hip_lib, n, h, k, lds):
         assert _rel(gmap2, gmap) < 1e-5
 
 
+
+def test_roi_backward_on_degenerate_boxes(hip_lib):
+    """The boxes the reference's own edge cases produce (proposals on the border, empty and inverted boxes, boxes far
+    outside the map, boxes much larger than it) through both scatter kernels against oracle/tv_ops.c's backward; k = 0 is a no-op."""
+    from millieye_amd import hip
+    from oracle import tv_ops
+    n, h = 3, 26
+    size = 16.0 * h
+    rois = torch.tensor([
+        [0, 10, 10, 10, 10],                     # empty box
+        [0, 100, 120, 60, 40],                   # inverted box (x2 < x1, y2 < y1)
+        [1, -200, -150, -20, -10],               # wholly outside (negative side)
+        [1, size + 50, size + 60, size + 300, size + 200],   # wholly outside (far side)
+        [2, -300, -300, 3 * size, 3 * size],     # much larger than the map
+        [2, 0, 0, size, size],                   # the whole map exactly
+        [0, size - 8, size - 8, size + 40, size + 40],   # straddles the far corner
+        [1, -5, 30, 7, 33],                      # thin sliver across the near edge
+        [2, 200.5, 100.25, 201.0, 100.75],       # sub-cell box
+    ], dtype=torch.float32)
+    k = rois.shape[0]
+    for ps, ch in ((False, 10), (True, 490)):
+        m = torch.zeros((n, ch, h, h), requires_grad=True)
+        out = (tv_ops.ps_roi_align if ps else tv_ops.roi_align)(m, rois, (7, 7), 1 / 16)
+        go = _t(f"rdg{ch}", tuple(out.shape))
+        out.backward(go)
+        gd, rd = go.cuda(), rois.cuda()
+        gmap = torch.zeros((n, h, h, ch)).cuda()
+        fn = hip.lib().me_ps_roi_align_bwd_f32 if ps else hip.lib().me_roi_align_bwd_f32
+        hip.check(fn(gd.data_ptr(), rd.data_ptr(), k, n, h, h, ch, 7, 1.0 / 16, gmap.data_ptr(), ch, hip.stream_ptr()), "roi bwd")
+        torch.cuda.synchronize()
+        ref = m.grad.permute(0, 2, 3, 1)
+        assert torch.isfinite(gmap).all()
+        assert float((gmap.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (ps, float((gmap.cpu() - ref).abs().max()))
+        before = gmap.clone()
+        hip.check(fn(gd.data_ptr(), rd.data_ptr(), 0, n, h, h, ch, 7, 1.0 / 16, gmap.data_ptr(), ch, hip.stream_ptr()), "roi bwd k=0")
+        torch.cuda.synchronize()
+        assert torch.equal(gmap, before)
+
+
 def _build(name, cfg, conf):
     from millieye_amd.my_models import Network, define_yolo
     net = Network(define_yolo(ph.cfg_path(cfg)), conf)
