@@ -268,6 +268,23 @@ class _BackwardGraph:
         self.g_in = None
         self.flat = None
         self.layout = None   # [(name, shape, offset, numel)]
+        self.scratch = None  # addresses of the library's per-stream workspaces at capture time
+
+
+def _scratch_ptrs():
+    """The library's per-stream workspaces (``hip._workspace``: the weight-gradient slabs of ``_gemm``, the NMS lists): their addresses are
+    baked into a capture, and a later call with a larger request - another model on the same stream, a bigger batch - REPLACES them.
+    Checked before every replay (like ``detector_graph.GraphedDetectorStep._scratch_ptrs``): a moved buffer means a new capture."""
+    return {k: t.data_ptr() for k, t in hip._ws_cache.items() if t is not None}
+
+
+def _scratch_moved(snapshot):
+    cache = hip._ws_cache
+    for k, ptr in snapshot.items():   # (workspaces that appeared since the capture cannot be in it)
+        t = cache.get(k)
+        if t is None or t.data_ptr() != ptr:
+            return True
+    return False
 
 
 def _graphed_backward(S, grad_out, needed):
@@ -279,6 +296,8 @@ def _graphed_backward(S, grad_out, needed):
     if rec.graph is False or torch.cuda.is_current_stream_capturing():
         return _backward(S, grad_out, needed)
     rec.runs += 1
+    if rec.graph not in (None, False) and _scratch_moved(rec.scratch):
+        rec.graph, rec.flat = None, None   # a workspace the capture points into was replaced: capture again (this call, eager warm-up done)
     if rec.graph is None and rec.runs <= 2:
         return _backward(S, grad_out, needed)   # eager warm-up: lazy one-time state (workspaces, kernel attributes) settles
     dev = S["fm"].device
@@ -296,7 +315,7 @@ def _graphed_backward(S, grad_out, needed):
             for nm in names:
                 layout.append((nm, tuple(G[nm].shape), off, G[nm].numel()))
                 off += G[nm].numel()
-            rec.layout, rec.graph = layout, graph
+            rec.layout, rec.graph, rec.scratch = layout, graph, _scratch_ptrs()
         except Exception as exc:   # a failed capture is not fatal and is not retried: this signature stays eager
             import warnings
             warnings.warn(f"millieye_amd: hipGraph capture of the stage-3 backward failed ({exc!r}); it runs eagerly")

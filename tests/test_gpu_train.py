@@ -689,10 +689,34 @@ def test_captured_backward_equals_the_eager_backward(hip_lib, monkeypatch):
                 opt.zero_grad()
             out.append((float(loss.detach()), rows.detach().cpu().clone(), int(metric["total"]), grads))
         arena = net.__dict__.get("_train_arena")
+        if graph and moved:
+            # a library workspace the capture points into is REPLACED (what a larger request on the same stream does): the next
+            # backward must notice and capture again instead of replaying launches that point into the old buffer
+            from millieye_amd import hip
+            recs = [r for r in arena.graphs.values() if r.graph not in (None, False)]
+            assert recs and recs[0].scratch
+            old_graph = recs[0].graph
+            for key in list(recs[0].scratch):
+                t = hip._ws_cache[key]
+                hip._ws_cache[key] = torch.empty(t.numel() + 4096, dtype=t.dtype, device=t.device)
+            x = torch.from_numpy(synth.uniform(f"{name}/cap/x0", (n, 3, s, s))).cuda()
+            maps, rboxes = synth.radar_inputs(f"{name}/cap/radar0", n, s // 16, boxes_per_image=3)
+            targets = torch.tensor([[0, 0, 0.3, 0.4, 0.3, 0.3], [1, 0, 0.6, 0.5, 0.4, 0.5]])
+            for p in net.parameters():
+                p.grad = None
+            loss, _rows, _metric, _att = net(x, torch.from_numpy(maps).cuda(), torch.from_numpy(rboxes).cuda(), targets.clone())
+            loss.backward()
+            torch.cuda.synchronize()
+            assert recs[0].graph is not old_graph and recs[0].graph not in (None, False), "the moved workspace went unnoticed"
+            assert all(hip._ws_cache[k].data_ptr() == v for k, v in recs[0].scratch.items())
+            assert all(torch.isfinite(p.grad).all() for p in heads if p.grad is not None)
         return out, arena
 
+    moved = False
     eager, arena_e = run(False)
     graphed, arena_g = run(True)
+    moved = True
+    run(True)
     assert arena_e is None and arena_g is not None
     recs = [r for r in arena_g.graphs.values()]
     assert any(r.graph not in (None, False) for r in recs), "the backward was never captured"
