@@ -27,7 +27,8 @@ for i in range(batch):
 targets = torch.tensor(tg, dtype=torch.float32).reshape(-1, 6)
 net.train(); net.base_detector.eval()
 heads = head_parameters(net)
-opt = torch.optim.Adam(heads, lr=5e-4, fused=True)
+from millieye_amd.optim import Adam
+opt = Adam(heads, lr=5e-4)   # the loop's optimizer (millieye_amd/train.py)
 random.seed(1)
 x2 = x.clone()
 flip = [0]
