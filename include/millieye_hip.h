@@ -640,6 +640,14 @@ typedef struct me_conv16_desc {
                             contiguous, so one LDS-DMA instruction moves 1 KiB of whole 128-byte lines.  May be NULL otherwise. */
   int32_t* tile_counters; /* as in me_conv_desc: arrival counters of the in-launch split-K reduction (zero on entry and exit) */
   int64_t tile_counters_len;
+  /* ABI 13: per-column-class tap masks, as me_conv_desc.tap_mask (ABI 10) - tap_mask_cols > 0: the output channels form
+     cout / tap_mask_cols (<= 4) classes of tap_mask_cols consecutive channels; bit t of tap_mask[class] clear = tap t
+     (ky * ksize + kx) of that class's filters is all zero and is skipped (the stride-2 data gradient of the 16-bit training step:
+     7 of the 16 (class, tap) pairs of its 2x2 parity convolution).  Per-tap tiles 1 / 2 / 3 / 11 / 12 / 13 only, whole tiles
+     (split_k <= 1), the tile width must divide tap_mask_cols.  A zeroed tail keeps the previous behaviour. */
+  uint32_t tap_mask[4];
+  int32_t tap_mask_cols;
+  int32_t reserved1;
 } me_conv16_desc;
 int me_conv2d_h16(const me_conv16_desc* d, void* stream);
 int64_t me_conv2d_h16_workspace_bytes(const me_conv16_desc* d);

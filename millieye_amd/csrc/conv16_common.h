@@ -58,6 +58,8 @@ struct Conv16P {
   int f16;         // 0 = bfloat16 storage, 1 = IEEE half
   int vec_epi;     // 16-byte epilogue allowed (bf16 out, no upsample, leaky / linear, pitches % 8, 16-byte aligned)
   int store_mode;  // me::store_mode(): 16-byte epilogue stores plain (0), nt (1) or sc1 write-through (2)
+  int mask_cols;        // me_conv16_desc.tap_mask_cols (0: no masks)
+  unsigned tapmask[4];  // me_conv16_desc.tap_mask: set taps of the four column classes (conv_igemm_buf_h16<..., MASKED = 1>)
 };
 
 __device__ __forceinline__ float act16(float v, int act) {

@@ -49,7 +49,9 @@ using namespace me_dma;
 // ---------------------------------------------------------------------------------------------
 // ABL (tuning only, wrong results): 1 = every DMA lane out of range (zero fill: no L2 / HBM traffic), 2 = no MFMAs,
 // 3 = no DMA instructions at all.
-template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int F16 = 0>
+// MASKED (ABI 13): the instance with the column-class tap masks (me_conv16_desc.tap_mask) - the K walk of a tile visits only the set
+// taps of its column class.  Separate instances on purpose: the inference kernels' code does not change.
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int F16 = 0, int MASKED = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P p) {
   using frag = typename H16<F16>::v8;
   constexpr int NST = 3;
@@ -142,7 +144,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
   const int s_begin = sid * p.sps;
   const int s_end = (s_begin + p.sps < p.stages) ? s_begin + p.sps : p.stages;
   int tap = 0, cc = 0, ky = 0, kx = 0;  // wave-uniform K walk: filter tap outer, channel chunk inner
-  if (s_begin != 0) {                   // (K-split pieces only: whole tiles skip the divisions)
+  unsigned tmask = 0xFFFFFFFFu;
+  if constexpr (MASKED) {               // (whole tiles only: the host refuses a K split with masks; a class is a multiple of BN wide)
+    tmask = p.tapmask[n0 / p.mask_cols] & ((1u << (p.ks * p.ks)) - 1u);
+    tap = __builtin_ctz(tmask);
+    ky = tap / p.ks;
+    kx = tap - ky * p.ks;
+  } else if (s_begin != 0) {            // (K-split pieces only: whole tiles skip the divisions)
     tap = s_begin / p.cs;
     cc = s_begin - tap * p.cs;
     ky = tap / p.ks;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
   unsigned a_off = 0, b_off = 0;
   auto enter_tap = [&]() {  // VALU work only here: once per filter tap
 #pragma unroll
-    for (int j = 0; j < LA; ++j) v_cur[j] = (ABL == 1 || ((v_pad[j] >> tap) & 1u)) ? kOobOffset : v_base[j];
+    for (int j = 0; j < LA; ++j) v_cur[j] = (ABL == 1 || ((v_pad[j] >> (MASKED ? (tap & 31) : tap)) & 1u)) ? kOobOffset : v_base[j];
     a_off = (unsigned)(((long long)ky * p.w + kx) * p.x_pitch * 2);
     b_off = (unsigned)tap * (unsigned)p.cin * 2u;
   };
@@ -177,11 +185,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
     b_off += 64u * KSUB;
     if (++cc == p.cs) {
       cc = 0;
-      ++tap;
-      if (++kx == p.ks) {
-        kx = 0;
-        ++ky;
-      }
+      do {   // the next tap (MASKED: the next SET tap of this tile's column class)
+        ++tap;
+        if (++kx == p.ks) {
+          kx = 0;
+          ++ky;
+        }
+      } while (MASKED && tap < p.ks * p.ks && !((tmask >> tap) & 1u));
       enter_tap();
     }
   };
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_igemm_buf_h16(Conv16P
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nstages = s_end - s_begin;
+  const int nstages = MASKED ? __builtin_popcount(tmask) * p.cs : s_end - s_begin;
   issue_stage(wave_lds);
   if (nstages > 1) issue_stage(wave_lds + STAGE_B);
 
@@ -564,7 +574,7 @@ bool addressable16(const Conv16P& p, int bm) {
   return a_max < (1ll << 31) && b_max < (1ll << 31);
 }
 
-template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int F16 = 0>
+template <int BM, int BN, int WR, int WC, int KSUB, int MINW = 1, int ABL = 0, int F16 = 0, int MASKED = 0>
 int launch16(Conv16P& p, hipStream_t stream) {
   static_assert(BM <= 256, "addressable16 / the descriptor window assume tiles of at most 256 rows");
   ME_REQUIRE(addressable16(p, BM), ME_E_TOOBIG,
@@ -579,7 +589,11 @@ int launch16(Conv16P& p, hipStream_t stream) {
   constexpr int NW = WR * WC;
   constexpr int LPW = ((BM + BN) / 16 + NW - 1) / NW;
   const size_t lds = (size_t)3 * KSUB * LPW * NW * 1024;
-  auto kern = conv_igemm_buf_h16<BM, BN, WR, WC, KSUB, MINW, ABL, F16>;
+  if constexpr (MASKED) {
+    ME_REQUIRE(p.splitk == 1 && p.mask_cols % BN == 0, ME_E_BADARG,
+               "me_conv2d_h16: tap masks need whole tiles (split_k <= 1) and a tile width (%d) that divides tap_mask_cols", BN);
+  }
+  auto kern = conv_igemm_buf_h16<BM, BN, WR, WC, KSUB, MINW, ABL, F16, MASKED>;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -623,6 +637,8 @@ int fill16(const me_conv16_desc* d, Conv16P& p) {
   p.ktot = d->ksize * d->ksize * d->cin;
   magic16((unsigned)(d->ho * d->wo), &p.hw_m, &p.hw_s);
   magic16((unsigned)d->wo, &p.wo_m, &p.wo_s);
+  p.mask_cols = d->tap_mask_cols > 0 ? d->tap_mask_cols : 0;
+  for (int i = 0; i < 4; ++i) p.tapmask[i] = d->tap_mask[i];
   p.cs = p.stages = p.tiles_m = p.tiles_n = 0;
   p.partial = nullptr;
   p.partial_bytes = 0;
@@ -711,6 +727,8 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
     const long long fit = d->workspace_bytes / slab;
     max_split = fit < kMaxSplit16 ? (int)fit : kMaxSplit16;
   }
+  ME_REQUIRE(p.mask_cols == 0 || d->tile == 1 || d->tile == 2 || d->tile == 3 || d->tile == 11 || d->tile == 12 || d->tile == 13,
+             ME_E_BADARG, "me_conv2d_h16: tap masks need an explicit per-tap tile id 1 / 2 / 3 / 11 / 12 / 13 (got %d)", d->tile);
   if (d->tile >= 100) {  // patch-resident tiles: K split only on request (compact slabs, checked by the launcher)
     p.splitk = d->split_k > 1 ? d->split_k : 1;
     p.partial = reinterpret_cast<float*>(d->workspace);
@@ -736,6 +754,26 @@ int me_conv2d_h16(const me_conv16_desc* d, void* stream_) {
   if (tile == 50) return me16::launch_ws1x1(p, stream);
   if (tile == 60) return me16::launch_ws3x3(p, stream);
   const bool k2 = d->cin % 64 == 0;  // two 32-channel sub-stages per pipeline stage when the channel count allows
+  if (p.mask_cols > 0) {  // column-class tap masks (ABI 13): the masked instances of the per-tap tiles
+    const int taps = d->ksize * d->ksize;
+    ME_REQUIRE(d->cout % p.mask_cols == 0 && d->cout / p.mask_cols <= 4, ME_E_BADARG,
+               "me_conv2d_h16: tap_mask_cols %d must cut cout %d into at most 4 classes", p.mask_cols, d->cout);
+    for (int i = 0; i < d->cout / p.mask_cols; ++i)
+      ME_REQUIRE((d->tap_mask[i] & ((1u << taps) - 1u)) != 0, ME_E_BADARG, "me_conv2d_h16: tap_mask[%d] selects no tap", i);
+    ME_REQUIRE(d->split_k <= 1, ME_E_BADARG, "me_conv2d_h16: tap masks and a K split do not combine");
+    p.splitk = 1;
+    const bool two = (tile == 1 || tile == 2 || tile == 3) && k2;
+#define ME_MASKED16(BM_, BN_) \
+  (p.f16 ? (two ? launch16<BM_, BN_, 2, 2, 2, 1, 0, 1, 1>(p, stream) : launch16<BM_, BN_, 2, 2, 1, 1, 0, 1, 1>(p, stream)) \
+         : (two ? launch16<BM_, BN_, 2, 2, 2, 1, 0, 0, 1>(p, stream) : launch16<BM_, BN_, 2, 2, 1, 1, 0, 0, 1>(p, stream)))
+    switch (tile) {
+      case 1: case 11: return ME_MASKED16(128, 128);
+      case 2: case 12: return ME_MASKED16(128, 64);
+      case 3: case 13: return ME_MASKED16(64, 64);
+      default: ME_REQUIRE(false, ME_E_BADARG, "me_conv2d_h16: tap masks need tile 1 / 2 / 3 / 11 / 12 / 13 (got %d)", tile);
+    }
+#undef ME_MASKED16
+  }
   if (p.f16) {
     switch (tile) {
       case 1: return k2 ? launch16<128, 128, 2, 2, 2, 1, 0, 1>(p, stream) : launch16<128, 128, 2, 2, 1, 1, 0, 1>(p, stream);

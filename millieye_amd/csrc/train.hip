@@ -2268,7 +2268,7 @@ static int launch_roi_bwd(const float* gout, const float* rois, int32_t k, int32
   // the scatter through LDS when a frame's slice of the map fits (MILLIEYE_ROI_BWD_LDS=0: the global-atomics kernel)
   static const int lds_env = getenv("MILLIEYE_ROI_BWD_LDS") ? atoi(getenv("MILLIEYE_ROI_BWD_LDS")) : 1;
   const long long slice = (long long)h * w * (ps ? c / 49 : c) * (long long)sizeof(float);
-  if (lds_env && slice <= 48 * 1024) {
+  if (lds_env && slice <= 48 * 1024 && n <= 65535) {   // (frames ride in gridDim.y)
     if (ps) {
       hipLaunchKernelGGL(roi_bwd_lds_kernel<true>, dim3(49, n), dim3(ROI_LDS_THREADS), (size_t)slice, stream, gout, rois, k, c, h,
                          w, scale, gmap, (long long)pitch, k_dev);

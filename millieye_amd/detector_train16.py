@@ -30,7 +30,7 @@ import os
 import torch
 
 from . import hip
-from .detector_train import (_PARITY_IDX, _State, _const_vectors, _conv_flops, _parity_weights, _resolve, _side_stream, _timed,  # noqa: F401
+from .detector_train import (_PARITY_IDX, _PARITY_MASKS_ON, _PARITY_TAP_MASKS, _State, _const_vectors, _conv_flops, _parity_weights, _resolve, _side_stream, _timed,  # noqa: F401
                              _TIMING)
 
 _HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
@@ -46,53 +46,59 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def conv16_auto(x, wgt, scale, shift, ksize, stride, pad, act, residual=None, y_f32=False, x_nchw=False):
+def conv16_auto(x, wgt, scale, shift, ksize, stride, pad, act, residual=None, y_f32=False, x_nchw=False, tap_masks=None):
     """``hip.conv2d_h16`` with the (tile, split_k) pair measured the first time a layer shape is seen (the training path has no engine
     plan whose autotuner would do it).  Candidates: the per-tap tiles with 1 / 2 / 4 K splits and, for 3x3 / stride-1 layers, the
     patch-resident tiles (their tiled weight copy is made per call: a few microseconds against tens)."""
     if x_nchw or wgt.shape[3] <= 4:
         return hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, y_f32=y_f32, x_nchw=x_nchw)
-    key = (tuple(x.shape), x.stride(2), wgt.shape[0], ksize, stride, pad, residual is not None, y_f32, x.dtype)
+    key = (tuple(x.shape), x.stride(2), wgt.shape[0], ksize, stride, pad, residual is not None, y_f32, x.dtype, tap_masks)
     hit = _AUTO16.get(key)
     if hit is None:
         cin = wgt.shape[3]
-        cands = [(0, 0)] + [(t, sp) for t in ((1, 2, 3, 4, 11, 12, 13, 14) if cin % 64 == 0 else (1, 2, 3, 4)) for sp in (1, 2, 4)]
+        # candidates (tile, split, masked): with ``tap_masks`` (the stride-2 data gradient's parity convolution: filters whose zero
+        # taps the masked instances skip, me_conv16_desc.tap_mask) every whole per-tap tile is tried both ways - a launch that fits
+        # one round of tiles lasts as long as its four-tap class, so the small maps may keep their K splits
+        cands = [(0, 0, False)] + [(t, sp, False) for t in ((1, 2, 3, 4, 11, 12, 13, 14) if cin % 64 == 0 else (1, 2, 3, 4)) for sp in (1, 2, 4)]
+        if tap_masks is not None:
+            cands += [(t, 1, True) for t in ((1, 2, 3, 11, 12, 13) if cin % 64 == 0 else (1, 2, 3)) if tap_masks[0] % (64 if t in (2, 3, 12, 13) else 128) == 0]
         if ksize == 3 and stride == 1 and pad == 1 and not y_f32 and cin % 32 == 0:
-            cands += [(t, 1) for t in (221, 201, 431, 131, 121, 621)]
+            cands += [(t, 1, False) for t in (221, 201, 431, 131, 121, 621)]
         if _MORE_TILES and not y_f32:
             # the streaming kernels of the inference plans (the library refuses the shapes they have no instance for): weights in
             # registers for the pointwise layers without a residual (tile 50), for the 3x3 layers with <= 64 input channels (60)
             if ksize == 1 and stride == 1 and residual is None:
-                cands.append((50, 1))
+                cands.append((50, 1, False))
             if ksize == 3 and cin <= 64:
-                cands.append((60, 1))
-            cands += [(15, sp) for sp in (1, 2)]   # 192 x 128
-        best = (float("inf"), 0, 0)
+                cands.append((60, 1, False))
+            cands += [(15, sp, False) for sp in (1, 2)]   # 192 x 128
+        best = (float("inf"), 0, 0, False)
         scratch = None
         torch.cuda.synchronize()
-        for tile, split in cands:
+        for tile, split, masked in cands:
+            tm = tap_masks if masked else None
             try:
                 wt = hip.tile_weights_h16(wgt) if tile >= 100 else None
                 for _ in range(2):
                     scratch = hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch,
-                                             y_f32=y_f32, tile=tile, split_k=split, wgt_tiled=wt)
+                                             y_f32=y_f32, tile=tile, split_k=split, wgt_tiled=wt, tap_masks=tm)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(3):
                     wt = hip.tile_weights_h16(wgt) if tile >= 100 else None
                     hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, out=scratch, y_f32=y_f32,
-                                   tile=tile, split_k=split, wgt_tiled=wt)
+                                   tile=tile, split_k=split, wgt_tiled=wt, tap_masks=tm)
                 b.record()
                 torch.cuda.synchronize()
                 ms = a.elapsed_time(b) / 3
             except hip.MeError:
                 continue
             if ms < best[0]:
-                best = (ms, tile, split)
-        hit = _AUTO16[key] = (best[1], best[2])
+                best = (ms, tile, split, masked)
+        hit = _AUTO16[key] = (best[1], best[2], best[3])
     wt = hip.tile_weights_h16(wgt) if hit[0] >= 100 else None
     return hip.conv2d_h16(x, wgt, scale, shift, ksize, stride, pad, act, residual=residual, y_f32=y_f32, tile=hit[0], split_k=hit[1],
-                          wgt_tiled=wt)
+                          wgt_tiled=wt, tap_masks=tap_masks if hit[2] else None)
 
 
 def _add16(a, b, out):
@@ -506,7 +512,10 @@ class DetectorTrainer16:
                         if pw is None or (not self.w16.direct and cw.parity_stamp != cw._stamp):
                             pw = _parity_weights(cw.wgt).to(half)
                         o4, z4 = _const_vectors(4 * cin, dev)
-                        dx4 = conv16_auto(dc, pw, o4, z4, 2, 1, 1, hip.ACT_LINEAR)
+                        # (round 6, as the fp32 step since round 5: 7 of the 16 (class, tap) pairs of the 2x2 parity filter are
+                        #  structurally zero and the masked tile instances skip them - a measured candidate of conv16_auto)
+                        masks = (cin, _PARITY_TAP_MASKS) if (cin % 64 == 0 and _PARITY_MASKS_ON) else None
+                        dx4 = conv16_auto(dc, pw, o4, z4, 2, 1, 1, hip.ACT_LINEAR, tap_masks=masks)
                         dx = dx4[:, 1:, 1:, :].reshape(n, ho, wo, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(n, h, w, cin)
                         contribute(i - 1, dx.contiguous(), True)
                     else:

@@ -56,6 +56,7 @@ class Conv16Desc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("wgt_tiled", C.c_void_p),
         ("tile_counters", C.c_void_p), ("tile_counters_len", C.c_int64),
+        ("tap_mask", C.c_uint32 * 4), ("tap_mask_cols", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -562,10 +563,12 @@ def tile_weights_h16(wgt_packed):
 
 
 def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=None, upsample=1, out=None,
-                x_nchw=False, y_f32=False, tile=0, split_k=0, half=torch.bfloat16, wgt_tiled=None, debug_ws=None):
+                x_nchw=False, y_f32=False, tile=0, split_k=0, half=torch.bfloat16, wgt_tiled=None, debug_ws=None, tap_masks=None):
     """16-bit-storage twin of :func:`conv2d`; ``half`` = ``torch.bfloat16`` (default) or ``torch.float16``.  ``x``: 16-bit
     NHWC [N,H,W,Cin] (or a channel slice), or - stem, Cin == 3 - float32 NCHW / NHWC; ``wgt_packed``: 16-bit [Cout,k,k,Cin]
-    (float32 for the stem); ``residual``: the output's dtype.  Returns 16-bit NHWC (float32 when ``y_f32``)."""
+    (float32 for the stem); ``residual``: the output's dtype.  Returns 16-bit NHWC (float32 when ``y_f32``).
+    ``tap_masks`` = ``(cols, (m0, m1, ...))`` as in :func:`conv2d` (``me_conv16_desc.tap_mask``, ABI 13): per-tap tiles 1 / 2 / 3 / 11 /
+    12 / 13, no K split."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda):
         raise MeError("x must be a CUDA tensor")
     if x_nchw:
@@ -604,10 +607,14 @@ def conv2d_h16(x, wgt_packed, scale, shift, ksize, stride, pad, act, residual=No
     d.act, d.upsample, d.x_nchw, d.y_f32, d.tile, d.split_k = act, upsample, 1 if x_nchw else 0, 1 if y_f32 else 0, \
         tile, split_k
     d.half_type = HALF_TYPES[half]
+    if tap_masks is not None:
+        d.tap_mask_cols = int(tap_masks[0])
+        for i, m in enumerate(tap_masks[1]):
+            d.tap_mask[i] = int(m)
     if tile >= 100 and wgt_tiled is None and cin % 32 == 0:
         wgt_tiled = tile_weights_h16(wgt_packed)  # callers that care about time pass their own copy
     d.wgt_tiled = wgt_tiled.data_ptr() if wgt_tiled is not None else None
-    need = lib().me_conv2d_h16_workspace_bytes(C.byref(d))
+    need = lib().me_conv2d_h16_workspace_bytes(C.byref(d)) if tap_masks is None else 0
     keep = None
     if need > 0:
         ws_ptr, keep = _workspace(need, x.device, slot="conv")

@@ -726,3 +726,47 @@ def test_detector_plan_with_one_launch_bottlenecks(hip_lib, monkeypatch, dtype):
     #  bar that does not move is the one against fp32)
     assert d_obj <= (0.03 if dtype == "bf16" else 0.005) and d_box <= (0.06 if dtype == "bf16" else 0.01)
     assert e_one <= 1.25 * e_pair + 1e-4
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,h", [(64, 128, 26), (128, 256, 13), (256, 64, 10)])
+def test_conv_h16_tap_masks_skip_the_zero_taps_bit_exactly(hip_lib, cin, cout, h, half):
+    """ABI 13, ``me_conv16_desc.tap_mask``: the 2x2 parity convolution of the 16-bit step's stride-2 data gradient
+    (detector_train._parity_weights rounded to the storage type: 7 of its 16 (class, tap) pairs are structurally zero) with the zero
+    taps SKIPPED by the masked tile instances equals the same tile multiplying them - bit for bit (a skipped tap would have added
+    +0.0) - on every per-tap tile whose width divides the class width; the pixel shuffle of the result is the transposed convolution;
+    what the masked instances cannot do is refused."""
+    from millieye_amd import hip, synth
+    from millieye_amd.detector_train import _PARITY_TAP_MASKS, _parity_weights
+    n = 3
+    dev = torch.device("cuda")
+    w = torch.from_numpy(synth.uniform(f"tm16/w{cin}", (cout, 3, 3, cin), -1, 1)).to(dev) / (9 * cin) ** 0.5   # forward OHWI
+    dc = torch.from_numpy(synth.uniform(f"tm16/dc{cin}", (n, h, h, cout), -1, 1)).to(dev).to(half)
+    pw = _parity_weights(w).to(half)
+    ones, zeros = torch.ones(4 * cin, device=dev), torch.zeros(4 * cin, device=dev)
+    masks = (cin, _PARITY_TAP_MASKS)
+    seen = 0
+    for tile in (1, 2, 3, 11, 12, 13):
+        width = 128 if tile in (1, 11) else 64
+        if (tile > 10 and cout % 64 != 0) or cin % width != 0:
+            with pytest.raises(hip.MeError):
+                hip.conv2d_h16(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=tile, split_k=1, tap_masks=masks)
+            continue
+        base = hip.conv2d_h16(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=tile, split_k=1)
+        got = hip.conv2d_h16(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=tile, split_k=1, tap_masks=masks)
+        assert torch.equal(got, base), f"tile {tile}: skipping the zero taps changed bits"
+        seen += 1
+    assert seen >= 2
+    dx = got[:, 1:, 1:, :].float().reshape(n, h, h, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * h, cin)
+    ref = F.conv_transpose2d(dc.float().permute(0, 3, 1, 2).cpu(), w.to(half).float().permute(0, 3, 1, 2).cpu(), stride=2, padding=1,
+                             output_padding=1)
+    err = float((dx.permute(0, 3, 1, 2).cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < (1e-2 if half == torch.bfloat16 else 2e-3), err   # (one rounding of the output to the storage type)
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=3, split_k=1, tap_masks=(cin, (1, 3, 0, 15)))   # a class without taps
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=3, split_k=2, tap_masks=masks)                  # masks + K split
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=4, split_k=1, tap_masks=masks)                  # a tile without a masked instance
+    with pytest.raises(hip.MeError):
+        hip.conv2d_h16(dc, pw, ones, zeros, 2, 1, 1, hip.ACT_LINEAR, tile=0, tap_masks=masks)                             # needs an explicit tile
