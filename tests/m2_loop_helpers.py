@@ -81,11 +81,12 @@ def prepare(net_cls):
     return net
 
 
-def run(net, tmpdir):
+def run(net, tmpdir, optimizer_cls=None):
     c, g = M2_LOOP_CASE, golden()
     targets = {k[len("targets/"):]: g[k] for k in g.files if k.startswith("targets/")}
     step_sums = []
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    # (optimizer_cls: millieye_amd.optim.AdamW in the GPU tests - the loop's default optimizer there - against the same goldens)
+    opt = (optimizer_cls or torch.optim.AdamW)(net.parameters(), lr=1e-4)
     real_step = opt.step
 
     def step(*a, **kw):

@@ -56,12 +56,16 @@ def test_listdataset_batches_bitexact_vs_reference(hip_lib, tmp_path):
     assert 0 < flips < 2 * c["batches"]
 
 
-def test_m2_train_loop_on_gpu_matches_reference_script(hip_lib, tmp_path):
+@pytest.mark.parametrize("optimizer", ["torch", "hip"])
+def test_m2_train_loop_on_gpu_matches_reference_script(hip_lib, tmp_path, optimizer):
+    """optimizer = "hip": millieye_amd.optim.AdamW (the loop's default on the GPU) instead of torch.optim.AdamW - the same trajectory of
+    the REAL reference's module2_mixed/train.py run."""
     from millieye_amd.module2.my_models import Network
+    from millieye_amd import optim
     net = ml.prepare(Network)
     net = net.to(net.device)
     assert net.device.type == "cuda"
-    hist = ml.run(net, tmp_path)
+    hist = ml.run(net, tmp_path, optimizer_cls=optim.AdamW if optimizer == "hip" else None)
     ml.check(net, hist, tmp_path, loss_tol=1e-3, param_atol=6.5e-4, sum_tol=2e-4, ap_tol=2e-3, late_ap_tol=2e-2)
 
 

@@ -17,12 +17,16 @@ from tests import train_loop_helpers as tl
 pytestmark = pytest.mark.gpu
 
 
-def test_train_loop_on_gpu_matches_reference_script(hip_lib, tmp_path):
+@pytest.mark.parametrize("optimizer", ["torch", "hip"])
+def test_train_loop_on_gpu_matches_reference_script(hip_lib, tmp_path, optimizer):
+    """optimizer = "hip": millieye_amd.optim.Adam (one launch per step; the loop's default on the GPU) instead of torch.optim.Adam -
+    the same trajectory of the REAL reference's train.py run (parameter sums after every step, losses, final weights)."""
     from millieye_amd.my_models import Network
+    from millieye_amd import optim
     net, frozen = tl.prepare(Network)
     net = net.to(net.device)
     assert net.device.type == "cuda"
-    hist = tl.run(net, tmp_path)
+    hist = tl.run(net, tmp_path, optimizer_cls=optim.Adam if optimizer == "hip" else None)
     tl.check(net, frozen, hist, tmp_path, loss_tol=1e-3, param_atol=3.2e-3, sum_tol=2e-4, ap_tol=2e-3, late_ap_tol=2e-2)
     # every trainable head tensor moved, frozen ones did not
     g = tl.golden()
